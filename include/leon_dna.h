@@ -1,0 +1,119 @@
+/*
+ * leon_dna.h -- C-ABI of the MI355X-native Leon DNA encode path (libleon_dna.so).
+ *
+ * This is the drop-in boundary for the one hot path SURVEY.md section 8 scopes: what gatb-core's
+ * Leon::startDnaCompression does by running Dispatcher::iterate(bank, DnaEncoder(this)) on pthreads
+ * (call shape verified at /root/reference/src/main.cpp:44 `Leon().run(argc, argv)`; everything below
+ * it lives in the un-vendored gatb-core submodule, /root/reference/.gitmodules:1-3, so the upstream
+ * names cited per entry point are [RECALLED] names, not file:line -- SURVEY.md section 0).
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types; every call returns 0 on success or a
+ * negative LEON_E_* code and never throws; leon_last_error() gives the message.  One ctx = one ordered
+ * read stream (one output file); calls on a ctx are serialised by the caller; HIP streams are private.
+ * There is NO CPU fallback: without a HIP device ctx_create fails with LEON_E_NO_DEVICE.
+ */
+#ifndef LEON_DNA_H
+#define LEON_DNA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LEON_DNA_ABI_VERSION 1
+
+enum {
+    LEON_OK = 0,
+    LEON_E_INVALID = -1,     /* bad argument / configuration */
+    LEON_E_NO_DEVICE = -2,   /* no usable HIP device (the product has no CPU path) */
+    LEON_E_HIP = -3,         /* HIP runtime error, message carries hipGetErrorString */
+    LEON_E_STATE = -4,       /* call order violated (e.g. encode after finish) */
+    LEON_E_OVERFLOW = -5,    /* an internal device buffer bound was hit (reported, never silently truncated) */
+    LEON_E_SINK = -6         /* the block sink returned non-zero */
+};
+
+typedef struct leon_dna_ctx leon_dna_ctx;
+
+/* Replaces the state a DnaEncoder copies from its owning Leon*: _kmerSize, Leon::READ_PER_BLOCK and the
+ * shared IBloom<kmer_type>* created by Leon::createBloom (BloomFactory BLOOM_NEIGHBOR, 7 hashes). */
+typedef struct leon_dna_cfg {
+    uint32_t struct_size;        /* sizeof(leon_dna_cfg) */
+    uint32_t kmer_size;          /* 3..31 (one 64-bit word; k <= 63 is a later row) */
+    uint32_t reads_per_block;    /* Leon::READ_PER_BLOCK, 50000 */
+    uint32_t bloom_n_hash;       /* 7 */
+    uint32_t bloom_block_nbits;  /* BloomCacheCoherent block_nbits, 12 */
+    int32_t  device_id;          /* HIP device ordinal */
+    uint64_t bloom_tai;          /* tai_bloom as handed to BloomNeighborCoherent (bits, before its padding) */
+    const uint64_t* random_values; /* optional 256-entry simplehash16 table; NULL = built-in */
+    uint64_t resolve_window;     /* reads per anchor-resolution window; 0 = default (1<<20) */
+    uint32_t flags;              /* LEON_F_* */
+    uint32_t reserved;
+} leon_dna_cfg;
+
+#define LEON_F_KEEP_TRACE 1u     /* keep per-read anchors / events of the last batch for leon_dna_trace_* */
+
+/* Replaces Leon::writeBlock(buffer, size, nReads, blockId): called on the calling thread, in increasing
+ * block_id; payload is owned by the library and valid until the sink returns.  Non-zero aborts. */
+typedef int (*leon_block_sink)(void* user, uint64_t block_id, const uint8_t* payload, uint64_t size,
+                               uint32_t n_reads);
+
+typedef struct leon_dna_stats {
+    uint64_t n_reads, n_bases, n_blocks, n_anchors, n_no_anchor, n_symbols, payload_bytes;
+    uint64_t resolve_rounds, resolve_windows;
+    /* HIP-event milliseconds of the last batch, measured on the library's own stream */
+    float ms_pack, ms_resolve, ms_sort, ms_walk, ms_symbols, ms_rangecoder, ms_d2h, ms_total;
+    uint32_t walk_launches, reserved;
+} leon_dna_stats;
+
+/* -- lifecycle (DnaEncoder ctor / dtor bracket one thread's work upstream) -- */
+int  leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out);
+void leon_dna_ctx_destroy(leon_dna_ctx* ctx);
+const char* leon_last_error(const leon_dna_ctx* ctx);      /* ctx may be NULL: last create error */
+int  leon_dna_abi_version(void);
+
+/* -- bloom (probe side is on the path; build side: Leon::createBloom's insert loop) -- */
+int leon_dna_bloom_nbytes(const leon_dna_ctx* ctx, uint64_t* nbytes);          /* Bloom::getSize, nchar */
+int leon_dna_bloom_upload(leon_dna_ctx* ctx, const uint8_t* bits, uint64_t nbytes);   /* StorageTools::loadBloom */
+int leon_dna_bloom_download(leon_dna_ctx* ctx, uint8_t* bits, uint64_t nbytes);       /* StorageTools::saveBloom */
+int leon_dna_bloom_clear(leon_dna_ctx* ctx);
+int leon_dna_bloom_insert(leon_dna_ctx* ctx, const uint64_t* kmers, uint64_t n);      /* host k-mers, IBloom::insert */
+int leon_dna_bloom_insert_device(leon_dna_ctx* ctx, const uint64_t* d_kmers, uint64_t n);
+int leon_dna_bloom_device_ptr(leon_dna_ctx* ctx, void** d_bits, uint64_t* nbytes);    /* for an RCCL broadcast */
+/* BloomNeighborCoherent::contains4 / contains over a list of k-mers (host in, host out) */
+int leon_dna_bloom_contains4(leon_dna_ctx* ctx, const uint64_t* kmers, uint64_t n, int right, uint8_t* out);
+int leon_dna_bloom_contains(leon_dna_ctx* ctx, const uint64_t* kmers, uint64_t n, uint8_t* out);
+
+/* -- the hot path: DnaEncoder::operator()(Sequence&) over a batch of reads in file order --
+ * bases: concatenated ASCII read data (A,C,G,T; any other byte is an N); offsets[n_reads+1].
+ * first_read_index must continue the stream; every batch but the last must hold a whole number of
+ * blocks (n_reads % reads_per_block == 0).  Blocks go to `sink` in increasing block_id. */
+int leon_dna_encode_batch(leon_dna_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads,
+                          uint64_t first_read_index, leon_block_sink sink, void* user);
+/* same with bases/offsets already resident in device memory (HBM) */
+int leon_dna_encode_batch_device(leon_dna_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets,
+                                 uint64_t n_reads, uint64_t first_read_index, leon_block_sink sink, void* user);
+
+/* Leon::endDnaCompression: flush the anchor-dictionary range coder (Leon::encodeInsertedAnchor stream).
+ * payload stays owned by ctx until destroy. */
+int leon_dna_finish(leon_dna_ctx* ctx, const uint8_t** dict_payload, uint64_t* dict_size, uint64_t* n_anchors);
+
+int leon_dna_get_stats(const leon_dna_ctx* ctx, leon_dna_stats* out);
+
+/* -- traces of the last batch (need LEON_F_KEEP_TRACE); for stage-wise parity tests -- */
+int leon_dna_trace_anchors(leon_dna_ctx* ctx, int32_t* anchor_pos, uint32_t* anchor_addr, uint8_t* flags,
+                           uint64_t n_reads);
+int leon_dna_trace_events(leon_dna_ctx* ctx, uint8_t* events, uint64_t n_bases);
+int leon_dna_anchor_kmers(leon_dna_ctx* ctx, uint64_t* kmers, uint64_t n_anchors);
+
+/* -- RangeEncoder::encode over independent symbol streams (one Order0Model set per stream) --
+ * syms: 2 bytes per symbol (model id, value); stream i covers symbols [begin[i], begin[i+1]).
+ * model ids as in DESIGN.md (8 small models, 8 numeric groups x 9).  Output concatenated, sizes[i]. */
+int leon_rc_encode_streams(leon_dna_ctx* ctx, const uint8_t* syms, const uint64_t* begin, uint64_t n_streams,
+                           uint8_t* out, uint64_t out_cap, uint64_t* sizes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,241 @@
+"""ctypes binding of include/leon_dna.h.  Mirrors the C-ABI one to one; no compute happens in Python."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+LEON_F_KEEP_TRACE = 1
+
+
+class LeonDnaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("leon_dna error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libleon_dna.so")
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("kmer_size", C.c_uint32), ("reads_per_block", C.c_uint32),
+                ("bloom_n_hash", C.c_uint32), ("bloom_block_nbits", C.c_uint32), ("device_id", C.c_int32),
+                ("bloom_tai", C.c_uint64), ("random_values", C.POINTER(C.c_uint64)), ("resolve_window", C.c_uint64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_reads", "n_bases", "n_blocks", "n_anchors", "n_no_anchor", "n_symbols",
+                                           "payload_bytes", "resolve_rounds", "resolve_windows")] + \
+               [(n, C.c_float) for n in ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder",
+                                         "ms_d2h", "ms_total")] + \
+               [("walk_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32)
+
+_u8p, _u32p, _i32p, _u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_int32, C.c_uint64))
+
+_EXPORTS = {
+    "leon_dna_abi_version": (C.c_int, []),
+    "leon_last_error": (C.c_char_p, [C.c_void_p]),
+    "leon_dna_ctx_create": (C.c_int, [C.POINTER(_Cfg), C.POINTER(C.c_void_p)]),
+    "leon_dna_ctx_destroy": (None, [C.c_void_p]),
+    "leon_dna_bloom_nbytes": (C.c_int, [C.c_void_p, _u64p]),
+    "leon_dna_bloom_upload": (C.c_int, [C.c_void_p, _u8p, C.c_uint64]),
+    "leon_dna_bloom_download": (C.c_int, [C.c_void_p, _u8p, C.c_uint64]),
+    "leon_dna_bloom_clear": (C.c_int, [C.c_void_p]),
+    "leon_dna_bloom_insert": (C.c_int, [C.c_void_p, _u64p, C.c_uint64]),
+    "leon_dna_bloom_insert_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "leon_dna_bloom_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _u64p]),
+    "leon_dna_bloom_contains4": (C.c_int, [C.c_void_p, _u64p, C.c_uint64, C.c_int, _u8p]),
+    "leon_dna_bloom_contains": (C.c_int, [C.c_void_p, _u64p, C.c_uint64, _u8p]),
+    "leon_dna_encode_batch": (C.c_int, [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, C.c_uint64, SINK, C.c_void_p]),
+    "leon_dna_encode_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, SINK,
+                                                C.c_void_p]),
+    "leon_dna_finish": (C.c_int, [C.c_void_p, C.POINTER(_u8p), _u64p, _u64p]),
+    "leon_dna_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "leon_dna_trace_anchors": (C.c_int, [C.c_void_p, _i32p, _u32p, _u8p, C.c_uint64]),
+    "leon_dna_trace_events": (C.c_int, [C.c_void_p, _u8p, C.c_uint64]),
+    "leon_dna_anchor_kmers": (C.c_int, [C.c_void_p, _u64p, C.c_uint64]),
+    "leon_rc_encode_streams": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_uint64, _u8p, C.c_uint64, _u64p]),
+}
+EXPORTED_SYMBOLS = tuple(_EXPORTS)
+_lib = None
+
+
+def load_library():
+    """dlopen libleon_dna.so and bind every symbol include/leon_dna.h declares.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise LeonDnaError(-2, "%s is missing: build it with leon_amd.build_library() (hipcc, gfx950); "
+                               "there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in _EXPORTS.items():
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class DnaEncodeContext:
+    """One ordered read stream on one GPU (wraps leon_dna_ctx)."""
+
+    def __init__(self, kmer_size=31, reads_per_block=50000, bloom_tai=0, bloom_n_hash=7, bloom_block_nbits=12,
+                 device_id=0, resolve_window=0, keep_trace=False, random_values=None):
+        self.lib = load_library()
+        cfg = _Cfg()
+        cfg.struct_size = C.sizeof(_Cfg)
+        cfg.kmer_size, cfg.reads_per_block = kmer_size, reads_per_block
+        cfg.bloom_n_hash, cfg.bloom_block_nbits, cfg.device_id = bloom_n_hash, bloom_block_nbits, device_id
+        cfg.bloom_tai, cfg.resolve_window = int(bloom_tai), int(resolve_window)
+        cfg.flags = LEON_F_KEEP_TRACE if keep_trace else 0
+        self._rv = None
+        if random_values is not None:
+            self._rv = np.ascontiguousarray(random_values, dtype=np.uint64)
+            assert len(self._rv) == 256
+            cfg.random_values = _ptr(self._rv, _u64p)
+        h = C.c_void_p()
+        rc = self.lib.leon_dna_ctx_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise LeonDnaError(rc, (self.lib.leon_last_error(None) or b"").decode())
+        self.h = h
+        self.kmer_size, self.reads_per_block = kmer_size, reads_per_block
+        self.next_read = 0
+
+    def _chk(self, rc):
+        if rc:
+            raise LeonDnaError(rc, (self.lib.leon_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.leon_dna_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # ---- bloom ----
+    @property
+    def bloom_nbytes(self):
+        n = C.c_uint64()
+        self._chk(self.lib.leon_dna_bloom_nbytes(self.h, C.byref(n)))
+        return n.value
+
+    def bloom_upload(self, bits):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        self._chk(self.lib.leon_dna_bloom_upload(self.h, _ptr(bits, _u8p), len(bits)))
+
+    def bloom_download(self):
+        out = np.zeros(self.bloom_nbytes, dtype=np.uint8)
+        self._chk(self.lib.leon_dna_bloom_download(self.h, _ptr(out, _u8p), len(out)))
+        return out
+
+    def bloom_clear(self):
+        self._chk(self.lib.leon_dna_bloom_clear(self.h))
+
+    def bloom_insert(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        self._chk(self.lib.leon_dna_bloom_insert(self.h, _ptr(kmers, _u64p), len(kmers)))
+
+    def bloom_insert_device(self, dev_ptr, n):
+        self._chk(self.lib.leon_dna_bloom_insert_device(self.h, C.c_void_p(int(dev_ptr)), int(n)))
+
+    def bloom_device_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.leon_dna_bloom_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def bloom_contains4(self, kmers, right):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.zeros(len(kmers), dtype=np.uint8)
+        self._chk(self.lib.leon_dna_bloom_contains4(self.h, _ptr(kmers, _u64p), len(kmers), int(right), _ptr(out, _u8p)))
+        return out
+
+    def bloom_contains(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.zeros(len(kmers), dtype=np.uint8)
+        self._chk(self.lib.leon_dna_bloom_contains(self.h, _ptr(kmers, _u64p), len(kmers), _ptr(out, _u8p)))
+        return out
+
+    # ---- encode ----
+    def _collect_sink(self, blocks):
+        def cb(user, block_id, payload, size, n_reads):
+            blocks.append((block_id, C.string_at(payload, size), n_reads))
+            return 0
+        return SINK(cb)
+
+    def encode_batch(self, bases, offsets, sink=None):
+        """bases: bytes / uint8 array, offsets: uint64[n+1].  Returns [(block_id, payload, n_reads)]."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        if not isinstance(bases, (bytes, bytearray)):
+            bases = np.ascontiguousarray(bases, dtype=np.uint8).tobytes()
+        blocks = []
+        cb = sink if sink is not None else self._collect_sink(blocks)
+        self._chk(self.lib.leon_dna_encode_batch(self.h, bases, _ptr(offsets, _u64p), n, self.next_read, cb, None))
+        self.next_read += n
+        return blocks
+
+    def encode_batch_device(self, d_bases_ptr, d_offsets_ptr, n_reads, sink=None):
+        blocks = []
+        cb = sink if sink is not None else self._collect_sink(blocks)
+        self._chk(self.lib.leon_dna_encode_batch_device(self.h, C.c_void_p(int(d_bases_ptr)), C.c_void_p(int(d_offsets_ptr)),
+                                                        int(n_reads), self.next_read, cb, None))
+        self.next_read += int(n_reads)
+        return blocks
+
+    def finish(self):
+        p, sz, na = _u8p(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.leon_dna_finish(self.h, C.byref(p), C.byref(sz), C.byref(na)))
+        return C.string_at(p, sz.value), na.value
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.lib.leon_dna_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    # ---- traces ----
+    def trace_anchors(self, n_reads):
+        pos = np.zeros(n_reads, dtype=np.int32)
+        addr = np.zeros(n_reads, dtype=np.uint32)
+        flags = np.zeros(n_reads, dtype=np.uint8)
+        self._chk(self.lib.leon_dna_trace_anchors(self.h, _ptr(pos, _i32p), _ptr(addr, _u32p), _ptr(flags, _u8p), n_reads))
+        return pos, addr, flags
+
+    def trace_events(self, n_bases):
+        ev = np.zeros(n_bases, dtype=np.uint8)
+        self._chk(self.lib.leon_dna_trace_events(self.h, _ptr(ev, _u8p), n_bases))
+        return ev
+
+    def anchor_kmers(self, n):
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        self._chk(self.lib.leon_dna_anchor_kmers(self.h, _ptr(out, _u64p), n))
+        return out[:n]
+
+    def rc_encode_streams(self, syms, begin):
+        """syms: uint8[2*n] (model, value) pairs; begin: uint64[n_streams+1].  Returns list of payload bytes."""
+        syms = np.ascontiguousarray(syms, dtype=np.uint8)
+        begin = np.ascontiguousarray(begin, dtype=np.uint64)
+        ns = len(begin) - 1
+        cap = 3 * (len(syms) // 2) + 64 * (ns + 1)
+        out = np.zeros(cap, dtype=np.uint8)
+        sizes = np.zeros(max(ns, 1), dtype=np.uint64)
+        self._chk(self.lib.leon_rc_encode_streams(self.h, _ptr(syms, _u8p), _ptr(begin, _u64p), ns, _ptr(out, _u8p), cap,
+                                                  _ptr(sizes, _u64p)))
+        res, w = [], 0
+        for i in range(ns):
+            res.append(out[w:w + int(sizes[i])].tobytes())
+            w += int(sizes[i])
+        return res

@@ -1,0 +1,651 @@
+// capi.hip -- the C-ABI of include/leon_dna.h: context, device memory, and the stage pipeline
+//   pack -> anchor resolution (windows, fixpoint rounds) -> anchor sort -> walk -> symbols -> range coder -> D2H.
+#include "../../include/leon_dna.h"
+#include "kernels.h"
+#include "host_rc.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace leon;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+uint64_t splitmix_rv(uint32_t idx) {     // built-in simplehash16 table, see DESIGN.md "recalled constants"
+    uint64_t s = 0x4C454F4EULL + (uint64_t)(idx + 1) * 0x9E3779B97F4A7C15ULL;
+    s = (s ^ (s >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    s = (s ^ (s >> 27)) * 0x94D049BB133111EBULL;
+    return s ^ (s >> 31);
+}
+uint64_t hash_seed0() {                  // HashFunctors::generate_hash_seed, seed_tab[0], user_seed 0
+    const uint64_t r0 = 0xAAAAAAAA55555555ULL, r3 = 0xB5B5B5B54B4B4B4BULL;
+    return r0 * r3;
+}
+
+__global__ void k_iota(uint32_t* v, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+
+}  // namespace
+
+struct leon_dna_ctx {
+    leon_dna_cfg cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    std::string err;
+    // bloom
+    uint8_t* d_bloom = nullptr;
+    uint64_t bloom_nchar = 0;
+    BloomDev B{};
+    uint16_t* d_rv16 = nullptr;
+    // dictionary
+    DictDev D{};
+    uint64_t dict_cap = 0;
+    uint64_t n_keys = 0;
+    unsigned long long* d_nkeys = nullptr;
+    uint64_t n_anchors = 0;
+    DevBuf anchor_kmers;
+    std::vector<uint64_t> h_anchor_kmers;        // all anchors so far, address order
+    uint64_t anchors_encoded = 0;
+    HostOrder0Model anchor_model{5};
+    HostRangeEncoder anchor_rc;
+    std::thread anchor_thread;
+    // stream state
+    uint64_t next_read = 0, next_block = 0;
+    bool partial_seen = false, finished = false;
+    // batch buffers
+    DevBuf in_bases, in_off, slot_off, packed, nmask, rlen, ncount;
+    DevBuf status, hit_pos, hit_slot, cand_pos, cand_slot, anchor_pos, anchor_addr, flags, sort_key, ins_flag, rank;
+    DevBuf ulist0, ulist1, counters, cub_tmp, sort_key2, perm, perm2, events, prev, sym_off, syms;
+    DevBuf blk_begin, out_off, out_size, rc_out, rc_scratch, dst_off, payload, errflag;
+    void* h_payload = nullptr; size_t h_payload_cap = 0;
+    uint64_t last_n = 0, last_bases = 0;
+    leon_dna_stats stats{};
+    hipEvent_t ev[10]{};
+};
+
+namespace {
+
+int fail(leon_dna_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((c), LEON_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+int dict_alloc(leon_dna_ctx* c, DictDev& D, uint64_t cap) {
+    HIPCHK(c, hipMalloc((void**)&D.keys, cap * 8));
+    HIPCHK(c, hipMalloc((void**)&D.fin, cap * 8));
+    HIPCHK(c, hipMalloc((void**)&D.tent, cap * 8));
+    HIPCHK(c, hipMalloc((void**)&D.addr, cap * 4));
+    D.mask = cap - 1;
+    D.n_keys = c->d_nkeys;
+    launch_dict_init(c->stream, D, cap);
+    return LEON_OK;
+}
+void dict_free(DictDev& D) {
+    if (D.keys) (void)hipFree(D.keys);
+    if (D.fin) (void)hipFree(D.fin);
+    if (D.tent) (void)hipFree(D.tent);
+    if (D.addr) (void)hipFree(D.addr);
+    D = DictDev{};
+}
+// capacity >= 2 * keys: linear probing stays short
+int dict_reserve(leon_dna_ctx* c, uint64_t keys) {
+    uint64_t need = 1024;
+    while (need < 2 * keys) need <<= 1;
+    if (need <= c->dict_cap) return LEON_OK;
+    if (need > (1ull << 32)) return fail(c, LEON_E_OVERFLOW, "anchor dictionary would exceed 2^32 slots");
+    DictDev nd{};
+    HIPCHK(c, hipMemsetAsync(c->d_nkeys, 0, 8, c->stream));
+    int rc = dict_alloc(c, nd, need);
+    if (rc) return rc;
+    if (c->dict_cap) {
+        launch_dict_rehash(c->stream, c->D, c->dict_cap, nd);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dict_free(c->D);
+    }
+    c->D = nd;
+    c->dict_cap = need;
+    return LEON_OK;
+}
+
+void encode_anchors_host(leon_dna_ctx* c, uint64_t upto) {
+    uint32_t k = c->cfg.kmer_size;
+    for (uint64_t a = c->anchors_encoded; a < upto; a++) {
+        uint64_t km = c->h_anchor_kmers[a];
+        for (uint32_t i = 0; i < k; i++) c->anchor_rc.encode(c->anchor_model, (uint32_t)(km >> (2 * (k - 1 - i))) & 3u);
+    }
+    c->anchors_encoded = upto;
+}
+
+ReadsDev reads_view(leon_dna_ctx* c, const uint64_t* d_off, uint64_t n) {
+    ReadsDev R{};
+    R.packed = c->packed.as<uint32_t>(); R.nmask = c->nmask.as<uint32_t>(); R.slot_off = c->slot_off.as<uint64_t>();
+    R.base_off = d_off; R.len = c->rlen.as<uint32_t>(); R.n_count = c->ncount.as<uint32_t>();
+    R.n = n; R.k = c->cfg.kmer_size;
+    return R;
+}
+
+int ensure_cub(leon_dna_ctx* c, size_t bytes) { HIPCHK(c, c->cub_tmp.ensure(bytes)); return LEON_OK; }
+
+}  // namespace
+
+extern "C" {
+
+int leon_dna_abi_version(void) { return LEON_DNA_ABI_VERSION; }
+
+const char* leon_last_error(const leon_dna_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, LEON_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(leon_dna_cfg)) return fail(nullptr, LEON_E_INVALID, "leon_dna_cfg.struct_size mismatch");
+    if (cfg->kmer_size < 3 || cfg->kmer_size > 31)
+        return fail(nullptr, LEON_E_INVALID, "kmer_size must be in 3..31 (two-word k-mers are not built yet)");
+    if (cfg->reads_per_block == 0) return fail(nullptr, LEON_E_INVALID, "reads_per_block must be > 0");
+    if (cfg->bloom_n_hash < 1 || cfg->bloom_n_hash > 10) return fail(nullptr, LEON_E_INVALID, "bloom_n_hash must be in 1..10");
+    if (cfg->bloom_block_nbits < 4 || cfg->bloom_block_nbits > 16)
+        return fail(nullptr, LEON_E_INVALID, "bloom_block_nbits must be in 4..16");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, LEON_E_NO_DEVICE, "no HIP device: the DNA encode path has no CPU fallback");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, LEON_E_INVALID, "device_id out of range");
+    leon_dna_ctx* c = new leon_dna_ctx();
+    c->cfg = *cfg;
+    c->cfg.random_values = nullptr;
+    if (c->cfg.resolve_window == 0) c->cfg.resolve_window = 1ull << 20;
+    c->device = cfg->device_id;
+#define CREATE_CHK(call)                                                                                         \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            int r_ = fail(nullptr, LEON_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));               \
+            leon_dna_ctx_destroy(c);                                                                             \
+            return r_;                                                                                           \
+        }                                                                                                        \
+    } while (0)
+    CREATE_CHK(hipSetDevice(c->device));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
+    // BloomCacheCoherent / BloomContainer geometry
+    uint64_t blk = 1ull << cfg->bloom_block_nbits;
+    uint64_t tai = cfg->bloom_tai + 2 * blk;
+    c->bloom_nchar = 1 + tai / 8;
+    if ((tai & (tai - 1)) == 0) tai--;
+    uint64_t reduced = tai - 2 * blk;
+    if (reduced == 0) { leon_dna_ctx_destroy(c); return fail(nullptr, LEON_E_INVALID, "bloom_tai too small"); }
+    CREATE_CHK(hipMalloc((void**)&c->d_bloom, c->bloom_nchar + 16));
+    CREATE_CHK(hipMemsetAsync(c->d_bloom, 0, c->bloom_nchar + 16, c->stream));
+    uint16_t rv16[256];
+    for (uint32_t i = 0; i < 256; i++) rv16[i] = (uint16_t)((cfg->random_values ? cfg->random_values[i] : splitmix_rv(i)) & 0xFFFF);
+    CREATE_CHK(hipMalloc((void**)&c->d_rv16, sizeof(rv16)));
+    CREATE_CHK(hipMemcpy(c->d_rv16, rv16, sizeof(rv16), hipMemcpyHostToDevice));
+    uint32_t k = cfg->kmer_size;
+    c->B.bits = c->d_bloom; c->B.reduced_tai = reduced; c->B.mod_magic = ~0ull / reduced; c->B.seed0 = hash_seed0();
+    c->B.maskkm2 = (1ull << (2 * (k - 2))) - 1; c->B.kmer_mask = (1ull << (2 * k)) - 1;
+    c->B.k = k; c->B.n_hash = cfg->bloom_n_hash; c->B.block_mask = (uint32_t)(blk - 1);
+    CREATE_CHK(hipMalloc((void**)&c->d_nkeys, 8));
+    CREATE_CHK(hipMemset(c->d_nkeys, 0, 8));
+    CREATE_CHK(c->counters.ensure(64));
+    CREATE_CHK(c->errflag.ensure(16));
+    CREATE_CHK(hipStreamSynchronize(c->stream));
+#undef CREATE_CHK
+    c->anchor_rc.clear();
+    *out = c;
+    return LEON_OK;
+}
+
+void leon_dna_ctx_destroy(leon_dna_ctx* c) {
+    if (!c) return;
+    if (c->anchor_thread.joinable()) c->anchor_thread.join();
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dict_free(c->D);
+    DevBuf* bufs[] = { &c->anchor_kmers, &c->in_bases, &c->in_off, &c->slot_off, &c->packed, &c->nmask, &c->rlen, &c->ncount,
+                       &c->status, &c->hit_pos, &c->hit_slot, &c->cand_pos, &c->cand_slot, &c->anchor_pos, &c->anchor_addr,
+                       &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
+                       &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
+                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag };
+    for (DevBuf* b : bufs) b->release();
+    if (c->d_bloom) (void)hipFree(c->d_bloom);
+    if (c->d_rv16) (void)hipFree(c->d_rv16);
+    if (c->d_nkeys) (void)hipFree(c->d_nkeys);
+    if (c->h_payload) (void)hipHostFree(c->h_payload);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------------------ bloom
+int leon_dna_bloom_nbytes(const leon_dna_ctx* c, uint64_t* n) {
+    if (!c || !n) return LEON_E_INVALID;
+    *n = c->bloom_nchar;
+    return LEON_OK;
+}
+int leon_dna_bloom_upload(leon_dna_ctx* c, const uint8_t* bits, uint64_t n) {
+    if (!c || !bits) return LEON_E_INVALID;
+    if (n != c->bloom_nchar) return fail(c, LEON_E_INVALID, "bloom_upload: size differs from leon_dna_bloom_nbytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(c->d_bloom, bits, n, hipMemcpyHostToDevice));
+    return LEON_OK;
+}
+int leon_dna_bloom_download(leon_dna_ctx* c, uint8_t* bits, uint64_t n) {
+    if (!c || !bits) return LEON_E_INVALID;
+    if (n != c->bloom_nchar) return fail(c, LEON_E_INVALID, "bloom_download: size differs from leon_dna_bloom_nbytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(bits, c->d_bloom, n, hipMemcpyDeviceToHost));
+    return LEON_OK;
+}
+int leon_dna_bloom_clear(leon_dna_ctx* c) {
+    if (!c) return LEON_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_bloom, 0, c->bloom_nchar + 16, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LEON_OK;
+}
+int leon_dna_bloom_insert_device(leon_dna_ctx* c, const uint64_t* d_kmers, uint64_t n) {
+    if (!c || (!d_kmers && n)) return LEON_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_bloom_insert(c->stream, c->B, c->d_rv16, d_kmers, n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LEON_OK;
+}
+int leon_dna_bloom_insert(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n) {
+    if (!c || (!kmers && n)) return LEON_E_INVALID;
+    if (!n) return LEON_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf tmp;
+    HIPCHK(c, tmp.ensure(n * 8));
+    hipError_t e = hipMemcpy(tmp.p, kmers, n * 8, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? leon_dna_bloom_insert_device(c, tmp.as<uint64_t>(), n)
+                             : fail(c, LEON_E_HIP, std::string("bloom_insert H2D: ") + hipGetErrorString(e));
+    tmp.release();
+    return rc;
+}
+int leon_dna_bloom_device_ptr(leon_dna_ctx* c, void** p, uint64_t* n) {
+    if (!c || !p || !n) return LEON_E_INVALID;
+    *p = c->d_bloom; *n = c->bloom_nchar;
+    return LEON_OK;
+}
+static int bloom_query(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, int mode, uint8_t* out) {
+    if (!c || ((!kmers || !out) && n)) return LEON_E_INVALID;
+    if (!n) return LEON_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf dk, dout;
+    HIPCHK(c, dk.ensure(n * 8));
+    HIPCHK(c, dout.ensure(n));
+    HIPCHK(c, hipMemcpy(dk.p, kmers, n * 8, hipMemcpyHostToDevice));
+    launch_bloom_query(c->stream, c->B, c->d_rv16, dk.as<uint64_t>(), n, mode, dout.as<uint8_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout.p, n, hipMemcpyDeviceToHost));
+    dk.release(); dout.release();
+    return LEON_OK;
+}
+int leon_dna_bloom_contains4(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, int right, uint8_t* out) {
+    return bloom_query(c, kmers, n, right ? 2 : 1, out);
+}
+int leon_dna_bloom_contains(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, uint8_t* out) {
+    return bloom_query(c, kmers, n, 0, out);
+}
+
+// ------------------------------------------------------------------------------------------------ encode
+int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
+                                 uint64_t first_read_index, leon_block_sink sink, void* user) {
+    if (!c) return LEON_E_INVALID;
+    if (c->finished) return fail(c, LEON_E_STATE, "encode_batch after finish");
+    if (first_read_index != c->next_read) return fail(c, LEON_E_STATE, "first_read_index does not continue the stream");
+    if (c->partial_seen && n) return fail(c, LEON_E_STATE, "a batch with a partial block must be the last one");
+    if (n == 0) return LEON_OK;
+    if (!d_bases || !d_off || !sink) return fail(c, LEON_E_INVALID, "null argument");
+    if (n > 0xFFFFFFF0ull) return fail(c, LEON_E_INVALID, "more than 2^32 reads in one batch");
+    const uint32_t rpb = c->cfg.reads_per_block, k = c->cfg.kmer_size;
+    if (n % rpb) c->partial_seen = true;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (c->anchor_thread.joinable()) c->anchor_thread.join();
+    c->stats = leon_dna_stats{};
+
+    // ---- sizes ----
+    uint64_t off_first = 0, off_last = 0;
+    HIPCHK(c, hipMemcpy(&off_first, d_off, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&off_last, d_off + n, 8, hipMemcpyDeviceToHost));
+    if (off_last < off_first) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
+    const uint64_t n_bases = off_last - off_first;
+    const uint64_t n_blocks = (n + rpb - 1) / rpb;
+
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    // ---- pack ----
+    HIPCHK(c, c->slot_off.ensure((n + 1) * 8));
+    launch_read_slots(s, d_off, n, c->slot_off.as<uint64_t>());
+    size_t tmp_bytes = 0;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
+    if (int rc = ensure_cub(c, tmp_bytes)) return rc;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
+    uint64_t n_slots = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_slots, c->slot_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, c->packed.ensure((n_slots * 2 + 8) * 4));
+    HIPCHK(c, c->nmask.ensure((n_slots + 4) * 4));
+    HIPCHK(c, c->rlen.ensure(n * 4));
+    HIPCHK(c, c->ncount.ensure(n * 4));
+    HIPCHK(c, hipMemsetAsync(c->packed.as<uint32_t>() + n_slots * 2, 0, 32, s));
+    launch_pack(s, d_bases + off_first * 0, d_off, c->slot_off.as<uint64_t>(), n, c->packed.as<uint32_t>(), c->nmask.as<uint32_t>(),
+                c->rlen.as<uint32_t>(), c->ncount.as<uint32_t>());
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    ReadsDev R = reads_view(c, d_off, n);
+
+    // ---- anchor resolution ----
+    HIPCHK(c, c->status.ensure(n));
+    HIPCHK(c, c->hit_pos.ensure(n * 4)); HIPCHK(c, c->hit_slot.ensure(n * 4));
+    HIPCHK(c, c->cand_pos.ensure(n * 4)); HIPCHK(c, c->cand_slot.ensure(n * 4));
+    HIPCHK(c, c->anchor_pos.ensure(n * 4)); HIPCHK(c, c->anchor_addr.ensure(n * 4));
+    HIPCHK(c, c->flags.ensure(n)); HIPCHK(c, c->sort_key.ensure(n * 8));
+    const uint64_t W = std::min<uint64_t>(c->cfg.resolve_window, n);
+    HIPCHK(c, c->ins_flag.ensure(W * 4)); HIPCHK(c, c->rank.ensure(W * 4));
+    HIPCHK(c, c->ulist0.ensure(W * 4)); HIPCHK(c, c->ulist1.ensure(W * 4));
+    ResolveDev V{};
+    V.status = c->status.as<uint8_t>(); V.hit_pos = c->hit_pos.as<uint32_t>(); V.hit_slot = c->hit_slot.as<uint32_t>();
+    V.cand_pos = c->cand_pos.as<uint32_t>(); V.cand_slot = c->cand_slot.as<uint32_t>();
+    V.anchor_pos = c->anchor_pos.as<int32_t>(); V.anchor_addr = c->anchor_addr.as<uint32_t>(); V.flags = c->flags.as<uint8_t>();
+    V.sort_key = c->sort_key.as<uint64_t>(); V.ins_flag = c->ins_flag.as<uint32_t>();
+    uint32_t* counters = c->counters.as<uint32_t>();            // [0],[1]: list counts
+    uint32_t* lists[2] = { c->ulist0.as<uint32_t>(), c->ulist1.as<uint32_t>() };
+    size_t scan_tmp = 0;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), W, s));
+    if (int rc = ensure_cub(c, scan_tmp)) return rc;
+    const uint64_t anchors_before = c->n_anchors;
+    for (uint64_t w0 = 0; w0 < n; w0 += W) {
+        uint64_t w1 = std::min(n, w0 + W);
+        if (int rc = dict_reserve(c, c->n_keys + (w1 - w0))) return rc;
+        HIPCHK(c, hipMemsetAsync(counters, 0, 8, s));
+        launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters);
+        uint32_t cnt = 0;
+        HIPCHK(c, hipMemcpyAsync(&cnt, counters, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const uint32_t cnt0 = cnt;
+        int cur = 0;
+        while (cnt > 0) {
+            int nxt = cur ^ 1;
+            HIPCHK(c, hipMemsetAsync(counters + nxt, 0, 4, s));
+            launch_check(s, R, c->D, V, first_read_index, lists[cur], counters + cur, cnt, lists[nxt], counters + nxt);
+            uint32_t ncnt = 0;
+            HIPCHK(c, hipMemcpyAsync(&ncnt, counters + nxt, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (ncnt >= cnt) return fail(c, LEON_E_STATE, "anchor resolution made no progress (internal error)");
+            launch_reset_tent(s, c->D, V, lists[cur], counters + cur, cnt);
+            launch_propose(s, c->D, V, first_read_index, lists[nxt], counters + nxt, ncnt);
+            cur = nxt; cnt = ncnt;
+            c->stats.resolve_rounds++;
+        }
+        if (cnt0 > 0) {
+            launch_final_pos(s, R, c->D, V, w0, w1, first_read_index);
+            launch_ins_flags(s, V, w0, w1);
+            HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), w1 - w0, s));
+            uint32_t last_rank = 0, last_flag = 0;
+            HIPCHK(c, hipMemcpyAsync(&last_rank, c->rank.as<uint32_t>() + (w1 - w0 - 1), 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(&last_flag, V.ins_flag + (w1 - w0 - 1), 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(&c->n_keys, c->d_nkeys, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            uint64_t n_new = (uint64_t)last_rank + last_flag;
+            if (c->n_anchors + n_new > 0xFFFFFFFFull) return fail(c, LEON_E_OVERFLOW, "more than 2^32 anchors");
+            if ((c->n_anchors + n_new) * 8 > c->anchor_kmers.cap) {           // grow, keeping what is there
+                DevBuf nb;
+                HIPCHK(c, nb.ensure(std::max<uint64_t>((c->n_anchors + n_new) * 2, 1024) * 8));
+                if (c->n_anchors) HIPCHK(c, hipMemcpyAsync(nb.p, c->anchor_kmers.p, c->n_anchors * 8, hipMemcpyDeviceToDevice, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+                c->anchor_kmers.release();
+                c->anchor_kmers = nb;
+            }
+            launch_assign_addr(s, c->D, V, w0, w1, c->rank.as<uint32_t>(), c->n_anchors, c->anchor_kmers.as<uint64_t>());
+            c->n_anchors += n_new;
+        }
+        launch_finalize_reads(s, R, c->D, V, w0, w1);
+        c->stats.resolve_windows++;
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    // new anchors go to the host thread that range-codes the dictionary stream, overlapped with the walk
+    if (c->n_anchors > anchors_before) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->h_anchor_kmers.resize(c->n_anchors);
+        HIPCHK(c, hipMemcpy(c->h_anchor_kmers.data() + anchors_before, c->anchor_kmers.as<uint64_t>() + anchors_before,
+                            (c->n_anchors - anchors_before) * 8, hipMemcpyDeviceToHost));
+        uint64_t upto = c->n_anchors;
+        c->anchor_thread = std::thread([c, upto] { encode_anchors_host(c, upto); });
+    }
+
+    // ---- sort reads by (anchor address, strand) ----
+    HIPCHK(c, c->sort_key2.ensure(n * 8)); HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(n * 4));
+    hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
+    size_t sort_tmp = 0;
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, V.sort_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>(),
+                                                 c->perm2.as<uint32_t>(), n, 0, 34, s));
+    if (int rc = ensure_cub(c, sort_tmp)) return rc;
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, sort_tmp, V.sort_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>(),
+                                                 c->perm2.as<uint32_t>(), n, 0, 34, s));
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+
+    // ---- walk ----
+    HIPCHK(c, c->events.ensure(n_bases + 16));
+    HIPCHK(c, hipMemsetAsync(c->events.p, 0, n_bases, s));
+    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, c->perm2.as<uint32_t>(), n, c->events.as<uint8_t>());
+    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    c->stats.walk_launches = 1;
+
+    // ---- symbols ----
+    HIPCHK(c, c->prev.ensure(n * 8));
+    HIPCHK(c, c->sym_off.ensure((n + 1) * 8));
+    launch_prev_anchored(s, V.anchor_pos, n, rpb, c->prev.as<int64_t>());
+    HIPCHK(c, hipMemsetAsync(c->sym_off.as<uint64_t>() + n, 0, 8, s));
+    launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(),
+                   c->sym_off.as<uint64_t>(), nullptr);
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), n + 1, s));
+    if (int rc = ensure_cub(c, tmp_bytes)) return rc;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), n + 1, s));
+    uint64_t n_syms = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_syms, c->sym_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, c->syms.ensure(n_syms * 2 + 256));
+    launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(),
+                   c->sym_off.as<uint64_t>(), c->syms.as<uint8_t>());
+    HIPCHK(c, c->blk_begin.ensure((n_blocks + 1) * 8)); HIPCHK(c, c->out_off.ensure((n_blocks + 1) * 8));
+    HIPCHK(c, c->out_size.ensure(n_blocks * 8)); HIPCHK(c, c->dst_off.ensure((n_blocks + 1) * 8));
+    launch_block_ranges(s, c->sym_off.as<uint64_t>(), n, rpb, n_blocks, c->blk_begin.as<uint64_t>(), c->out_off.as<uint64_t>());
+    HIPCHK(c, hipEventRecord(c->ev[6], s));
+
+    // ---- range coder ----
+    const uint64_t rc_cap = 3 * n_syms + 64 * (n_blocks + 1);
+    HIPCHK(c, c->rc_out.ensure(rc_cap));
+    HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(n_blocks)));
+    HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
+    launch_rc_encode(s, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), n_blocks, c->rc_out.as<uint8_t>(),
+                     c->out_off.as<uint64_t>(), c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[7], s));
+
+    // ---- gather + D2H ----
+    std::vector<uint64_t> sizes(n_blocks), dst(n_blocks + 1, 0);
+    int errflag = 0;
+    HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, n_blocks * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (errflag) return fail(c, LEON_E_OVERFLOW, "range coder output exceeded its 3 bytes/symbol bound");
+    for (uint64_t b = 0; b < n_blocks; b++) dst[b + 1] = dst[b] + sizes[b];
+    const uint64_t payload_bytes = dst[n_blocks];
+    HIPCHK(c, c->payload.ensure(payload_bytes + 16));
+    HIPCHK(c, hipMemcpyAsync(c->dst_off.p, dst.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
+    launch_gather_payload(s, c->rc_out.as<uint8_t>(), c->out_off.as<uint64_t>(), c->dst_off.as<uint64_t>(), c->out_size.as<uint64_t>(),
+                          n_blocks, c->payload.as<uint8_t>());
+    if (payload_bytes + 16 > c->h_payload_cap) {
+        if (c->h_payload) HIPCHK(c, hipHostFree(c->h_payload));
+        c->h_payload = nullptr; c->h_payload_cap = 0;
+        size_t want = payload_bytes + payload_bytes / 4 + 4096;
+        HIPCHK(c, hipHostMalloc(&c->h_payload, want, hipHostMallocDefault));
+        c->h_payload_cap = want;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_payload, c->payload.p, payload_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->ev[8], s));
+    HIPCHK(c, hipStreamSynchronize(s));
+
+    // ---- stats ----
+    auto ms = [&](int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, c->ev[a], c->ev[b]); return v; };
+    c->stats.n_reads = n; c->stats.n_bases = n_bases; c->stats.n_blocks = n_blocks; c->stats.n_anchors = c->n_anchors;
+    c->stats.n_symbols = n_syms; c->stats.payload_bytes = payload_bytes;
+    c->stats.ms_pack = ms(0, 1); c->stats.ms_resolve = ms(1, 2); c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5);
+    c->stats.ms_symbols = ms(5, 6); c->stats.ms_rangecoder = ms(6, 7); c->stats.ms_d2h = ms(7, 8); c->stats.ms_total = ms(0, 8);
+    c->last_n = n; c->last_bases = n_bases;
+    c->next_read += n;
+
+    // ---- Leon::writeBlock, in block order ----
+    const uint8_t* hp = (const uint8_t*)c->h_payload;
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        uint32_t nr = (uint32_t)std::min<uint64_t>(rpb, n - b * rpb);
+        if (sink(user, c->next_block + b, hp + dst[b], sizes[b], nr)) return fail(c, LEON_E_SINK, "block sink returned non-zero");
+    }
+    c->next_block += n_blocks;
+    (void)k;
+    return LEON_OK;
+}
+
+int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t* off, uint64_t n, uint64_t first_read_index,
+                          leon_block_sink sink, void* user) {
+    if (!c) return LEON_E_INVALID;
+    if (n == 0) return leon_dna_encode_batch_device(c, nullptr, nullptr, 0, first_read_index, sink, user);
+    if (!bases || !off) return fail(c, LEON_E_INVALID, "null argument");
+    if (off[n] < off[0]) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t nb = off[n] - off[0];
+    HIPCHK(c, c->in_bases.ensure(nb + 64));
+    HIPCHK(c, c->in_off.ensure((n + 1) * 8));
+    // the device copy is rebased so that offsets index it directly
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t i = 0; i <= n; i++) rel[i] = off[i] - off[0];
+    HIPCHK(c, hipMemcpy(c->in_bases.p, bases + off[0], nb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->in_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    return leon_dna_encode_batch_device(c, c->in_bases.as<uint8_t>(), c->in_off.as<uint64_t>(), n, first_read_index, sink, user);
+}
+
+int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, uint64_t* n_anchors) {
+    if (!c || !payload || !size || !n_anchors) return LEON_E_INVALID;
+    if (c->anchor_thread.joinable()) c->anchor_thread.join();
+    if (!c->finished) {
+        encode_anchors_host(c, c->n_anchors);
+        c->anchor_rc.flush();
+        c->finished = true;
+    }
+    *payload = c->anchor_rc.bytes().data();
+    *size = c->anchor_rc.bytes().size();
+    *n_anchors = c->n_anchors;
+    return LEON_OK;
+}
+
+int leon_dna_get_stats(const leon_dna_ctx* c, leon_dna_stats* out) {
+    if (!c || !out) return LEON_E_INVALID;
+    *out = c->stats;
+    out->n_anchors = c->n_anchors;
+    return LEON_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ traces
+int leon_dna_trace_anchors(leon_dna_ctx* c, int32_t* pos, uint32_t* addr, uint8_t* flags, uint64_t n) {
+    if (!c) return LEON_E_INVALID;
+    if (n != c->last_n) return fail(c, LEON_E_INVALID, "trace size differs from the last batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (pos) HIPCHK(c, hipMemcpy(pos, c->anchor_pos.p, n * 4, hipMemcpyDeviceToHost));
+    if (addr) HIPCHK(c, hipMemcpy(addr, c->anchor_addr.p, n * 4, hipMemcpyDeviceToHost));
+    if (flags) HIPCHK(c, hipMemcpy(flags, c->flags.p, n, hipMemcpyDeviceToHost));
+    return LEON_OK;
+}
+int leon_dna_trace_events(leon_dna_ctx* c, uint8_t* events, uint64_t n_bases) {
+    if (!c || !events) return LEON_E_INVALID;
+    if (n_bases != c->last_bases) return fail(c, LEON_E_INVALID, "trace size differs from the last batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(events, c->events.p, n_bases, hipMemcpyDeviceToHost));
+    return LEON_OK;
+}
+int leon_dna_anchor_kmers(leon_dna_ctx* c, uint64_t* kmers, uint64_t n) {
+    if (!c || (!kmers && n)) return LEON_E_INVALID;
+    if (n > c->n_anchors) return fail(c, LEON_E_INVALID, "more anchors requested than exist");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n) HIPCHK(c, hipMemcpy(kmers, c->anchor_kmers.p, n * 8, hipMemcpyDeviceToHost));
+    return LEON_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ raw range coder
+int leon_rc_encode_streams(leon_dna_ctx* c, const uint8_t* syms, const uint64_t* begin, uint64_t n_streams,
+                           uint8_t* out, uint64_t out_cap, uint64_t* sizes) {
+    if (!c || !begin || !sizes || (!out && out_cap)) return LEON_E_INVALID;
+    if (!n_streams) return LEON_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    uint64_t n_syms = begin[n_streams] - begin[0];
+    if (begin[0] != 0) return fail(c, LEON_E_INVALID, "begin[0] must be 0");
+    for (uint64_t i = 0; i < n_syms; i++) {
+        uint32_t m = syms[2 * i], v = syms[2 * i + 1];
+        if (m >= N_MODELS || (m < N_SMALL_MODELS && v >= small_model_size(m))) return fail(c, LEON_E_INVALID, "bad symbol");
+    }
+    DevBuf dsyms, dbegin, doff, dsize, dout, dscr;
+    HIPCHK(c, dsyms.ensure(n_syms * 2 + 256)); HIPCHK(c, dbegin.ensure((n_streams + 1) * 8)); HIPCHK(c, doff.ensure((n_streams + 1) * 8));
+    HIPCHK(c, dsize.ensure(n_streams * 8)); HIPCHK(c, dscr.ensure(rc_model_scratch_bytes(n_streams)));
+    std::vector<uint64_t> off(n_streams + 1);
+    for (uint64_t b = 0; b <= n_streams; b++) off[b] = 3 * begin[b] + 64 * b;
+    HIPCHK(c, dout.ensure(off[n_streams] + 64));
+    if (n_syms) HIPCHK(c, hipMemcpy(dsyms.p, syms, n_syms * 2, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dbegin.p, begin, (n_streams + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(doff.p, off.data(), (n_streams + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
+    launch_rc_encode(s, dsyms.as<uint8_t>(), dbegin.as<uint64_t>(), n_streams, dout.as<uint8_t>(), doff.as<uint64_t>(),
+                     dsize.as<uint64_t>(), dscr.as<uint32_t>(), c->errflag.as<int>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    int errflag = 0;
+    HIPCHK(c, hipMemcpy(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(sizes, dsize.p, n_streams * 8, hipMemcpyDeviceToHost));
+    int rc = LEON_OK;
+    if (errflag) rc = fail(c, LEON_E_OVERFLOW, "range coder output exceeded its bound");
+    uint64_t w = 0;
+    for (uint64_t b = 0; b < n_streams && rc == LEON_OK; b++) {
+        if (w + sizes[b] > out_cap) { rc = fail(c, LEON_E_OVERFLOW, "out_cap too small"); break; }
+        hipError_t e = hipMemcpy(out + w, dout.as<uint8_t>() + off[b], sizes[b], hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(c, LEON_E_HIP, hipGetErrorString(e)); break; }
+        w += sizes[b];
+    }
+    dsyms.release(); dbegin.release(); doff.release(); dsize.release(); dout.release(); dscr.release();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,609 @@
+// dna_kernels.hip -- gfx950 kernels of Leon's DNA encode path, everything except the range coder.
+// Upstream functions named in comments are gatb-core names [RECALLED]; the source
+// is absent from /root/reference, so there is no file:line to cite.
+#include "kernels.h"
+
+namespace leon {
+
+static inline uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap = 256 * 32) {
+    uint64_t g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (uint32_t)g;
+}
+
+// ================================================================================================
+// bloom: BloomNeighborCoherent::insert / contains / contains4
+// ================================================================================================
+__global__ void __launch_bounds__(256) k_bloom_insert(BloomDev B, const uint16_t* rv16g, const uint64_t* kmers, uint64_t n) {
+    __shared__ uint16_t rv16[256];
+    load_rv16(rv16, rv16g);
+    uint32_t* words = (uint32_t*)B.bits;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t item = kmers[i];
+        uint32_t k = B.k;
+        uint32_t pv = cano2((uint32_t)(((item >> (2 * (k - 1))) & 3) << 2 | (item & 3)));
+        uint64_t hp = (item >> 2) & B.maskkm2;
+        BloomKeys K;
+        bloom_keys(B, rv16, hp, revcomp64(hp, k - 2), K);
+        for (uint32_t h = 0; h < B.n_hash; h++) {
+            uint64_t pos = K.racine + K.key[h] + pv;
+            atomicOr(&words[pos >> 5], 1u << (pos & 31));
+        }
+    }
+}
+void launch_bloom_insert(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* kmers, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_bloom_insert, dim3(grid_for(n, 256)), dim3(256), 0, s, B, rv16, kmers, n);
+}
+
+__global__ void __launch_bounds__(256) k_bloom_query(BloomDev B, const uint16_t* rv16g, const uint64_t* kmers, uint64_t n,
+                                                    int mode, uint8_t* out) {
+    __shared__ uint16_t rv16[256];
+    load_rv16(rv16, rv16g);
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t km = kmers[i];
+        if (mode == 0) out[i] = bloom_contains(B, rv16, km) ? 1 : 0;
+        else out[i] = (uint8_t)bloom_contains4(B, rv16, km, revcomp64(km, B.k), mode == 2);
+    }
+}
+void launch_bloom_query(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* kmers, uint64_t n, int mode, uint8_t* out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_bloom_query, dim3(grid_for(n, 256)), dim3(256), 0, s, B, rv16, kmers, n, mode, out);
+}
+
+// ================================================================================================
+// pack: ASCII -> 2-bit words + N mask  (DnaEncoder::buildKmers replaces N by 'A' and remembers _Npos)
+// ================================================================================================
+__global__ void k_read_slots(const uint64_t* off, uint64_t n, uint64_t* slots) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x)
+        slots[i] = i < n ? (off[i + 1] - off[i] + 31) / 32 : 0;
+}
+void launch_read_slots(hipStream_t s, const uint64_t* off, uint64_t n, uint64_t* slots) {
+    hipLaunchKernelGGL(k_read_slots, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, off, n, slots);
+}
+
+// one wave per read; lane l packs bases [16l, 16l+16) of each 1024-base stretch
+__global__ void __launch_bounds__(256) k_pack(const uint8_t* bases, const uint64_t* off, const uint64_t* slot_off, uint64_t n,
+                                             uint32_t* packed, uint32_t* nmask, uint32_t* len_out, uint32_t* ncount) {
+    uint32_t lane = lane_id();
+    uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n; r += nwaves) {
+        uint64_t o = off[r];
+        uint32_t len = (uint32_t)(off[r + 1] - o);
+        uint64_t so = slot_off[r];
+        uint32_t ndw = (uint32_t)(slot_off[r + 1] - so) * 2;
+        const uint8_t* src = bases + o;
+        uint32_t nn = 0;
+        for (uint32_t dw = lane; dw < ndw; dw += 64) {          // ndw is even: lanes come in (even, odd) pairs
+            uint32_t word = 0, nb = 0;
+            uint32_t j0 = dw * 16;
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) {
+                uint32_t pos = j0 + j;
+                uint32_t c = pos < len ? src[pos] : 'A';
+                bool valid = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+                uint32_t code = valid ? ((c >> 1) & 3u) : 0u;
+                word |= code << (30 - 2 * j);
+                nb |= (valid ? 0u : 1u) << j;
+            }
+            packed[so * 2 + dw] = word;
+            uint32_t other = __shfl_down(nb, 1);
+            if ((dw & 1) == 0) nmask[so + (dw >> 1)] = nb | (other << 16);
+            nn += __popc(nb);
+        }
+        for (int d = 32; d > 0; d >>= 1) nn += __shfl_xor(nn, d);
+        if (lane == 0) { len_out[r] = len; ncount[r] = nn; }
+    }
+}
+void launch_pack(hipStream_t s, const uint8_t* bases, const uint64_t* off, const uint64_t* slot_off, uint64_t n,
+                 uint32_t* packed, uint32_t* nmask, uint32_t* len, uint32_t* ncount) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_pack, dim3(grid_for(n, 4, 256 * 64)), dim3(256), 0, s, bases, off, slot_off, n, packed, nmask, len, ncount);
+}
+
+// ================================================================================================
+// anchor dictionary (Leon::anchorExist / findAndInsertAnchor with sequential, -nb-cores 1 semantics)
+// ================================================================================================
+__global__ void k_dict_init(DictDev D, uint64_t cap) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+        D.keys[i] = KEY_EMPTY; D.fin[i] = IDX_INF; D.tent[i] = IDX_INF; D.addr[i] = 0;
+    }
+}
+void launch_dict_init(hipStream_t s, DictDev D, uint64_t cap) {
+    hipLaunchKernelGGL(k_dict_init, dim3(grid_for(cap, 256)), dim3(256), 0, s, D, cap);
+}
+
+__device__ inline uint32_t dict_find(const DictDev& D, uint64_t key) {       // 0xFFFFFFFF if absent
+    uint64_t slot = mix64(key) & D.mask;
+    for (;;) {
+        uint64_t cur = D.keys[slot];
+        if (cur == key) return (uint32_t)slot;
+        if (cur == KEY_EMPTY) return 0xFFFFFFFFu;
+        slot = (slot + 1) & D.mask;
+    }
+}
+__device__ inline uint32_t dict_find_or_insert(const DictDev& D, uint64_t key) {
+    uint64_t slot = mix64(key) & D.mask;
+    for (;;) {
+        uint64_t cur = D.keys[slot];
+        if (cur == key) return (uint32_t)slot;
+        if (cur == KEY_EMPTY) {
+            uint64_t old = atomicCAS((unsigned long long*)&D.keys[slot], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+            if (old == KEY_EMPTY) { atomicAdd(D.n_keys, 1ull); return (uint32_t)slot; }
+            if (old == key) return (uint32_t)slot;
+        }
+        slot = (slot + 1) & D.mask;
+    }
+}
+__global__ void k_dict_rehash(DictDev from, uint64_t from_cap, DictDev to) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < from_cap; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t key = from.keys[i];
+        if (key == KEY_EMPTY) continue;
+        uint32_t s = dict_find_or_insert(to, key);
+        to.fin[s] = from.fin[i]; to.tent[s] = IDX_INF; to.addr[s] = from.addr[i];
+    }
+}
+void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to) {
+    hipLaunchKernelGGL(k_dict_rehash, dim3(grid_for(from_cap, 256)), dim3(256), 0, s, from, from_cap, to);
+}
+
+__device__ inline uint64_t canon_at(const uint32_t* pk, uint32_t p, uint32_t k, uint64_t* fwd = nullptr) {
+    uint64_t km = kmer_at(pk, p, k);
+    if (fwd) *fwd = km;
+    uint64_t rc = revcomp64(km, k);
+    return rc < km ? rc : km;
+}
+
+// first position in [lo, hi) (scan order) whose canonical k-mer is in the bloom; -1 if none. Wave-uniform result.
+__device__ inline int first_in_bloom(const BloomDev& B, const uint16_t* rv16, const uint32_t* pk, uint32_t k,
+                                     uint32_t lo, uint32_t hi, uint32_t lane) {
+    for (uint32_t base = lo; base < hi; base += 64) {
+        uint32_t p = base + lane;
+        bool valid = p < hi;
+        bool c = false;
+        if (valid) c = bloom_contains(B, rv16, canon_at(pk, p, k));
+        unsigned long long b = __ballot(c);
+        if (b) return (int)(base + __builtin_ctzll(b));
+    }
+    return -1;
+}
+
+// Pass A of a window: DnaEncoder::findExistingAnchor against the dictionary as it stood before the window,
+// else the candidate Leon::findAndInsertAnchor would insert.  One wave per read, one lane per k-mer.
+__global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, const uint16_t* rv16g, DictDev D, ResolveDev V,
+                                                    uint64_t w0, uint64_t w1, uint64_t first_global,
+                                                    uint32_t* ulist, uint32_t* ucount) {
+    __shared__ uint16_t rv16[256];
+    load_rv16(rv16, rv16g);
+    uint32_t lane = lane_id(), k = R.k;
+    uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = w0 + wave; i < w1; i += nwaves) {
+        uint32_t len = R.len[i];
+        uint64_t g = first_global + i;
+        if (len < k) { if (lane == 0) V.status[i] = ST_NOANCHOR; continue; }
+        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+        uint32_t nk = len - k + 1;
+        bool done = false;
+        for (uint32_t base = 0; base < nk; base += 64) {
+            uint32_t p = base + lane;
+            bool hit = false; uint32_t slot = 0xFFFFFFFFu;
+            if (p < nk) {
+                slot = dict_find(D, canon_at(pk, p, k));
+                hit = slot != 0xFFFFFFFFu && D.fin[slot] < g;
+            }
+            unsigned long long b = __ballot(hit);
+            if (b) {
+                uint32_t l = (uint32_t)__builtin_ctzll(b);
+                uint32_t hs = __shfl(slot, l);
+                if (lane == 0) { V.status[i] = ST_HIT; V.hit_pos[i] = base + l; V.hit_slot[i] = hs; }
+                done = true;
+                break;
+            }
+        }
+        if (done) continue;
+        // Leon::findAndInsertAnchor scan order: [n/2, n/2+10), [0, n/2), [n/2+10, n)
+        uint32_t iMin = nk / 2, iMax = nk / 2 + 10;
+        if (iMax > nk) iMax = nk;
+        int cp = first_in_bloom(B, rv16, pk, k, iMin, iMax, lane);
+        if (cp < 0) cp = first_in_bloom(B, rv16, pk, k, 0, iMin, lane);
+        if (cp < 0) cp = first_in_bloom(B, rv16, pk, k, iMax, nk, lane);
+        if (lane == 0) {
+            if (cp < 0) V.status[i] = ST_NOANCHOR;
+            else {
+                uint32_t slot = dict_find_or_insert(D, canon_at(pk, (uint32_t)cp, k));
+                atomicMin((unsigned long long*)&D.tent[slot], (unsigned long long)g);
+                V.status[i] = ST_UNRESOLVED; V.cand_pos[i] = (uint32_t)cp; V.cand_slot[i] = slot;
+                ulist[atomicAdd(ucount, 1u)] = (uint32_t)i;
+            }
+        }
+    }
+}
+void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
+                        uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount) {
+    if (w1 <= w0) return;
+    hipLaunchKernelGGL(k_lookup_cand, dim3(grid_for(w1 - w0, 4, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
+                       first_global, ulist, ucount);
+}
+
+// One resolution round over the unresolved reads: a read becomes a non-inserter as soon as one of its
+// k-mers is finally owned by an earlier read, an inserter when no earlier read even proposes one of them.
+__global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global,
+                                              const uint32_t* ulist, const uint32_t* ucount,
+                                              uint32_t* next_list, uint32_t* next_count) {
+    uint32_t lane = lane_id(), k = R.k;
+    uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t count = *ucount;
+    for (uint64_t e = wave; e < count; e += nwaves) {
+        uint32_t i = ulist[e];
+        uint64_t g = first_global + i;
+        uint32_t nk = R.len[i] - k + 1;
+        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+        bool anyfin = false, anyblock = false;
+        for (uint32_t base = 0; base < nk && !anyfin; base += 64) {
+            uint32_t p = base + lane;
+            bool f = false, t = false;
+            if (p < nk) {
+                uint32_t slot = dict_find(D, canon_at(pk, p, k));
+                if (slot != 0xFFFFFFFFu) {
+                    f = __hip_atomic_load(&D.fin[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g;
+                    t = D.tent[slot] < g;
+                }
+            }
+            anyfin = __ballot(f) != 0;
+            anyblock = anyblock || (__ballot(t) != 0);
+        }
+        if (lane == 0) {
+            if (anyfin) V.status[i] = ST_HITNEW;
+            else if (anyblock) next_list[atomicAdd(next_count, 1u)] = i;
+            else {
+                V.status[i] = ST_INSERTER;
+                __hip_atomic_store(&D.fin[V.cand_slot[i]], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+void launch_check(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* ulist,
+                  const uint32_t* ucount, uint32_t max_count, uint32_t* next_list, uint32_t* next_count) {
+    if (!max_count) return;
+    hipLaunchKernelGGL(k_check, dim3(grid_for(max_count, 4, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, ulist, ucount,
+                       next_list, next_count);
+}
+
+__global__ void k_reset_tent(DictDev D, ResolveDev V, const uint32_t* list, const uint32_t* count) {
+    uint32_t n = *count;
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x)
+        D.tent[V.cand_slot[list[e]]] = IDX_INF;
+}
+void launch_reset_tent(hipStream_t s, DictDev D, ResolveDev V, const uint32_t* list, const uint32_t* count, uint32_t max_count) {
+    if (!max_count) return;
+    hipLaunchKernelGGL(k_reset_tent, dim3(grid_for(max_count, 256)), dim3(256), 0, s, D, V, list, count);
+}
+__global__ void k_propose(DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, const uint32_t* count) {
+    uint32_t n = *count;
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t i = list[e];
+        atomicMin((unsigned long long*)&D.tent[V.cand_slot[i]], (unsigned long long)(first_global + i));
+    }
+}
+void launch_propose(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list,
+                    const uint32_t* count, uint32_t max_count) {
+    if (!max_count) return;
+    hipLaunchKernelGGL(k_propose, dim3(grid_for(max_count, 256)), dim3(256), 0, s, D, V, first_global, list, count);
+}
+
+// After the window's fixpoint: findExistingAnchor's answer = FIRST position whose k-mer an earlier read owns.
+__global__ void __launch_bounds__(256) k_final_pos(ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t first_global) {
+    uint32_t lane = lane_id(), k = R.k;
+    uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = w0 + wave; i < w1; i += nwaves) {
+        uint8_t st = V.status[i];
+        if (st != ST_HIT && st != ST_HITNEW) continue;
+        uint64_t g = first_global + i;
+        uint32_t limit = st == ST_HIT ? V.hit_pos[i] : R.len[i] - k + 1;
+        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+        for (uint32_t base = 0; base < limit; base += 64) {
+            uint32_t p = base + lane;
+            bool hit = false; uint32_t slot = 0xFFFFFFFFu;
+            if (p < limit) {
+                slot = dict_find(D, canon_at(pk, p, k));
+                hit = slot != 0xFFFFFFFFu && D.fin[slot] < g;
+            }
+            unsigned long long b = __ballot(hit);
+            if (b) {
+                uint32_t l = (uint32_t)__builtin_ctzll(b);
+                uint32_t hs = __shfl(slot, l);
+                if (lane == 0) { V.hit_pos[i] = base + l; V.hit_slot[i] = hs; }
+                break;
+            }
+        }
+    }
+}
+void launch_final_pos(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t first_global) {
+    if (w1 <= w0) return;
+    hipLaunchKernelGGL(k_final_pos, dim3(grid_for(w1 - w0, 4, 256 * 16)), dim3(256), 0, s, R, D, V, w0, w1, first_global);
+}
+
+__global__ void k_ins_flags(ResolveDev V, uint64_t w0, uint64_t w1) {
+    for (uint64_t i = w0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < w1; i += (uint64_t)gridDim.x * blockDim.x)
+        V.ins_flag[i - w0] = V.status[i] == ST_INSERTER ? 1u : 0u;
+}
+void launch_ins_flags(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1) {
+    if (w1 <= w0) return;
+    hipLaunchKernelGGL(k_ins_flags, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, V, w0, w1);
+}
+// addresses in insertion (= read) order: Leon::findAndInsertAnchor's `_anchorAdress++`
+__global__ void k_assign_addr(DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, const uint32_t* rank, uint64_t addr_base,
+                              uint64_t* anchor_kmers) {
+    for (uint64_t i = w0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < w1; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (V.status[i] != ST_INSERTER) continue;
+        uint64_t a = addr_base + rank[i - w0];
+        uint32_t slot = V.cand_slot[i];
+        D.addr[slot] = (uint32_t)a;
+        anchor_kmers[a] = D.keys[slot];
+        V.hit_pos[i] = V.cand_pos[i];
+        V.hit_slot[i] = slot;
+    }
+}
+void launch_assign_addr(hipStream_t s, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, const uint32_t* rank,
+                        uint64_t addr_base, uint64_t* anchor_kmers) {
+    if (w1 <= w0) return;
+    hipLaunchKernelGGL(k_assign_addr, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, D, V, w0, w1, rank, addr_base, anchor_kmers);
+}
+__global__ void k_finalize_reads(ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1) {
+    uint32_t k = R.k;
+    for (uint64_t i = w0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < w1; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint8_t st = V.status[i];
+        if (st == ST_NOANCHOR) {
+            V.anchor_pos[i] = -1; V.anchor_addr[i] = 0; V.flags[i] = 0; V.sort_key[i] = 1ull << 33;   // after every anchored read
+            continue;
+        }
+        uint32_t pos = V.hit_pos[i];
+        uint32_t addr = D.addr[V.hit_slot[i]];
+        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+        uint64_t km = kmer_at(pk, pos, k);
+        uint32_t rev = revcomp64(km, k) < km ? 1u : 0u;      // anchor != min(anchor, revcomp(anchor))
+        V.anchor_pos[i] = (int32_t)pos; V.anchor_addr[i] = addr;
+        V.flags[i] = (uint8_t)(rev | (st == ST_INSERTER ? 2u : 0u));
+        V.sort_key[i] = ((uint64_t)addr << 1) | rev;
+    }
+}
+void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1) {
+    if (w1 <= w0) return;
+    hipLaunchKernelGGL(k_finalize_reads, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, R, D, V, w0, w1);
+}
+
+// ================================================================================================
+// walk: DnaEncoder::encodeAnchorRead's two loops over buildBifurcationList.  One lane per read, reads taken
+// in anchor-sorted order so that neighbouring lanes probe the same bloom windows at the same step.
+// ================================================================================================
+__device__ inline void walk_step(const BloomDev& B, const uint16_t* rv16, uint32_t k, uint64_t& kmer, uint64_t& rc,
+                                 uint32_t nt, bool right, uint8_t* ev_pos) {
+    uint32_t res4 = bloom_contains4(B, rv16, kmer, rc, right);
+    uint32_t cnt = __popc(res4);
+    bool solid = (res4 >> nt) & 1u;
+    uint32_t first = res4 ? (uint32_t)__builtin_ctz(res4) : 0u;
+    uint32_t follow = nt;
+    if (solid) {
+        if (cnt == 2) *ev_pos = (uint8_t)(first == nt ? EV_BIN0 : EV_BIN1);
+        else if (cnt > 2) *ev_pos = (uint8_t)(EV_NT0 + nt);
+    } else {
+        if (cnt >= 1) { *ev_pos = (uint8_t)((EV_NT0 + nt) | EV_ERROR); follow = first; }
+        else *ev_pos = (uint8_t)(EV_NT0 + nt);
+    }
+    // AbstractDnaCoder::codeSeedBin, keeping the reverse complement alongside
+    if (right) {
+        kmer = ((kmer << 2) | follow) & B.kmer_mask;
+        rc = (rc >> 2) | ((uint64_t)(follow ^ 2u) << (2 * (k - 1)));
+    } else {
+        kmer = (kmer >> 2) | ((uint64_t)follow << (2 * (k - 1)));
+        rc = ((rc << 2) | (follow ^ 2u)) & B.kmer_mask;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
+                                             const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
+    __shared__ uint16_t rv16[256];
+    load_rv16(rv16, rv16g);
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n_walk) return;
+    uint32_t i = perm[t];
+    int32_t a = anchor_pos[i];
+    if (a < 0) return;
+    uint32_t k = R.k, len = R.len[i];
+    const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+    const uint32_t* nm = R.nmask + R.slot_off[i];
+    bool hasN = R.n_count[i] != 0;
+    uint8_t* ev = events + (R.base_off[i] - R.base_off[0]);
+    uint64_t anchor = kmer_at(pk, (uint32_t)a, k);
+    uint64_t anchor_rc = revcomp64(anchor, k);
+
+    uint64_t kmer = anchor, rc = anchor_rc;
+    for (int32_t pos = a - 1; pos >= 0; pos--) {
+        uint32_t nt = base_at(pk, (uint32_t)pos);
+        if (hasN && ((nm[pos >> 5] >> (pos & 31)) & 1u)) {      // N: coded as 'A', nothing stored
+            kmer = kmer >> 2; rc = ((rc << 2) | 2u) & B.kmer_mask;
+            continue;
+        }
+        walk_step(B, rv16, k, kmer, rc, nt, false, ev + pos);
+    }
+    kmer = anchor; rc = anchor_rc;
+    for (uint32_t pos = (uint32_t)a + k; pos < len; pos++) {
+        uint32_t nt = base_at(pk, pos);
+        if (hasN && ((nm[pos >> 5] >> (pos & 31)) & 1u)) {
+            kmer = (kmer << 2) & B.kmer_mask; rc = (rc >> 2) | (2ull << (2 * (k - 1)));
+            continue;
+        }
+        walk_step(B, rv16, k, kmer, rc, nt, true, ev + pos);
+    }
+}
+void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos,
+                 const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
+    if (!n_walk) return;
+    uint64_t g = (n_walk + 255) / 256;
+    hipLaunchKernelGGL(k_walk, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, perm, n_walk, events);
+}
+
+// ================================================================================================
+// symbols: the order in which encodeAnchorRead / encodeNoAnchorRead feed the range coder
+// ================================================================================================
+// prev[i] = index of the previous anchored read of the same block (-1 none): _prevReadSize/_prevAnchorPos/...
+__global__ void __launch_bounds__(256) k_prev_anchored(const int32_t* anchor_pos, uint64_t n, uint32_t rpb, int64_t* prev) {
+    __shared__ long long wmax[4];
+    __shared__ long long carry_s;
+    uint64_t b0 = (uint64_t)blockIdx.x * rpb;
+    uint64_t b1 = b0 + rpb < n ? b0 + rpb : n;
+    uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = -1;
+    __syncthreads();
+    for (uint64_t base = b0; base < b1; base += 256) {
+        uint64_t i = base + threadIdx.x;
+        long long v = (i < b1 && anchor_pos[i] >= 0) ? (long long)i : -1;
+        long long inc = v;                                   // inclusive max-scan inside the wave
+        for (int d = 1; d < 64; d <<= 1) {
+            long long o = __shfl_up(inc, d);
+            if ((int)lane >= d && o > inc) inc = o;
+        }
+        if (lane == 63) wmax[w] = inc;
+        __syncthreads();
+        long long pre = carry_s;
+        for (uint32_t j = 0; j < w; j++) if (wmax[j] > pre) pre = wmax[j];
+        long long exc = __shfl_up(inc, 1);
+        if (lane == 0) exc = -1;
+        if (pre > exc) exc = pre;
+        if (i < b1) prev[i] = exc;
+        __syncthreads();
+        if (threadIdx.x == 255) { long long m = inc > pre ? inc : pre; carry_s = m; }
+        __syncthreads();
+    }
+}
+void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, uint32_t rpb, int64_t* prev) {
+    if (!n) return;
+    uint64_t nb = (n + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_prev_anchored, dim3((uint32_t)nb), dim3(256), 0, s, anchor_pos, n, rpb, prev);
+}
+
+struct SymSink {
+    uint8_t* p;           // nullptr: count only
+    uint64_t n;
+    __device__ inline void put(uint32_t model, uint32_t sym) {
+        if (p) { p[2 * n] = (uint8_t)model; p[2 * n + 1] = (uint8_t)sym; }
+        n++;
+    }
+    // CompressionUtils::encodeNumeric
+    __device__ inline void numeric(uint32_t group, uint64_t v) {
+        uint32_t bc = 1;
+        while (bc < 8 && (v >> (8 * bc)) != 0) bc++;
+        put(numeric_model_id(group, 0), bc);
+        for (uint32_t b = 0; b < bc; b++) put(numeric_model_id(group, b + 1), (uint32_t)(v >> (8 * b)) & 0xff);
+    }
+    // CompressionUtils::getDeltaValue + the delta-type symbol
+    __device__ inline void delta(uint32_t type_model, uint32_t group, uint64_t value, uint64_t prev) {
+        uint32_t dt = 0; uint64_t dv = value;
+        if (value > prev) { uint64_t d = value - prev; if (d < value) { dt = 1; dv = d; } }
+        else              { uint64_t d = prev - value; if (d < value) { dt = 2; dv = d; } }
+        put(type_model, dt);
+        numeric(group, dv);
+    }
+};
+
+__global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr,
+                                                const uint8_t* flags, const int64_t* prev, const uint8_t* events,
+                                                uint64_t* sym_off, uint8_t* syms) {
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= R.n) return;
+    uint32_t len = R.len[i], k = R.k;
+    const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+    const uint32_t* nm = R.nmask + R.slot_off[i];
+    uint32_t nN = R.n_count[i];
+    SymSink S;
+    S.p = syms ? syms + 2 * sym_off[i] : nullptr;
+    S.n = 0;
+    int32_t a = anchor_pos[i];
+    if (a < 0) {                                              // DnaEncoder::encodeNoAnchorRead
+        S.put(M_READ_TYPE, 1);
+        S.numeric(G_NOANCHOR_READSIZE, len);
+        for (uint32_t p = 0; p < len; p++) {
+            bool isN = nN && ((nm[p >> 5] >> (p & 31)) & 1u);
+            S.put(M_NOANCHOR_READ, isN ? 4u : base_at(pk, p));
+        }
+    } else {                                                  // DnaEncoder::encodeAnchorRead
+        int64_t q = prev[i];
+        uint64_t pLen = 0, pPos = 0, pAddr = 0;
+        if (q >= 0) { pLen = R.len[q]; pPos = (uint64_t)anchor_pos[q]; pAddr = anchor_addr[q]; }
+        S.put(M_READ_TYPE, 0);
+        S.delta(M_READSIZE_DT, G_READSIZE, len, pLen);
+        S.delta(M_ANCHORPOS_DT, G_ANCHOR_POS, (uint64_t)a, pPos);
+        S.delta(M_ANCHORADDR_DT, G_ANCHOR_ADDRESS, anchor_addr[i], pAddr);
+        S.put(M_ANCHOR_REVCOMP, flags[i] & 1u);
+        const uint8_t* ev = events + (R.base_off[i] - R.base_off[0]);
+        S.numeric(G_NUMERIC, nN);                             // N positions, delta coded
+        if (nN) {
+            uint32_t prevN = 0;
+            for (uint32_t p = 0; p < len; p++)
+                if ((nm[p >> 5] >> (p & 31)) & 1u) { S.numeric(G_NPOS, p - prevN); prevN = p; }
+        }
+        uint32_t nErr = 0;                                    // error positions, ascending
+        for (uint32_t p = 0; p < len; p++) nErr += (ev[p] >> 3) & 1u;
+        S.numeric(G_LEFT_ERROR, nErr);
+        if (nErr) {
+            uint32_t prevE = 0;
+            for (uint32_t p = 0; p < len; p++)
+                if (ev[p] & EV_ERROR) { S.numeric(G_ERRPOS, p - prevE); prevE = p; }
+        }
+        for (int32_t p = a - 1; p >= 0; p--) {                // bifurcations: left walk, then right walk
+            uint32_t c = ev[p] & 7u;
+            if (c >= EV_NT0) S.put(M_BIFURCATION, c - EV_NT0); else if (c) S.put(M_BIFURCATION_BINARY, c - EV_BIN0);
+        }
+        for (uint32_t p = (uint32_t)a + k; p < len; p++) {
+            uint32_t c = ev[p] & 7u;
+            if (c >= EV_NT0) S.put(M_BIFURCATION, c - EV_NT0); else if (c) S.put(M_BIFURCATION_BINARY, c - EV_BIN0);
+        }
+    }
+    if (!syms) sym_off[i] = S.n;
+}
+void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr, const uint8_t* flags,
+                    const int64_t* prev, const uint8_t* events, uint64_t* sym_off, uint8_t* syms) {
+    if (!R.n) return;
+    uint64_t g = (R.n + 255) / 256;
+    hipLaunchKernelGGL(k_symbols, dim3((uint32_t)g), dim3(256), 0, s, R, anchor_pos, anchor_addr, flags, prev, events, sym_off, syms);
+}
+
+// per block: symbol range and output capacity offsets (3 bytes per symbol + 64)
+__global__ void k_block_ranges(const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
+                               uint64_t* blk_begin, uint64_t* out_off) {
+    for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b <= n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = b * rpb;
+        if (r > n_reads) r = n_reads;
+        uint64_t so = sym_off[r];                             // sym_off has n_reads+1 entries
+        blk_begin[b] = so;
+        out_off[b] = 3 * so + 64 * b;
+    }
+}
+void launch_block_ranges(hipStream_t s, const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
+                         uint64_t* blk_begin, uint64_t* out_off) {
+    hipLaunchKernelGGL(k_block_ranges, dim3(grid_for(n_blocks + 1, 256)), dim3(256), 0, s, sym_off, n_reads, rpb, n_blocks,
+                       blk_begin, out_off);
+}
+
+__global__ void k_gather_payload(const uint8_t* out, const uint64_t* out_off, const uint64_t* dst_off, const uint64_t* sizes,
+                                 uint64_t n_blocks, uint8_t* dst) {
+    for (uint64_t b = blockIdx.y; b < n_blocks; b += gridDim.y) {
+        const uint8_t* src = out + out_off[b];
+        uint8_t* d = dst + dst_off[b];
+        uint64_t n = sizes[b];
+        for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) d[i] = src[i];
+    }
+}
+void launch_gather_payload(hipStream_t s, const uint8_t* out, const uint64_t* out_off, const uint64_t* dst_off,
+                           const uint64_t* sizes, uint64_t n_blocks, uint8_t* dst) {
+    if (!n_blocks) return;
+    uint32_t gy = n_blocks > 65535 ? 65535u : (uint32_t)n_blocks;
+    hipLaunchKernelGGL(k_gather_payload, dim3(8, gy), dim3(256), 0, s, out, out_off, dst_off, sizes, n_blocks, dst);
+}
+
+}  // namespace leon

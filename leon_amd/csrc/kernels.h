@@ -1,0 +1,81 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (definitions in *.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "leon_device.h"
+
+namespace leon {
+
+// device view of one batch of reads
+struct ReadsDev {
+    const uint32_t* packed;     // 2 dwords per 32-base slot
+    const uint32_t* nmask;      // 1 dword per slot, bit j&31 of dword j>>5 set <=> base j is an N
+    const uint64_t* slot_off;   // first slot of each read (n+1 entries)
+    const uint64_t* base_off;   // caller's offsets (n+1 entries), base_off[0] may be non-zero
+    const uint32_t* len;
+    const uint32_t* n_count;    // number of N per read
+    uint64_t n;
+    uint32_t k, pad;
+};
+
+// anchor dictionary: open addressing, linear probing (replaces Leon::_anchorKmers, Hash16<kmer,u32>)
+struct DictDev {
+    uint64_t* keys;     // canonical k-mer or KEY_EMPTY
+    uint64_t* fin;      // global index of the read that inserted the key, IDX_INF while only proposed
+    uint64_t* tent;     // smallest global read index currently proposing the key (per resolution round)
+    uint32_t* addr;     // anchor address once assigned
+    uint64_t mask;      // capacity - 1
+    unsigned long long* n_keys;
+};
+
+enum : uint8_t { ST_NOANCHOR = 0, ST_HIT = 1, ST_UNRESOLVED = 2, ST_INSERTER = 3, ST_HITNEW = 4 };
+
+struct ResolveDev {
+    uint8_t* status;
+    uint32_t* hit_pos; uint32_t* hit_slot;
+    uint32_t* cand_pos; uint32_t* cand_slot;
+    int32_t* anchor_pos; uint32_t* anchor_addr; uint8_t* flags; uint64_t* sort_key;
+    uint32_t* ins_flag;          // per read of the current window
+};
+
+// ---- bloom ----
+void launch_bloom_insert(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* kmers, uint64_t n);
+void launch_bloom_query(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* kmers, uint64_t n,
+                        int mode /*0 contains, 1 contains4 left, 2 contains4 right*/, uint8_t* out);
+// ---- pack ----
+void launch_read_slots(hipStream_t s, const uint64_t* base_off, uint64_t n, uint64_t* slots);
+void launch_pack(hipStream_t s, const uint8_t* bases, const uint64_t* base_off, const uint64_t* slot_off, uint64_t n,
+                 uint32_t* packed, uint32_t* nmask, uint32_t* len, uint32_t* n_count);
+// ---- anchor resolution ----
+void launch_dict_init(hipStream_t s, DictDev D, uint64_t cap);
+void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to);
+void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
+                        uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount);
+void launch_check(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global,
+                  const uint32_t* ulist, const uint32_t* ucount, uint32_t max_count, uint32_t* next_list, uint32_t* next_count);
+void launch_reset_tent(hipStream_t s, DictDev D, ResolveDev V, const uint32_t* list, const uint32_t* count, uint32_t max_count);
+void launch_propose(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list,
+                    const uint32_t* count, uint32_t max_count);
+void launch_final_pos(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t first_global);
+void launch_ins_flags(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1);
+void launch_assign_addr(hipStream_t s, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, const uint32_t* rank,
+                        uint64_t addr_base, uint64_t* anchor_kmers);
+void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1);
+// ---- walk ----
+void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos,
+                 const uint32_t* perm, uint64_t n_walk, uint8_t* events);
+// ---- symbols ----
+void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, uint32_t rpb, int64_t* prev);
+void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr,
+                    const uint8_t* flags, const int64_t* prev, const uint8_t* events, uint64_t* sym_off /*count or offsets*/,
+                    uint8_t* syms /*nullptr = count pass*/);
+void launch_block_ranges(hipStream_t s, const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
+                         uint64_t* blk_begin /*n_blocks+1*/, uint64_t* out_off /*n_blocks+1*/);
+// ---- range coder ----
+void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
+                      uint8_t* out, const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err);
+size_t rc_model_scratch_bytes(uint64_t n_blocks);
+void launch_gather_payload(hipStream_t s, const uint8_t* out, const uint64_t* out_off, const uint64_t* dst_off,
+                           const uint64_t* sizes, uint64_t n_blocks, uint8_t* dst);
+
+}  // namespace leon

@@ -1,0 +1,163 @@
+// leon_device.h -- device-side building blocks shared by the gfx950 kernels of the DNA encode path.
+// k-mer model (gatb kmer/impl/Model.hpp [RECALLED]): 2-bit code A0 C1 T2 G3, first base in the highest
+// bits, one 64-bit word (k <= 31).  Bloom geometry: BloomNeighborCoherent (Bloom.hpp [RECALLED]).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace leon {
+
+// ---- model ids of the symbol stream (AbstractDnaCoder's Order0Model members [RECALLED]) ----
+enum : uint32_t {
+    M_READ_TYPE = 0, M_NOANCHOR_READ = 1, M_BIFURCATION = 2, M_BIFURCATION_BINARY = 3,
+    M_READSIZE_DT = 4, M_ANCHORPOS_DT = 5, M_ANCHORADDR_DT = 6, M_ANCHOR_REVCOMP = 7,
+    N_SMALL_MODELS = 8,
+    // numeric groups (CompressionUtils::encodeNumeric: byte-count model + one model per byte index)
+    G_ANCHOR_ADDRESS = 0, G_ANCHOR_POS = 1, G_NOANCHOR_READSIZE = 2, G_READSIZE = 3,
+    G_NPOS = 4, G_ERRPOS = 5, G_NUMERIC = 6, G_LEFT_ERROR = 7,
+    N_NUM_GROUPS = 8, MODELS_PER_NUMERIC = 9,
+    N_MODELS = N_SMALL_MODELS + N_NUM_GROUPS * MODELS_PER_NUMERIC   // 80
+};
+__host__ __device__ inline uint32_t small_model_size(uint32_t m) {
+    // readType 2, noAnchorRead 5, bifurcation 5, binary 2, three delta-type models 3, revcomp 2
+    return (0x23332552u >> (4 * m)) & 15u;
+}
+__host__ __device__ inline uint32_t numeric_model_id(uint32_t group, uint32_t idx) {
+    return N_SMALL_MODELS + group * MODELS_PER_NUMERIC + idx;
+}
+
+// event byte written by the walk per read position
+enum : uint8_t { EV_BIN0 = 1, EV_BIN1 = 2, EV_NT0 = 3, EV_ERROR = 8 };
+
+constexpr uint64_t KEY_EMPTY = ~0ull;
+constexpr uint64_t IDX_INF = ~0ull;
+
+struct BloomDev {
+    const uint8_t* bits;
+    uint64_t reduced_tai, mod_magic, seed0, maskkm2, kmer_mask;
+    uint32_t k, n_hash, block_mask, pad;
+};
+
+// ---- 64-bit helpers ----
+__device__ inline uint64_t revcomp64(uint64_t x, uint32_t k) {
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x);
+    x ^= 0xAAAAAAAAAAAAAAAAULL;
+    return x >> (64 - 2 * k);
+}
+// NativeInt64::hash64 [RECALLED]
+__device__ inline uint64_t hash64(uint64_t key, uint64_t seed) {
+    uint64_t hash = seed;
+    hash ^= (hash << 7) ^ key * (hash >> 3) ^ (~((hash << 11) + (key ^ (hash >> 5))));
+    hash = (~hash) + (hash << 21);
+    hash = hash ^ (hash >> 24);
+    hash = (hash + (hash << 3)) + (hash << 8);
+    hash = hash ^ (hash >> 14);
+    hash = (hash + (hash << 2)) + (hash << 4);
+    hash = hash ^ (hash >> 28);
+    hash = hash + (hash << 31);
+    return hash;
+}
+// n mod d with magic = floor((2^64-1)/d): one mulhi, one multiply, one conditional subtract
+__device__ inline uint64_t fastmod(uint64_t n, uint64_t d, uint64_t magic) {
+    uint64_t q = __umul64hi(n, magic);
+    uint64_t r = n - q * d;
+    if (r >= d) r -= d;
+    if (r >= d) r -= d;
+    return r;
+}
+__device__ inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+// cano2[16] of BloomNeighborCoherent as 16 nibbles
+__device__ inline uint32_t cano2(uint32_t v) { return (uint32_t)(0x51D9409873543210ULL >> (4 * v)) & 15u; }
+
+// ---- packed reads: 16 bases per dword, base j of a read at bits 30-2*(j&15) of dword j>>4 ----
+__device__ inline uint32_t base_at(const uint32_t* pk, uint32_t pos) {
+    return (pk[pos >> 4] >> (30 - 2 * (pos & 15))) & 3u;
+}
+// k-mer starting at base p (needs dwords p>>4 .. (p>>4)+2 readable: reads are padded to 32-base slots + 1 slot)
+__device__ inline uint64_t kmer_at(const uint32_t* pk, uint32_t p, uint32_t k) {
+    uint32_t d = p >> 4, s = 2 * (p & 15);
+    uint64_t hi = ((uint64_t)pk[d] << 32) | pk[d + 1];
+    uint64_t lo = pk[d + 2];
+    uint64_t x = s ? ((hi << s) | (lo >> (32 - s))) : hi;
+    return x >> (64 - 2 * k);
+}
+
+// ---- BloomNeighborCoherent geometry ----
+// racine and the per-hash offsets depend only on the canonical middle (k-2)-mer
+struct BloomKeys { uint64_t racine; uint32_t key[10]; };
+
+__device__ inline void bloom_keys(const BloomDev& B, const uint16_t* rv16, uint64_t hp_fwd, uint64_t hp_rc, BloomKeys& K) {
+    uint64_t hp = hp_rc < hp_fwd ? hp_rc : hp_fwd;
+    K.racine = fastmod(hash64(hp, B.seed0), B.reduced_tai, B.mod_magic);
+    K.key[0] = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < 10; i++) {
+        if (i < B.n_hash) {
+            uint32_t in = (uint32_t)(hp >> i);
+            K.key[i] = (uint32_t)(rv16[in & 255] ^ rv16[(in >> 8) & 255]) & B.block_mask;
+        }
+    }
+}
+// 64 bits of the bloom starting at bit `bitpos` (array is padded by 16 bytes)
+__device__ inline uint64_t bloom_window(const BloomDev& B, uint64_t bitpos) {
+    const uint32_t* w = (const uint32_t*)B.bits + (bitpos >> 5);
+    uint64_t v = ((uint64_t)w[1] << 32) | w[0];
+    return v >> (bitpos & 31);
+}
+// contains4: pv4 packs the four canonical prefix+suffix values (4 bits each, neighbour nt in nibble nt)
+__device__ inline uint32_t bloom_probe4(const BloomDev& B, const BloomKeys& K, uint32_t pv4) {
+    uint32_t alive = 15u;
+#pragma unroll
+    for (uint32_t i = 0; i < 10; i++) {
+        if (i < B.n_hash) {
+            uint32_t w = (uint32_t)bloom_window(B, K.racine + K.key[i]);
+            uint32_t m = ((w >> (pv4 & 15)) & 1u) | (((w >> ((pv4 >> 4) & 15)) & 1u) << 1) |
+                         (((w >> ((pv4 >> 8) & 15)) & 1u) << 2) | (((w >> ((pv4 >> 12) & 15)) & 1u) << 3);
+            alive &= m;
+        }
+    }
+    return alive;
+}
+// BloomNeighborCoherent::contains(item)
+__device__ inline bool bloom_contains(const BloomDev& B, const uint16_t* rv16, uint64_t item) {
+    uint32_t k = B.k;
+    uint32_t pv = cano2((uint32_t)(((item >> (2 * (k - 1))) & 3) << 2 | (item & 3)));
+    uint64_t hp = (item >> 2) & B.maskkm2;
+    BloomKeys K;
+    bloom_keys(B, rv16, hp, revcomp64(hp, k - 2), K);
+    bool ok = true;
+    for (uint32_t i = 0; i < B.n_hash && ok; i++) ok = (bloom_window(B, K.racine + K.key[i] + pv) & 1ull) != 0;
+    return ok;
+}
+// BloomNeighborCoherent::contains4(item, right) from a k-mer and its reverse complement
+__device__ inline uint32_t bloom_contains4(const BloomDev& B, const uint16_t* rv16, uint64_t kmer, uint64_t rc, bool right) {
+    uint32_t k = B.k;
+    uint64_t hpf, hpr; uint32_t pv4;
+    if (right) {          // elem = kmer[1..k-1] + X : middle = kmer[2..k-1], prefix = kmer[1], suffix varies
+        hpf = kmer & B.maskkm2; hpr = rc >> 4;
+        uint32_t p = (uint32_t)(kmer >> (2 * (k - 2))) & 3u;
+        pv4 = cano2(p << 2) | (cano2((p << 2) | 1) << 4) | (cano2((p << 2) | 2) << 8) | (cano2((p << 2) | 3) << 12);
+    } else {              // elem = X + kmer[0..k-2] : middle = kmer[0..k-3], prefix varies, suffix = kmer[k-2]
+        hpf = kmer >> 4; hpr = rc & B.maskkm2;
+        uint32_t s = (uint32_t)(kmer >> 2) & 3u;
+        pv4 = cano2(s) | (cano2(4 | s) << 4) | (cano2(8 | s) << 8) | (cano2(12 | s) << 12);
+    }
+    BloomKeys K;
+    bloom_keys(B, rv16, hpf, hpr, K);
+    return bloom_probe4(B, K, pv4);
+}
+
+// stage the low 16 bits of the 256-entry simplehash16 table in LDS
+__device__ inline void load_rv16(uint16_t* lds, const uint16_t* g) {
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) lds[i] = g[i];
+    __syncthreads();
+}
+
+__device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
+
+}  // namespace leon

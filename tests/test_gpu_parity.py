@@ -1,0 +1,200 @@
+"""-m gpu: the HIP path, called through the C-ABI, against the CPU oracle on the same seeded inputs.
+Bit-exact everywhere (integer / byte work)."""
+import numpy as np
+import pytest
+
+import common
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(k, rpb, tai, **kw):
+    import leon_amd
+    return leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=rpb, bloom_tai=tai, keep_trace=True, **kw)
+
+
+def _kmers_of(bases, off, k, limit=20000):
+    code = np.zeros(256, dtype=np.uint64)
+    for c, v in zip(b"ACTG", range(4)):
+        code[c] = v
+    arr = np.frombuffer(bases, dtype=np.uint8)
+    out = []
+    for r in range(len(off) - 1):
+        s, e = int(off[r]), int(off[r + 1])
+        if e - s < k:
+            continue
+        km = 0
+        mask = (1 << (2 * k)) - 1
+        for i in range(s, e):
+            km = ((km << 2) | int(code[arr[i]])) & mask
+            if i - s + 1 >= k:
+                out.append(km)
+        if len(out) >= limit:
+            break
+    return np.array(out[:limit], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("k", [31, 21, 9])
+def test_bloom_build_and_probe(k):
+    bases, off = common.synthetic(3000, 120, 30000, seed=5)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ctx = _ctx(k, 1000, tai)
+    assert ctx.bloom_nbytes == len(bl.bits)
+    ctx.bloom_insert(solid)
+    assert np.array_equal(ctx.bloom_download(), bl.bits)          # insert kernel == oracle insert, bit for bit
+    q = _kmers_of(bases, off, k)
+    rng = np.random.default_rng(0)
+    q = np.concatenate([q, rng.integers(0, 1 << (2 * k), size=5000, dtype=np.uint64)])
+    exp_c = np.array([bl.contains(x) for x in q], dtype=np.uint8)
+    exp_l = np.array([bl.contains4(x, 0) for x in q], dtype=np.uint8)
+    exp_r = np.array([bl.contains4(x, 1) for x in q], dtype=np.uint8)
+    assert np.array_equal(ctx.bloom_contains(q), exp_c)
+    assert np.array_equal(ctx.bloom_contains4(q, 0), exp_l)
+    assert np.array_equal(ctx.bloom_contains4(q, 1), exp_r)
+    ctx.close()
+
+
+def _random_symbol_streams(rng, n_streams, max_len):
+    sizes = [2, 5, 5, 2, 3, 3, 3, 2] + [256] * 72
+    syms, begin = [], [0]
+    for s in range(n_streams):
+        n = int(rng.integers(0, max_len))
+        # a realistic mix: mostly small models and the low numeric models, some rare high ones
+        m = rng.choice(80, size=n, p=_model_probs())
+        v = np.array([rng.integers(0, sizes[x]) if rng.random() < 0.3 else min(sizes[x] - 1, int(rng.geometric(0.3)) - 1)
+                      for x in m], dtype=np.uint8)
+        syms.append(np.stack([m.astype(np.uint8), v], axis=1).reshape(-1))
+        begin.append(begin[-1] + n)
+    return (np.concatenate(syms) if syms else np.zeros(0, np.uint8)), np.array(begin, dtype=np.uint64), sizes
+
+
+def _model_probs():
+    p = np.full(80, 0.002)
+    p[:8] = 0.05
+    for g in range(8):
+        p[8 + 9 * g] = 0.03
+        p[8 + 9 * g + 1] = 0.03
+    return p / p.sum()
+
+
+def test_range_coder_streams():
+    rng = np.random.default_rng(7)
+    syms, begin, sizes = _random_symbol_streams(rng, 12, 6000)
+    ctx = _ctx(31, 1000, 1000)
+    got = ctx.rc_encode_streams(syms, begin)
+    for i in range(len(begin) - 1):
+        a, b = int(begin[i]), int(begin[i + 1])
+        exp = O.rc_encode_stream(syms[2 * a:2 * b:2], syms[2 * a + 1:2 * b:2], sizes)
+        assert got[i] == exp, "stream %d differs" % i
+    ctx.close()
+
+
+def _full_compare(bases, off, k, rpb, window=0, batches=1, bloom=None):
+    bl, solid, tai = bloom if bloom is not None else common.make_bloom(bases, off, k)
+    ref = O.encode(bases, off, k, rpb, bl)
+    ctx = _ctx(k, rpb, tai, resolve_window=window)
+    ctx.bloom_upload(bl.bits)
+    n = len(off) - 1
+    blocks = []
+    # split into `batches` calls on block boundaries
+    nb = (n + rpb - 1) // rpb
+    per = max(1, nb // batches) * rpb
+    r0 = 0
+    pos_all, addr_all, flags_all, ev_all = [], [], [], []
+    while r0 < n:
+        r1 = min(n, r0 + per)
+        blocks += ctx.encode_batch(bases, off[r0:r1 + 1])
+        p, a, f = ctx.trace_anchors(r1 - r0)
+        pos_all.append(p); addr_all.append(a); flags_all.append(f)
+        ev_all.append(ctx.trace_events(int(off[r1] - off[r0])))
+        r0 = r1
+    dict_payload, n_anchors = ctx.finish()
+    pos, addr, flags, ev = (np.concatenate(x) for x in (pos_all, addr_all, flags_all, ev_all))
+    # stage-wise: anchors, then events, then bytes
+    assert np.array_equal(pos, ref.anchor_pos), "anchor positions differ"
+    anchored = ref.anchor_pos >= 0
+    assert np.array_equal(addr[anchored], ref.anchor_addr[anchored]), "anchor addresses differ"
+    assert np.array_equal(flags[anchored], ref.flags[anchored]), "revcomp/inserted flags differ"
+    assert n_anchors == ref.n_anchors
+    assert np.array_equal(ctx.anchor_kmers(n_anchors), ref.anchor_kmers)
+    assert np.array_equal(ev, ref.events), "walk events differ"
+    assert [b[0] for b in blocks] == list(range(len(ref.blocks)))
+    assert [b[2] for b in blocks] == ref.block_nreads
+    for i, (b, r) in enumerate(zip(blocks, ref.blocks)):
+        assert b[1] == r, "block %d payload differs" % i
+    assert dict_payload == ref.anchor_dict
+    st = ctx.stats()
+    ctx.close()
+    return ref, st
+
+
+def test_toy_fasta_bit_exact():
+    bases, off = common.toy_reads()
+    _full_compare(bases, off, 31, 50)
+
+
+def test_toy_fasta_default_block_size():
+    bases, off = common.toy_reads()
+    _full_compare(bases, off, 31, 50000)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_rate=0.003), dict(ragged=True, n_rate=0.001), dict(err=0.05)])
+def test_synthetic_bit_exact(kw):
+    bases, off = common.synthetic(6000, 150, 20000, seed=11, **kw)
+    _full_compare(bases, off, 31, 1000)
+
+
+def test_small_windows_and_batches():
+    # tiny resolution windows force many fixpoint rounds and cross-window dictionary reuse
+    bases, off = common.synthetic(5000, 100, 8000, seed=3)
+    _full_compare(bases, off, 31, 500, window=64)
+    _full_compare(bases, off, 31, 500, window=1000, batches=3)
+
+
+def test_other_kmer_sizes_and_lengths():
+    bases, off = common.synthetic(3000, 250, 15000, seed=9, n_rate=0.001)
+    _full_compare(bases, off, 21, 700)
+    bases, off = common.synthetic(2000, 40, 3000, seed=10)
+    _full_compare(bases, off, 15, 300)
+
+
+def test_edge_cases():
+    k = 31
+    bases, off = common.synthetic(2000, 150, 10000, seed=21)
+    bl = common.make_bloom(bases, off, k)
+    # reads shorter than k, exactly k, all-N, garbage reads with no solid k-mer, empty read
+    extra = [b"ACGT", b"A" * 31, b"N" * 50, b"ACGTTGCA" * 20, b"", b"ACGTNNNNACGT" * 10]
+    arr = np.frombuffer(bases, dtype=np.uint8)
+    reads = [arr[int(off[i]):int(off[i + 1])].tobytes() for i in range(300)]
+    mixed = []
+    for i, r in enumerate(reads):
+        mixed.append(r)
+        if i % 50 == 0:
+            mixed.append(extra[(i // 50) % len(extra)])
+    b2, off2 = O.reads_to_arrays(mixed)
+    _full_compare(b2, off2, k, 100, bloom=bl)
+    # a single read, and an empty bloom (nothing anchors)
+    b3, off3 = O.reads_to_arrays([reads[0]])
+    _full_compare(b3, off3, k, 100, bloom=bl)
+    empty = O.Bloom(1000, k)
+    _full_compare(b2, off2, k, 100, bloom=(empty, None, 1000))
+
+
+def test_roundtrip_through_oracle_decoder():
+    k, rpb = 31, 1000
+    bases, off = common.synthetic(4000, 150, 20000, seed=31, n_rate=0.002)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ctx = _ctx(k, rpb, tai)
+    ctx.bloom_insert(solid)
+    blocks = ctx.encode_batch(bases, off)
+    dict_payload, n_anchors = ctx.finish()
+    anchors = O.decode_anchor_dict(dict_payload, n_anchors, k)
+    r = 0
+    for _, payload, nr in blocks:
+        dec = O.decode_block(k, bl, anchors, payload, nr, 10 ** 7)
+        for j, d in enumerate(dec):
+            assert d == bases[int(off[r + j]):int(off[r + j + 1])]
+        r += nr
+    assert r == len(off) - 1
+    ctx.close()
