@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- compressed-input MB/s of the DNA encode path on synthetic 150 bp reads (BASELINE.json metric).
+
+One "step" = one pass of the hot path (pack -> anchor resolution -> walk -> symbols -> range coder -> blocks
+handed to the sink, plus leon_dna_finish) over the whole synthetic read set, inputs resident in HBM.
+N > 1: one process per GPU (torch.distributed / RCCL); rank 0 builds the bloom and broadcasts it over xGMI,
+every rank encodes its contiguous range of read blocks.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K = 31
+L = 150
+N_HASH = 7
+BITS_PER_KMER = 12
+RPB = 50000
+CHUNK = 1_000_000           # reads generated per torch call; also the unit of the rank partition
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("LEON_BENCH_READS", 100_000_000)),
+                    help="total reads of the job (BASELINE.json metric: 100M x 150 bp)")
+    ap.add_argument("--genome", type=int, default=0, help="genome length; default reads*150/30 (30x coverage)")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("LEON_BENCH_CPU_SAMPLE", 1_000_000)),
+                    help="reads timed through the CPU restatement on rank 0 at N=1 (0 = skip)")
+    ap.add_argument("--err", type=float, default=0.01)
+    return ap.parse_args()
+
+
+def gen_genome(G, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(42)
+    return torch.randint(0, 4, (G,), dtype=torch.uint8, device=device, generator=g)   # gatb codes A0 C1 T2 G3
+
+
+def gen_reads_chunk(genome, chunk_id, n, err, device):
+    """reads of chunk `chunk_id` (same bytes whatever the world size): uint8 [n, L] ASCII"""
+    g = torch.Generator(device=device)
+    g.manual_seed(43 + chunk_id)
+    G = genome.numel()
+    starts = torch.randint(0, G - L + 1, (n,), device=device, generator=g)
+    idx = starts[:, None] + torch.arange(L, device=device)[None, :]
+    codes = genome[idx]
+    rev = torch.rand(n, device=device, generator=g) < 0.5
+    codes = torch.where(rev[:, None], codes.flip(1) ^ 2, codes)                     # reverse complement
+    if err > 0:
+        m = torch.rand(n, L, device=device, generator=g) < err
+        sub = (codes + torch.randint(1, 4, (n, L), dtype=torch.uint8, device=device, generator=g)) & 3
+        codes = torch.where(m, sub, codes)
+    lut = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=device)          # A C T G
+    return lut[codes.long()]
+
+
+def insert_genome_kmers(ctx, genome, k):
+    """bloom <- every canonical k-mer of the genome (stand-in for DSK's solid set at 30x, abundance >= 3)"""
+    G = genome.numel()
+    step = 32_000_000
+    for s in range(0, G - k + 1, step):
+        n = min(step, G - k + 1 - s)
+        c = genome[s:s + n + k - 1].to(torch.int64)
+        fwd = torch.zeros(n, dtype=torch.int64, device=genome.device)
+        rc = torch.zeros(n, dtype=torch.int64, device=genome.device)
+        for j in range(k):
+            fwd = (fwd << 2) | c[j:j + n]
+            rc |= (c[j:j + n] ^ 2) << (2 * j)
+        canon = torch.minimum(fwd, rc).contiguous()
+        torch.cuda.synchronize()
+        ctx.bloom_insert_device(canon.data_ptr(), n)
+        del c, fwd, rc, canon
+
+
+def walk_bytes_per_read(k):
+    """algorithmic bytes of ONE read in the walk kernel: the 2-bit read in, and for each of the
+    L-k extension steps the n_hash 64-byte sectors of the bloom that hold the probed bits (4 successors share them)."""
+    return (L + 3) // 4 + (L - k) * N_HASH * 64
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (WORLD_SIZE=%d expected)" % a.gpus)
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import leon_amd
+    from leon_amd import capi
+    from leon_amd.shard import block_range
+
+    n_total = (a.reads // RPB) * RPB or RPB
+    G = a.genome or max(n_total * L // 30, 10 * L)
+    n_blocks = n_total // RPB
+    b0, b1 = block_range(rank, world, n_blocks)
+    r0, r1 = b0 * RPB, b1 * RPB
+    n_local = r1 - r0
+
+    genome = gen_genome(G, device)
+    tai = (G - K + 1) * BITS_PER_KMER
+    ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local)
+    nbytes = ctx.bloom_nbytes
+    t_b = time.time()
+    if world == 1:
+        insert_genome_kmers(ctx, genome, K)
+        bcast_ms = 0.0
+    else:                                   # rank 0 builds, RCCL broadcast over xGMI, device to device
+        bits = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if rank == 0:
+            insert_genome_kmers(ctx, genome, K)
+            ctx.bloom_download_device(bits.data_ptr(), nbytes)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.time()
+        dist.broadcast(bits, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.time() - t0) * 1e3
+        if rank != 0:
+            ctx.bloom_upload_device(bits.data_ptr(), nbytes)
+        del bits
+    bloom_s = time.time() - t_b
+
+    # this rank's reads, generated chunk by chunk so the data set does not depend on the world size
+    reads = torch.empty((n_local, L), dtype=torch.uint8, device=device)
+    for c0 in range(r0 // CHUNK, (r1 + CHUNK - 1) // CHUNK):
+        lo, hi = max(r0, c0 * CHUNK), min(r1, (c0 + 1) * CHUNK)
+        chunk = gen_reads_chunk(genome, c0, CHUNK, a.err, device)
+        reads[lo - r0:hi - r0] = chunk[lo - c0 * CHUNK:hi - c0 * CHUNK]
+        del chunk
+    offsets = (torch.arange(n_local + 1, dtype=torch.int64, device=device) * L).contiguous()
+    del genome
+    torch.cuda.synchronize()
+
+    payload = [0, 0]
+
+    def sink(user, block_id, p, size, n_reads):
+        payload[0] += size
+        payload[1] += 1
+        return 0
+    cb = capi.SINK(sink)
+
+    def step():
+        ctx.reset_stream()
+        payload[0] = payload[1] = 0
+        ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_local, sink=cb)
+        d, na = ctx.finish()
+        return len(d), na
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    times, walk_ms, stage = [], [], None
+    for _ in range(a.steps):
+        sync()
+        t0 = time.perf_counter()
+        dict_bytes, n_anchors = step()
+        sync()
+        times.append(time.perf_counter() - t0)
+        st = ctx.stats()
+        walk_ms.append(st["ms_walk"])
+        stage = st
+    total_s = torch.tensor([sum(times)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(total_s, op=dist.ReduceOp.MAX)
+    total_s = float(total_s.item())
+    ms_per_step = total_s / a.steps * 1e3
+    value = n_total * L / 1e6 / (total_s / a.steps)
+
+    # dominant kernel: k_walk, HIP events recorded on the library's launch stream around each launch
+    walk_avg_ms = float(np.mean(walk_ms))
+    alg_bytes = n_local * walk_bytes_per_read(K)
+    achieved = alg_bytes / (walk_avg_ms * 1e-3) / 1e9
+    roofline = {"kernel": "k_walk", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(walk_avg_ms, 3)}
+
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_sample > 0:
+        cpu = cpu_baseline(ctx, reads, min(a.cpu_sample, n_local))
+
+    if rank == 0:
+        out = {
+            "metric": "compressed input MB/s (DNA encode path)", "value": round(value, 1), "unit": "MB/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%d x %d bp synthetic reads, k=%d, genome %d bp (30x), 1%% substitutions, "
+                                   "bloom %d bits/k-mer x %d hashes built from the genome's k-mers"
+                                   % (n_total, L, K, G, BITS_PER_KMER, N_HASH),
+                       "reads": n_total, "read_len": L, "kmer_size": K, "reads_per_block": RPB,
+                       "sharding": "contiguous block ranges, bloom broadcast over RCCL, one anchor dictionary per rank"
+                                   if world > 1 else "single GPU",
+                       "bloom_bytes": nbytes, "bloom_bcast_ms": round(bcast_ms, 2), "bloom_build_s": round(bloom_s, 2)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
+            "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
+                      "symbols": stage["n_symbols"], "resolve_rounds": stage["resolve_rounds"],
+                      "bits_per_base": round(8.0 * (payload[0] + dict_bytes) / (n_local * L), 4)},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, reads, n):
+    """the CPU restatement (oracle, kind=port, one thread) timed on the first n reads of the same workload"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    bases = reads[:n].contiguous().cpu().numpy().tobytes()
+    off = (np.arange(n + 1, dtype=np.uint64) * L)
+    bl = O.Bloom(ctx.bloom_tai, K, N_HASH, 12)
+    bl.set_bits(ctx.bloom_download())
+    t0 = time.perf_counter()
+    O.encode(bases, off, K, RPB, bl, trace=False)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * L / 1e6 / dt, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the workload (%.1f s), oracle/leon_oracle.c single thread; "
+                      "reference Leon itself cannot be built here (gatb-core absent)" % (n, dt)}
+
+
+if __name__ == "__main__":
+    main()

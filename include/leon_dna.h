@@ -81,6 +81,9 @@ int leon_dna_bloom_clear(leon_dna_ctx* ctx);
 int leon_dna_bloom_insert(leon_dna_ctx* ctx, const uint64_t* kmers, uint64_t n);      /* host k-mers, IBloom::insert */
 int leon_dna_bloom_insert_device(leon_dna_ctx* ctx, const uint64_t* d_kmers, uint64_t n);
 int leon_dna_bloom_device_ptr(leon_dna_ctx* ctx, void** d_bits, uint64_t* nbytes);    /* for an RCCL broadcast */
+/* device-to-device forms of upload/download: the bloom travels between GPUs over xGMI, never via the host */
+int leon_dna_bloom_upload_device(leon_dna_ctx* ctx, const uint8_t* d_bits, uint64_t nbytes);
+int leon_dna_bloom_download_device(leon_dna_ctx* ctx, uint8_t* d_bits, uint64_t nbytes);
 /* BloomNeighborCoherent::contains4 / contains over a list of k-mers (host in, host out) */
 int leon_dna_bloom_contains4(leon_dna_ctx* ctx, const uint64_t* kmers, uint64_t n, int right, uint8_t* out);
 int leon_dna_bloom_contains(leon_dna_ctx* ctx, const uint64_t* kmers, uint64_t n, uint8_t* out);
@@ -98,6 +101,10 @@ int leon_dna_encode_batch_device(leon_dna_ctx* ctx, const uint8_t* d_bases, cons
 /* Leon::endDnaCompression: flush the anchor-dictionary range coder (Leon::encodeInsertedAnchor stream).
  * payload stays owned by ctx until destroy. */
 int leon_dna_finish(leon_dna_ctx* ctx, const uint8_t** dict_payload, uint64_t* dict_size, uint64_t* n_anchors);
+
+/* Start a new output file on the same context: forgets the anchor dictionary, the dictionary stream and the
+ * read/block counters (a fresh Leon object upstream); keeps the bloom and the device buffers. */
+int leon_dna_reset_stream(leon_dna_ctx* ctx);
 
 int leon_dna_get_stats(const leon_dna_ctx* ctx, leon_dna_stats* out);
 

@@ -6,5 +6,6 @@ tests and bench.py; it has no CPU path and raises if the library is missing.
 """
 from .capi import LeonDnaError, DnaEncodeContext, lib_path, load_library  # noqa: F401
 from .build import build_library  # noqa: F401
+from .shard import block_range, merge_block_tables  # noqa: F401
 
 __all__ = ["LeonDnaError", "DnaEncodeContext", "lib_path", "load_library", "build_library"]

@@ -53,12 +53,15 @@ _EXPORTS = {
     "leon_dna_bloom_insert": (C.c_int, [C.c_void_p, _u64p, C.c_uint64]),
     "leon_dna_bloom_insert_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "leon_dna_bloom_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _u64p]),
+    "leon_dna_bloom_upload_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "leon_dna_bloom_download_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "leon_dna_bloom_contains4": (C.c_int, [C.c_void_p, _u64p, C.c_uint64, C.c_int, _u8p]),
     "leon_dna_bloom_contains": (C.c_int, [C.c_void_p, _u64p, C.c_uint64, _u8p]),
     "leon_dna_encode_batch": (C.c_int, [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, C.c_uint64, SINK, C.c_void_p]),
     "leon_dna_encode_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, SINK,
                                                 C.c_void_p]),
     "leon_dna_finish": (C.c_int, [C.c_void_p, C.POINTER(_u8p), _u64p, _u64p]),
+    "leon_dna_reset_stream": (C.c_int, [C.c_void_p]),
     "leon_dna_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "leon_dna_trace_anchors": (C.c_int, [C.c_void_p, _i32p, _u32p, _u8p, C.c_uint64]),
     "leon_dna_trace_events": (C.c_int, [C.c_void_p, _u8p, C.c_uint64]),
@@ -113,6 +116,7 @@ class DnaEncodeContext:
             raise LeonDnaError(rc, (self.lib.leon_last_error(None) or b"").decode())
         self.h = h
         self.kmer_size, self.reads_per_block = kmer_size, reads_per_block
+        self.bloom_tai, self.bloom_n_hash, self.bloom_block_nbits = int(bloom_tai), bloom_n_hash, bloom_block_nbits
         self.next_read = 0
 
     def _chk(self, rc):
@@ -157,6 +161,12 @@ class DnaEncodeContext:
         self._chk(self.lib.leon_dna_bloom_device_ptr(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def bloom_upload_device(self, dev_ptr, n):
+        self._chk(self.lib.leon_dna_bloom_upload_device(self.h, C.c_void_p(int(dev_ptr)), int(n)))
+
+    def bloom_download_device(self, dev_ptr, n):
+        self._chk(self.lib.leon_dna_bloom_download_device(self.h, C.c_void_p(int(dev_ptr)), int(n)))
+
     def bloom_contains4(self, kmers, right):
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
         out = np.zeros(len(kmers), dtype=np.uint8)
@@ -200,6 +210,10 @@ class DnaEncodeContext:
         p, sz, na = _u8p(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.leon_dna_finish(self.h, C.byref(p), C.byref(sz), C.byref(na)))
         return C.string_at(p, sz.value), na.value
+
+    def reset_stream(self):
+        self._chk(self.lib.leon_dna_reset_stream(self.h))
+        self.next_read = 0
 
     def stats(self):
         s = Stats()

@@ -299,6 +299,22 @@ int leon_dna_bloom_device_ptr(leon_dna_ctx* c, void** p, uint64_t* n) {
     *p = c->d_bloom; *n = c->bloom_nchar;
     return LEON_OK;
 }
+int leon_dna_bloom_upload_device(leon_dna_ctx* c, const uint8_t* d_bits, uint64_t n) {
+    if (!c || !d_bits) return LEON_E_INVALID;
+    if (n != c->bloom_nchar) return fail(c, LEON_E_INVALID, "bloom_upload_device: size differs from leon_dna_bloom_nbytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_bloom, d_bits, n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LEON_OK;
+}
+int leon_dna_bloom_download_device(leon_dna_ctx* c, uint8_t* d_bits, uint64_t n) {
+    if (!c || !d_bits) return LEON_E_INVALID;
+    if (n != c->bloom_nchar) return fail(c, LEON_E_INVALID, "bloom_download_device: size differs from leon_dna_bloom_nbytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(d_bits, c->d_bloom, n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LEON_OK;
+}
 static int bloom_query(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, int mode, uint8_t* out) {
     if (!c || ((!kmers || !out) && n)) return LEON_E_INVALID;
     if (!n) return LEON_OK;
@@ -570,6 +586,25 @@ int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, ui
     *payload = c->anchor_rc.bytes().data();
     *size = c->anchor_rc.bytes().size();
     *n_anchors = c->n_anchors;
+    return LEON_OK;
+}
+
+int leon_dna_reset_stream(leon_dna_ctx* c) {
+    if (!c) return LEON_E_INVALID;
+    if (c->anchor_thread.joinable()) c->anchor_thread.join();
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->dict_cap) {
+        HIPCHK(c, hipMemsetAsync(c->d_nkeys, 0, 8, c->stream));
+        launch_dict_init(c->stream, c->D, c->dict_cap);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->n_keys = 0; c->n_anchors = 0; c->anchors_encoded = 0;
+    c->h_anchor_kmers.clear();
+    c->anchor_model.clear();
+    c->anchor_rc.clear();
+    c->next_read = 0; c->next_block = 0; c->partial_seen = false; c->finished = false;
+    c->last_n = 0; c->last_bases = 0;
     return LEON_OK;
 }
 

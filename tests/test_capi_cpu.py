@@ -1,0 +1,63 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/leon_dna.h declares,
+and fails loudly without a GPU (no CPU fallback).  No compute is run here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "leon_dna.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(leon_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(n for n in names if n != "leon_block_sink"))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import leon_amd
+    if not os.path.exists(leon_amd.lib_path()):
+        leon_amd.build_library()
+    return leon_amd.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from leon_amd import capi
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    raw = ctypes.CDLL(capi.lib_path())
+    for name in declared:
+        assert hasattr(raw, name), "libleon_dna.so does not export " + name
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared, "the Python binding and the header disagree"
+    assert lib.leon_dna_abi_version() == 1
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    import leon_amd
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(leon_amd.LeonDnaError) as e:
+        leon_amd.DnaEncodeContext(kmer_size=31, bloom_tai=1000)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_config_validation_messages(lib):
+    import leon_amd
+    for kw in (dict(kmer_size=63), dict(kmer_size=2), dict(reads_per_block=0), dict(bloom_n_hash=0)):
+        with pytest.raises(leon_amd.LeonDnaError) as e:
+            leon_amd.DnaEncodeContext(bloom_tai=1000, **kw)
+        assert e.value.code == -1
+
+
+def test_product_does_not_touch_the_oracle():
+    # the product tree must not import, link or call anything under oracle/
+    for d, _, files in os.walk(os.path.join(ROOT, "leon_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "leon_oracle" not in txt and "oracle_lib" not in txt, os.path.join(d, f)
+    assert "oracle" not in open(os.path.join(ROOT, "include", "leon_dna.h")).read().lower()

@@ -198,3 +198,28 @@ def test_roundtrip_through_oracle_decoder():
         r += nr
     assert r == len(off) - 1
     ctx.close()
+
+
+def test_hip_path_matches_committed_golden_fixtures():
+    """the HIP path against tests/golden/self_golden.json (sha256 of every block), without the oracle encoder"""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(common.GOLDEN, "self_golden.json")))
+    for case in gold["cases"]:
+        if case["name"].startswith("toy"):
+            bases, off = common.toy_reads()
+        elif case["name"].startswith("synthetic 3000"):
+            bases, off = common.synthetic(3000, 150, 12000, seed=101, n_rate=0.002)
+        else:
+            bases, off = common.synthetic(2000, 100, 6000, seed=102, ragged=True)
+        solid = O.count_solid(bases, off, case["k"], case["min_abundance"])
+        ctx = _ctx(case["k"], case["reads_per_block"], case["bloom_tai"])
+        ctx.bloom_insert(solid)
+        assert hashlib.sha256(ctx.bloom_download().tobytes()).hexdigest() == case["bloom_sha256"]
+        blocks = ctx.encode_batch(bases, off)
+        d, na = ctx.finish()
+        assert [hashlib.sha256(b[1]).hexdigest() for b in blocks] == case["block_sha256"]
+        assert hashlib.sha256(d).hexdigest() == case["anchor_dict_sha256"] and na == case["n_anchors"]
+        assert ctx.stats()["n_symbols"] == case["n_symbols"]
+        ctx.close()
