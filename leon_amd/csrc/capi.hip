@@ -504,7 +504,7 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     HIPCHK(c, hipEventRecord(c->ev[6], s));
 
     // ---- range coder ----
-    const uint64_t rc_cap = 3 * n_syms + 64 * (n_blocks + 1);
+    const uint64_t rc_cap = 3 * n_syms + 72 * (n_blocks + 1);
     HIPCHK(c, c->rc_out.ensure(rc_cap));
     HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(n_blocks)));
     HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
@@ -519,7 +519,8 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, n_blocks * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (errflag) return fail(c, LEON_E_OVERFLOW, "range coder output exceeded its 3 bytes/symbol bound");
+    if (errflag) return fail(c, LEON_E_OVERFLOW, errflag == 2 ? "a read block has 2^30 symbols or more"
+                                                              : "range coder output exceeded its 3 bytes/symbol bound");
     for (uint64_t b = 0; b < n_blocks; b++) dst[b + 1] = dst[b] + sizes[b];
     const uint64_t payload_bytes = dst[n_blocks];
     HIPCHK(c, c->payload.ensure(payload_bytes + 16));
@@ -657,7 +658,7 @@ int leon_rc_encode_streams(leon_dna_ctx* c, const uint8_t* syms, const uint64_t*
     HIPCHK(c, dsyms.ensure(n_syms * 2 + 256)); HIPCHK(c, dbegin.ensure((n_streams + 1) * 8)); HIPCHK(c, doff.ensure((n_streams + 1) * 8));
     HIPCHK(c, dsize.ensure(n_streams * 8)); HIPCHK(c, dscr.ensure(rc_model_scratch_bytes(n_streams)));
     std::vector<uint64_t> off(n_streams + 1);
-    for (uint64_t b = 0; b <= n_streams; b++) off[b] = 3 * begin[b] + 64 * b;
+    for (uint64_t b = 0; b <= n_streams; b++) off[b] = ((3 * begin[b] + 7) & ~7ull) + 64 * b;
     HIPCHK(c, dout.ensure(off[n_streams] + 64));
     if (n_syms) HIPCHK(c, hipMemcpy(dsyms.p, syms, n_syms * 2, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dbegin.p, begin, (n_streams + 1) * 8, hipMemcpyHostToDevice));

@@ -573,7 +573,7 @@ void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const 
     hipLaunchKernelGGL(k_symbols, dim3((uint32_t)g), dim3(256), 0, s, R, anchor_pos, anchor_addr, flags, prev, events, sym_off, syms);
 }
 
-// per block: symbol range and output capacity offsets (3 bytes per symbol + 64)
+// per block: symbol range and output capacity offsets (3 bytes per symbol + 64 or more)
 __global__ void k_block_ranges(const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
                                uint64_t* blk_begin, uint64_t* out_off) {
     for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b <= n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
@@ -581,7 +581,7 @@ __global__ void k_block_ranges(const uint64_t* sym_off, uint64_t n_reads, uint32
         if (r > n_reads) r = n_reads;
         uint64_t so = sym_off[r];                             // sym_off has n_reads+1 entries
         blk_begin[b] = so;
-        out_off[b] = 3 * so + 64 * b;
+        out_off[b] = ((3 * so + 7) & ~7ull) + 64 * b;    // 8-byte aligned: the coder stores 8 bytes at a time
     }
 }
 void launch_block_ranges(hipStream_t s, const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
