@@ -65,6 +65,7 @@ typedef struct leon_dna_stats {
     /* HIP-event milliseconds of the last batch, measured on the library's own stream */
     float ms_pack, ms_resolve, ms_sort, ms_walk, ms_symbols, ms_rangecoder, ms_d2h, ms_total;
     uint32_t walk_launches, reserved;
+    float ms_anchor_wait, reserved2;   /* host ms leon_dna_finish waited for the dictionary-stream thread */
 } leon_dna_stats;
 
 /* -- lifecycle (DnaEncoder ctor / dtor bracket one thread's work upstream) -- */
@@ -101,6 +102,11 @@ int leon_dna_encode_batch_device(leon_dna_ctx* ctx, const uint8_t* d_bases, cons
 /* Leon::endDnaCompression: flush the anchor-dictionary range coder (Leon::encodeInsertedAnchor stream).
  * payload stays owned by ctx until destroy. */
 int leon_dna_finish(leon_dna_ctx* ctx, const uint8_t** dict_payload, uint64_t* dict_size, uint64_t* n_anchors);
+
+/* Host-only helper (no GPU, no ctx): the dictionary stream leon_dna_finish returns for a given anchor list, i.e.
+ * Leon::encodeInsertedAnchor over `kmers` in address order followed by the flush.  Used by the CPU tests. */
+int leon_host_anchor_dict_encode(const uint64_t* kmers, uint64_t n_anchors, uint32_t kmer_size, uint8_t* out,
+                                 uint64_t out_cap, uint64_t* size);
 
 /* Start a new output file on the same context: forgets the anchor dictionary, the dictionary stream and the
  * read/block counters (a fresh Leon object upstream); keeps the bloom and the device buffers. */

@@ -31,10 +31,11 @@ class Stats(C.Structure):
                                            "payload_bytes", "resolve_rounds", "resolve_windows")] + \
                [(n, C.c_float) for n in ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder",
                                          "ms_d2h", "ms_total")] + \
-               [("walk_launches", C.c_uint32), ("reserved", C.c_uint32)]
+               [("walk_launches", C.c_uint32), ("reserved", C.c_uint32), ("ms_anchor_wait", C.c_float),
+                ("reserved2", C.c_float)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
 
 
 SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32)
@@ -62,6 +63,7 @@ _EXPORTS = {
                                                 C.c_void_p]),
     "leon_dna_finish": (C.c_int, [C.c_void_p, C.POINTER(_u8p), _u64p, _u64p]),
     "leon_dna_reset_stream": (C.c_int, [C.c_void_p]),
+    "leon_host_anchor_dict_encode": (C.c_int, [_u64p, C.c_uint64, C.c_uint32, _u8p, C.c_uint64, _u64p]),
     "leon_dna_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "leon_dna_trace_anchors": (C.c_int, [C.c_void_p, _i32p, _u32p, _u8p, C.c_uint64]),
     "leon_dna_trace_events": (C.c_int, [C.c_void_p, _u8p, C.c_uint64]),
@@ -91,6 +93,19 @@ def load_library():
 
 def _ptr(a, t):
     return a.ctypes.data_as(t)
+
+
+def host_anchor_dict_encode(kmers, k):
+    """the dictionary stream for a list of anchors (host-only entry point; runs without a GPU)"""
+    lib = load_library()
+    kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+    cap = len(kmers) * k + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    size = C.c_uint64()
+    rc = lib.leon_host_anchor_dict_encode(_ptr(kmers, _u64p), len(kmers), k, _ptr(out, _u8p), cap, C.byref(size))
+    if rc:
+        raise LeonDnaError(rc, "leon_host_anchor_dict_encode failed")
+    return out[:size.value].tobytes()
 
 
 class DnaEncodeContext:

@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -68,11 +69,8 @@ struct leon_dna_ctx {
     unsigned long long* d_nkeys = nullptr;
     uint64_t n_anchors = 0;
     DevBuf anchor_kmers;
-    std::vector<uint64_t> h_anchor_kmers;        // all anchors so far, address order
-    uint64_t anchors_encoded = 0;
-    HostOrder0Model anchor_model{5};
-    HostRangeEncoder anchor_rc;
-    std::thread anchor_thread;
+    AnchorDictWorker* anchor_worker = nullptr;   // host thread coding the dictionary stream, fed per window
+    double anchor_wait_ms = 0;
     // stream state
     uint64_t next_read = 0, next_block = 0;
     bool partial_seen = false, finished = false;
@@ -135,15 +133,6 @@ int dict_reserve(leon_dna_ctx* c, uint64_t keys) {
     c->D = nd;
     c->dict_cap = need;
     return LEON_OK;
-}
-
-void encode_anchors_host(leon_dna_ctx* c, uint64_t upto) {
-    uint32_t k = c->cfg.kmer_size;
-    for (uint64_t a = c->anchors_encoded; a < upto; a++) {
-        uint64_t km = c->h_anchor_kmers[a];
-        for (uint32_t i = 0; i < k; i++) c->anchor_rc.encode(c->anchor_model, (uint32_t)(km >> (2 * (k - 1 - i))) & 3u);
-    }
-    c->anchors_encoded = upto;
 }
 
 ReadsDev reads_view(leon_dna_ctx* c, const uint64_t* d_off, uint64_t n) {
@@ -219,14 +208,14 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     CREATE_CHK(c->errflag.ensure(16));
     CREATE_CHK(hipStreamSynchronize(c->stream));
 #undef CREATE_CHK
-    c->anchor_rc.clear();
+    c->anchor_worker = new AnchorDictWorker(cfg->kmer_size);
     *out = c;
     return LEON_OK;
 }
 
 void leon_dna_ctx_destroy(leon_dna_ctx* c) {
     if (!c) return;
-    if (c->anchor_thread.joinable()) c->anchor_thread.join();
+    delete c->anchor_worker;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dict_free(c->D);
@@ -351,7 +340,6 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     if (n % rpb) c->partial_seen = true;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    if (c->anchor_thread.joinable()) c->anchor_thread.join();
     c->stats = leon_dna_stats{};
 
     // ---- sizes ----
@@ -402,7 +390,6 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     size_t scan_tmp = 0;
     HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), W, s));
     if (int rc = ensure_cub(c, scan_tmp)) return rc;
-    const uint64_t anchors_before = c->n_anchors;
     for (uint64_t w0 = 0; w0 < n; w0 += W) {
         uint64_t w1 = std::min(n, w0 + W);
         if (int rc = dict_reserve(c, c->n_keys + (w1 - w0))) return rc;
@@ -446,6 +433,12 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
                 c->anchor_kmers = nb;
             }
             launch_assign_addr(s, c->D, V, w0, w1, c->rank.as<uint32_t>(), c->n_anchors, c->anchor_kmers.as<uint64_t>());
+            if (n_new) {       // the window's new anchors go straight to the host thread coding the dictionary stream
+                std::vector<uint64_t> fresh(n_new);
+                HIPCHK(c, hipMemcpyAsync(fresh.data(), c->anchor_kmers.as<uint64_t>() + c->n_anchors, n_new * 8, hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+                c->anchor_worker->push(std::move(fresh));
+            }
             c->n_anchors += n_new;
         }
         launch_finalize_reads(s, R, c->D, V, w0, w1);
@@ -453,16 +446,6 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    // new anchors go to the host thread that range-codes the dictionary stream, overlapped with the walk
-    if (c->n_anchors > anchors_before) {
-        HIPCHK(c, hipStreamSynchronize(s));
-        c->h_anchor_kmers.resize(c->n_anchors);
-        HIPCHK(c, hipMemcpy(c->h_anchor_kmers.data() + anchors_before, c->anchor_kmers.as<uint64_t>() + anchors_before,
-                            (c->n_anchors - anchors_before) * 8, hipMemcpyDeviceToHost));
-        uint64_t upto = c->n_anchors;
-        c->anchor_thread = std::thread([c, upto] { encode_anchors_host(c, upto); });
-    }
-
     // ---- sort reads by (anchor address, strand) ----
     HIPCHK(c, c->sort_key2.ensure(n * 8)); HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(n * 4));
     hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
@@ -578,21 +561,22 @@ int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t*
 
 int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, uint64_t* n_anchors) {
     if (!c || !payload || !size || !n_anchors) return LEON_E_INVALID;
-    if (c->anchor_thread.joinable()) c->anchor_thread.join();
+    auto t0 = std::chrono::steady_clock::now();
+    c->anchor_worker->drain();
+    c->anchor_wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!c->finished) {
-        encode_anchors_host(c, c->n_anchors);
-        c->anchor_rc.flush();
+        c->anchor_worker->coder().flush();
         c->finished = true;
     }
-    *payload = c->anchor_rc.bytes().data();
-    *size = c->anchor_rc.bytes().size();
+    *payload = c->anchor_worker->coder().data();
+    *size = c->anchor_worker->coder().size();
     *n_anchors = c->n_anchors;
     return LEON_OK;
 }
 
 int leon_dna_reset_stream(leon_dna_ctx* c) {
     if (!c) return LEON_E_INVALID;
-    if (c->anchor_thread.joinable()) c->anchor_thread.join();
+    c->anchor_worker->reset();
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->dict_cap) {
@@ -600,10 +584,7 @@ int leon_dna_reset_stream(leon_dna_ctx* c) {
         launch_dict_init(c->stream, c->D, c->dict_cap);
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    c->n_keys = 0; c->n_anchors = 0; c->anchors_encoded = 0;
-    c->h_anchor_kmers.clear();
-    c->anchor_model.clear();
-    c->anchor_rc.clear();
+    c->n_keys = 0; c->n_anchors = 0;
     c->next_read = 0; c->next_block = 0; c->partial_seen = false; c->finished = false;
     c->last_n = 0; c->last_bases = 0;
     return LEON_OK;
@@ -613,6 +594,7 @@ int leon_dna_get_stats(const leon_dna_ctx* c, leon_dna_stats* out) {
     if (!c || !out) return LEON_E_INVALID;
     *out = c->stats;
     out->n_anchors = c->n_anchors;
+    out->ms_anchor_wait = (float)c->anchor_wait_ms;
     return LEON_OK;
 }
 
@@ -638,6 +620,18 @@ int leon_dna_anchor_kmers(leon_dna_ctx* c, uint64_t* kmers, uint64_t n) {
     if (n > c->n_anchors) return fail(c, LEON_E_INVALID, "more anchors requested than exist");
     HIPCHK(c, hipSetDevice(c->device));
     if (n) HIPCHK(c, hipMemcpy(kmers, c->anchor_kmers.p, n * 8, hipMemcpyDeviceToHost));
+    return LEON_OK;
+}
+
+// host-only: the dictionary stream of a list of anchors (what the worker thread produces); no GPU involved
+int leon_host_anchor_dict_encode(const uint64_t* kmers, uint64_t n, uint32_t k, uint8_t* out, uint64_t out_cap, uint64_t* size) {
+    if ((!kmers && n) || !size || k < 1 || k > 31) return LEON_E_INVALID;
+    AnchorDictCoder coder;
+    for (uint64_t i = 0; i < n; i++) coder.encode_kmer(kmers[i], k);
+    coder.flush();
+    *size = coder.size();
+    if (coder.size() > out_cap) return LEON_E_OVERFLOW;
+    if (out) memcpy(out, coder.data(), coder.size());
     return LEON_OK;
 }
 

@@ -61,3 +61,19 @@ def test_product_does_not_touch_the_oracle():
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "leon_oracle" not in txt and "oracle_lib" not in txt, os.path.join(d, f)
     assert "oracle" not in open(os.path.join(ROOT, "include", "leon_dna.h")).read().lower()
+
+
+def test_host_anchor_dict_stream_matches_oracle(lib):
+    """leon_dna_finish's dictionary stream is coded on a host thread (one serial chain per file); its coder runs
+    without a GPU and must equal the oracle's range coder over the anchors' bases on _anchorDictModel(5)."""
+    import numpy as np
+    import oracle_lib as O
+    from leon_amd import capi
+    rng = np.random.default_rng(3)
+    sizes = [2, 5, 5, 2, 3, 3, 3, 2] + [256] * 72
+    for k, n in [(31, 0), (31, 1), (31, 700), (21, 3000), (5, 10)]:
+        kmers = rng.integers(0, 1 << (2 * k), size=n, dtype=np.uint64)
+        syms = np.array([(int(x) >> (2 * (k - 1 - i))) & 3 for x in kmers for i in range(k)], dtype=np.uint8)
+        exp = O.rc_encode_stream(np.ones(len(syms), dtype=np.uint8), syms, sizes)   # model 1: alphabet 5
+        assert capi.host_anchor_dict_encode(kmers, k) == exp
+        assert O.decode_anchor_dict(exp, n, k).tolist() == kmers.tolist()
