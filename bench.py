@@ -85,9 +85,11 @@ def insert_genome_kmers(ctx, genome, k):
 
 
 def walk_bytes_per_read(k):
-    """algorithmic bytes of ONE read in the walk kernel: the 2-bit read in, and for each of the
-    L-k extension steps the n_hash 64-byte sectors of the bloom that hold the probed bits (4 successors share them)."""
-    return (L + 3) // 4 + (L - k) * N_HASH * 64
+    """algorithmic bytes of ONE read in the dominant kernel k_walk, SURVEY.md section 8(d)'s per-unit terms for it:
+    the 2-bit read in, ONE 64-byte bloom line per extension step (L-k steps), the per-position event bytes out.
+    (DESIGN.md 'Roofline accounting': the restated bloom spreads a step's 7 probes over a 514-byte window, so
+    without reuse between reads a step could cost up to 7 sectors; the PMC traffic is reported next to it.)"""
+    return (L + 3) // 4 + (L - k) * 64 + (L + 3) // 4
 
 
 def main():
@@ -194,8 +196,9 @@ def main():
     walk_avg_ms = float(np.mean(walk_ms))
     alg_bytes = n_local * walk_bytes_per_read(K)
     achieved = alg_bytes / (walk_avg_ms * 1e-3) / 1e9
+    traffic = os.environ.get("LEON_WALK_TRAFFIC_BYTES")       # PMC-measured HBM bytes per launch (profiles/)
     roofline = {"kernel": "k_walk", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(traffic) if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(walk_avg_ms, 3)}
 
     cpu = None

@@ -78,15 +78,21 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t* bases, const uint64
         uint32_t nn = 0;
         for (uint32_t dw = lane; dw < ndw; dw += 64) {          // ndw is even: lanes come in (even, odd) pairs
             uint32_t word = 0, nb = 0;
-            uint32_t j0 = dw * 16;
+            const uint32_t j0 = dw * 16;
 #pragma unroll
-            for (uint32_t j = 0; j < 16; j++) {
-                uint32_t pos = j0 + j;
-                uint32_t c = pos < len ? src[pos] : 'A';
-                bool valid = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
-                uint32_t code = valid ? ((c >> 1) & 3u) : 0u;
-                word |= code << (30 - 2 * j);
-                nb |= (valid ? 0u : 1u) << j;
+            for (uint32_t q4 = 0; q4 < 4; q4++) {               // four (unaligned) dword loads of 4 bases each
+                uint32_t four = 0x41414141u;                    // "AAAA" past the end of the read
+                const uint32_t p0 = j0 + 4 * q4;
+                if (p0 + 4 <= len) __builtin_memcpy(&four, src + p0, 4);
+                else if (p0 < len) { for (uint32_t j = 0; p0 + j < len; j++) four = (four & ~(0xFFu << (8 * j))) | ((uint32_t)src[p0 + j] << (8 * j)); }
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t c = (four >> (8 * j)) & 0xFFu;
+                    const bool valid = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+                    const uint32_t code = valid ? ((c >> 1) & 3u) : 0u;
+                    word |= code << (30 - 2 * (4 * q4 + j));
+                    nb |= (valid ? 0u : 1u) << (4 * q4 + j);
+                }
             }
             packed[so * 2 + dw] = word;
             uint32_t other = __shfl_down(nb, 1);
@@ -422,21 +428,31 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
     uint64_t anchor = kmer_at(pk, (uint32_t)a, k);
     uint64_t anchor_rc = revcomp64(anchor, k);
 
+    // the read's 2-bit word (16 bases) and N-mask word (32 bases) stay in registers between reloads
+    uint32_t pw = 0, pw_idx = 0xFFFFFFFFu, nw = 0, nw_idx = 0xFFFFFFFFu;
     uint64_t kmer = anchor, rc = anchor_rc;
     for (int32_t pos = a - 1; pos >= 0; pos--) {
-        uint32_t nt = base_at(pk, (uint32_t)pos);
-        if (hasN && ((nm[pos >> 5] >> (pos & 31)) & 1u)) {      // N: coded as 'A', nothing stored
-            kmer = kmer >> 2; rc = ((rc << 2) | 2u) & B.kmer_mask;
-            continue;
+        if (((uint32_t)pos >> 4) != pw_idx) { pw_idx = (uint32_t)pos >> 4; pw = pk[pw_idx]; }
+        uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
+        if (hasN) {
+            if (((uint32_t)pos >> 5) != nw_idx) { nw_idx = (uint32_t)pos >> 5; nw = nm[nw_idx]; }
+            if ((nw >> (pos & 31)) & 1u) {                        // N: coded as 'A', nothing stored
+                kmer = kmer >> 2; rc = ((rc << 2) | 2u) & B.kmer_mask;
+                continue;
+            }
         }
         walk_step(B, rv16, k, kmer, rc, nt, false, ev + pos);
     }
     kmer = anchor; rc = anchor_rc;
     for (uint32_t pos = (uint32_t)a + k; pos < len; pos++) {
-        uint32_t nt = base_at(pk, pos);
-        if (hasN && ((nm[pos >> 5] >> (pos & 31)) & 1u)) {
-            kmer = (kmer << 2) & B.kmer_mask; rc = (rc >> 2) | (2ull << (2 * (k - 1)));
-            continue;
+        if ((pos >> 4) != pw_idx) { pw_idx = pos >> 4; pw = pk[pw_idx]; }
+        uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
+        if (hasN) {
+            if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
+            if ((nw >> (pos & 31)) & 1u) {
+                kmer = (kmer << 2) & B.kmer_mask; rc = (rc >> 2) | (2ull << (2 * (k - 1)));
+                continue;
+            }
         }
         walk_step(B, rv16, k, kmer, rc, nt, true, ev + pos);
     }
@@ -547,21 +563,47 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
             for (uint32_t p = 0; p < len; p++)
                 if ((nm[p >> 5] >> (p & 31)) & 1u) { S.numeric(G_NPOS, p - prevN); prevN = p; }
         }
+        // events are read four positions at a time (unaligned dword loads; the buffer is padded)
         uint32_t nErr = 0;                                    // error positions, ascending
-        for (uint32_t p = 0; p < len; p++) nErr += (ev[p] >> 3) & 1u;
+        for (uint32_t p = 0; p < len; p += 4) {
+            uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
+            if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
+            nErr += __popc(w4 & 0x08080808u);
+        }
         S.numeric(G_LEFT_ERROR, nErr);
         if (nErr) {
             uint32_t prevE = 0;
-            for (uint32_t p = 0; p < len; p++)
-                if (ev[p] & EV_ERROR) { S.numeric(G_ERRPOS, p - prevE); prevE = p; }
+            for (uint32_t p = 0; p < len; p += 4) {
+                uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
+                if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
+                uint32_t e4 = w4 & 0x08080808u;
+                while (e4) {
+                    uint32_t q = p + ((uint32_t)__builtin_ctz(e4) >> 3);
+                    S.numeric(G_ERRPOS, q - prevE); prevE = q;
+                    e4 &= e4 - 1;
+                }
+            }
         }
-        for (int32_t p = a - 1; p >= 0; p--) {                // bifurcations: left walk, then right walk
-            uint32_t c = ev[p] & 7u;
-            if (c >= EV_NT0) S.put(M_BIFURCATION, c - EV_NT0); else if (c) S.put(M_BIFURCATION_BINARY, c - EV_BIN0);
+        // bifurcations: left walk (a-1 .. 0), then right walk (a+k .. len-1)
+        for (int32_t hi = a; hi > 0; hi -= 4) {               // positions hi-4 .. hi-1, descending
+            const int32_t lo4 = hi - 4;
+            uint32_t w4;
+            if (lo4 >= 0) __builtin_memcpy(&w4, ev + lo4, 4);
+            else { w4 = 0; for (int32_t q = 0; q < hi; q++) w4 |= (uint32_t)ev[q] << (8 * (q - lo4)); }
+            if ((w4 & 0x07070707u) == 0) continue;
+            for (int32_t j = 3; j >= 0; j--) {
+                const uint32_t cc = (w4 >> (8 * j)) & 7u;
+                if (cc >= EV_NT0) S.put(M_BIFURCATION, cc - EV_NT0); else if (cc) S.put(M_BIFURCATION_BINARY, cc - EV_BIN0);
+            }
         }
-        for (uint32_t p = (uint32_t)a + k; p < len; p++) {
-            uint32_t c = ev[p] & 7u;
-            if (c >= EV_NT0) S.put(M_BIFURCATION, c - EV_NT0); else if (c) S.put(M_BIFURCATION_BINARY, c - EV_BIN0);
+        for (uint32_t p = (uint32_t)a + k; p < len; p += 4) {
+            uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
+            if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
+            if ((w4 & 0x07070707u) == 0) continue;
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t cc = (w4 >> (8 * j)) & 7u;
+                if (cc >= EV_NT0) S.put(M_BIFURCATION, cc - EV_NT0); else if (cc) S.put(M_BIFURCATION_BINARY, cc - EV_BIN0);
+            }
         }
     }
     if (!syms) sym_off[i] = S.n;

@@ -103,11 +103,12 @@ __device__ inline void bloom_keys(const BloomDev& B, const uint16_t* rv16, uint6
         }
     }
 }
-// 64 bits of the bloom starting at bit `bitpos` (array is padded by 16 bytes)
-__device__ inline uint64_t bloom_window(const BloomDev& B, uint64_t bitpos) {
-    const uint32_t* w = (const uint32_t*)B.bits + (bitpos >> 5);
-    uint64_t v = ((uint64_t)w[1] << 32) | w[0];
-    return v >> (bitpos & 31);
+// 25 or more bits of the bloom starting at bit `bitpos`: ONE unaligned dword load (the array is padded by 16 bytes;
+// gfx950 serves unaligned dword loads in hardware) -- the memory pipeline pays per request, not per byte
+__device__ inline uint32_t bloom_window(const BloomDev& B, uint64_t bitpos) {
+    uint32_t w;
+    __builtin_memcpy(&w, B.bits + (bitpos >> 3), 4);
+    return w >> (bitpos & 7);
 }
 // contains4: pv4 packs the four canonical prefix+suffix values (4 bits each, neighbour nt in nibble nt)
 __device__ inline uint32_t bloom_probe4(const BloomDev& B, const BloomKeys& K, uint32_t pv4) {
@@ -115,7 +116,7 @@ __device__ inline uint32_t bloom_probe4(const BloomDev& B, const BloomKeys& K, u
 #pragma unroll
     for (uint32_t i = 0; i < 10; i++) {
         if (i < B.n_hash) {
-            uint32_t w = (uint32_t)bloom_window(B, K.racine + K.key[i]);
+            uint32_t w = bloom_window(B, K.racine + K.key[i]);
             uint32_t m = ((w >> (pv4 & 15)) & 1u) | (((w >> ((pv4 >> 4) & 15)) & 1u) << 1) |
                          (((w >> ((pv4 >> 8) & 15)) & 1u) << 2) | (((w >> ((pv4 >> 12) & 15)) & 1u) << 3);
             alive &= m;
@@ -131,7 +132,7 @@ __device__ inline bool bloom_contains(const BloomDev& B, const uint16_t* rv16, u
     BloomKeys K;
     bloom_keys(B, rv16, hp, revcomp64(hp, k - 2), K);
     bool ok = true;
-    for (uint32_t i = 0; i < B.n_hash && ok; i++) ok = (bloom_window(B, K.racine + K.key[i] + pv) & 1ull) != 0;
+    for (uint32_t i = 0; i < B.n_hash && ok; i++) ok = (bloom_window(B, K.racine + K.key[i] + pv) & 1u) != 0;
     return ok;
 }
 // BloomNeighborCoherent::contains4(item, right) from a k-mer and its reverse complement

@@ -12,7 +12,8 @@
 
 namespace leon {
 
-constexpr uint32_t RC_NSLOT = 24;            // numeric models cached in LDS per block
+constexpr uint32_t RC_NSLOT_BIG = 24;        // numeric models cached in LDS per block (5 blocks per CU) ...
+constexpr uint32_t RC_NSLOT_SMALL = 14;      // ... or, when there are more blocks than that keeps resident, 8 per CU
 constexpr uint32_t RC_LW = 20;               // word offset of Lw[] inside a model
 constexpr uint32_t RC_STRIDE = 280;          // 256-ary model: H[17] pad Lw[256] + one zero word (F(256) = H[16] + 0)
 constexpr uint32_t RC_SSTRIDE = 40;          // small model (alphabet <= 5): same layout, only the first 16-block
@@ -23,7 +24,7 @@ constexpr uint64_t RC_BOTTOM = 1ull << 48;
 constexpr uint32_t RC_MAX_TOTAL = 1u << 30;  // chain arithmetic assumes total < 2^30 (checked by the host per block)
 
 size_t rc_model_scratch_bytes(uint64_t n_blocks) {
-    return (size_t)n_blocks * (RC_NNUM - RC_NSLOT) * RC_STRIDE * sizeof(uint32_t);
+    return (size_t)n_blocks * (RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE * sizeof(uint32_t);
 }
 
 // A model keeps the cumulative count F(x) = H[x>>4] + Lw[x], x in 0..256 (F(256) = H[16] + the zero word).
@@ -37,7 +38,7 @@ template <typename P> __device__ inline void model_init(P s, uint32_t lane, bool
 }
 
 
-template <int ABLATE>
+template <int ABLATE, uint32_t RC_NSLOT>
 __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                                                   uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
                                                   uint32_t* scratch, int* err) {
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
         }
         const uint64_t ntiles = (s1 - s0 + 63) / 64;
         const uint16_t* sym16 = (const uint16_t*)syms;
-        uint32_t* gmodels = scratch + b * (uint64_t)(RC_NNUM - RC_NSLOT) * RC_STRIDE;
+        uint32_t* gmodels = scratch + b * (uint64_t)(RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE;
         // coder state (wave 0)
         uint64_t low = 0, range = ~0ull, nout = 0, acc = 0;
         uint8_t* dst = out + out_off[b];
@@ -213,9 +214,13 @@ void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_be
     if (!n_blocks) return;
     uint32_t g = n_blocks > 65535 ? 65535u : (uint32_t)n_blocks;
     static const int ablate = getenv("LEON_RC_ABLATE") ? atoi(getenv("LEON_RC_ABLATE")) : 0;   // timing experiments only
-    if (ablate == 1) hipLaunchKernelGGL(k_rc_encode<1>, dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err);
-    else if (ablate == 2) hipLaunchKernelGGL(k_rc_encode<2>, dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err);
-    else hipLaunchKernelGGL(k_rc_encode<0>, dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err);
+    const bool small = n_blocks > 256 * 5;                   // keep every block resident: 8 x 19.6 KB per CU
+#define RC_LAUNCH(A, N) hipLaunchKernelGGL((k_rc_encode<A, N>), dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
+    if (ablate == 1) RC_LAUNCH(1, RC_NSLOT_BIG);
+    else if (ablate == 2) RC_LAUNCH(2, RC_NSLOT_BIG);
+    else if (small) RC_LAUNCH(0, RC_NSLOT_SMALL);
+    else RC_LAUNCH(0, RC_NSLOT_BIG);
+#undef RC_LAUNCH
 }
 
 }  // namespace leon
