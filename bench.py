@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("LEON_BENCH_READS", 100_000_000)),
                     help="total reads of the job (BASELINE.json metric: 100M x 150 bp)")
     ap.add_argument("--genome", type=int, default=0, help="genome length; default reads*150/30 (30x coverage)")
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("LEON_BENCH_CPU_SAMPLE", 1_000_000)),
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("LEON_BENCH_CPU_SAMPLE", 600_000)),
                     help="reads timed through the CPU restatement on rank 0 at N=1 (0 = skip)")
     ap.add_argument("--err", type=float, default=0.01)
     return ap.parse_args()
@@ -196,7 +196,14 @@ def main():
     walk_avg_ms = float(np.mean(walk_ms))
     alg_bytes = n_local * walk_bytes_per_read(K)
     achieved = alg_bytes / (walk_avg_ms * 1e-3) / 1e9
-    traffic = os.environ.get("LEON_WALK_TRAFFIC_BYTES")       # PMC-measured HBM bytes per launch (profiles/)
+    traffic = None                                            # PMC-measured HBM bytes per launch (profiles/README.md)
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "walk_traffic.json")))
+        wl = tj["workload"]
+        if (wl["reads"], wl["read_len"], wl["kmer_size"], wl["genome"], wl["n_gpus"]) == (n_total, L, K, G, world):
+            traffic = tj["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"kernel": "k_walk", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(traffic) if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(walk_avg_ms, 3)}

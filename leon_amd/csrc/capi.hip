@@ -361,11 +361,11 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     uint64_t n_slots = 0;
     HIPCHK(c, hipMemcpyAsync(&n_slots, c->slot_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, c->packed.ensure((n_slots * 2 + 8) * 4));
+    HIPCHK(c, c->packed.ensure((n_slots * 2 + 16) * 4));     // wave loads reach 12 dwords past a pass start
     HIPCHK(c, c->nmask.ensure((n_slots + 4) * 4));
     HIPCHK(c, c->rlen.ensure(n * 4));
     HIPCHK(c, c->ncount.ensure(n * 4));
-    HIPCHK(c, hipMemsetAsync(c->packed.as<uint32_t>() + n_slots * 2, 0, 32, s));
+    HIPCHK(c, hipMemsetAsync(c->packed.as<uint32_t>() + n_slots * 2, 0, 64, s));
     launch_pack(s, d_bases + off_first * 0, d_off, c->slot_off.as<uint64_t>(), n, c->packed.as<uint32_t>(), c->nmask.as<uint32_t>(),
                 c->rlen.as<uint32_t>(), c->ncount.as<uint32_t>());
     HIPCHK(c, hipEventRecord(c->ev[1], s));

@@ -162,14 +162,32 @@ __device__ inline uint64_t canon_at(const uint32_t* pk, uint32_t p, uint32_t k, 
     return rc < km ? rc : km;
 }
 
+// Wave-per-read kernels: the dwords covering k-mers [base, base+64) are loaded once (lane l < 12 holds dword
+// (base>>4)+l) and every lane assembles its k-mer with three cross-lane reads instead of three gathers.
+// Must be called by all 64 lanes (p is clamped by the caller).
+__device__ inline uint32_t pass_words(const uint32_t* pk, uint32_t base, uint32_t lane) {
+    return lane < 12 ? pk[(base >> 4) + lane] : 0u;
+}
+__device__ inline uint64_t canon_from_words(uint32_t words, uint32_t base, uint32_t p, uint32_t k) {
+    const uint32_t d = (p >> 4) - (base >> 4), sh = 2 * (p & 15);
+    const uint64_t w0 = (uint32_t)__shfl((int)words, (int)d), w1 = (uint32_t)__shfl((int)words, (int)d + 1);
+    const uint64_t w2 = (uint32_t)__shfl((int)words, (int)d + 2);
+    const uint64_t hi = (w0 << 32) | w1;
+    const uint64_t x = sh ? ((hi << sh) | (w2 >> (32 - sh))) : hi;
+    const uint64_t km = x >> (64 - 2 * k);
+    const uint64_t rc = revcomp64(km, k);
+    return rc < km ? rc : km;
+}
+
 // first position in [lo, hi) (scan order) whose canonical k-mer is in the bloom; -1 if none. Wave-uniform result.
 __device__ inline int first_in_bloom(const BloomDev& B, const uint16_t* rv16, const uint32_t* pk, uint32_t k,
                                      uint32_t lo, uint32_t hi, uint32_t lane) {
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t p = base + lane;
         bool valid = p < hi;
+        const uint64_t cn = canon_from_words(pass_words(pk, base, lane), base, valid ? p : hi - 1, k);
         bool c = false;
-        if (valid) c = bloom_contains(B, rv16, canon_at(pk, p, k));
+        if (valid) c = bloom_contains(B, rv16, cn);
         unsigned long long b = __ballot(c);
         if (b) return (int)(base + __builtin_ctzll(b));
     }
@@ -196,8 +214,9 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
         for (uint32_t base = 0; base < nk; base += 64) {
             uint32_t p = base + lane;
             bool hit = false; uint32_t slot = 0xFFFFFFFFu;
+            const uint64_t cn = canon_from_words(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
             if (p < nk) {
-                slot = dict_find(D, canon_at(pk, p, k));
+                slot = dict_find(D, cn);
                 hit = slot != 0xFFFFFFFFu && D.fin[slot] < g;
             }
             unsigned long long b = __ballot(hit);
@@ -252,8 +271,9 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
         for (uint32_t base = 0; base < nk && !anyfin; base += 64) {
             uint32_t p = base + lane;
             bool f = false, t = false;
+            const uint64_t cn = canon_from_words(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
             if (p < nk) {
-                uint32_t slot = dict_find(D, canon_at(pk, p, k));
+                uint32_t slot = dict_find(D, cn);
                 if (slot != 0xFFFFFFFFu) {
                     f = __hip_atomic_load(&D.fin[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g;
                     t = D.tent[slot] < g;
@@ -315,8 +335,9 @@ __global__ void __launch_bounds__(256) k_final_pos(ReadsDev R, DictDev D, Resolv
         for (uint32_t base = 0; base < limit; base += 64) {
             uint32_t p = base + lane;
             bool hit = false; uint32_t slot = 0xFFFFFFFFu;
+            const uint64_t cn = canon_from_words(pass_words(pk, base, lane), base, p < limit ? p : limit - 1, k);
             if (p < limit) {
-                slot = dict_find(D, canon_at(pk, p, k));
+                slot = dict_find(D, cn);
                 hit = slot != 0xFFFFFFFFu && D.fin[slot] < g;
             }
             unsigned long long b = __ballot(hit);

@@ -223,3 +223,22 @@ def test_hip_path_matches_committed_golden_fixtures():
         assert hashlib.sha256(d).hexdigest() == case["anchor_dict_sha256"] and na == case["n_anchors"]
         assert ctx.stats()["n_symbols"] == case["n_symbols"]
         ctx.close()
+
+
+def test_long_reads_two_byte_numerics():
+    # read length > 255: sizes, anchor positions and error-position deltas need two-byte numerics,
+    # the k-mer lanes need several passes per read
+    bases, off = common.synthetic(1500, 700, 30000, seed=41, err=0.004, n_rate=0.0005)
+    _full_compare(bases, off, 31, 400)
+    bases, off = common.synthetic(300, 3000, 40000, seed=42, err=0.002)
+    _full_compare(bases, off, 27, 100, window=128)
+
+
+def test_high_error_and_low_complexity():
+    # many unanchorable reads and long bifurcation lists; homopolymer / repeat genome stresses the dictionary
+    bases, off = common.synthetic(3000, 150, 20000, seed=43, err=0.15)
+    _full_compare(bases, off, 31, 1000)
+    rep = (b"ACGTACGTTTGACCA" * 40)[:500]
+    reads = [rep[i % 300:i % 300 + 120] for i in range(800)] + [b"A" * 100] * 50 + [b"AC" * 60] * 50
+    b2, off2 = O.reads_to_arrays(reads)
+    _full_compare(b2, off2, 21, 250, window=100)
