@@ -1,0 +1,190 @@
+// leon_host.cpp -- see leon_host.hpp.  Host glue only: every byte of the DNA stream comes from libleon_dna.so.
+//
+// Interim container written by `-c` (little endian), until the .leon HDF5 layout row is built:
+//   "LEONDNA1" | u32 k | u32 reads_per_block | u64 n_reads | u64 n_blocks | u64 n_anchors | u64 dict_bytes |
+//   u64 bloom_tai | u64 bloom_bytes | u32 n_hash | u32 block_nbits |
+//   n_blocks x (u64 size, u64 n_reads) | dictionary stream | bloom bytes | block payloads
+#include "leon_host.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+namespace leon_host {
+
+const char* Leon::STR_COMPRESS = "-c";
+const char* Leon::STR_DECOMPRESS = "-d";
+
+namespace {
+void check(leon_dna_ctx* ctx, int rc, const char* what) {
+    if (rc != LEON_OK) throw Exception(std::string(what) + ": " + leon_last_error(ctx));
+}
+int sink(void* user, uint64_t block_id, const uint8_t* payload, uint64_t size, uint32_t n_reads) {
+    static_cast<Leon*>(user)->writeBlock(payload, size, (int)n_reads, block_id);
+    return 0;
+}
+inline uint64_t revcomp(uint64_t x, unsigned k) {
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x) ^ 0xAAAAAAAAAAAAAAAAULL;
+    return x >> (64 - 2 * k);
+}
+// FASTA / FASTQ (plain text) -> sequences; stands in for gatb's Bank (out of scope)
+std::vector<Sequence> read_bank(const std::string& path) {
+    std::ifstream in(path);
+    if (!in) throw Exception("cannot open " + path);
+    std::vector<Sequence> out;
+    std::string line;
+    bool fastq = false, first = true;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (first) { fastq = line[0] == '@'; first = false; }
+        if (fastq) {
+            Sequence s; s.comment = line.substr(1);
+            if (!std::getline(in, s.data)) break;
+            std::string plus;
+            if (!std::getline(in, plus) || !std::getline(in, s.quality)) throw Exception("truncated FASTQ record in " + path);
+            s.index = out.size(); out.push_back(std::move(s));
+        } else if (line[0] == '>') {
+            Sequence s; s.comment = line.substr(1); s.index = out.size(); out.push_back(std::move(s));
+        } else {
+            if (out.empty()) throw Exception("FASTA data before the first header in " + path);
+            out.back().data += line;
+        }
+    }
+    return out;
+}
+// exact canonical k-mer counting by sorting: stands in for DSK (SortingCountAlgorithm), the step before the path
+std::vector<uint64_t> solid_kmers(const std::vector<Sequence>& seqs, unsigned k, unsigned min_abundance) {
+    std::vector<uint64_t> all;
+    const uint64_t mask = (k < 32 ? (1ULL << (2 * k)) : 0) - 1;
+    for (const Sequence& s : seqs) {
+        uint64_t km = 0; unsigned valid = 0;
+        for (char c : s.data) {
+            int code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'T' ? 2 : c == 'G' ? 3 : 4;
+            if (code == 4) { valid = 0; km = 0; continue; }
+            km = ((km << 2) | (uint64_t)code) & mask;
+            if (++valid >= k) { uint64_t rc = revcomp(km, k); all.push_back(rc < km ? rc : km); }
+        }
+    }
+    std::sort(all.begin(), all.end());
+    std::vector<uint64_t> solid;
+    for (size_t i = 0; i < all.size();) {
+        size_t j = i;
+        while (j < all.size() && all[j] == all[i]) j++;
+        if (j - i >= min_abundance) solid.push_back(all[i]);
+        i = j;
+    }
+    return solid;
+}
+template <typename T> void put(std::ofstream& o, T v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ DnaEncoder
+DnaEncoder::DnaEncoder(Leon* leon) : leon_(leon), offsets_(1, 0) {}
+DnaEncoder::DnaEncoder(const DnaEncoder& o) : leon_(o.leon_), offsets_(1, 0) {}
+DnaEncoder::~DnaEncoder() {
+    try { flush(); } catch (...) {}
+}
+void DnaEncoder::operator()(Sequence& s) {
+    bases_.append(s.getDataBuffer(), s.getDataSize());
+    offsets_.push_back(bases_.size());
+    if (offsets_.size() - 1 == leon_->_batchReads) flush();
+}
+void DnaEncoder::flush() {
+    const uint64_t n = offsets_.size() - 1;
+    if (!n) return;
+    check(leon_->_ctx, leon_dna_encode_batch(leon_->_ctx, reinterpret_cast<const uint8_t*>(bases_.data()), offsets_.data(), n,
+                                             leon_->_nextRead, sink, leon_), "leon_dna_encode_batch");
+    leon_->_nextRead += n;
+    bases_.clear();
+    offsets_.assign(1, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ Leon
+Leon::Leon() {}
+Leon::~Leon() { if (_ctx) leon_dna_ctx_destroy(_ctx); }
+
+void Leon::run(int argc, char* argv[]) {
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](const char* flag) -> std::string {
+            if (i + 1 >= argc) throw Exception(std::string("option ") + flag + " needs a value");
+            return argv[++i];
+        };
+        if (a == "-file") _inputFilename = need("-file");
+        else if (a == STR_COMPRESS) _compress = true;
+        else if (a == STR_DECOMPRESS) _decompress = true;
+        else if (a == "-kmer-size") _kmerSize = (size_t)std::stoul(need("-kmer-size"));
+        else if (a == "-abundance") _abundance = std::stoi(need("-abundance"));
+        else if (a == "-nb-cores") (void)need("-nb-cores");          // accepted; the device replaces the thread pool
+        else if (a == "-gpus") _gpus = std::stoi(need("-gpus"));
+        else if (a == "-verbose") _verbose = std::stoi(need("-verbose")) != 0;
+        else if (a == "-lossless" || a == "-seq-only" || a == "-noheader" || a == "-noqual") {}   // other streams: not built
+        else throw Exception("unknown option " + a);
+    }
+    if (_inputFilename.empty()) throw Exception("option -file is mandatory");
+    if (_compress == _decompress) throw Exception("choose one of -c (compress) or -d (decompress)");
+    execute();
+}
+
+void Leon::execute() {
+    if (_compress) executeCompression(); else executeDecompression();
+}
+
+void Leon::writeBlock(const uint8_t* data, uint64_t size, int encodedSequenceCount, uint64_t blockID) {
+    if (blockID != _blockSizes.size() / 2) throw Exception("blocks arrived out of order");
+    _blocks.insert(_blocks.end(), data, data + size);
+    _blockSizes.push_back(size);
+    _blockSizes.push_back((uint64_t)encodedSequenceCount);
+}
+
+void Leon::executeCompression() {
+    if (_kmerSize < 3 || _kmerSize > 31) throw Exception("-kmer-size must be < 32 (larger k needs the two-word build)");
+    std::vector<Sequence> bank = read_bank(_inputFilename);
+    std::vector<uint64_t> solid = solid_kmers(bank, (unsigned)_kmerSize, (unsigned)std::max(_abundance, 1));
+    const uint64_t tai = std::max<uint64_t>(solid.size() * 12, 1000);       // NBITS_PER_KMER = 12 [RECALLED]
+    leon_dna_cfg cfg = {};
+    cfg.struct_size = sizeof(cfg);
+    cfg.kmer_size = (uint32_t)_kmerSize; cfg.reads_per_block = READ_PER_BLOCK;
+    cfg.bloom_n_hash = 7; cfg.bloom_block_nbits = 12; cfg.bloom_tai = tai; cfg.device_id = 0;
+    check(nullptr, leon_dna_ctx_create(&cfg, &_ctx), "leon_dna_ctx_create");
+    check(_ctx, leon_dna_bloom_insert(_ctx, solid.data(), solid.size()), "leon_dna_bloom_insert");
+    {
+        DnaEncoder enc(this);                       // upstream: Dispatcher::iterate(itSeq, DnaEncoder(this), READ_PER_BLOCK)
+        for (Sequence& s : bank) enc(s);
+    }                                               // ~DnaEncoder flushes the last (partial) block
+    const uint8_t* dict = nullptr; uint64_t dict_size = 0, n_anchors = 0;
+    check(_ctx, leon_dna_finish(_ctx, &dict, &dict_size, &n_anchors), "leon_dna_finish");
+    uint64_t bloom_bytes = 0;
+    check(_ctx, leon_dna_bloom_nbytes(_ctx, &bloom_bytes), "leon_dna_bloom_nbytes");
+    std::vector<uint8_t> bloom(bloom_bytes);
+    check(_ctx, leon_dna_bloom_download(_ctx, bloom.data(), bloom_bytes), "leon_dna_bloom_download");
+
+    // output name: strip nothing, append ".leon" (data/toy.fasta -> data/toy.fasta.leon, /root/reference/INSTALL:21-23)
+    _outputFilename = _inputFilename + ".leon";
+    std::ofstream o(_outputFilename, std::ios::binary);
+    if (!o) throw Exception("cannot write " + _outputFilename);
+    o.write("LEONDNA1", 8);
+    put<uint32_t>(o, (uint32_t)_kmerSize); put<uint32_t>(o, READ_PER_BLOCK);
+    put<uint64_t>(o, bank.size()); put<uint64_t>(o, _blockSizes.size() / 2); put<uint64_t>(o, n_anchors);
+    put<uint64_t>(o, dict_size); put<uint64_t>(o, tai); put<uint64_t>(o, bloom_bytes); put<uint32_t>(o, 7); put<uint32_t>(o, 12);
+    o.write(reinterpret_cast<const char*>(_blockSizes.data()), (std::streamsize)(_blockSizes.size() * 8));
+    o.write(reinterpret_cast<const char*>(dict), (std::streamsize)dict_size);
+    o.write(reinterpret_cast<const char*>(bloom.data()), (std::streamsize)bloom_bytes);
+    o.write(reinterpret_cast<const char*>(_blocks.data()), (std::streamsize)_blocks.size());
+    uint64_t n_bases = 0;
+    for (const Sequence& s : bank) n_bases += s.getDataSize();
+    std::cout << "DNA stream: " << bank.size() << " reads, " << n_bases << " bases -> " << (_blocks.size() + dict_size)
+              << " bytes (" << n_anchors << " anchors, " << _blockSizes.size() / 2 << " blocks), written to " << _outputFilename
+              << std::endl;
+}
+
+void Leon::executeDecompression() {
+    throw Exception("decompression (-d) is not built in this round: DnaDecoder on the device is the next row (DESIGN.md section 11)");
+}
+
+}  // namespace leon_host
