@@ -101,11 +101,18 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (WORLD_SIZE=%d expected)" % a.gpus)
     import torch.distributed as dist
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev:                       # rehearsal of the N>1 path on a one-GPU box (LEON_BENCH_BACKEND=gloo)
+        local = local % max(n_dev, 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("LEON_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI; gloo only to rehearse
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import leon_amd
     from leon_amd import capi
