@@ -3,8 +3,10 @@
 
 One "step" = one pass of the hot path (pack -> anchor resolution -> walk -> symbols -> range coder -> blocks
 handed to the sink, plus leon_dna_finish) over the whole synthetic read set, inputs resident in HBM.
-N > 1: one process per GPU (torch.distributed / RCCL); rank 0 builds the bloom and broadcasts it over xGMI,
-every rank encodes its contiguous range of read blocks.  Prints ONE JSON line on rank 0.
+N > 1: one process per GPU (torch.distributed / RCCL); rank 0 builds the bloom and broadcasts it over xGMI; every
+rank holds the read set, resolves the anchors of all reads (replicated: file-order dictionary semantics without any
+exchange, leon_dna_set_shard) and walks / codes its contiguous range of read blocks; rank 0 writes the dictionary
+stream.  The job is one file of fixed size: strong scaling.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
@@ -122,12 +124,12 @@ def main():
     G = a.genome or max(n_total * L // 30, 10 * L)
     n_blocks = n_total // RPB
     b0, b1 = block_range(rank, world, n_blocks)
-    r0, r1 = b0 * RPB, b1 * RPB
-    n_local = r1 - r0
+    n_local = (b1 - b0) * RPB                # reads this rank walks and codes (it resolves all n_total)
 
     genome = gen_genome(G, device)
     tai = (G - K + 1) * BITS_PER_KMER
     ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local)
+    ctx.set_shard(rank, world)
     nbytes = ctx.bloom_nbytes
     t_b = time.time()
     if world == 1:
@@ -148,14 +150,14 @@ def main():
         del bits
     bloom_s = time.time() - t_b
 
-    # this rank's reads, generated chunk by chunk so the data set does not depend on the world size
-    reads = torch.empty((n_local, L), dtype=torch.uint8, device=device)
-    for c0 in range(r0 // CHUNK, (r1 + CHUNK - 1) // CHUNK):
-        lo, hi = max(r0, c0 * CHUNK), min(r1, (c0 + 1) * CHUNK)
+    # the whole read set on every rank (same seeds everywhere), generated chunk by chunk
+    reads = torch.empty((n_total, L), dtype=torch.uint8, device=device)
+    for c0 in range(0, (n_total + CHUNK - 1) // CHUNK):
+        lo, hi = c0 * CHUNK, min(n_total, (c0 + 1) * CHUNK)
         chunk = gen_reads_chunk(genome, c0, CHUNK, a.err, device)
-        reads[lo - r0:hi - r0] = chunk[lo - c0 * CHUNK:hi - c0 * CHUNK]
+        reads[lo:hi] = chunk[:hi - lo]
         del chunk
-    offsets = (torch.arange(n_local + 1, dtype=torch.int64, device=device) * L).contiguous()
+    offsets = (torch.arange(n_total + 1, dtype=torch.int64, device=device) * L).contiguous()
     del genome
     torch.cuda.synchronize()
 
@@ -170,7 +172,7 @@ def main():
     def step():
         ctx.reset_stream()
         payload[0] = payload[1] = 0
-        ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_local, sink=cb)
+        ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_total, sink=cb)
         d, na = ctx.finish()
         return len(d), na
 
@@ -217,7 +219,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
-        cpu = cpu_baseline(ctx, reads, min(a.cpu_sample, n_local))
+        cpu = cpu_baseline(ctx, reads, min(a.cpu_sample, n_total))
 
     if rank == 0:
         out = {
@@ -228,15 +230,16 @@ def main():
                                    "bloom %d bits/k-mer x %d hashes built from the genome's k-mers"
                                    % (n_total, L, K, G, BITS_PER_KMER, N_HASH),
                        "reads": n_total, "read_len": L, "kmer_size": K, "reads_per_block": RPB,
-                       "sharding": "contiguous block ranges, bloom broadcast over RCCL, one anchor dictionary per rank"
-                                   if world > 1 else "single GPU",
+                       "sharding": "bloom broadcast over RCCL; anchor resolution replicated on every rank (file-order "
+                                   "dictionary, no exchange); walk + range coder on contiguous block ranges; "
+                                   "dictionary stream on rank 0" if world > 1 else "single GPU",
                        "bloom_bytes": nbytes, "bloom_bcast_ms": round(bcast_ms, 2), "bloom_build_s": round(bloom_s, 2)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
                       "symbols": stage["n_symbols"], "resolve_rounds": stage["resolve_rounds"],
-                      "bits_per_base": round(8.0 * (payload[0] + dict_bytes) / (n_local * L), 4)},
+                      "bits_per_base": round(8.0 * (payload[0] + dict_bytes) / (max(n_local, 1) * L), 4)},
         }
         print(json.dumps(out))
     if world > 1:

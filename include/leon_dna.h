@@ -99,6 +99,12 @@ int leon_dna_encode_batch(leon_dna_ctx* ctx, const uint8_t* bases, const uint64_
 int leon_dna_encode_batch_device(leon_dna_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets,
                                  uint64_t n_reads, uint64_t first_read_index, leon_block_sink sink, void* user);
 
+/* N contexts, one per GPU, working on ONE output file: every rank is fed the SAME batches; each resolves the
+ * anchors of all reads (replicated, so the dictionary and every read's anchor are file-order exact on every rank
+ * without any exchange), then walks and codes only its contiguous share of each batch's blocks, which its sink
+ * receives with their global block ids.  Rank 0 alone produces the dictionary stream.  Default: rank 0 of 1. */
+int leon_dna_set_shard(leon_dna_ctx* ctx, uint32_t rank, uint32_t world);
+
 /* Leon::endDnaCompression: flush the anchor-dictionary range coder (Leon::encodeInsertedAnchor stream).
  * payload stays owned by ctx until destroy. */
 int leon_dna_finish(leon_dna_ctx* ctx, const uint8_t** dict_payload, uint64_t* dict_size, uint64_t* n_anchors);

@@ -63,6 +63,7 @@ _EXPORTS = {
                                                 C.c_void_p]),
     "leon_dna_finish": (C.c_int, [C.c_void_p, C.POINTER(_u8p), _u64p, _u64p]),
     "leon_dna_reset_stream": (C.c_int, [C.c_void_p]),
+    "leon_dna_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "leon_host_anchor_dict_encode": (C.c_int, [_u64p, C.c_uint64, C.c_uint32, _u8p, C.c_uint64, _u64p]),
     "leon_dna_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "leon_dna_trace_anchors": (C.c_int, [C.c_void_p, _i32p, _u32p, _u8p, C.c_uint64]),
@@ -225,6 +226,9 @@ class DnaEncodeContext:
         p, sz, na = _u8p(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.leon_dna_finish(self.h, C.byref(p), C.byref(sz), C.byref(na)))
         return C.string_at(p, sz.value), na.value
+
+    def set_shard(self, rank, world):
+        self._chk(self.lib.leon_dna_set_shard(self.h, rank, world))
 
     def reset_stream(self):
         self._chk(self.lib.leon_dna_reset_stream(self.h))

@@ -73,6 +73,7 @@ struct leon_dna_ctx {
     double anchor_wait_ms = 0;
     // stream state
     uint64_t next_read = 0, next_block = 0;
+    uint32_t shard_rank = 0, shard_world = 1;    // leon_dna_set_shard
     bool partial_seen = false, finished = false;
     // batch buffers
     DevBuf in_bases, in_off, slot_off, packed, nmask, rlen, ncount;
@@ -348,6 +349,7 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     HIPCHK(c, hipMemcpy(&off_last, d_off + n, 8, hipMemcpyDeviceToHost));
     if (off_last < off_first) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
     const uint64_t n_bases = off_last - off_first;
+    (void)n_bases;
     const uint64_t n_blocks = (n + rpb - 1) / rpb;
 
     HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -433,7 +435,7 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
                 c->anchor_kmers = nb;
             }
             launch_assign_addr(s, c->D, V, w0, w1, c->rank.as<uint32_t>(), c->n_anchors, c->anchor_kmers.as<uint64_t>());
-            if (n_new) {       // the window's new anchors go straight to the host thread coding the dictionary stream
+            if (n_new && c->shard_rank == 0) {   // the window's new anchors go straight to the host thread coding the dictionary stream
                 std::vector<uint64_t> fresh(n_new);
                 HIPCHK(c, hipMemcpyAsync(fresh.data(), c->anchor_kmers.as<uint64_t>() + c->n_anchors, n_new * 8, hipMemcpyDeviceToHost, s));
                 HIPCHK(c, hipStreamSynchronize(s));
@@ -446,70 +448,96 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    // ---- sort reads by (anchor address, strand) ----
-    HIPCHK(c, c->sort_key2.ensure(n * 8)); HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(n * 4));
+    // ---- this rank's share of the batch: a contiguous range of whole blocks (all of it when not sharded) ----
+    uint64_t lb0 = 0, lb1 = n_blocks;
+    if (c->shard_world > 1) {
+        const uint64_t q = n_blocks / c->shard_world, rm = n_blocks % c->shard_world, rk = c->shard_rank;
+        lb0 = rk * q + std::min<uint64_t>(rk, rm);
+        lb1 = lb0 + q + (rk < rm ? 1 : 0);
+    }
+    const uint64_t nbl = lb1 - lb0;
+    const uint64_t r0 = std::min<uint64_t>(n, lb0 * rpb), r1 = std::min<uint64_t>(n, lb1 * rpb), nl = r1 - r0;
+    uint64_t off_r0 = off_first, off_r1 = off_last;
+    if (c->shard_world > 1) {
+        HIPCHK(c, hipMemcpy(&off_r0, d_off + r0, 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&off_r1, d_off + r1, 8, hipMemcpyDeviceToHost));
+    }
+    const uint64_t nl_bases = off_r1 - off_r0;
+    R.ev_origin = r0;
+    auto ms = [&](int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, c->ev[a], c->ev[b]); return v; };
+    c->stats.n_reads = nl; c->stats.n_bases = nl_bases; c->stats.n_blocks = nbl; c->stats.n_anchors = c->n_anchors;
+    c->last_n = n; c->last_bases = nl_bases;
+    if (nl == 0) {                                            // nothing of this batch is ours to encode
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->stats.ms_pack = ms(0, 1); c->stats.ms_resolve = ms(1, 2); c->stats.ms_total = ms(0, 2);
+        c->next_read += n; c->next_block += n_blocks;
+        return LEON_OK;
+    }
+
+    // ---- sort the share's reads by (anchor address, strand) ----
+    HIPCHK(c, c->sort_key2.ensure(nl * 8)); HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(nl * 4));
     hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
     size_t sort_tmp = 0;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, V.sort_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>(),
-                                                 c->perm2.as<uint32_t>(), n, 0, 34, s));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
+                                                 c->perm2.as<uint32_t>(), nl, 0, 34, s));
     if (int rc = ensure_cub(c, sort_tmp)) return rc;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, sort_tmp, V.sort_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>(),
-                                                 c->perm2.as<uint32_t>(), n, 0, 34, s));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
+                                                 c->perm2.as<uint32_t>(), nl, 0, 34, s));
     HIPCHK(c, hipEventRecord(c->ev[3], s));
 
     // ---- walk ----
-    HIPCHK(c, c->events.ensure(n_bases + 16));
-    HIPCHK(c, hipMemsetAsync(c->events.p, 0, n_bases, s));
+    HIPCHK(c, c->events.ensure(nl_bases + 16));
+    HIPCHK(c, hipMemsetAsync(c->events.p, 0, nl_bases + 16, s));
     HIPCHK(c, hipEventRecord(c->ev[4], s));
-    launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, c->perm2.as<uint32_t>(), n, c->events.as<uint8_t>());
+    launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, c->perm2.as<uint32_t>(), nl, c->events.as<uint8_t>());
     HIPCHK(c, hipEventRecord(c->ev[5], s));
     c->stats.walk_launches = 1;
 
     // ---- symbols ----
     HIPCHK(c, c->prev.ensure(n * 8));
-    HIPCHK(c, c->sym_off.ensure((n + 1) * 8));
-    launch_prev_anchored(s, V.anchor_pos, n, rpb, c->prev.as<int64_t>());
-    HIPCHK(c, hipMemsetAsync(c->sym_off.as<uint64_t>() + n, 0, 8, s));
-    launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(),
+    HIPCHK(c, c->sym_off.ensure((nl + 1) * 8));
+    launch_prev_anchored(s, V.anchor_pos, n, rpb, lb0, nbl, c->prev.as<int64_t>());
+    HIPCHK(c, hipMemsetAsync(c->sym_off.as<uint64_t>() + nl, 0, 8, s));
+    launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(), r0, nl,
                    c->sym_off.as<uint64_t>(), nullptr);
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), n + 1, s));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
     if (int rc = ensure_cub(c, tmp_bytes)) return rc;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), n + 1, s));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
     uint64_t n_syms = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_syms, c->sym_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&n_syms, c->sym_off.as<uint64_t>() + nl, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, c->syms.ensure(n_syms * 2 + 256));
-    launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(),
+    launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(), r0, nl,
                    c->sym_off.as<uint64_t>(), c->syms.as<uint8_t>());
-    HIPCHK(c, c->blk_begin.ensure((n_blocks + 1) * 8)); HIPCHK(c, c->out_off.ensure((n_blocks + 1) * 8));
-    HIPCHK(c, c->out_size.ensure(n_blocks * 8)); HIPCHK(c, c->dst_off.ensure((n_blocks + 1) * 8));
-    launch_block_ranges(s, c->sym_off.as<uint64_t>(), n, rpb, n_blocks, c->blk_begin.as<uint64_t>(), c->out_off.as<uint64_t>());
+    HIPCHK(c, c->blk_begin.ensure((nbl + 1) * 8)); HIPCHK(c, c->out_off.ensure((nbl + 1) * 8));
+    HIPCHK(c, c->out_size.ensure(nbl * 8)); HIPCHK(c, c->dst_off.ensure((nbl + 1) * 8));
+    launch_block_ranges(s, c->sym_off.as<uint64_t>(), nl, rpb, nbl, c->blk_begin.as<uint64_t>(), c->out_off.as<uint64_t>());
     HIPCHK(c, hipEventRecord(c->ev[6], s));
 
     // ---- range coder ----
-    const uint64_t rc_cap = 3 * n_syms + 72 * (n_blocks + 1);
+    const uint64_t rc_cap = 3 * n_syms + 72 * (nbl + 1);
     HIPCHK(c, c->rc_out.ensure(rc_cap));
-    HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(n_blocks)));
+    HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
     HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
-    launch_rc_encode(s, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), n_blocks, c->rc_out.as<uint8_t>(),
+    launch_rc_encode(s, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, c->rc_out.as<uint8_t>(),
                      c->out_off.as<uint64_t>(), c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[7], s));
 
     // ---- gather + D2H ----
-    std::vector<uint64_t> sizes(n_blocks), dst(n_blocks + 1, 0);
+    std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
     int errflag = 0;
-    HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, n_blocks * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, nbl * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (errflag) return fail(c, LEON_E_OVERFLOW, errflag == 2 ? "a read block has 2^30 symbols or more"
                                                               : "range coder output exceeded its 3 bytes/symbol bound");
-    for (uint64_t b = 0; b < n_blocks; b++) dst[b + 1] = dst[b] + sizes[b];
-    const uint64_t payload_bytes = dst[n_blocks];
+    for (uint64_t b = 0; b < nbl; b++) dst[b + 1] = dst[b] + sizes[b];
+    const uint64_t payload_bytes = dst[nbl];
     HIPCHK(c, c->payload.ensure(payload_bytes + 16));
-    HIPCHK(c, hipMemcpyAsync(c->dst_off.p, dst.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->dst_off.p, dst.data(), (nbl + 1) * 8, hipMemcpyHostToDevice, s));
     launch_gather_payload(s, c->rc_out.as<uint8_t>(), c->out_off.as<uint64_t>(), c->dst_off.as<uint64_t>(), c->out_size.as<uint64_t>(),
-                          n_blocks, c->payload.as<uint8_t>());
+                          nbl, c->payload.as<uint8_t>());
     if (payload_bytes + 16 > c->h_payload_cap) {
         if (c->h_payload) HIPCHK(c, hipHostFree(c->h_payload));
         c->h_payload = nullptr; c->h_payload_cap = 0;
@@ -522,19 +550,16 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     HIPCHK(c, hipStreamSynchronize(s));
 
     // ---- stats ----
-    auto ms = [&](int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, c->ev[a], c->ev[b]); return v; };
-    c->stats.n_reads = n; c->stats.n_bases = n_bases; c->stats.n_blocks = n_blocks; c->stats.n_anchors = c->n_anchors;
     c->stats.n_symbols = n_syms; c->stats.payload_bytes = payload_bytes;
     c->stats.ms_pack = ms(0, 1); c->stats.ms_resolve = ms(1, 2); c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5);
     c->stats.ms_symbols = ms(5, 6); c->stats.ms_rangecoder = ms(6, 7); c->stats.ms_d2h = ms(7, 8); c->stats.ms_total = ms(0, 8);
-    c->last_n = n; c->last_bases = n_bases;
     c->next_read += n;
 
     // ---- Leon::writeBlock, in block order ----
     const uint8_t* hp = (const uint8_t*)c->h_payload;
-    for (uint64_t b = 0; b < n_blocks; b++) {
-        uint32_t nr = (uint32_t)std::min<uint64_t>(rpb, n - b * rpb);
-        if (sink(user, c->next_block + b, hp + dst[b], sizes[b], nr)) return fail(c, LEON_E_SINK, "block sink returned non-zero");
+    for (uint64_t b = 0; b < nbl; b++) {
+        uint32_t nr = (uint32_t)std::min<uint64_t>(rpb, n - (lb0 + b) * rpb);
+        if (sink(user, c->next_block + lb0 + b, hp + dst[b], sizes[b], nr)) return fail(c, LEON_E_SINK, "block sink returned non-zero");
     }
     c->next_block += n_blocks;
     (void)k;
@@ -565,12 +590,20 @@ int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, ui
     c->anchor_worker->drain();
     c->anchor_wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!c->finished) {
-        c->anchor_worker->coder().flush();
+        if (c->shard_rank == 0) c->anchor_worker->coder().flush();
         c->finished = true;
     }
     *payload = c->anchor_worker->coder().data();
-    *size = c->anchor_worker->coder().size();
+    *size = c->shard_rank == 0 ? c->anchor_worker->coder().size() : 0;      // the dictionary stream is rank 0's to write
     *n_anchors = c->n_anchors;
+    return LEON_OK;
+}
+
+int leon_dna_set_shard(leon_dna_ctx* c, uint32_t rank, uint32_t world) {
+    if (!c) return LEON_E_INVALID;
+    if (world == 0 || rank >= world) return fail(c, LEON_E_INVALID, "set_shard: need rank < world");
+    if (c->next_read) return fail(c, LEON_E_STATE, "set_shard must precede the first batch of a stream");
+    c->shard_rank = rank; c->shard_world = world;
     return LEON_OK;
 }
 

@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
     const uint32_t* pk = R.packed + 2 * R.slot_off[i];
     const uint32_t* nm = R.nmask + R.slot_off[i];
     bool hasN = R.n_count[i] != 0;
-    uint8_t* ev = events + (R.base_off[i] - R.base_off[0]);
+    uint8_t* ev = events + (R.base_off[i] - R.base_off[R.ev_origin]);
     uint64_t anchor = kmer_at(pk, (uint32_t)a, k);
     uint64_t anchor_rc = revcomp64(anchor, k);
 
@@ -489,10 +489,11 @@ void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, co
 // symbols: the order in which encodeAnchorRead / encodeNoAnchorRead feed the range coder
 // ================================================================================================
 // prev[i] = index of the previous anchored read of the same block (-1 none): _prevReadSize/_prevAnchorPos/...
-__global__ void __launch_bounds__(256) k_prev_anchored(const int32_t* anchor_pos, uint64_t n, uint32_t rpb, int64_t* prev) {
+__global__ void __launch_bounds__(256) k_prev_anchored(const int32_t* anchor_pos, uint64_t n, uint32_t rpb, uint64_t first_block,
+                                                      int64_t* prev) {
     __shared__ long long wmax[4];
     __shared__ long long carry_s;
-    uint64_t b0 = (uint64_t)blockIdx.x * rpb;
+    uint64_t b0 = (first_block + blockIdx.x) * rpb;
     uint64_t b1 = b0 + rpb < n ? b0 + rpb : n;
     uint32_t lane = lane_id(), w = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = -1;
@@ -518,10 +519,10 @@ __global__ void __launch_bounds__(256) k_prev_anchored(const int32_t* anchor_pos
         __syncthreads();
     }
 }
-void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, uint32_t rpb, int64_t* prev) {
-    if (!n) return;
-    uint64_t nb = (n + rpb - 1) / rpb;
-    hipLaunchKernelGGL(k_prev_anchored, dim3((uint32_t)nb), dim3(256), 0, s, anchor_pos, n, rpb, prev);
+void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, uint32_t rpb, uint64_t first_block,
+                          uint64_t n_blocks, int64_t* prev) {
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(k_prev_anchored, dim3((uint32_t)n_blocks), dim3(256), 0, s, anchor_pos, n, rpb, first_block, prev);
 }
 
 struct SymSink {
@@ -550,15 +551,16 @@ struct SymSink {
 
 __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr,
                                                 const uint8_t* flags, const int64_t* prev, const uint8_t* events,
-                                                uint64_t* sym_off, uint8_t* syms) {
-    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (i >= R.n) return;
+                                                uint64_t r0, uint64_t n_local, uint64_t* sym_off, uint8_t* syms) {
+    uint64_t li = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (li >= n_local) return;
+    const uint64_t i = r0 + li;
     uint32_t len = R.len[i], k = R.k;
     const uint32_t* pk = R.packed + 2 * R.slot_off[i];
     const uint32_t* nm = R.nmask + R.slot_off[i];
     uint32_t nN = R.n_count[i];
     SymSink S;
-    S.p = syms ? syms + 2 * sym_off[i] : nullptr;
+    S.p = syms ? syms + 2 * sym_off[li] : nullptr;
     S.n = 0;
     int32_t a = anchor_pos[i];
     if (a < 0) {                                              // DnaEncoder::encodeNoAnchorRead
@@ -577,7 +579,7 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
         S.delta(M_ANCHORPOS_DT, G_ANCHOR_POS, (uint64_t)a, pPos);
         S.delta(M_ANCHORADDR_DT, G_ANCHOR_ADDRESS, anchor_addr[i], pAddr);
         S.put(M_ANCHOR_REVCOMP, flags[i] & 1u);
-        const uint8_t* ev = events + (R.base_off[i] - R.base_off[0]);
+        const uint8_t* ev = events + (R.base_off[i] - R.base_off[R.ev_origin]);
         S.numeric(G_NUMERIC, nN);                             // N positions, delta coded
         if (nN) {
             uint32_t prevN = 0;
@@ -627,13 +629,14 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
             }
         }
     }
-    if (!syms) sym_off[i] = S.n;
+    if (!syms) sym_off[li] = S.n;
 }
 void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr, const uint8_t* flags,
-                    const int64_t* prev, const uint8_t* events, uint64_t* sym_off, uint8_t* syms) {
-    if (!R.n) return;
-    uint64_t g = (R.n + 255) / 256;
-    hipLaunchKernelGGL(k_symbols, dim3((uint32_t)g), dim3(256), 0, s, R, anchor_pos, anchor_addr, flags, prev, events, sym_off, syms);
+                    const int64_t* prev, const uint8_t* events, uint64_t r0, uint64_t n_local, uint64_t* sym_off, uint8_t* syms) {
+    if (!n_local) return;
+    uint64_t g = (n_local + 255) / 256;
+    hipLaunchKernelGGL(k_symbols, dim3((uint32_t)g), dim3(256), 0, s, R, anchor_pos, anchor_addr, flags, prev, events, r0, n_local,
+                       sym_off, syms);
 }
 
 // per block: symbol range and output capacity offsets (3 bytes per symbol + 64 or more)

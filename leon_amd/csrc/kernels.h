@@ -15,6 +15,7 @@ struct ReadsDev {
     const uint32_t* len;
     const uint32_t* n_count;    // number of N per read
     uint64_t n;
+    uint64_t ev_origin;         // read whose first base is byte 0 of the event buffer (first read of this rank's share)
     uint32_t k, pad;
 };
 
@@ -65,10 +66,11 @@ void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, u
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos,
                  const uint32_t* perm, uint64_t n_walk, uint8_t* events);
 // ---- symbols ----
-void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, uint32_t rpb, int64_t* prev);
+void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, uint32_t rpb, uint64_t first_block,
+                          uint64_t n_blocks, int64_t* prev);
 void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr,
-                    const uint8_t* flags, const int64_t* prev, const uint8_t* events, uint64_t* sym_off /*count or offsets*/,
-                    uint8_t* syms /*nullptr = count pass*/);
+                    const uint8_t* flags, const int64_t* prev, const uint8_t* events, uint64_t r0, uint64_t n_local,
+                    uint64_t* sym_off /*count or offsets, indexed from r0*/, uint8_t* syms /*nullptr = count pass*/);
 void launch_block_ranges(hipStream_t s, const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
                          uint64_t* blk_begin /*n_blocks+1*/, uint64_t* out_off /*n_blocks+1*/);
 // ---- range coder ----

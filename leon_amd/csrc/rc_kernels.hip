@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
 
         for (uint64_t t = 0; t <= ntiles; t++) {
             if (wave == 1) {
-                if (t < ntiles) {
+                if (t < ntiles && (ABLATE != 3 || t < 2)) {
                     // =================== modeler: tile t -> ring[t & 1] ===================
                     const uint64_t base = s0 + t * 64;
                     const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
@@ -218,6 +218,7 @@ void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_be
 #define RC_LAUNCH(A, N) hipLaunchKernelGGL((k_rc_encode<A, N>), dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
     if (ablate == 1) RC_LAUNCH(1, RC_NSLOT_BIG);
     else if (ablate == 2) RC_LAUNCH(2, RC_NSLOT_BIG);
+    else if (ablate == 3) RC_LAUNCH(3, RC_NSLOT_BIG);
     else if (small) RC_LAUNCH(0, RC_NSLOT_SMALL);
     else RC_LAUNCH(0, RC_NSLOT_BIG);
 #undef RC_LAUNCH

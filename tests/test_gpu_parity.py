@@ -242,3 +242,30 @@ def test_high_error_and_low_complexity():
     reads = [rep[i % 300:i % 300 + 120] for i in range(800)] + [b"A" * 100] * 50 + [b"AC" * 60] * 50
     b2, off2 = O.reads_to_arrays(reads)
     _full_compare(b2, off2, 21, 250, window=100)
+
+
+def test_sharded_contexts_reproduce_the_single_stream():
+    """leon_dna_set_shard: N contexts fed the same batches resolve the same file-order dictionary and split the
+    blocks; their union must be byte-identical to the one-context stream (= the oracle's)."""
+    k, rpb = 31, 300
+    bases, off = common.synthetic(4000, 150, 15000, seed=51, n_rate=0.001)     # 14 blocks, the last partial
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ref = O.encode(bases, off, k, rpb, bl, trace=False)
+    for world in (2, 3, 5):
+        got, dicts = [], []
+        for rank in range(world):
+            ctx = _ctx(k, rpb, tai, resolve_window=1000)
+            ctx.set_shard(rank, world)
+            ctx.bloom_upload(bl.bits)
+            # two batches (whole blocks in the first one) to exercise global block ids across calls
+            cut = 6 * rpb
+            blocks = ctx.encode_batch(bases, off[:cut + 1]) + ctx.encode_batch(bases, off[cut:])
+            d, na = ctx.finish()
+            assert na == ref.n_anchors
+            dicts.append(d)
+            got += blocks
+            ctx.close()
+        got.sort()
+        assert [g[0] for g in got] == list(range(len(ref.blocks)))
+        assert [g[1] for g in got] == ref.blocks and [g[2] for g in got] == ref.block_nreads
+        assert dicts[0] == ref.anchor_dict and all(len(d) == 0 for d in dicts[1:])
