@@ -53,6 +53,8 @@ typedef struct leon_dna_cfg {
 } leon_dna_cfg;
 
 #define LEON_F_KEEP_TRACE 1u     /* keep per-read anchors / events of the last batch for leon_dna_trace_* */
+#define LEON_F_DICT_ON_DEVICE 2u /* code the anchor-dictionary stream with the device range coder (one serial chain on one
+                                    workgroup, ~50x slower than the default host thread: DESIGN.md 4.4) instead of the host thread */
 
 /* Replaces Leon::writeBlock(buffer, size, nReads, blockId): called on the calling thread, in increasing
  * block_id; payload is owned by the library and valid until the sink returns.  Non-zero aborts. */

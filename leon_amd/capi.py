@@ -7,6 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 LEON_F_KEEP_TRACE = 1
+LEON_F_DICT_ON_DEVICE = 2
 
 
 class LeonDnaError(RuntimeError):
@@ -113,14 +114,14 @@ class DnaEncodeContext:
     """One ordered read stream on one GPU (wraps leon_dna_ctx)."""
 
     def __init__(self, kmer_size=31, reads_per_block=50000, bloom_tai=0, bloom_n_hash=7, bloom_block_nbits=12,
-                 device_id=0, resolve_window=0, keep_trace=False, random_values=None):
+                 device_id=0, resolve_window=0, keep_trace=False, random_values=None, dict_on_device=False):
         self.lib = load_library()
         cfg = _Cfg()
         cfg.struct_size = C.sizeof(_Cfg)
         cfg.kmer_size, cfg.reads_per_block = kmer_size, reads_per_block
         cfg.bloom_n_hash, cfg.bloom_block_nbits, cfg.device_id = bloom_n_hash, bloom_block_nbits, device_id
         cfg.bloom_tai, cfg.resolve_window = int(bloom_tai), int(resolve_window)
-        cfg.flags = LEON_F_KEEP_TRACE if keep_trace else 0
+        cfg.flags = (LEON_F_KEEP_TRACE if keep_trace else 0) | (LEON_F_DICT_ON_DEVICE if dict_on_device else 0)
         self._rv = None
         if random_values is not None:
             self._rv = np.ascontiguousarray(random_values, dtype=np.uint64)

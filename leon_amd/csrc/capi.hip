@@ -46,6 +46,16 @@ uint64_t hash_seed0() {                  // HashFunctors::generate_hash_seed, se
     return r0 * r3;
 }
 
+// anchor k-mers -> the dictionary stream's symbols: k bases per anchor, first base first, on the 5-ary model
+__global__ void k_anchor_symbols(const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms) {
+    const uint64_t total = n_anchors * k;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = i / k; const uint32_t j = (uint32_t)(i % k);
+        syms[2 * i] = (uint8_t)M_NOANCHOR_READ;               // any 5-symbol Order0Model: _anchorDictModel(5)
+        syms[2 * i + 1] = (uint8_t)((kmers[a] >> (2 * (k - 1 - j))) & 3u);
+    }
+}
+
 __global__ void k_iota(uint32_t* v, uint64_t n) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
 }
@@ -71,6 +81,7 @@ struct leon_dna_ctx {
     DevBuf anchor_kmers;
     AnchorDictWorker* anchor_worker = nullptr;   // host thread coding the dictionary stream, fed per window
     double anchor_wait_ms = 0;
+    std::vector<uint8_t> dict_device_out;        // LEON_F_DICT_ON_DEVICE: the stream coded by k_rc_encode
     // stream state
     uint64_t next_read = 0, next_block = 0;
     uint32_t shard_rank = 0, shard_world = 1;    // leon_dna_set_shard
@@ -435,7 +446,7 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
                 c->anchor_kmers = nb;
             }
             launch_assign_addr(s, c->D, V, w0, w1, c->rank.as<uint32_t>(), c->n_anchors, c->anchor_kmers.as<uint64_t>());
-            if (n_new && c->shard_rank == 0) {   // the window's new anchors go straight to the host thread coding the dictionary stream
+            if (n_new && c->shard_rank == 0 && !(c->cfg.flags & LEON_F_DICT_ON_DEVICE)) {   // the window's new anchors go straight to the host thread coding the dictionary stream
                 std::vector<uint64_t> fresh(n_new);
                 HIPCHK(c, hipMemcpyAsync(fresh.data(), c->anchor_kmers.as<uint64_t>() + c->n_anchors, n_new * 8, hipMemcpyDeviceToHost, s));
                 HIPCHK(c, hipStreamSynchronize(s));
@@ -587,6 +598,42 @@ int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t*
 int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, uint64_t* n_anchors) {
     if (!c || !payload || !size || !n_anchors) return LEON_E_INVALID;
     auto t0 = std::chrono::steady_clock::now();
+    if (c->cfg.flags & LEON_F_DICT_ON_DEVICE) {
+        if (!c->finished) {
+            c->dict_device_out.clear();
+            if (c->shard_rank == 0) {
+                HIPCHK(c, hipSetDevice(c->device));
+                hipStream_t s = c->stream;
+                const uint64_t nsym = c->n_anchors * c->cfg.kmer_size;
+                DevBuf dsyms, dbegin, doff, dsize, dout, dscr;
+                HIPCHK(c, dsyms.ensure(nsym * 2 + 256)); HIPCHK(c, dbegin.ensure(16)); HIPCHK(c, doff.ensure(16)); HIPCHK(c, dsize.ensure(8));
+                const uint64_t begin[2] = { 0, nsym }, off[2] = { 0, ((3 * nsym + 7) & ~7ull) + 64 };
+                HIPCHK(c, dout.ensure(off[1] + 64)); HIPCHK(c, dscr.ensure(rc_model_scratch_bytes(1)));
+                HIPCHK(c, hipMemcpy(dbegin.p, begin, 16, hipMemcpyHostToDevice));
+                HIPCHK(c, hipMemcpy(doff.p, off, 16, hipMemcpyHostToDevice));
+                if (nsym) hipLaunchKernelGGL(k_anchor_symbols, dim3((uint32_t)std::min<uint64_t>((nsym + 255) / 256, 8192)), dim3(256), 0, s,
+                                             c->anchor_kmers.as<uint64_t>(), c->n_anchors, c->cfg.kmer_size, dsyms.as<uint8_t>());
+                HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
+                launch_rc_encode(s, dsyms.as<uint8_t>(), dbegin.as<uint64_t>(), 1, dout.as<uint8_t>(), doff.as<uint64_t>(), dsize.as<uint64_t>(),
+                                 dscr.as<uint32_t>(), c->errflag.as<int>());
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipStreamSynchronize(s));
+                uint64_t sz = 0; int errflag = 0;
+                HIPCHK(c, hipMemcpy(&sz, dsize.p, 8, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost));
+                if (errflag) return fail(c, LEON_E_OVERFLOW, "dictionary stream: device range coder bound hit");
+                c->dict_device_out.resize(sz);
+                if (sz) HIPCHK(c, hipMemcpy(c->dict_device_out.data(), dout.p, sz, hipMemcpyDeviceToHost));
+                dsyms.release(); dbegin.release(); doff.release(); dsize.release(); dout.release(); dscr.release();
+            }
+            c->finished = true;
+        }
+        c->anchor_wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *payload = c->dict_device_out.data();
+        *size = c->dict_device_out.size();
+        *n_anchors = c->n_anchors;
+        return LEON_OK;
+    }
     c->anchor_worker->drain();
     c->anchor_wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!c->finished) {

@@ -269,3 +269,22 @@ def test_sharded_contexts_reproduce_the_single_stream():
         assert [g[0] for g in got] == list(range(len(ref.blocks)))
         assert [g[1] for g in got] == ref.blocks and [g[2] for g in got] == ref.block_nreads
         assert dicts[0] == ref.anchor_dict and all(len(d) == 0 for d in dicts[1:])
+
+
+def test_dictionary_stream_on_device_equals_host_thread():
+    """the file-wide anchor-dictionary stream: default = host worker thread; LEON_F_DICT_ON_DEVICE = the device range
+    coder on one workgroup.  Same bytes (and == oracle)."""
+    k, rpb = 31, 1000
+    bases, off = common.synthetic(5000, 150, 30000, seed=61)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ref = O.encode(bases, off, k, rpb, bl, trace=False)
+    outs = []
+    for on_dev in (False, True):
+        ctx = _ctx(k, rpb, tai, dict_on_device=on_dev)
+        ctx.bloom_upload(bl.bits)
+        blocks = ctx.encode_batch(bases, off)
+        d, na = ctx.finish()
+        assert [b[1] for b in blocks] == ref.blocks and na == ref.n_anchors
+        outs.append(d)
+        ctx.close()
+    assert outs[0] == outs[1] == ref.anchor_dict
