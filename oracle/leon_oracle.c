@@ -41,6 +41,24 @@ static inline int nt2bin(char c) {
 }
 static const char BIN2NT[5] = { 'A', 'C', 'T', 'G', 'N' };
 
+/* k-mers: LargeInt<1> (one 64-bit word) for k < 32, LargeInt<2> / NativeInt128 for 32 <= k < 64 (gatb KSIZE_LIST
+ * "32 64 96 128" [RECALLED]).  Held in 128 bits here; W = words of the upstream type, which decides hash1. */
+typedef unsigned __int128 kmer_t;
+#define KWORDS(k) ((k) >= 32 ? 2u : 1u)
+static inline uint64_t rev2bit64(uint64_t x) {
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    return __builtin_bswap64(x) ^ 0xAAAAAAAAAAAAAAAAULL;
+}
+static inline kmer_t revcomp_k(kmer_t x, uint32_t k) {
+    kmer_t r = ((kmer_t)rev2bit64((uint64_t)x) << 64) | rev2bit64((uint64_t)(x >> 64));
+    return r >> (128 - 2 * k);
+}
+static inline kmer_t canonical_k(kmer_t x, uint32_t k) { kmer_t r = revcomp_k(x, k); return r < x ? r : x; }
+static inline kmer_t kmask(uint32_t nbases) { return nbases >= 64 ? ~(kmer_t)0 : (((kmer_t)1) << (2 * nbases)) - 1; }
+static inline kmer_t kload(const uint64_t* w, uint32_t W) { return W == 2 ? (((kmer_t)w[1] << 64) | w[0]) : (kmer_t)w[0]; }
+static inline void kstore(uint64_t* w, uint32_t W, kmer_t x) { w[0] = (uint64_t)x; if (W == 2) w[1] = (uint64_t)(x >> 64); }
+
 /* LargeInt/NativeInt64 revcomp: reverse the 2-bit groups, complement = code ^ 2 */
 uint64_t lo_revcomp(uint64_t x, uint32_t k) {
     x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
@@ -66,6 +84,13 @@ uint64_t lo_hash64(uint64_t key, uint64_t seed) {
     hash = hash ^ (hash >> 28);
     hash = hash + (hash << 31);
     return hash;
+}
+
+/* hash1(LargeInt<precision>): XOR of hash64 over the 64-bit chunks of the TYPE (both chunks for W = 2, even if 0) */
+static inline uint64_t hash1_k(kmer_t x, uint32_t W, uint64_t seed) {
+    uint64_t h = lo_hash64((uint64_t)x, seed);
+    if (W == 2) h ^= lo_hash64((uint64_t)(x >> 64), seed);
+    return h;
 }
 
 /* HashFunctors::generate_hash_seed (Bloom.hpp), user_seed = 0 */
@@ -115,14 +140,15 @@ static inline uint64_t simplehash16(uint64_t key, int shift) {
 struct lo_bloom {
     uint8_t* blooma;
     uint64_t tai, nchar, reduced_tai, mask_block;
-    uint32_t k, n_hash, block_nbits;
-    uint64_t maskkm2, kmer_mask, seed0;
+    uint32_t k, n_hash, block_nbits, W;
+    kmer_t maskkm2, kmer_mask;
+    uint64_t seed0;
 };
 static const uint8_t bit_mask[8] = { 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80 };
 static const uint8_t cano2[16] = { 0, 1, 2, 3, 4, 5, 3, 7, 8, 9, 0, 4, 9, 13, 1, 5 };
 
 lo_bloom* lo_bloom_new(uint64_t tai_bloom, uint32_t k, uint32_t n_hash, uint32_t block_nbits) {
-    if (k < 3 || k > 31 || n_hash < 1 || n_hash > 10 || block_nbits < 4 || block_nbits > 16) return NULL;
+    if (k < 3 || k > 63 || n_hash < 1 || n_hash > 10 || block_nbits < 4 || block_nbits > 16) return NULL;
     rv_init();
     lo_bloom* b = (lo_bloom*)calloc(1, sizeof(*b));
     /* BloomCacheCoherent ctor: Bloom(tai_bloom + 2*(1<<block_nbits), nbHash) */
@@ -134,8 +160,9 @@ lo_bloom* lo_bloom_new(uint64_t tai_bloom, uint32_t k, uint32_t n_hash, uint32_t
     b->k = k; b->n_hash = n_hash; b->block_nbits = block_nbits;
     b->mask_block = (1ULL << block_nbits) - 1;
     b->reduced_tai = b->tai - 2 * (1ULL << block_nbits);
-    b->maskkm2 = (1ULL << ((k - 2) * 2)) - 1;
-    b->kmer_mask = (1ULL << (k * 2)) - 1;
+    b->W = KWORDS(k);
+    b->maskkm2 = kmask(k - 2);
+    b->kmer_mask = kmask(k);
     b->seed0 = lo_hash_seed(0);
     return b;
 }
@@ -146,48 +173,51 @@ uint64_t lo_bloom_tai(const lo_bloom* b) { return b->tai; }
 uint64_t lo_bloom_reduced_tai(const lo_bloom* b) { return b->reduced_tai; }
 
 /* positions of one k-mer: BloomNeighborCoherent::insert / contains */
-static void bloom_positions(const lo_bloom* b, uint64_t item, uint64_t* pos) {
+static void bloom_positions(const lo_bloom* b, kmer_t item, uint64_t* pos) {
     uint32_t k = b->k;
-    uint64_t suffix = item & 3;
-    uint64_t prefix = (item >> ((k - 1) * 2)) & 3;
+    uint64_t suffix = (uint64_t)(item & 3);
+    uint64_t prefix = (uint64_t)((item >> ((k - 1) * 2)) & 3);
     uint64_t pv = cano2[(prefix << 2) + suffix];
-    uint64_t hashpart = (item >> 2) & b->maskkm2;
-    uint64_t rev = lo_revcomp(hashpart, k - 2);
+    kmer_t hashpart = (item >> 2) & b->maskkm2;
+    kmer_t rev = revcomp_k(hashpart, k - 2);
     if (rev < hashpart) hashpart = rev;
-    uint64_t racine = lo_hash64(hashpart, b->seed0) % b->reduced_tai;
+    uint64_t racine = hash1_k(hashpart, b->W, b->seed0) % b->reduced_tai;
     uint64_t h0 = racine + (pv & b->mask_block);
     pos[0] = h0;
-    for (uint32_t i = 1; i < b->n_hash; i++) pos[i] = h0 + (simplehash16(hashpart, (int)i) & b->mask_block);
+    /* simplehash16(LargeInt<precision>) looks at value[0] only */
+    for (uint32_t i = 1; i < b->n_hash; i++) pos[i] = h0 + (simplehash16((uint64_t)hashpart, (int)i) & b->mask_block);
 }
-void lo_bloom_insert(lo_bloom* b, const uint64_t* kmers, uint64_t n) {
+void lo_bloom_insert(lo_bloom* b, const uint64_t* kmers, uint64_t n) {       /* W words per k-mer */
     uint64_t pos[16];
     for (uint64_t j = 0; j < n; j++) {
-        bloom_positions(b, kmers[j], pos);
+        bloom_positions(b, kload(kmers + j * b->W, b->W), pos);
         for (uint32_t i = 0; i < b->n_hash; i++) b->blooma[pos[i] >> 3] |= bit_mask[pos[i] & 7];
     }
 }
-int lo_bloom_contains(const lo_bloom* b, uint64_t kmer) {
+static int bloom_contains_k(const lo_bloom* b, kmer_t kmer) {
     uint64_t pos[16];
     bloom_positions(b, kmer, pos);
     for (uint32_t i = 0; i < b->n_hash; i++)
         if ((b->blooma[pos[i] >> 3] & bit_mask[pos[i] & 7]) == 0) return 0;
     return 1;
 }
+int lo_bloom_contains(const lo_bloom* b, uint64_t kmer) { return bloom_contains_k(b, (kmer_t)kmer); }
+int lo_bloom_contains_w(const lo_bloom* b, const uint64_t* words) { return bloom_contains_k(b, kload(words, b->W)); }
 /* BloomNeighborCoherent::contains4: bit nt of the result <=> neighbour with base code nt present */
-unsigned lo_bloom_contains4(const lo_bloom* b, uint64_t item, int right) {
+static unsigned bloom_contains4_k(const lo_bloom* b, kmer_t item, int right) {
     uint32_t k = b->k;
-    uint64_t elem = right ? ((item << 2) & b->kmer_mask) : (item >> 2);
-    uint64_t hashpart = (elem >> 2) & b->maskkm2;
-    uint64_t rev = lo_revcomp(hashpart, k - 2);
+    kmer_t elem = right ? ((item << 2) & b->kmer_mask) : (item >> 2);
+    kmer_t hashpart = (elem >> 2) & b->maskkm2;
+    kmer_t rev = revcomp_k(hashpart, k - 2);
     if (rev < hashpart) hashpart = rev;
-    uint64_t racine = lo_hash64(hashpart, b->seed0) % b->reduced_tai;
+    uint64_t racine = hash1_k(hashpart, b->W, b->seed0) % b->reduced_tai;
     uint64_t keys[16];
-    for (uint32_t i = 1; i < b->n_hash; i++) keys[i] = simplehash16(hashpart, (int)i) & b->mask_block;
+    for (uint32_t i = 1; i < b->n_hash; i++) keys[i] = simplehash16((uint64_t)hashpart, (int)i) & b->mask_block;
     unsigned res = 0;
     for (uint64_t nt = 0; nt < 4; nt++) {
-        uint64_t tmp = right ? (elem + nt) : (elem + (nt << ((k - 1) * 2)));
-        uint64_t suffix = tmp & 3;
-        uint64_t prefix = (tmp >> ((k - 1) * 2)) & 3;
+        kmer_t tmp = right ? (elem + nt) : (elem + ((kmer_t)nt << ((k - 1) * 2)));
+        uint64_t suffix = (uint64_t)(tmp & 3);
+        uint64_t prefix = (uint64_t)((tmp >> ((k - 1) * 2)) & 3);
         uint64_t h0 = racine + (cano2[(prefix << 2) + suffix] & b->mask_block);
         int ok = (b->blooma[h0 >> 3] & bit_mask[h0 & 7]) != 0;
         for (uint32_t i = 1; ok && i < b->n_hash; i++) {
@@ -198,6 +228,8 @@ unsigned lo_bloom_contains4(const lo_bloom* b, uint64_t item, int right) {
     }
     return res;
 }
+unsigned lo_bloom_contains4(const lo_bloom* b, uint64_t item, int right) { return bloom_contains4_k(b, (kmer_t)item, right); }
+unsigned lo_bloom_contains4_w(const lo_bloom* b, const uint64_t* words, int right) { return bloom_contains4_k(b, kload(words, b->W), right); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* RangeCoder.cpp: Order0Model, RangeEncoder, RangeDecoder                                     */
@@ -330,41 +362,42 @@ static void dm_start_block(dnamodels* d) {                    /* AbstractDnaCode
 }
 
 /* AbstractDnaCoder::codeSeedBin */
-static inline uint64_t code_seed(uint64_t kmer, int nt, int right, uint32_t k) {
-    if (right) return ((kmer << 2) | (uint64_t)nt) & ((1ULL << (2 * k)) - 1);
-    return (kmer >> 2) | ((uint64_t)nt << (2 * (k - 1)));
+static inline kmer_t code_seed(kmer_t kmer, int nt, int right, uint32_t k) {
+    if (right) return ((kmer << 2) | (kmer_t)nt) & kmask(k);
+    return (kmer >> 2) | ((kmer_t)nt << (2 * (k - 1)));
 }
 
 /* ------------------------------------------------------------------------------------------ */
 /* anchor dictionary: Leon::_anchorKmers (Hash16) -- here open addressing                     */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { uint64_t* keys; uint32_t* vals; uint64_t cap, n; } amap;
-#define AMAP_EMPTY (~0ULL)
+typedef struct { kmer_t* keys; uint32_t* vals; uint64_t cap, n; } amap;
+#define AMAP_EMPTY (~(kmer_t)0)
 static inline uint64_t mix64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
 static void amap_alloc(amap* m, uint64_t cap) {
     m->cap = cap; m->n = 0;
-    m->keys = (uint64_t*)malloc(cap * 8); m->vals = (uint32_t*)malloc(cap * 4);
+    m->keys = (kmer_t*)malloc(cap * sizeof(kmer_t)); m->vals = (uint32_t*)malloc(cap * 4);
     for (uint64_t i = 0; i < cap; i++) m->keys[i] = AMAP_EMPTY;
 }
-static int amap_get(const amap* m, uint64_t key, uint32_t* val) {
-    uint64_t i = mix64(key) & (m->cap - 1);
+static inline uint64_t khash(kmer_t key) { return mix64((uint64_t)key ^ mix64((uint64_t)(key >> 64) + 0x9E3779B97F4A7C15ULL)); }
+static int amap_get(const amap* m, kmer_t key, uint32_t* val) {
+    uint64_t i = khash(key) & (m->cap - 1);
     while (m->keys[i] != AMAP_EMPTY) {
         if (m->keys[i] == key) { *val = m->vals[i]; return 1; }
         i = (i + 1) & (m->cap - 1);
     }
     return 0;
 }
-static void amap_put(amap* m, uint64_t key, uint32_t val) {
+static void amap_put(amap* m, kmer_t key, uint32_t val) {
     if ((m->n + 1) * 2 > m->cap) {
         amap old = *m;
         amap_alloc(m, old.cap * 2);
         for (uint64_t i = 0; i < old.cap; i++) if (old.keys[i] != AMAP_EMPTY) amap_put(m, old.keys[i], old.vals[i]);
         free(old.keys); free(old.vals);
     }
-    uint64_t i = mix64(key) & (m->cap - 1);
+    uint64_t i = khash(key) & (m->cap - 1);
     while (m->keys[i] != AMAP_EMPTY) i = (i + 1) & (m->cap - 1);
     m->keys[i] = key; m->vals[i] = val; m->n++;
 }
@@ -373,7 +406,7 @@ static void amap_put(amap* m, uint64_t key, uint32_t val) {
 /* DnaEncoder + the Leon members it calls back into                                            */
 /* ------------------------------------------------------------------------------------------ */
 struct lo_encoder {
-    uint32_t k, rpb;
+    uint32_t k, rpb, W;
     const lo_bloom* bloom;
     dnamodels dm;
     rcenc rc;
@@ -388,7 +421,7 @@ struct lo_encoder {
     int32_t* tr_pos; uint32_t* tr_addr; uint8_t* tr_flags; uint64_t tr_cap;
     bytevec events;
     /* scratch */
-    uint64_t* kmers; char* seq; uint32_t* Npos; uint32_t* errPos; uint8_t* bifVal; uint8_t* bifType;
+    kmer_t* kmers; char* seq; uint32_t* Npos; uint32_t* errPos; uint8_t* bifVal; uint8_t* bifType;
     uint32_t scratch_cap;
     int finished;
 };
@@ -396,7 +429,7 @@ struct lo_encoder {
 lo_encoder* lo_encoder_new(uint32_t k, uint32_t rpb, const lo_bloom* bloom) {
     if (!bloom || bloom->k != k || rpb == 0) return NULL;
     lo_encoder* e = (lo_encoder*)calloc(1, sizeof(*e));
-    e->k = k; e->rpb = rpb; e->bloom = bloom;
+    e->k = k; e->rpb = rpb; e->bloom = bloom; e->W = KWORDS(k);
     dm_init(&e->dm);
     enc_clear(&e->rc); enc_clear(&e->arc);
     m_init(&e->anchorDictModel, 5);
@@ -415,7 +448,7 @@ void lo_encoder_free(lo_encoder* e) {
 static void scratch_reserve(lo_encoder* e, uint32_t len) {
     if (len <= e->scratch_cap) return;
     uint32_t c = len + 64;
-    e->kmers = (uint64_t*)realloc(e->kmers, (size_t)c * 8);
+    e->kmers = (kmer_t*)realloc(e->kmers, (size_t)c * sizeof(kmer_t));
     e->seq = (char*)realloc(e->seq, c);
     e->Npos = (uint32_t*)realloc(e->Npos, (size_t)c * 4);
     e->errPos = (uint32_t*)realloc(e->errPos, (size_t)c * 4);
@@ -445,16 +478,16 @@ static void write_block(lo_encoder* e) {
 }
 
 /* Leon::encodeInsertedAnchor: kmer.toString(k), one symbol per base on _anchorDictModel */
-static void encode_inserted_anchor(lo_encoder* e, uint64_t kmer) {
+static void encode_inserted_anchor(lo_encoder* e, kmer_t kmer) {
     for (uint32_t i = 0; i < e->k; i++) {
         int nt = (int)((kmer >> (2 * (e->k - 1 - i))) & 3);
         enc_encode(&e->arc, &e->anchorDictModel, (uint8_t)nt);
     }
     if (e->n_anchors == e->ak_cap) {
         e->ak_cap = e->ak_cap ? e->ak_cap * 2 : 1024;
-        e->anchor_kmers = (uint64_t*)realloc(e->anchor_kmers, e->ak_cap * 8);
+        e->anchor_kmers = (uint64_t*)realloc(e->anchor_kmers, e->ak_cap * 8 * e->W);
     }
-    e->anchor_kmers[e->n_anchors] = kmer;
+    kstore(e->anchor_kmers + e->n_anchors * e->W, e->W, kmer);          /* W words per anchor */
 }
 
 /* Leon::findAndInsertAnchor: scan [n/2, n/2+10), then [0, n/2), then [n/2+10, n) */
@@ -464,8 +497,8 @@ static int find_and_insert_anchor(lo_encoder* e, uint32_t nk, uint32_t* addr) {
     int lo[3] = { iMin, 0, iMax }, hi[3] = { iMax, iMin, (int)nk };
     for (int s = 0; s < 3; s++)
         for (int i = lo[s]; i < hi[s]; i++) {
-            uint64_t kmin = lo_canonical(e->kmers[i], e->k);
-            if (lo_bloom_contains(e->bloom, kmin)) {
+            kmer_t kmin = canonical_k(e->kmers[i], e->k);
+            if (bloom_contains_k(e->bloom, kmin)) {
                 encode_inserted_anchor(e, kmin);
                 amap_put(&e->anchors, kmin, (uint32_t)e->n_anchors);
                 *addr = (uint32_t)e->n_anchors;
@@ -512,16 +545,16 @@ int lo_encoder_add_read(lo_encoder* e, const char* orig, uint32_t len) {
     }
     uint32_t nk = len - k + 1;
     {
-        uint64_t km = 0, mask = (1ULL << (2 * k)) - 1;
+        kmer_t km = 0, mask = kmask(k);
         for (uint32_t i = 0; i < len; i++) {
-            km = ((km << 2) | (uint64_t)nt2bin(e->seq[i])) & mask;
+            km = ((km << 2) | (kmer_t)nt2bin(e->seq[i])) & mask;
             if (i + 1 >= k) e->kmers[i + 1 - k] = km;
         }
     }
     /* findExistingAnchor */
     int anchorPos = -1; uint32_t anchorAddress = 0;
     for (uint32_t i = 0; i < nk; i++)
-        if (amap_get(&e->anchors, lo_canonical(e->kmers[i], k), &anchorAddress)) { anchorPos = (int)i; break; }
+        if (amap_get(&e->anchors, canonical_k(e->kmers[i], k), &anchorAddress)) { anchorPos = (int)i; break; }
     if (anchorPos == -1) {
         anchorPos = find_and_insert_anchor(e, nk, &anchorAddress);
         if (anchorPos != -1) tflags |= 2;
@@ -543,14 +576,14 @@ int lo_encoder_add_read(lo_encoder* e, const char* orig, uint32_t len) {
         enc_encode(rc, &dm->anchorAddressDeltaType, dt); encode_numeric(rc, &dm->anchorAddress, dv);
         dm->prevAnchorAddress = anchorAddress;
 
-        uint64_t anchor = e->kmers[anchorPos];
-        int rev = anchor != lo_canonical(anchor, k);
+        kmer_t anchor = e->kmers[anchorPos];
+        int rev = anchor != canonical_k(anchor, k);
         enc_encode(rc, &dm->readAnchorRevcomp, (uint8_t)rev);
         tpos = anchorPos; taddr = anchorAddress; tflags |= (uint8_t)rev;
 
         uint32_t nBif = 0, nErr = 0;
         for (int dir = 0; dir < 2; dir++) {                   /* left walk, then right walk */
-            uint64_t kmer = anchor;
+            kmer_t kmer = anchor;
             int pos = dir == 0 ? anchorPos - 1 : anchorPos + (int)k;
             int step = dir == 0 ? -1 : 1;
             for (; pos >= 0 && pos < (int)len; pos += step) {
@@ -559,7 +592,7 @@ int lo_encoder_add_read(lo_encoder* e, const char* orig, uint32_t len) {
                 int isN = 0;
                 for (uint32_t j = 0; j < nN; j++) if ((int)e->Npos[j] == pos) { isN = 1; break; }
                 if (isN) { kmer = code_seed(kmer, nextBin, dir, k); continue; }
-                unsigned res4 = lo_bloom_contains4(e->bloom, kmer, dir);
+                unsigned res4 = bloom_contains4_k(e->bloom, kmer, dir);
                 int cnt = 0, first = -1, second = -1, solid = 0;
                 for (int nt = 0; nt < 4; nt++)
                     if (res4 & (1u << nt)) {
@@ -652,12 +685,13 @@ uint64_t lo_encoder_n_symbols(const lo_encoder* e) { return e->rc.n_sym; }
 /* ------------------------------------------------------------------------------------------ */
 int lo_decode_anchor_dict(const uint8_t* payload, uint64_t size, uint64_t n_anchors, uint32_t k, uint64_t* out) {
     rcdec d; o0model m;
+    uint32_t W = KWORDS(k);
     dec_init(&d, payload, size);
     m_init(&m, 5);
     for (uint64_t a = 0; a < n_anchors; a++) {
-        uint64_t km = 0;
-        for (uint32_t i = 0; i < k; i++) km = (km << 2) | (dec_next(&d, &m) & 3);
-        out[a] = km;
+        kmer_t km = 0;
+        for (uint32_t i = 0; i < k; i++) km = (km << 2) | (kmer_t)(dec_next(&d, &m) & 3);
+        kstore(out + a * W, W, km);                               /* W words per anchor */
     }
     return 0;
 }
@@ -706,12 +740,12 @@ int64_t lo_decode_block(uint32_t k, const lo_bloom* bloom, const uint64_t* ancho
         prev = 0;
         for (uint64_t i = 0; i < nErr; i++) { prev += decode_numeric(&d, &dm.leftErrorPos); errPos[i] = (uint32_t)prev; }
 
-        uint64_t anchor = anchors[addr];
-        if (rev) anchor = lo_revcomp(anchor, k);
+        kmer_t anchor = kload(anchors + addr * KWORDS(k), KWORDS(k));
+        if (rev) anchor = revcomp_k(anchor, k);
         char* s = out + w;
         for (uint32_t i = 0; i < k; i++) s[apos + i] = BIN2NT[(anchor >> (2 * (k - 1 - i))) & 3];
         for (int dir = 0; dir < 2; dir++) {                   /* DnaDecoder::extendAnchor */
-            uint64_t kmer = anchor;
+            kmer_t kmer = anchor;
             int pos = dir == 0 ? (int)apos - 1 : (int)apos + (int)k;
             int step = dir == 0 ? -1 : 1;
             for (; pos >= 0 && pos < (int)len; pos += step) {
@@ -720,7 +754,7 @@ int64_t lo_decode_block(uint32_t k, const lo_bloom* bloom, const uint64_t* ancho
                     kmer = code_seed(kmer, 0, dir, k);
                     continue;
                 }
-                unsigned res4 = lo_bloom_contains4(bloom, kmer, dir);
+                unsigned res4 = bloom_contains4_k(bloom, kmer, dir);
                 int cnt = 0, first = -1, second = -1;
                 for (int nt = 0; nt < 4; nt++)
                     if (res4 & (1u << nt)) { cnt++; if (first < 0) first = nt; else if (second < 0) second = nt; }
@@ -752,32 +786,33 @@ int64_t lo_decode_block(uint32_t k, const lo_bloom* bloom, const uint64_t* ancho
 /* ------------------------------------------------------------------------------------------ */
 /* exact canonical k-mer counting (test stand-in for DSK)                                      */
 /* ------------------------------------------------------------------------------------------ */
-static int cmp_u64(const void* a, const void* b) {
-    uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+static int cmp_kmer(const void* a, const void* b) {
+    kmer_t x = *(const kmer_t*)a, y = *(const kmer_t*)b;
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 uint64_t lo_count_solid(const char* bases, const uint64_t* off, uint64_t n_reads, uint32_t k,
-                        uint32_t min_abundance, uint64_t* out, uint64_t out_cap) {
+                        uint32_t min_abundance, uint64_t* out, uint64_t out_cap) {      /* out: W words per k-mer */
     uint64_t total = 0;
+    uint32_t W = KWORDS(k);
     for (uint64_t r = 0; r < n_reads; r++) { uint64_t l = off[r + 1] - off[r]; if (l >= k) total += l - k + 1; }
-    uint64_t* all = (uint64_t*)malloc((total ? total : 1) * 8);
-    uint64_t n = 0, mask = (1ULL << (2 * k)) - 1;
+    kmer_t* all = (kmer_t*)malloc((total ? total : 1) * sizeof(kmer_t));
+    uint64_t n = 0; kmer_t mask = kmask(k);
     for (uint64_t r = 0; r < n_reads; r++) {
         const char* s = bases + off[r]; uint64_t l = off[r + 1] - off[r];
-        uint64_t km = 0; uint32_t valid = 0;
+        kmer_t km = 0; uint32_t valid = 0;
         for (uint64_t i = 0; i < l; i++) {
             int c = nt2bin(s[i]);
             if (c == 4) { valid = 0; km = 0; continue; }       /* DSK skips k-mers containing N */
-            km = ((km << 2) | (uint64_t)c) & mask;
-            if (++valid >= k) all[n++] = lo_canonical(km, k);
+            km = ((km << 2) | (kmer_t)c) & mask;
+            if (++valid >= k) all[n++] = canonical_k(km, k);
         }
     }
-    qsort(all, n, 8, cmp_u64);
+    qsort(all, n, sizeof(kmer_t), cmp_kmer);
     uint64_t ns = 0;
     for (uint64_t i = 0; i < n;) {
         uint64_t j = i;
         while (j < n && all[j] == all[i]) j++;
-        if (j - i >= min_abundance) { if (out && ns < out_cap) out[ns] = all[i]; ns++; }
+        if (j - i >= min_abundance) { if (out && ns < out_cap) kstore(out + ns * W, W, all[i]); ns++; }
         i = j;
     }
     free(all);

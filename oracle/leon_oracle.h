@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-/* ---- k-mer helpers (k <= 31, one 64-bit word) ---- */
+/* ---- k-mer helpers.  k <= 31: one 64-bit word per k-mer; 32 <= k <= 63: two words (low, high), as upstream's
+ * LargeInt<2>.  Arrays of k-mers hold W = (k >= 32 ? 2 : 1) words per k-mer. ---- */
 uint64_t lo_revcomp(uint64_t kmer, uint32_t k);
 uint64_t lo_canonical(uint64_t kmer, uint32_t k);
 uint64_t lo_hash64(uint64_t key, uint64_t seed);      /* NativeInt64 hash1 */
@@ -47,6 +48,8 @@ void      lo_bloom_free(lo_bloom* b);
 void      lo_bloom_insert(lo_bloom* b, const uint64_t* kmers, uint64_t n);
 int       lo_bloom_contains(const lo_bloom* b, uint64_t kmer);
 unsigned  lo_bloom_contains4(const lo_bloom* b, uint64_t kmer, int right);
+int       lo_bloom_contains_w(const lo_bloom* b, const uint64_t* words);
+unsigned  lo_bloom_contains4_w(const lo_bloom* b, const uint64_t* words, int right);
 uint8_t*  lo_bloom_bits(lo_bloom* b);
 uint64_t  lo_bloom_nbytes(const lo_bloom* b);
 uint64_t  lo_bloom_tai(const lo_bloom* b);            /* after the power-of-two adjustment */

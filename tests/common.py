@@ -24,7 +24,7 @@ def synthetic(n_reads, read_len, genome_len, seed=1, **kw):
 
 def make_bloom(bases, off, k, min_abundance=3, n_hash=7, block_nbits=12):
     solid = O.count_solid(bases, off, k, min_abundance)
-    tai = max(len(solid) * NB_BITS_PER_KMER, 1000)
+    tai = max(len(solid) // O.kwords(k) * NB_BITS_PER_KMER, 1000)
     bl = O.Bloom(tai, k, n_hash, block_nbits)
     bl.insert(solid)
     return bl, solid, tai

@@ -37,6 +37,8 @@ def _load():
         "lo_bloom_insert": (None, [C.c_void_p, u64p, C.c_uint64]),
         "lo_bloom_contains": (C.c_int, [C.c_void_p, C.c_uint64]),
         "lo_bloom_contains4": (C.c_uint, [C.c_void_p, C.c_uint64, C.c_int]),
+        "lo_bloom_contains_w": (C.c_int, [C.c_void_p, u64p]),
+        "lo_bloom_contains4_w": (C.c_uint, [C.c_void_p, u64p, C.c_int]),
         "lo_bloom_bits": (u8p, [C.c_void_p]),
         "lo_bloom_nbytes": (C.c_uint64, [C.c_void_p]),
         "lo_bloom_tai": (C.c_uint64, [C.c_void_p]),
@@ -85,6 +87,24 @@ def _copy(ptr, n, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
 
 
+def kwords(k):
+    """64-bit words per k-mer: upstream's LargeInt<1> below k = 32, LargeInt<2> for 32 <= k < 64"""
+    return 2 if k >= 32 else 1
+
+
+def kmer_words(x, k):
+    """python int k-mer -> uint64 array of kwords(k) words (low word first)"""
+    x = int(x)
+    return np.array([x & 0xFFFFFFFFFFFFFFFF, x >> 64][:kwords(k)], dtype=np.uint64)
+
+
+def kmers_to_ints(words, k):
+    """flat word array (kwords(k) per k-mer) -> list of python ints"""
+    w = kwords(k)
+    a = np.asarray(words, dtype=np.uint64).reshape(-1, w)
+    return [int(r[0]) | (int(r[1]) << 64 if w == 2 else 0) for r in a]
+
+
 def reads_to_arrays(reads):
     """list of str/bytes -> (bases bytes, offsets uint64[n+1])"""
     bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
@@ -102,14 +122,17 @@ class Bloom:
         self.k, self.n_hash, self.block_nbits, self.tai_bloom = k, n_hash, block_nbits, int(tai_bloom)
 
     def insert(self, kmers):
-        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
-        lib.lo_bloom_insert(self.h, _p(kmers, u64p), len(kmers))
+        """kmers: flat uint64 array, kwords(k) words per k-mer"""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
+        lib.lo_bloom_insert(self.h, _p(kmers, u64p), len(kmers) // kwords(self.k))
 
     def contains(self, kmer):
-        return bool(lib.lo_bloom_contains(self.h, int(kmer)))
+        w = kmer_words(kmer, self.k)
+        return bool(lib.lo_bloom_contains_w(self.h, _p(w, u64p)))
 
     def contains4(self, kmer, right):
-        return int(lib.lo_bloom_contains4(self.h, int(kmer), int(right)))
+        w = kmer_words(kmer, self.k)
+        return int(lib.lo_bloom_contains4_w(self.h, _p(w, u64p), int(right)))
 
     @property
     def bits(self):
@@ -164,7 +187,7 @@ def encode(bases, offsets, k, reads_per_block, bloom, trace=True):
         p = lib.lo_encoder_anchor_dict(e, C.byref(sz), C.byref(na))
         res.anchor_dict = _copy(p, sz.value, np.uint8).tobytes()
         res.n_anchors = na.value
-        res.anchor_kmers = _copy(lib.lo_encoder_anchor_kmers(e), na.value, np.uint64)
+        res.anchor_kmers = _copy(lib.lo_encoder_anchor_kmers(e), na.value * kwords(k), np.uint64)
         res.n_symbols = lib.lo_encoder_n_symbols(e)
         if trace:
             res.anchor_pos = _copy(lib.lo_encoder_read_anchor_pos(e), n, np.int32)
@@ -179,19 +202,20 @@ def encode(bases, offsets, k, reads_per_block, bloom, trace=True):
 
 
 def decode_anchor_dict(payload, n_anchors, k):
-    out = np.zeros(max(n_anchors, 1), dtype=np.uint64)
+    w = kwords(k)
+    out = np.zeros(max(n_anchors, 1) * w, dtype=np.uint64)
     buf = np.frombuffer(payload, dtype=np.uint8)
     lib.lo_decode_anchor_dict(_p(buf, u8p), len(buf), n_anchors, k, _p(out, u64p))
-    return out[:n_anchors]
+    return out[:n_anchors * w]
 
 
 def decode_block(k, bloom, anchors, payload, n_reads, max_bases):
-    anchors = np.ascontiguousarray(anchors, dtype=np.uint64)
+    anchors = np.ascontiguousarray(anchors, dtype=np.uint64).reshape(-1)
     if len(anchors) == 0:
-        anchors = np.zeros(1, dtype=np.uint64)
+        anchors = np.zeros(2, dtype=np.uint64)
         na = 0
     else:
-        na = len(anchors)
+        na = len(anchors) // kwords(k)
     buf = np.frombuffer(payload, dtype=np.uint8)
     out = C.create_string_buffer(int(max_bases) + 1)
     lens = np.zeros(max(n_reads, 1), dtype=np.uint32)
@@ -210,10 +234,11 @@ def decode_block(k, bloom, anchors, payload, n_reads, max_bases):
 def count_solid(bases, offsets, k, min_abundance):
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
+    w = kwords(k)
     ns = lib.lo_count_solid(bases, _p(offsets, u64p), n, k, min_abundance, None, 0)
-    out = np.zeros(max(ns, 1), dtype=np.uint64)
+    out = np.zeros(max(ns, 1) * w, dtype=np.uint64)
     lib.lo_count_solid(bases, _p(offsets, u64p), n, k, min_abundance, _p(out, u64p), ns)
-    return out[:ns]
+    return out[:ns * w]                      # kwords(k) words per k-mer
 
 
 def rc_encode_stream(models, syms, model_sizes):

@@ -188,3 +188,30 @@ def test_edge_reads_roundtrip():
     for payload, nr in zip(res.blocks, res.block_nreads):
         out += O.decode_block(k, bl, anchors, payload, nr, 10000)
     assert out == reads
+
+
+@pytest.mark.parametrize("k", [32, 47, 63])
+def test_two_word_kmers_roundtrip(k):
+    """32 <= k <= 63: LargeInt<2> k-mers (config 5 of BASELINE.json uses k = 63)"""
+    bases, off = common.synthetic(1500, 250, 12000, seed=70 + k, n_rate=0.001)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    assert len(solid) % 2 == 0 and O.kwords(k) == 2
+    ints = O.kmers_to_ints(solid, k)
+    for x in ints[:50]:
+        assert x < (1 << (2 * k)) and bl.contains(x)
+        rc = 0
+        y = x
+        for _ in range(k):
+            rc = (rc << 2) | ((y & 3) ^ 2)
+            y >>= 2
+        assert bl.contains(rc) and x <= rc                          # canonical, strand-symmetric bloom
+    res = O.encode(bases, off, k, 400, bl)
+    assert (res.anchor_pos >= 0).sum() > 1000
+    anchors = O.decode_anchor_dict(res.anchor_dict, res.n_anchors, k)
+    assert np.array_equal(anchors, res.anchor_kmers)
+    r = 0
+    for payload, nr in zip(res.blocks, res.block_nreads):
+        for j, d in enumerate(O.decode_block(k, bl, anchors, payload, nr, len(bases) + 16)):
+            assert d == bases[int(off[r + j]):int(off[r + j + 1])]
+        r += nr
+    assert r == 1500
