@@ -40,7 +40,8 @@ typedef struct leon_dna_ctx leon_dna_ctx;
  * shared IBloom<kmer_type>* created by Leon::createBloom (BloomFactory BLOOM_NEIGHBOR, 7 hashes). */
 typedef struct leon_dna_cfg {
     uint32_t struct_size;        /* sizeof(leon_dna_cfg) */
-    uint32_t kmer_size;          /* 3..31 (one 64-bit word; k <= 63 is a later row) */
+    uint32_t kmer_size;          /* 3..63.  k-mers cross this ABI as W 64-bit words each, low word first:
+                                    W = 1 below 32 (upstream LargeInt<1>), W = 2 from 32 to 63 (LargeInt<2>) */
     uint32_t reads_per_block;    /* Leon::READ_PER_BLOCK, 50000 */
     uint32_t bloom_n_hash;       /* 7 */
     uint32_t bloom_block_nbits;  /* BloomCacheCoherent block_nbits, 12 */
@@ -81,7 +82,7 @@ int leon_dna_bloom_nbytes(const leon_dna_ctx* ctx, uint64_t* nbytes);          /
 int leon_dna_bloom_upload(leon_dna_ctx* ctx, const uint8_t* bits, uint64_t nbytes);   /* StorageTools::loadBloom */
 int leon_dna_bloom_download(leon_dna_ctx* ctx, uint8_t* bits, uint64_t nbytes);       /* StorageTools::saveBloom */
 int leon_dna_bloom_clear(leon_dna_ctx* ctx);
-int leon_dna_bloom_insert(leon_dna_ctx* ctx, const uint64_t* kmers, uint64_t n);      /* host k-mers, IBloom::insert */
+int leon_dna_bloom_insert(leon_dna_ctx* ctx, const uint64_t* kmers, uint64_t n);      /* n host k-mers (n*W words), IBloom::insert */
 int leon_dna_bloom_insert_device(leon_dna_ctx* ctx, const uint64_t* d_kmers, uint64_t n);
 int leon_dna_bloom_device_ptr(leon_dna_ctx* ctx, void** d_bits, uint64_t* nbytes);    /* for an RCCL broadcast */
 /* device-to-device forms of upload/download: the bloom travels between GPUs over xGMI, never via the host */

@@ -97,14 +97,21 @@ def _ptr(a, t):
     return a.ctypes.data_as(t)
 
 
+def kmer_words(k):
+    """64-bit words per k-mer at the C-ABI: 1 below k = 32, 2 from 32 to 63"""
+    return 2 if k >= 32 else 1
+
+
 def host_anchor_dict_encode(kmers, k):
-    """the dictionary stream for a list of anchors (host-only entry point; runs without a GPU)"""
+    """the dictionary stream for a list of anchors (host-only entry point; runs without a GPU).
+    kmers: flat uint64 array, kmer_words(k) words per anchor."""
     lib = load_library()
-    kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
-    cap = len(kmers) * k + 64
+    kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
+    n = len(kmers) // kmer_words(k)
+    cap = n * k + 64
     out = np.zeros(cap, dtype=np.uint8)
     size = C.c_uint64()
-    rc = lib.leon_host_anchor_dict_encode(_ptr(kmers, _u64p), len(kmers), k, _ptr(out, _u8p), cap, C.byref(size))
+    rc = lib.leon_host_anchor_dict_encode(_ptr(kmers, _u64p), n, k, _ptr(out, _u8p), cap, C.byref(size))
     if rc:
         raise LeonDnaError(rc, "leon_host_anchor_dict_encode failed")
     return out[:size.value].tobytes()
@@ -167,8 +174,9 @@ class DnaEncodeContext:
         self._chk(self.lib.leon_dna_bloom_clear(self.h))
 
     def bloom_insert(self, kmers):
-        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
-        self._chk(self.lib.leon_dna_bloom_insert(self.h, _ptr(kmers, _u64p), len(kmers)))
+        """kmers: flat uint64 array, kmer_words(k) words per k-mer"""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
+        self._chk(self.lib.leon_dna_bloom_insert(self.h, _ptr(kmers, _u64p), len(kmers) // kmer_words(self.kmer_size)))
 
     def bloom_insert_device(self, dev_ptr, n):
         self._chk(self.lib.leon_dna_bloom_insert_device(self.h, C.c_void_p(int(dev_ptr)), int(n)))
@@ -185,15 +193,17 @@ class DnaEncodeContext:
         self._chk(self.lib.leon_dna_bloom_download_device(self.h, C.c_void_p(int(dev_ptr)), int(n)))
 
     def bloom_contains4(self, kmers, right):
-        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
-        out = np.zeros(len(kmers), dtype=np.uint8)
-        self._chk(self.lib.leon_dna_bloom_contains4(self.h, _ptr(kmers, _u64p), len(kmers), int(right), _ptr(out, _u8p)))
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
+        n = len(kmers) // kmer_words(self.kmer_size)
+        out = np.zeros(n, dtype=np.uint8)
+        self._chk(self.lib.leon_dna_bloom_contains4(self.h, _ptr(kmers, _u64p), n, int(right), _ptr(out, _u8p)))
         return out
 
     def bloom_contains(self, kmers):
-        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
-        out = np.zeros(len(kmers), dtype=np.uint8)
-        self._chk(self.lib.leon_dna_bloom_contains(self.h, _ptr(kmers, _u64p), len(kmers), _ptr(out, _u8p)))
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
+        n = len(kmers) // kmer_words(self.kmer_size)
+        out = np.zeros(n, dtype=np.uint8)
+        self._chk(self.lib.leon_dna_bloom_contains(self.h, _ptr(kmers, _u64p), n, _ptr(out, _u8p)))
         return out
 
     # ---- encode ----
@@ -254,9 +264,10 @@ class DnaEncodeContext:
         return ev
 
     def anchor_kmers(self, n):
-        out = np.zeros(max(n, 1), dtype=np.uint64)
+        w = kmer_words(self.kmer_size)
+        out = np.zeros(max(n, 1) * w, dtype=np.uint64)
         self._chk(self.lib.leon_dna_anchor_kmers(self.h, _ptr(out, _u64p), n))
-        return out[:n]
+        return out[:n * w]
 
     def rc_encode_streams(self, syms, begin):
         """syms: uint8[2*n] (model, value) pairs; begin: uint64[n_streams+1].  Returns list of payload bytes."""

@@ -46,16 +46,6 @@ uint64_t hash_seed0() {                  // HashFunctors::generate_hash_seed, se
     return r0 * r3;
 }
 
-// anchor k-mers -> the dictionary stream's symbols: k bases per anchor, first base first, on the 5-ary model
-__global__ void k_anchor_symbols(const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms) {
-    const uint64_t total = n_anchors * k;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t a = i / k; const uint32_t j = (uint32_t)(i % k);
-        syms[2 * i] = (uint8_t)M_NOANCHOR_READ;               // any 5-symbol Order0Model: _anchorDictModel(5)
-        syms[2 * i + 1] = (uint8_t)((kmers[a] >> (2 * (k - 1 - j))) & 3u);
-    }
-}
-
 __global__ void k_iota(uint32_t* v, uint64_t n) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
 }
@@ -111,13 +101,14 @@ int fail(leon_dna_ctx* c, int code, const std::string& msg) {
     } while (0)
 
 int dict_alloc(leon_dna_ctx* c, DictDev& D, uint64_t cap) {
-    HIPCHK(c, hipMalloc((void**)&D.keys, cap * 8));
+    const uint32_t W = kmer_words(c->cfg.kmer_size);
+    HIPCHK(c, hipMalloc((void**)&D.keys, cap * 8 * W));
     HIPCHK(c, hipMalloc((void**)&D.fin, cap * 8));
     HIPCHK(c, hipMalloc((void**)&D.tent, cap * 8));
     HIPCHK(c, hipMalloc((void**)&D.addr, cap * 4));
     D.mask = cap - 1;
     D.n_keys = c->d_nkeys;
-    launch_dict_init(c->stream, D, cap);
+    launch_dict_init(c->stream, D, cap, W);
     return LEON_OK;
 }
 void dict_free(DictDev& D) {
@@ -138,7 +129,7 @@ int dict_reserve(leon_dna_ctx* c, uint64_t keys) {
     int rc = dict_alloc(c, nd, need);
     if (rc) return rc;
     if (c->dict_cap) {
-        launch_dict_rehash(c->stream, c->D, c->dict_cap, nd);
+        launch_dict_rehash(c->stream, c->D, c->dict_cap, nd, c->cfg.kmer_size);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         dict_free(c->D);
     }
@@ -169,8 +160,8 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     if (!cfg || !out) return fail(nullptr, LEON_E_INVALID, "null argument");
     *out = nullptr;
     if (cfg->struct_size != sizeof(leon_dna_cfg)) return fail(nullptr, LEON_E_INVALID, "leon_dna_cfg.struct_size mismatch");
-    if (cfg->kmer_size < 3 || cfg->kmer_size > 31)
-        return fail(nullptr, LEON_E_INVALID, "kmer_size must be in 3..31 (two-word k-mers are not built yet)");
+    if (cfg->kmer_size < 3 || cfg->kmer_size > 63)
+        return fail(nullptr, LEON_E_INVALID, "kmer_size must be in 3..63 (one 64-bit word below 32, two words from 32 to 63)");
     if (cfg->reads_per_block == 0) return fail(nullptr, LEON_E_INVALID, "reads_per_block must be > 0");
     if (cfg->bloom_n_hash < 1 || cfg->bloom_n_hash > 10) return fail(nullptr, LEON_E_INVALID, "bloom_n_hash must be in 1..10");
     if (cfg->bloom_block_nbits < 4 || cfg->bloom_block_nbits > 16)
@@ -212,7 +203,6 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     CREATE_CHK(hipMemcpy(c->d_rv16, rv16, sizeof(rv16), hipMemcpyHostToDevice));
     uint32_t k = cfg->kmer_size;
     c->B.bits = c->d_bloom; c->B.reduced_tai = reduced; c->B.mod_magic = ~0ull / reduced; c->B.seed0 = hash_seed0();
-    c->B.maskkm2 = (1ull << (2 * (k - 2))) - 1; c->B.kmer_mask = (1ull << (2 * k)) - 1;
     c->B.k = k; c->B.n_hash = cfg->bloom_n_hash; c->B.block_mask = (uint32_t)(blk - 1);
     CREATE_CHK(hipMalloc((void**)&c->d_nkeys, 8));
     CREATE_CHK(hipMemset(c->d_nkeys, 0, 8));
@@ -288,8 +278,9 @@ int leon_dna_bloom_insert(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n) {
     if (!n) return LEON_OK;
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf tmp;
-    HIPCHK(c, tmp.ensure(n * 8));
-    hipError_t e = hipMemcpy(tmp.p, kmers, n * 8, hipMemcpyHostToDevice);
+    const uint64_t bytes = n * 8 * kmer_words(c->cfg.kmer_size);
+    HIPCHK(c, tmp.ensure(bytes));
+    hipError_t e = hipMemcpy(tmp.p, kmers, bytes, hipMemcpyHostToDevice);
     int rc = e == hipSuccess ? leon_dna_bloom_insert_device(c, tmp.as<uint64_t>(), n)
                              : fail(c, LEON_E_HIP, std::string("bloom_insert H2D: ") + hipGetErrorString(e));
     tmp.release();
@@ -321,9 +312,10 @@ static int bloom_query(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, int m
     if (!n) return LEON_OK;
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf dk, dout;
-    HIPCHK(c, dk.ensure(n * 8));
+    const uint64_t bytes = n * 8 * kmer_words(c->cfg.kmer_size);
+    HIPCHK(c, dk.ensure(bytes));
     HIPCHK(c, dout.ensure(n));
-    HIPCHK(c, hipMemcpy(dk.p, kmers, n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dk.p, kmers, bytes, hipMemcpyHostToDevice));
     launch_bloom_query(c->stream, c->B, c->d_rv16, dk.as<uint64_t>(), n, mode, dout.as<uint8_t>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -437,18 +429,19 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
             HIPCHK(c, hipStreamSynchronize(s));
             uint64_t n_new = (uint64_t)last_rank + last_flag;
             if (c->n_anchors + n_new > 0xFFFFFFFFull) return fail(c, LEON_E_OVERFLOW, "more than 2^32 anchors");
-            if ((c->n_anchors + n_new) * 8 > c->anchor_kmers.cap) {           // grow, keeping what is there
+            const uint64_t KW = kmer_words(k);                              // 64-bit words per anchor k-mer
+            if ((c->n_anchors + n_new) * 8 * KW > c->anchor_kmers.cap) {      // grow, keeping what is there
                 DevBuf nb;
-                HIPCHK(c, nb.ensure(std::max<uint64_t>((c->n_anchors + n_new) * 2, 1024) * 8));
-                if (c->n_anchors) HIPCHK(c, hipMemcpyAsync(nb.p, c->anchor_kmers.p, c->n_anchors * 8, hipMemcpyDeviceToDevice, s));
+                HIPCHK(c, nb.ensure(std::max<uint64_t>((c->n_anchors + n_new) * 2, 1024) * 8 * KW));
+                if (c->n_anchors) HIPCHK(c, hipMemcpyAsync(nb.p, c->anchor_kmers.p, c->n_anchors * 8 * KW, hipMemcpyDeviceToDevice, s));
                 HIPCHK(c, hipStreamSynchronize(s));
                 c->anchor_kmers.release();
                 c->anchor_kmers = nb;
             }
-            launch_assign_addr(s, c->D, V, w0, w1, c->rank.as<uint32_t>(), c->n_anchors, c->anchor_kmers.as<uint64_t>());
+            launch_assign_addr(s, c->D, V, w0, w1, c->rank.as<uint32_t>(), c->n_anchors, c->anchor_kmers.as<uint64_t>(), k);
             if (n_new && c->shard_rank == 0 && !(c->cfg.flags & LEON_F_DICT_ON_DEVICE)) {   // the window's new anchors go straight to the host thread coding the dictionary stream
-                std::vector<uint64_t> fresh(n_new);
-                HIPCHK(c, hipMemcpyAsync(fresh.data(), c->anchor_kmers.as<uint64_t>() + c->n_anchors, n_new * 8, hipMemcpyDeviceToHost, s));
+                std::vector<uint64_t> fresh(n_new * KW);
+                HIPCHK(c, hipMemcpyAsync(fresh.data(), c->anchor_kmers.as<uint64_t>() + c->n_anchors * KW, n_new * 8 * KW, hipMemcpyDeviceToHost, s));
                 HIPCHK(c, hipStreamSynchronize(s));
                 c->anchor_worker->push(std::move(fresh));
             }
@@ -611,8 +604,7 @@ int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, ui
                 HIPCHK(c, dout.ensure(off[1] + 64)); HIPCHK(c, dscr.ensure(rc_model_scratch_bytes(1)));
                 HIPCHK(c, hipMemcpy(dbegin.p, begin, 16, hipMemcpyHostToDevice));
                 HIPCHK(c, hipMemcpy(doff.p, off, 16, hipMemcpyHostToDevice));
-                if (nsym) hipLaunchKernelGGL(k_anchor_symbols, dim3((uint32_t)std::min<uint64_t>((nsym + 255) / 256, 8192)), dim3(256), 0, s,
-                                             c->anchor_kmers.as<uint64_t>(), c->n_anchors, c->cfg.kmer_size, dsyms.as<uint8_t>());
+                launch_anchor_symbols(s, c->anchor_kmers.as<uint64_t>(), c->n_anchors, c->cfg.kmer_size, dsyms.as<uint8_t>());
                 HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
                 launch_rc_encode(s, dsyms.as<uint8_t>(), dbegin.as<uint64_t>(), 1, dout.as<uint8_t>(), doff.as<uint64_t>(), dsize.as<uint64_t>(),
                                  dscr.as<uint32_t>(), c->errflag.as<int>());
@@ -661,7 +653,7 @@ int leon_dna_reset_stream(leon_dna_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->dict_cap) {
         HIPCHK(c, hipMemsetAsync(c->d_nkeys, 0, 8, c->stream));
-        launch_dict_init(c->stream, c->D, c->dict_cap);
+        launch_dict_init(c->stream, c->D, c->dict_cap, kmer_words(c->cfg.kmer_size));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->n_keys = 0; c->n_anchors = 0;
@@ -699,15 +691,16 @@ int leon_dna_anchor_kmers(leon_dna_ctx* c, uint64_t* kmers, uint64_t n) {
     if (!c || (!kmers && n)) return LEON_E_INVALID;
     if (n > c->n_anchors) return fail(c, LEON_E_INVALID, "more anchors requested than exist");
     HIPCHK(c, hipSetDevice(c->device));
-    if (n) HIPCHK(c, hipMemcpy(kmers, c->anchor_kmers.p, n * 8, hipMemcpyDeviceToHost));
+    if (n) HIPCHK(c, hipMemcpy(kmers, c->anchor_kmers.p, n * 8 * kmer_words(c->cfg.kmer_size), hipMemcpyDeviceToHost));
     return LEON_OK;
 }
 
 // host-only: the dictionary stream of a list of anchors (what the worker thread produces); no GPU involved
 int leon_host_anchor_dict_encode(const uint64_t* kmers, uint64_t n, uint32_t k, uint8_t* out, uint64_t out_cap, uint64_t* size) {
-    if ((!kmers && n) || !size || k < 1 || k > 31) return LEON_E_INVALID;
+    if ((!kmers && n) || !size || k < 1 || k > 63) return LEON_E_INVALID;
     AnchorDictCoder coder;
-    for (uint64_t i = 0; i < n; i++) coder.encode_kmer(kmers[i], k);
+    const uint32_t W = kmer_words(k);
+    for (uint64_t i = 0; i < n; i++) coder.encode_kmer(kmers + i * W, k);
     coder.flush();
     *size = coder.size();
     if (coder.size() > out_cap) return LEON_E_OVERFLOW;

@@ -1,6 +1,8 @@
 // dna_kernels.hip -- gfx950 kernels of Leon's DNA encode path, everything except the range coder.
 // Upstream functions named in comments are gatb-core names [RECALLED]; the source
 // is absent from /root/reference, so there is no file:line to cite.
+// Kernels that touch k-mers are templates on the k-mer type K (uint64_t for k < 32, unsigned __int128 for
+// 32 <= k < 64); the launchers pick the instance from k.
 #include "kernels.h"
 
 namespace leon {
@@ -11,45 +13,44 @@ static inline uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap
     if (g > cap) g = cap;
     return (uint32_t)g;
 }
+#define DISPATCH_K(k, CALL) do { if ((k) >= 32) { typedef u128 K; CALL; } else { typedef uint64_t K; CALL; } } while (0)
 
 // ================================================================================================
-// bloom: BloomNeighborCoherent::insert / contains / contains4
+// bloom: BloomNeighborCoherent::insert / contains / contains4      (k-mers: W words each, low word first)
 // ================================================================================================
+template <typename K>
 __global__ void __launch_bounds__(256) k_bloom_insert(BloomDev B, const uint16_t* rv16g, const uint64_t* kmers, uint64_t n) {
     __shared__ uint16_t rv16[256];
     load_rv16(rv16, rv16g);
     uint32_t* words = (uint32_t*)B.bits;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t item = kmers[i];
-        uint32_t k = B.k;
-        uint32_t pv = cano2((uint32_t)(((item >> (2 * (k - 1))) & 3) << 2 | (item & 3)));
-        uint64_t hp = (item >> 2) & B.maskkm2;
-        BloomKeys K;
-        bloom_keys(B, rv16, hp, revcomp64(hp, k - 2), K);
+        BloomKeys Kk;
+        const uint32_t pv = bloom_item_keys<K>(B, rv16, load_kmer<K>(kmers + i * KT<K>::W), Kk);
         for (uint32_t h = 0; h < B.n_hash; h++) {
-            uint64_t pos = K.racine + K.key[h] + pv;
+            uint64_t pos = Kk.racine + Kk.key[h] + pv;
             atomicOr(&words[pos >> 5], 1u << (pos & 31));
         }
     }
 }
 void launch_bloom_insert(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* kmers, uint64_t n) {
     if (!n) return;
-    hipLaunchKernelGGL(k_bloom_insert, dim3(grid_for(n, 256)), dim3(256), 0, s, B, rv16, kmers, n);
+    DISPATCH_K(B.k, hipLaunchKernelGGL(k_bloom_insert<K>, dim3(grid_for(n, 256)), dim3(256), 0, s, B, rv16, kmers, n));
 }
 
+template <typename K>
 __global__ void __launch_bounds__(256) k_bloom_query(BloomDev B, const uint16_t* rv16g, const uint64_t* kmers, uint64_t n,
                                                     int mode, uint8_t* out) {
     __shared__ uint16_t rv16[256];
     load_rv16(rv16, rv16g);
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t km = kmers[i];
-        if (mode == 0) out[i] = bloom_contains(B, rv16, km) ? 1 : 0;
-        else out[i] = (uint8_t)bloom_contains4(B, rv16, km, revcomp64(km, B.k), mode == 2);
+        const K km = load_kmer<K>(kmers + i * KT<K>::W);
+        if (mode == 0) out[i] = bloom_contains<K>(B, rv16, km) ? 1 : 0;
+        else out[i] = (uint8_t)bloom_contains4<K>(B, rv16, km, revcomp(km, B.k), mode == 2);
     }
 }
 void launch_bloom_query(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* kmers, uint64_t n, int mode, uint8_t* out) {
     if (!n) return;
-    hipLaunchKernelGGL(k_bloom_query, dim3(grid_for(n, 256)), dim3(256), 0, s, B, rv16, kmers, n, mode, out);
+    DISPATCH_K(B.k, hipLaunchKernelGGL(k_bloom_query<K>, dim3(grid_for(n, 256)), dim3(256), 0, s, B, rv16, kmers, n, mode, out));
 }
 
 // ================================================================================================
@@ -109,20 +110,26 @@ void launch_pack(hipStream_t s, const uint8_t* bases, const uint64_t* off, const
     hipLaunchKernelGGL(k_pack, dim3(grid_for(n, 4, 256 * 64)), dim3(256), 0, s, bases, off, slot_off, n, packed, nmask, len, ncount);
 }
 
+
 // ================================================================================================
 // anchor dictionary (Leon::anchorExist / findAndInsertAnchor with sequential, -nb-cores 1 semantics)
+// One-word keys: keys[slot], KEY_EMPTY when free.  Two-word keys: keys[2*slot] = low, keys[2*slot+1] = high word;
+// the high word (< 2^62 for a real k-mer) doubles as the claim word: KEY_EMPTY free, KEY_LOCKED while the low word is written.
 // ================================================================================================
-__global__ void k_dict_init(DictDev D, uint64_t cap) {
+__global__ void k_dict_init(DictDev D, uint64_t cap, uint32_t W) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
-        D.keys[i] = KEY_EMPTY; D.fin[i] = IDX_INF; D.tent[i] = IDX_INF; D.addr[i] = 0;
+        D.keys[i * W] = KEY_EMPTY; if (W == 2) D.keys[i * 2 + 1] = KEY_EMPTY;
+        D.fin[i] = IDX_INF; D.tent[i] = IDX_INF; D.addr[i] = 0;
     }
 }
-void launch_dict_init(hipStream_t s, DictDev D, uint64_t cap) {
-    hipLaunchKernelGGL(k_dict_init, dim3(grid_for(cap, 256)), dim3(256), 0, s, D, cap);
+void launch_dict_init(hipStream_t s, DictDev D, uint64_t cap, uint32_t W) {
+    hipLaunchKernelGGL(k_dict_init, dim3(grid_for(cap, 256)), dim3(256), 0, s, D, cap, W);
 }
 
-__device__ inline uint32_t dict_find(const DictDev& D, uint64_t key) {       // 0xFFFFFFFF if absent
-    uint64_t slot = mix64(key) & D.mask;
+// ---- look-up (any lane; 0xFFFFFFFF if absent).  A key being inserted by the running kernel may be missed: such a
+// key is only proposed (fin = INF), so missing it changes nothing.
+__device__ inline uint32_t dict_find(const DictDev& D, uint64_t key) {
+    uint64_t slot = key_hash(key) & D.mask;
     for (;;) {
         uint64_t cur = D.keys[slot];
         if (cur == key) return (uint32_t)slot;
@@ -130,8 +137,20 @@ __device__ inline uint32_t dict_find(const DictDev& D, uint64_t key) {       // 
         slot = (slot + 1) & D.mask;
     }
 }
-__device__ inline uint32_t dict_find_or_insert(const DictDev& D, uint64_t key) {
-    uint64_t slot = mix64(key) & D.mask;
+__device__ inline uint32_t dict_find(const DictDev& D, u128 key) {
+    const uint64_t klo = (uint64_t)key, khi = (uint64_t)(key >> 64);
+    uint64_t slot = key_hash(key) & D.mask;
+    for (;;) {
+        const uint64_t hi = D.keys[2 * slot + 1];
+        if (hi == KEY_EMPTY) return 0xFFFFFFFFu;
+        if (hi == khi && D.keys[2 * slot] == klo) return (uint32_t)slot;
+        slot = (slot + 1) & D.mask;
+    }
+}
+// ---- find or insert.  SPIN = true: called by ONE lane per wave (a lane may wait for another wave's insert to
+// complete); SPIN = false: the keys being inserted are all distinct (rehash), a locked slot is someone else's.
+template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDev& D, uint64_t key) {
+    uint64_t slot = key_hash(key) & D.mask;
     for (;;) {
         uint64_t cur = D.keys[slot];
         if (cur == key) return (uint32_t)slot;
@@ -143,51 +162,84 @@ __device__ inline uint32_t dict_find_or_insert(const DictDev& D, uint64_t key) {
         slot = (slot + 1) & D.mask;
     }
 }
-__global__ void k_dict_rehash(DictDev from, uint64_t from_cap, DictDev to) {
+template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDev& D, u128 key) {
+    const uint64_t klo = (uint64_t)key, khi = (uint64_t)(key >> 64);
+    uint64_t slot = key_hash(key) & D.mask;
+    for (;;) {
+        uint64_t* phi = &D.keys[2 * slot + 1];
+        uint64_t hi = __hip_atomic_load(phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hi == KEY_EMPTY) {
+            hi = atomicCAS((unsigned long long*)phi, (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_LOCKED);
+            if (hi == KEY_EMPTY) {                                       // ours: low word first, then publish the high word
+                __hip_atomic_store(&D.keys[2 * slot], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(phi, khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(D.n_keys, 1ull);
+                return (uint32_t)slot;
+            }
+        }
+        if (SPIN) {
+            for (uint32_t spin = 0; hi == KEY_LOCKED && spin < (1u << 20); spin++) {
+                __builtin_amdgcn_s_sleep(1);
+                hi = __hip_atomic_load(phi, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (hi == khi && __hip_atomic_load(&D.keys[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == klo) return (uint32_t)slot;
+        slot = (slot + 1) & D.mask;
+    }
+}
+template <typename K> __device__ inline K dict_key(const DictDev& D, uint32_t slot);
+template <> __device__ inline uint64_t dict_key<uint64_t>(const DictDev& D, uint32_t slot) { return D.keys[slot]; }
+template <> __device__ inline u128 dict_key<u128>(const DictDev& D, uint32_t slot) { return ((u128)D.keys[2 * (uint64_t)slot + 1] << 64) | D.keys[2 * (uint64_t)slot]; }
+
+template <typename K> __global__ void k_dict_rehash(DictDev from, uint64_t from_cap, DictDev to) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < from_cap; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t key = from.keys[i];
-        if (key == KEY_EMPTY) continue;
-        uint32_t s = dict_find_or_insert(to, key);
+        if (from.keys[i * KT<K>::W + (KT<K>::W - 1)] == KEY_EMPTY) continue;
+        uint32_t s = dict_find_or_insert<false>(to, dict_key<K>(from, (uint32_t)i));
         to.fin[s] = from.fin[i]; to.tent[s] = IDX_INF; to.addr[s] = from.addr[i];
     }
 }
-void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to) {
-    hipLaunchKernelGGL(k_dict_rehash, dim3(grid_for(from_cap, 256)), dim3(256), 0, s, from, from_cap, to);
+void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to, uint32_t k) {
+    DISPATCH_K(k, hipLaunchKernelGGL(k_dict_rehash<K>, dim3(grid_for(from_cap, 256)), dim3(256), 0, s, from, from_cap, to));
 }
 
-__device__ inline uint64_t canon_at(const uint32_t* pk, uint32_t p, uint32_t k, uint64_t* fwd = nullptr) {
-    uint64_t km = kmer_at(pk, p, k);
-    if (fwd) *fwd = km;
-    uint64_t rc = revcomp64(km, k);
+template <typename K> __device__ inline K canon_at(const uint32_t* pk, uint32_t p, uint32_t k) {
+    const K km = kmer_at<K>(pk, p, k);
+    const K rc = revcomp(km, k);
     return rc < km ? rc : km;
 }
 
 // Wave-per-read kernels: the dwords covering k-mers [base, base+64) are loaded once (lane l < 12 holds dword
-// (base>>4)+l) and every lane assembles its k-mer with three cross-lane reads instead of three gathers.
+// (base>>4)+l) and every lane assembles its k-mer with cross-lane reads instead of gathers.
 // Must be called by all 64 lanes (p is clamped by the caller).
 __device__ inline uint32_t pass_words(const uint32_t* pk, uint32_t base, uint32_t lane) {
     return lane < 12 ? pk[(base >> 4) + lane] : 0u;
 }
-__device__ inline uint64_t canon_from_words(uint32_t words, uint32_t base, uint32_t p, uint32_t k) {
-    const uint32_t d = (p >> 4) - (base >> 4), sh = 2 * (p & 15);
-    const uint64_t w0 = (uint32_t)__shfl((int)words, (int)d), w1 = (uint32_t)__shfl((int)words, (int)d + 1);
-    const uint64_t w2 = (uint32_t)__shfl((int)words, (int)d + 2);
-    const uint64_t hi = (w0 << 32) | w1;
-    const uint64_t x = sh ? ((hi << sh) | (w2 >> (32 - sh))) : hi;
-    const uint64_t km = x >> (64 - 2 * k);
-    const uint64_t rc = revcomp64(km, k);
+template <typename K> __device__ inline K canon_from_words(uint32_t words, uint32_t base, uint32_t p, uint32_t k);
+template <> __device__ inline uint64_t canon_from_words<uint64_t>(uint32_t words, uint32_t base, uint32_t p, uint32_t k) {
+    const int d = (int)((p >> 4) - (base >> 4));
+    const uint64_t km = kmer_from3((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1),
+                                   (uint32_t)__shfl((int)words, d + 2), p & 15, k);
+    const uint64_t rc = revcomp(km, k);
+    return rc < km ? rc : km;
+}
+template <> __device__ inline u128 canon_from_words<u128>(uint32_t words, uint32_t base, uint32_t p, uint32_t k) {
+    const int d = (int)((p >> 4) - (base >> 4));                     // d + 4 <= 8 < 12
+    const u128 km = kmer_from5((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1), (uint32_t)__shfl((int)words, d + 2),
+                               (uint32_t)__shfl((int)words, d + 3), (uint32_t)__shfl((int)words, d + 4), p & 15, k);
+    const u128 rc = revcomp(km, k);
     return rc < km ? rc : km;
 }
 
 // first position in [lo, hi) (scan order) whose canonical k-mer is in the bloom; -1 if none. Wave-uniform result.
+template <typename K>
 __device__ inline int first_in_bloom(const BloomDev& B, const uint16_t* rv16, const uint32_t* pk, uint32_t k,
                                      uint32_t lo, uint32_t hi, uint32_t lane) {
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t p = base + lane;
         bool valid = p < hi;
-        const uint64_t cn = canon_from_words(pass_words(pk, base, lane), base, valid ? p : hi - 1, k);
+        const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, valid ? p : hi - 1, k);
         bool c = false;
-        if (valid) c = bloom_contains(B, rv16, cn);
+        if (valid) c = bloom_contains<K>(B, rv16, cn);
         unsigned long long b = __ballot(c);
         if (b) return (int)(base + __builtin_ctzll(b));
     }
@@ -196,6 +248,7 @@ __device__ inline int first_in_bloom(const BloomDev& B, const uint16_t* rv16, co
 
 // Pass A of a window: DnaEncoder::findExistingAnchor against the dictionary as it stood before the window,
 // else the candidate Leon::findAndInsertAnchor would insert.  One wave per read, one lane per k-mer.
+template <typename K>
 __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, const uint16_t* rv16g, DictDev D, ResolveDev V,
                                                     uint64_t w0, uint64_t w1, uint64_t first_global,
                                                     uint32_t* ulist, uint32_t* ucount) {
@@ -214,7 +267,7 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
         for (uint32_t base = 0; base < nk; base += 64) {
             uint32_t p = base + lane;
             bool hit = false; uint32_t slot = 0xFFFFFFFFu;
-            const uint64_t cn = canon_from_words(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
+            const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
             if (p < nk) {
                 slot = dict_find(D, cn);
                 hit = slot != 0xFFFFFFFFu && D.fin[slot] < g;
@@ -232,13 +285,13 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
         // Leon::findAndInsertAnchor scan order: [n/2, n/2+10), [0, n/2), [n/2+10, n)
         uint32_t iMin = nk / 2, iMax = nk / 2 + 10;
         if (iMax > nk) iMax = nk;
-        int cp = first_in_bloom(B, rv16, pk, k, iMin, iMax, lane);
-        if (cp < 0) cp = first_in_bloom(B, rv16, pk, k, 0, iMin, lane);
-        if (cp < 0) cp = first_in_bloom(B, rv16, pk, k, iMax, nk, lane);
+        int cp = first_in_bloom<K>(B, rv16, pk, k, iMin, iMax, lane);
+        if (cp < 0) cp = first_in_bloom<K>(B, rv16, pk, k, 0, iMin, lane);
+        if (cp < 0) cp = first_in_bloom<K>(B, rv16, pk, k, iMax, nk, lane);
         if (lane == 0) {
             if (cp < 0) V.status[i] = ST_NOANCHOR;
             else {
-                uint32_t slot = dict_find_or_insert(D, canon_at(pk, (uint32_t)cp, k));
+                uint32_t slot = dict_find_or_insert<true>(D, canon_at<K>(pk, (uint32_t)cp, k));
                 atomicMin((unsigned long long*)&D.tent[slot], (unsigned long long)g);
                 V.status[i] = ST_UNRESOLVED; V.cand_pos[i] = (uint32_t)cp; V.cand_slot[i] = slot;
                 ulist[atomicAdd(ucount, 1u)] = (uint32_t)i;
@@ -249,12 +302,13 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
 void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
                         uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount) {
     if (w1 <= w0) return;
-    hipLaunchKernelGGL(k_lookup_cand, dim3(grid_for(w1 - w0, 4, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
-                       first_global, ulist, ucount);
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_lookup_cand<K>, dim3(grid_for(w1 - w0, 4, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
+                                       first_global, ulist, ucount));
 }
 
 // One resolution round over the unresolved reads: a read becomes a non-inserter as soon as one of its
 // k-mers is finally owned by an earlier read, an inserter when no earlier read even proposes one of them.
+template <typename K>
 __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global,
                                               const uint32_t* ulist, const uint32_t* ucount,
                                               uint32_t* next_list, uint32_t* next_count) {
@@ -271,7 +325,7 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
         for (uint32_t base = 0; base < nk && !anyfin; base += 64) {
             uint32_t p = base + lane;
             bool f = false, t = false;
-            const uint64_t cn = canon_from_words(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
+            const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
             if (p < nk) {
                 uint32_t slot = dict_find(D, cn);
                 if (slot != 0xFFFFFFFFu) {
@@ -295,8 +349,8 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
 void launch_check(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* ulist,
                   const uint32_t* ucount, uint32_t max_count, uint32_t* next_list, uint32_t* next_count) {
     if (!max_count) return;
-    hipLaunchKernelGGL(k_check, dim3(grid_for(max_count, 4, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, ulist, ucount,
-                       next_list, next_count);
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_check<K>, dim3(grid_for(max_count, 4, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, ulist,
+                                       ucount, next_list, next_count));
 }
 
 __global__ void k_reset_tent(DictDev D, ResolveDev V, const uint32_t* list, const uint32_t* count) {
@@ -322,6 +376,7 @@ void launch_propose(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_globa
 }
 
 // After the window's fixpoint: findExistingAnchor's answer = FIRST position whose k-mer an earlier read owns.
+template <typename K>
 __global__ void __launch_bounds__(256) k_final_pos(ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t first_global) {
     uint32_t lane = lane_id(), k = R.k;
     uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
@@ -335,7 +390,7 @@ __global__ void __launch_bounds__(256) k_final_pos(ReadsDev R, DictDev D, Resolv
         for (uint32_t base = 0; base < limit; base += 64) {
             uint32_t p = base + lane;
             bool hit = false; uint32_t slot = 0xFFFFFFFFu;
-            const uint64_t cn = canon_from_words(pass_words(pk, base, lane), base, p < limit ? p : limit - 1, k);
+            const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < limit ? p : limit - 1, k);
             if (p < limit) {
                 slot = dict_find(D, cn);
                 hit = slot != 0xFFFFFFFFu && D.fin[slot] < g;
@@ -352,7 +407,7 @@ __global__ void __launch_bounds__(256) k_final_pos(ReadsDev R, DictDev D, Resolv
 }
 void launch_final_pos(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t first_global) {
     if (w1 <= w0) return;
-    hipLaunchKernelGGL(k_final_pos, dim3(grid_for(w1 - w0, 4, 256 * 16)), dim3(256), 0, s, R, D, V, w0, w1, first_global);
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_final_pos<K>, dim3(grid_for(w1 - w0, 4, 256 * 16)), dim3(256), 0, s, R, D, V, w0, w1, first_global));
 }
 
 __global__ void k_ins_flags(ResolveDev V, uint64_t w0, uint64_t w1) {
@@ -364,6 +419,7 @@ void launch_ins_flags(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1) {
     hipLaunchKernelGGL(k_ins_flags, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, V, w0, w1);
 }
 // addresses in insertion (= read) order: Leon::findAndInsertAnchor's `_anchorAdress++`
+template <typename K>
 __global__ void k_assign_addr(DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, const uint32_t* rank, uint64_t addr_base,
                               uint64_t* anchor_kmers) {
     for (uint64_t i = w0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < w1; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -371,16 +427,17 @@ __global__ void k_assign_addr(DictDev D, ResolveDev V, uint64_t w0, uint64_t w1,
         uint64_t a = addr_base + rank[i - w0];
         uint32_t slot = V.cand_slot[i];
         D.addr[slot] = (uint32_t)a;
-        anchor_kmers[a] = D.keys[slot];
+        store_kmer(anchor_kmers + a * KT<K>::W, dict_key<K>(D, slot));
         V.hit_pos[i] = V.cand_pos[i];
         V.hit_slot[i] = slot;
     }
 }
 void launch_assign_addr(hipStream_t s, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, const uint32_t* rank,
-                        uint64_t addr_base, uint64_t* anchor_kmers) {
+                        uint64_t addr_base, uint64_t* anchor_kmers, uint32_t k) {
     if (w1 <= w0) return;
-    hipLaunchKernelGGL(k_assign_addr, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, D, V, w0, w1, rank, addr_base, anchor_kmers);
+    DISPATCH_K(k, hipLaunchKernelGGL(k_assign_addr<K>, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, D, V, w0, w1, rank, addr_base, anchor_kmers));
 }
+template <typename K>
 __global__ void k_finalize_reads(ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1) {
     uint32_t k = R.k;
     for (uint64_t i = w0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < w1; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -392,8 +449,8 @@ __global__ void k_finalize_reads(ReadsDev R, DictDev D, ResolveDev V, uint64_t w
         uint32_t pos = V.hit_pos[i];
         uint32_t addr = D.addr[V.hit_slot[i]];
         const uint32_t* pk = R.packed + 2 * R.slot_off[i];
-        uint64_t km = kmer_at(pk, pos, k);
-        uint32_t rev = revcomp64(km, k) < km ? 1u : 0u;      // anchor != min(anchor, revcomp(anchor))
+        const K km = kmer_at<K>(pk, pos, k);
+        uint32_t rev = revcomp(km, k) < km ? 1u : 0u;      // anchor != min(anchor, revcomp(anchor))
         V.anchor_pos[i] = (int32_t)pos; V.anchor_addr[i] = addr;
         V.flags[i] = (uint8_t)(rev | (st == ST_INSERTER ? 2u : 0u));
         V.sort_key[i] = ((uint64_t)addr << 1) | rev;
@@ -401,16 +458,32 @@ __global__ void k_finalize_reads(ReadsDev R, DictDev D, ResolveDev V, uint64_t w
 }
 void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1) {
     if (w1 <= w0) return;
-    hipLaunchKernelGGL(k_finalize_reads, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, R, D, V, w0, w1);
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_finalize_reads<K>, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, R, D, V, w0, w1));
+}
+
+// the dictionary stream's symbols: k bases per anchor, first base first, on a 5-symbol Order0Model (_anchorDictModel)
+template <typename K>
+__global__ void k_anchor_symbols(const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms) {
+    const uint64_t total = n_anchors * k;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = i / k; const uint32_t j = (uint32_t)(i % k);
+        syms[2 * i] = (uint8_t)M_NOANCHOR_READ;
+        syms[2 * i + 1] = (uint8_t)((uint64_t)(load_kmer<K>(kmers + a * KT<K>::W) >> (2 * (k - 1 - j))) & 3u);
+    }
+}
+void launch_anchor_symbols(hipStream_t s, const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms) {
+    if (!n_anchors) return;
+    DISPATCH_K(k, hipLaunchKernelGGL(k_anchor_symbols<K>, dim3(grid_for(n_anchors * k, 256, 8192)), dim3(256), 0, s, kmers, n_anchors, k, syms));
 }
 
 // ================================================================================================
 // walk: DnaEncoder::encodeAnchorRead's two loops over buildBifurcationList.  One lane per read, reads taken
 // in anchor-sorted order so that neighbouring lanes probe the same bloom windows at the same step.
 // ================================================================================================
-__device__ inline void walk_step(const BloomDev& B, const uint16_t* rv16, uint32_t k, uint64_t& kmer, uint64_t& rc,
+template <typename K>
+__device__ inline void walk_step(const BloomDev& B, const uint16_t* rv16, uint32_t k, K kmask_k, K& kmer, K& rc,
                                  uint32_t nt, bool right, uint8_t* ev_pos) {
-    uint32_t res4 = bloom_contains4(B, rv16, kmer, rc, right);
+    uint32_t res4 = bloom_contains4<K>(B, rv16, kmer, rc, right);
     uint32_t cnt = __popc(res4);
     bool solid = (res4 >> nt) & 1u;
     uint32_t first = res4 ? (uint32_t)__builtin_ctz(res4) : 0u;
@@ -424,14 +497,15 @@ __device__ inline void walk_step(const BloomDev& B, const uint16_t* rv16, uint32
     }
     // AbstractDnaCoder::codeSeedBin, keeping the reverse complement alongside
     if (right) {
-        kmer = ((kmer << 2) | follow) & B.kmer_mask;
-        rc = (rc >> 2) | ((uint64_t)(follow ^ 2u) << (2 * (k - 1)));
+        kmer = ((kmer << 2) | (K)follow) & kmask_k;
+        rc = (rc >> 2) | ((K)(follow ^ 2u) << (2 * (k - 1)));
     } else {
-        kmer = (kmer >> 2) | ((uint64_t)follow << (2 * (k - 1)));
-        rc = ((rc << 2) | (follow ^ 2u)) & B.kmer_mask;
+        kmer = (kmer >> 2) | ((K)follow << (2 * (k - 1)));
+        rc = ((rc << 2) | (K)(follow ^ 2u)) & kmask_k;
     }
 }
 
+template <typename K>
 __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
                                              const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
     __shared__ uint16_t rv16[256];
@@ -442,27 +516,28 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
     int32_t a = anchor_pos[i];
     if (a < 0) return;
     uint32_t k = R.k, len = R.len[i];
+    const K kmask_k = kmask<K>(k);
     const uint32_t* pk = R.packed + 2 * R.slot_off[i];
     const uint32_t* nm = R.nmask + R.slot_off[i];
     bool hasN = R.n_count[i] != 0;
     uint8_t* ev = events + (R.base_off[i] - R.base_off[R.ev_origin]);
-    uint64_t anchor = kmer_at(pk, (uint32_t)a, k);
-    uint64_t anchor_rc = revcomp64(anchor, k);
+    const K anchor = kmer_at<K>(pk, (uint32_t)a, k);
+    const K anchor_rc = revcomp(anchor, k);
 
     // the read's 2-bit word (16 bases) and N-mask word (32 bases) stay in registers between reloads
     uint32_t pw = 0, pw_idx = 0xFFFFFFFFu, nw = 0, nw_idx = 0xFFFFFFFFu;
-    uint64_t kmer = anchor, rc = anchor_rc;
+    K kmer = anchor, rc = anchor_rc;
     for (int32_t pos = a - 1; pos >= 0; pos--) {
         if (((uint32_t)pos >> 4) != pw_idx) { pw_idx = (uint32_t)pos >> 4; pw = pk[pw_idx]; }
         uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
         if (hasN) {
             if (((uint32_t)pos >> 5) != nw_idx) { nw_idx = (uint32_t)pos >> 5; nw = nm[nw_idx]; }
             if ((nw >> (pos & 31)) & 1u) {                        // N: coded as 'A', nothing stored
-                kmer = kmer >> 2; rc = ((rc << 2) | 2u) & B.kmer_mask;
+                kmer = kmer >> 2; rc = ((rc << 2) | (K)2u) & kmask_k;
                 continue;
             }
         }
-        walk_step(B, rv16, k, kmer, rc, nt, false, ev + pos);
+        walk_step<K>(B, rv16, k, kmask_k, kmer, rc, nt, false, ev + pos);
     }
     kmer = anchor; rc = anchor_rc;
     for (uint32_t pos = (uint32_t)a + k; pos < len; pos++) {
@@ -471,18 +546,18 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
         if (hasN) {
             if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
             if ((nw >> (pos & 31)) & 1u) {
-                kmer = (kmer << 2) & B.kmer_mask; rc = (rc >> 2) | (2ull << (2 * (k - 1)));
+                kmer = (kmer << 2) & kmask_k; rc = (rc >> 2) | ((K)2u << (2 * (k - 1)));
                 continue;
             }
         }
-        walk_step(B, rv16, k, kmer, rc, nt, true, ev + pos);
+        walk_step<K>(B, rv16, k, kmask_k, kmer, rc, nt, true, ev + pos);
     }
 }
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos,
                  const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
     if (!n_walk) return;
     uint64_t g = (n_walk + 255) / 256;
-    hipLaunchKernelGGL(k_walk, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, perm, n_walk, events);
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, perm, n_walk, events));
 }
 
 // ================================================================================================

@@ -22,10 +22,14 @@ public:
         low_ = 0; range_ = ~0ull; n_ = 0; buf_.clear(); w_ = 0;
         for (int i = 0; i <= 5; i++) cum_[i] = i;              // Order0Model::clear: _charRanges[i] = i
     }
-    // k-mer in the 2-bit code, first base in the highest bits (LargeInt::toString order)
-    inline void encode_kmer(uint64_t km, uint32_t k) {
+    // k-mer in the 2-bit code (w[0] low word, w[1] high word when k >= 32), first base in the highest bits
+    // (LargeInt::toString order)
+    inline void encode_kmer(const uint64_t* w, uint32_t k) {
         if (buf_.size() < w_ + 8 * (size_t)k + 16) buf_.resize(buf_.size() * 2 + 8 * (size_t)k + 4096);
-        for (uint32_t i = 0; i < k; i++) encode((uint32_t)(km >> (2 * (k - 1 - i))) & 3u);
+        for (uint32_t i = 0; i < k; i++) {
+            const uint32_t bit = 2 * (k - 1 - i);
+            encode((uint32_t)(w[bit >> 6] >> (bit & 63)) & 3u);
+        }
     }
     void flush() {                                             // RangeEncoder::flush
         if (buf_.size() < w_ + 8) buf_.resize(w_ + 8);
@@ -98,7 +102,8 @@ private:
                 batch = std::move(q_.front());
                 q_.pop_front();
             }
-            for (uint64_t km : batch) coder_.encode_kmer(km, k_);
+            const uint32_t W = k_ >= 32 ? 2u : 1u;
+            for (size_t a = 0; a + W <= batch.size(); a += W) coder_.encode_kmer(batch.data() + a, k_);
             {
                 std::lock_guard<std::mutex> g(mu_);
                 pending_--;

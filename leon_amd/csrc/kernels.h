@@ -21,7 +21,7 @@ struct ReadsDev {
 
 // anchor dictionary: open addressing, linear probing (replaces Leon::_anchorKmers, Hash16<kmer,u32>)
 struct DictDev {
-    uint64_t* keys;     // canonical k-mer or KEY_EMPTY
+    uint64_t* keys;     // canonical k-mer (W words per slot) or KEY_EMPTY in the (high) word
     uint64_t* fin;      // global index of the read that inserted the key, IDX_INF while only proposed
     uint64_t* tent;     // smallest global read index currently proposing the key (per resolution round)
     uint32_t* addr;     // anchor address once assigned
@@ -48,8 +48,8 @@ void launch_read_slots(hipStream_t s, const uint64_t* base_off, uint64_t n, uint
 void launch_pack(hipStream_t s, const uint8_t* bases, const uint64_t* base_off, const uint64_t* slot_off, uint64_t n,
                  uint32_t* packed, uint32_t* nmask, uint32_t* len, uint32_t* n_count);
 // ---- anchor resolution ----
-void launch_dict_init(hipStream_t s, DictDev D, uint64_t cap);
-void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to);
+void launch_dict_init(hipStream_t s, DictDev D, uint64_t cap, uint32_t W);
+void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to, uint32_t k);
 void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
                         uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount);
 void launch_check(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global,
@@ -60,7 +60,8 @@ void launch_propose(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_globa
 void launch_final_pos(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t first_global);
 void launch_ins_flags(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1);
 void launch_assign_addr(hipStream_t s, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, const uint32_t* rank,
-                        uint64_t addr_base, uint64_t* anchor_kmers);
+                        uint64_t addr_base, uint64_t* anchor_kmers, uint32_t k);
+void launch_anchor_symbols(hipStream_t s, const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms);
 void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1);
 // ---- walk ----
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos,

@@ -1,11 +1,18 @@
 // leon_device.h -- device-side building blocks shared by the gfx950 kernels of the DNA encode path.
-// k-mer model (gatb kmer/impl/Model.hpp [RECALLED]): 2-bit code A0 C1 T2 G3, first base in the highest
-// bits, one 64-bit word (k <= 31).  Bloom geometry: BloomNeighborCoherent (Bloom.hpp [RECALLED]).
+// k-mer model (gatb kmer/impl/Model.hpp [RECALLED]): 2-bit code A0 C1 T2 G3, first base in the highest bits.
+// The k-mer type K is uint64_t for k < 32 (upstream LargeInt<1>) and unsigned __int128 for 32 <= k < 64
+// (LargeInt<2> / NativeInt128); kernels are templates on K.  Bloom geometry: BloomNeighborCoherent (Bloom.hpp [RECALLED]).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace leon {
+
+typedef unsigned __int128 u128;
+template <typename K> struct KT;
+template <> struct KT<uint64_t> { static constexpr uint32_t W = 1; };
+template <> struct KT<u128> { static constexpr uint32_t W = 2; };
+__host__ __device__ inline uint32_t kmer_words(uint32_t k) { return k >= 32 ? 2u : 1u; }
 
 // ---- model ids of the symbol stream (AbstractDnaCoder's Order0Model members [RECALLED]) ----
 enum : uint32_t {
@@ -29,22 +36,27 @@ __host__ __device__ inline uint32_t numeric_model_id(uint32_t group, uint32_t id
 // event byte written by the walk per read position
 enum : uint8_t { EV_BIN0 = 1, EV_BIN1 = 2, EV_NT0 = 3, EV_ERROR = 8 };
 
-constexpr uint64_t KEY_EMPTY = ~0ull;
+constexpr uint64_t KEY_EMPTY = ~0ull;            // one-word keys; two-word keys: high word ~0 = empty, ~0-1 = being written
+constexpr uint64_t KEY_LOCKED = ~0ull - 1;
 constexpr uint64_t IDX_INF = ~0ull;
 
 struct BloomDev {
     const uint8_t* bits;
-    uint64_t reduced_tai, mod_magic, seed0, maskkm2, kmer_mask;
+    uint64_t reduced_tai, mod_magic, seed0;
     uint32_t k, n_hash, block_mask, pad;
 };
 
-// ---- 64-bit helpers ----
-__device__ inline uint64_t revcomp64(uint64_t x, uint32_t k) {
+// ---- k-mer arithmetic ----
+template <typename K> __device__ inline K kmask(uint32_t nbases) { return (((K)1) << (2 * nbases)) - 1; }   // nbases < 32 * W
+__device__ inline uint64_t rev2bit64(uint64_t x) {                   // reverse the 32 2-bit groups and complement them
     x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
     x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-    x = __builtin_bswap64(x);
-    x ^= 0xAAAAAAAAAAAAAAAAULL;
-    return x >> (64 - 2 * k);
+    return __builtin_bswap64(x) ^ 0xAAAAAAAAAAAAAAAAULL;
+}
+__device__ inline uint64_t revcomp(uint64_t x, uint32_t k) { return rev2bit64(x) >> (64 - 2 * k); }
+__device__ inline u128 revcomp(u128 x, uint32_t k) {
+    u128 r = ((u128)rev2bit64((uint64_t)x) << 64) | rev2bit64((uint64_t)(x >> 64));
+    return r >> (128 - 2 * k);
 }
 // NativeInt64::hash64 [RECALLED]
 __device__ inline uint64_t hash64(uint64_t key, uint64_t seed) {
@@ -59,7 +71,10 @@ __device__ inline uint64_t hash64(uint64_t key, uint64_t seed) {
     hash = hash + (hash << 31);
     return hash;
 }
-// n mod d with magic = floor((2^64-1)/d): one mulhi, one multiply, one conditional subtract
+// hash1(LargeInt<precision>): XOR of hash64 over the type's 64-bit chunks [RECALLED]
+__device__ inline uint64_t hash1(uint64_t x, uint64_t seed) { return hash64(x, seed); }
+__device__ inline uint64_t hash1(u128 x, uint64_t seed) { return hash64((uint64_t)x, seed) ^ hash64((uint64_t)(x >> 64), seed); }
+// n mod d with magic = floor((2^64-1)/d): one mulhi, one multiply, conditional subtracts
 __device__ inline uint64_t fastmod(uint64_t n, uint64_t d, uint64_t magic) {
     uint64_t q = __umul64hi(n, magic);
     uint64_t r = n - q * d;
@@ -71,6 +86,8 @@ __device__ inline uint64_t mix64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
+__device__ inline uint64_t key_hash(uint64_t k) { return mix64(k); }
+__device__ inline uint64_t key_hash(u128 k) { return mix64((uint64_t)k ^ mix64((uint64_t)(k >> 64) + 0x9E3779B97F4A7C15ULL)); }
 // cano2[16] of BloomNeighborCoherent as 16 nibbles
 __device__ inline uint32_t cano2(uint32_t v) { return (uint32_t)(0x51D9409873543210ULL >> (4 * v)) & 15u; }
 
@@ -78,28 +95,45 @@ __device__ inline uint32_t cano2(uint32_t v) { return (uint32_t)(0x51D9409873543
 __device__ inline uint32_t base_at(const uint32_t* pk, uint32_t pos) {
     return (pk[pos >> 4] >> (30 - 2 * (pos & 15))) & 3u;
 }
-// k-mer starting at base p (needs dwords p>>4 .. (p>>4)+2 readable: reads are padded to 32-base slots + 1 slot)
-__device__ inline uint64_t kmer_at(const uint32_t* pk, uint32_t p, uint32_t k) {
-    uint32_t d = p >> 4, s = 2 * (p & 15);
-    uint64_t hi = ((uint64_t)pk[d] << 32) | pk[d + 1];
-    uint64_t lo = pk[d + 2];
-    uint64_t x = s ? ((hi << s) | (lo >> (32 - s))) : hi;
+// k-mer from consecutive dwords w[0..] whose first base is `first` bases before the k-mer (first < 16)
+__device__ inline uint64_t kmer_from3(uint64_t w0, uint64_t w1, uint64_t w2, uint32_t first, uint32_t k) {
+    const uint32_t s = 2 * first;
+    const uint64_t hi = (w0 << 32) | w1;
+    const uint64_t x = s ? ((hi << s) | (w2 >> (32 - s))) : hi;
     return x >> (64 - 2 * k);
+}
+__device__ inline u128 kmer_from5(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint64_t w4, uint32_t first, uint32_t k) {
+    const uint32_t s = 2 * first;
+    const u128 hi = ((u128)((w0 << 32) | w1) << 64) | ((w2 << 32) | w3);
+    const u128 x = s ? ((hi << s) | (u128)(w4 >> (32 - s))) : hi;
+    return x >> (128 - 2 * k);
+}
+// k-mer starting at base p (the packed buffer is padded so that the dwords read past a read exist)
+template <typename K> __device__ inline K kmer_at(const uint32_t* pk, uint32_t p, uint32_t k);
+template <> __device__ inline uint64_t kmer_at<uint64_t>(const uint32_t* pk, uint32_t p, uint32_t k) {
+    const uint32_t d = p >> 4;
+    return kmer_from3(pk[d], pk[d + 1], pk[d + 2], p & 15, k);
+}
+template <> __device__ inline u128 kmer_at<u128>(const uint32_t* pk, uint32_t p, uint32_t k) {
+    const uint32_t d = p >> 4;
+    return kmer_from5(pk[d], pk[d + 1], pk[d + 2], pk[d + 3], pk[d + 4], p & 15, k);
 }
 
 // ---- BloomNeighborCoherent geometry ----
 // racine and the per-hash offsets depend only on the canonical middle (k-2)-mer
 struct BloomKeys { uint64_t racine; uint32_t key[10]; };
 
-__device__ inline void bloom_keys(const BloomDev& B, const uint16_t* rv16, uint64_t hp_fwd, uint64_t hp_rc, BloomKeys& K) {
-    uint64_t hp = hp_rc < hp_fwd ? hp_rc : hp_fwd;
-    K.racine = fastmod(hash64(hp, B.seed0), B.reduced_tai, B.mod_magic);
-    K.key[0] = 0;
+template <typename K>
+__device__ inline void bloom_keys(const BloomDev& B, const uint16_t* rv16, K hp_fwd, K hp_rc, BloomKeys& Kk) {
+    const K hp = hp_rc < hp_fwd ? hp_rc : hp_fwd;
+    Kk.racine = fastmod(hash1(hp, B.seed0), B.reduced_tai, B.mod_magic);
+    Kk.key[0] = 0;
+    const uint32_t low = (uint32_t)(uint64_t)hp;                  // simplehash16 looks at value[0] >> i, 16 bits
 #pragma unroll
     for (uint32_t i = 1; i < 10; i++) {
         if (i < B.n_hash) {
-            uint32_t in = (uint32_t)(hp >> i);
-            K.key[i] = (uint32_t)(rv16[in & 255] ^ rv16[(in >> 8) & 255]) & B.block_mask;
+            const uint32_t in = low >> i;
+            Kk.key[i] = (uint32_t)(rv16[in & 255] ^ rv16[(in >> 8) & 255]) & B.block_mask;
         }
     }
 }
@@ -111,12 +145,12 @@ __device__ inline uint32_t bloom_window(const BloomDev& B, uint64_t bitpos) {
     return w >> (bitpos & 7);
 }
 // contains4: pv4 packs the four canonical prefix+suffix values (4 bits each, neighbour nt in nibble nt)
-__device__ inline uint32_t bloom_probe4(const BloomDev& B, const BloomKeys& K, uint32_t pv4) {
+__device__ inline uint32_t bloom_probe4(const BloomDev& B, const BloomKeys& Kk, uint32_t pv4) {
     uint32_t alive = 15u;
 #pragma unroll
     for (uint32_t i = 0; i < 10; i++) {
         if (i < B.n_hash) {
-            uint32_t w = bloom_window(B, K.racine + K.key[i]);
+            uint32_t w = bloom_window(B, Kk.racine + Kk.key[i]);
             uint32_t m = ((w >> (pv4 & 15)) & 1u) | (((w >> ((pv4 >> 4) & 15)) & 1u) << 1) |
                          (((w >> ((pv4 >> 8) & 15)) & 1u) << 2) | (((w >> ((pv4 >> 12) & 15)) & 1u) << 3);
             alive &= m;
@@ -124,33 +158,40 @@ __device__ inline uint32_t bloom_probe4(const BloomDev& B, const BloomKeys& K, u
     }
     return alive;
 }
-// BloomNeighborCoherent::contains(item)
-__device__ inline bool bloom_contains(const BloomDev& B, const uint16_t* rv16, uint64_t item) {
-    uint32_t k = B.k;
-    uint32_t pv = cano2((uint32_t)(((item >> (2 * (k - 1))) & 3) << 2 | (item & 3)));
-    uint64_t hp = (item >> 2) & B.maskkm2;
-    BloomKeys K;
-    bloom_keys(B, rv16, hp, revcomp64(hp, k - 2), K);
+// BloomNeighborCoherent positions of one k-mer (insert / contains)
+template <typename K>
+__device__ inline uint32_t bloom_item_keys(const BloomDev& B, const uint16_t* rv16, K item, BloomKeys& Kk) {
+    const uint32_t k = B.k;
+    const uint32_t pv = cano2((uint32_t)((uint64_t)(item >> (2 * (k - 1))) & 3) << 2 | ((uint32_t)(uint64_t)item & 3u));
+    const K hp = (item >> 2) & kmask<K>(k - 2);
+    bloom_keys<K>(B, rv16, hp, revcomp(hp, k - 2), Kk);
+    return pv;
+}
+template <typename K> __device__ inline bool bloom_contains(const BloomDev& B, const uint16_t* rv16, K item) {
+    BloomKeys Kk;
+    const uint32_t pv = bloom_item_keys<K>(B, rv16, item, Kk);
     bool ok = true;
-    for (uint32_t i = 0; i < B.n_hash && ok; i++) ok = (bloom_window(B, K.racine + K.key[i] + pv) & 1u) != 0;
+    for (uint32_t i = 0; i < B.n_hash && ok; i++) ok = (bloom_window(B, Kk.racine + Kk.key[i] + pv) & 1u) != 0;
     return ok;
 }
 // BloomNeighborCoherent::contains4(item, right) from a k-mer and its reverse complement
-__device__ inline uint32_t bloom_contains4(const BloomDev& B, const uint16_t* rv16, uint64_t kmer, uint64_t rc, bool right) {
-    uint32_t k = B.k;
-    uint64_t hpf, hpr; uint32_t pv4;
+template <typename K>
+__device__ inline uint32_t bloom_contains4(const BloomDev& B, const uint16_t* rv16, K kmer, K rc, bool right) {
+    const uint32_t k = B.k;
+    const K mkm2 = kmask<K>(k - 2);
+    K hpf, hpr; uint32_t pv4;
     if (right) {          // elem = kmer[1..k-1] + X : middle = kmer[2..k-1], prefix = kmer[1], suffix varies
-        hpf = kmer & B.maskkm2; hpr = rc >> 4;
-        uint32_t p = (uint32_t)(kmer >> (2 * (k - 2))) & 3u;
+        hpf = kmer & mkm2; hpr = rc >> 4;
+        const uint32_t p = (uint32_t)(uint64_t)(kmer >> (2 * (k - 2))) & 3u;
         pv4 = cano2(p << 2) | (cano2((p << 2) | 1) << 4) | (cano2((p << 2) | 2) << 8) | (cano2((p << 2) | 3) << 12);
     } else {              // elem = X + kmer[0..k-2] : middle = kmer[0..k-3], prefix varies, suffix = kmer[k-2]
-        hpf = kmer >> 4; hpr = rc & B.maskkm2;
-        uint32_t s = (uint32_t)(kmer >> 2) & 3u;
+        hpf = kmer >> 4; hpr = rc & mkm2;
+        const uint32_t s = (uint32_t)(uint64_t)(kmer >> 2) & 3u;
         pv4 = cano2(s) | (cano2(4 | s) << 4) | (cano2(8 | s) << 8) | (cano2(12 | s) << 12);
     }
-    BloomKeys K;
-    bloom_keys(B, rv16, hpf, hpr, K);
-    return bloom_probe4(B, K, pv4);
+    BloomKeys Kk;
+    bloom_keys<K>(B, rv16, hpf, hpr, Kk);
+    return bloom_probe4(B, Kk, pv4);
 }
 
 // stage the low 16 bits of the 256-entry simplehash16 table in LDS
@@ -160,5 +201,12 @@ __device__ inline void load_rv16(uint16_t* lds, const uint16_t* g) {
 }
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// k-mers cross the C-ABI as W 64-bit words each, low word first
+template <typename K> __device__ inline K load_kmer(const uint64_t* w);
+template <> __device__ inline uint64_t load_kmer<uint64_t>(const uint64_t* w) { return w[0]; }
+template <> __device__ inline u128 load_kmer<u128>(const uint64_t* w) { return ((u128)w[1] << 64) | w[0]; }
+__device__ inline void store_kmer(uint64_t* w, uint64_t x) { w[0] = x; }
+__device__ inline void store_kmer(uint64_t* w, u128 x) { w[0] = (uint64_t)x; w[1] = (uint64_t)(x >> 64); }
 
 }  // namespace leon

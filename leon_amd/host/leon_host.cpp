@@ -143,7 +143,7 @@ void Leon::writeBlock(const uint8_t* data, uint64_t size, int encodedSequenceCou
 }
 
 void Leon::executeCompression() {
-    if (_kmerSize < 3 || _kmerSize > 31) throw Exception("-kmer-size must be < 32 (larger k needs the two-word build)");
+    if (_kmerSize < 3 || _kmerSize > 31) throw Exception("-kmer-size must be < 32 in this CLI (the library takes k <= 63; the host k-mer counter is one-word)");
     std::vector<Sequence> bank = read_bank(_inputFilename);
     std::vector<uint64_t> solid = solid_kmers(bank, (unsigned)_kmerSize, (unsigned)std::max(_abundance, 1));
     const uint64_t tai = std::max<uint64_t>(solid.size() * 12, 1000);       // NBITS_PER_KMER = 12 [RECALLED]

@@ -47,7 +47,7 @@ def test_no_cpu_fallback(lib):
 
 def test_config_validation_messages(lib):
     import leon_amd
-    for kw in (dict(kmer_size=63), dict(kmer_size=2), dict(reads_per_block=0), dict(bloom_n_hash=0)):
+    for kw in (dict(kmer_size=64), dict(kmer_size=2), dict(reads_per_block=0), dict(bloom_n_hash=0)):
         with pytest.raises(leon_amd.LeonDnaError) as e:
             leon_amd.DnaEncodeContext(bloom_tai=1000, **kw)
         assert e.value.code == -1
@@ -71,9 +71,11 @@ def test_host_anchor_dict_stream_matches_oracle(lib):
     from leon_amd import capi
     rng = np.random.default_rng(3)
     sizes = [2, 5, 5, 2, 3, 3, 3, 2] + [256] * 72
-    for k, n in [(31, 0), (31, 1), (31, 700), (21, 3000), (5, 10)]:
-        kmers = rng.integers(0, 1 << (2 * k), size=n, dtype=np.uint64)
-        syms = np.array([(int(x) >> (2 * (k - 1 - i))) & 3 for x in kmers for i in range(k)], dtype=np.uint8)
+    for k, n in [(31, 0), (31, 1), (31, 700), (21, 3000), (5, 10), (32, 50), (63, 900)]:
+        ints = [(int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 1 << 62)) << 62)) & ((1 << (2 * k)) - 1) for _ in range(n)]
+        w = O.kwords(k)
+        kmers = np.array([[x & 0xFFFFFFFFFFFFFFFF, x >> 64][:w] for x in ints], dtype=np.uint64).reshape(-1)
+        syms = np.array([(x >> (2 * (k - 1 - i))) & 3 for x in ints for i in range(k)], dtype=np.uint8)
         exp = O.rc_encode_stream(np.ones(len(syms), dtype=np.uint8), syms, sizes)   # model 1: alphabet 5
         assert capi.host_anchor_dict_encode(kmers, k) == exp
-        assert O.decode_anchor_dict(exp, n, k).tolist() == kmers.tolist()
+        assert O.kmers_to_ints(O.decode_anchor_dict(exp, n, k), k) == ints

@@ -15,27 +15,39 @@ def _ctx(k, rpb, tai, **kw):
 
 
 def _kmers_of(bases, off, k, limit=20000):
-    code = np.zeros(256, dtype=np.uint64)
-    for c, v in zip(b"ACTG", range(4)):
-        code[c] = v
-    arr = np.frombuffer(bases, dtype=np.uint8)
+    """python-int k-mers of the reads (first base in the highest bits)"""
+    code = {65: 0, 67: 1, 84: 2, 71: 3}
     out = []
+    mask = (1 << (2 * k)) - 1
     for r in range(len(off) - 1):
         s, e = int(off[r]), int(off[r + 1])
-        if e - s < k:
-            continue
-        km = 0
-        mask = (1 << (2 * k)) - 1
+        km, valid = 0, 0
         for i in range(s, e):
-            km = ((km << 2) | int(code[arr[i]])) & mask
-            if i - s + 1 >= k:
+            c = code.get(bases[i])
+            if c is None:
+                km, valid = 0, 0
+                continue
+            km = ((km << 2) | c) & mask
+            valid += 1
+            if valid >= k:
                 out.append(km)
         if len(out) >= limit:
             break
-    return np.array(out[:limit], dtype=np.uint64)
+    return out[:limit]
 
 
-@pytest.mark.parametrize("k", [31, 21, 9])
+def _words(ints, k):
+    """python ints -> flat uint64 array, kwords(k) words per k-mer (low word first)"""
+    w = O.kwords(k)
+    a = np.zeros((len(ints), w), dtype=np.uint64)
+    for i, x in enumerate(ints):
+        a[i, 0] = x & 0xFFFFFFFFFFFFFFFF
+        if w == 2:
+            a[i, 1] = x >> 64
+    return a.reshape(-1)
+
+
+@pytest.mark.parametrize("k", [31, 21, 9, 32, 47, 63])
 def test_bloom_build_and_probe(k):
     bases, off = common.synthetic(3000, 120, 30000, seed=5)
     bl, solid, tai = common.make_bloom(bases, off, k)
@@ -43,15 +55,17 @@ def test_bloom_build_and_probe(k):
     assert ctx.bloom_nbytes == len(bl.bits)
     ctx.bloom_insert(solid)
     assert np.array_equal(ctx.bloom_download(), bl.bits)          # insert kernel == oracle insert, bit for bit
-    q = _kmers_of(bases, off, k)
+    q = _kmers_of(bases, off, k, limit=6000)
     rng = np.random.default_rng(0)
-    q = np.concatenate([q, rng.integers(0, 1 << (2 * k), size=5000, dtype=np.uint64)])
+    q += [int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 1 << 62)) << 62) & ((1 << (2 * k)) - 1) for _ in range(3000)]
+    q = [x & ((1 << (2 * k)) - 1) for x in q]
     exp_c = np.array([bl.contains(x) for x in q], dtype=np.uint8)
     exp_l = np.array([bl.contains4(x, 0) for x in q], dtype=np.uint8)
     exp_r = np.array([bl.contains4(x, 1) for x in q], dtype=np.uint8)
-    assert np.array_equal(ctx.bloom_contains(q), exp_c)
-    assert np.array_equal(ctx.bloom_contains4(q, 0), exp_l)
-    assert np.array_equal(ctx.bloom_contains4(q, 1), exp_r)
+    qw = _words(q, k)
+    assert np.array_equal(ctx.bloom_contains(qw), exp_c)
+    assert np.array_equal(ctx.bloom_contains4(qw, 0), exp_l)
+    assert np.array_equal(ctx.bloom_contains4(qw, 1), exp_r)
     ctx.close()
 
 
@@ -288,3 +302,12 @@ def test_dictionary_stream_on_device_equals_host_thread():
         outs.append(d)
         ctx.close()
     assert outs[0] == outs[1] == ref.anchor_dict
+
+
+@pytest.mark.parametrize("k", [32, 47, 63])
+def test_two_word_kmers_bit_exact(k):
+    """32 <= k <= 63 (BASELINE.json config 5 uses k = 63, 250 bp reads): the unsigned __int128 instances of the kernels"""
+    bases, off = common.synthetic(3000, 250, 15000, seed=80 + k, n_rate=0.001)
+    _full_compare(bases, off, k, 700, window=1000)
+    bases, off = common.synthetic(1200, 100, 5000, seed=90 + k, ragged=True)
+    _full_compare(bases, off, k, 500, window=64, batches=2)
