@@ -483,17 +483,17 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
     size_t sort_tmp = 0;
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
-                                                 c->perm2.as<uint32_t>(), nl, 0, 34, s));
+                                                 c->perm2.as<uint32_t>(), nl, 0, 33, s));
     if (int rc = ensure_cub(c, sort_tmp)) return rc;
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
-                                                 c->perm2.as<uint32_t>(), nl, 0, 34, s));
+                                                 c->perm2.as<uint32_t>(), nl, 0, 33, s));
     HIPCHK(c, hipEventRecord(c->ev[3], s));
 
     // ---- walk ----
     HIPCHK(c, c->events.ensure(nl_bases + 16));
     HIPCHK(c, hipMemsetAsync(c->events.p, 0, nl_bases + 16, s));
     HIPCHK(c, hipEventRecord(c->ev[4], s));
-    launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, c->perm2.as<uint32_t>(), nl, c->events.as<uint8_t>());
+    launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, V.flags, c->perm2.as<uint32_t>(), nl, c->events.as<uint8_t>());
     HIPCHK(c, hipEventRecord(c->ev[5], s));
     c->stats.walk_launches = 1;
 

@@ -443,7 +443,7 @@ __global__ void k_finalize_reads(ReadsDev R, DictDev D, ResolveDev V, uint64_t w
     for (uint64_t i = w0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < w1; i += (uint64_t)gridDim.x * blockDim.x) {
         uint8_t st = V.status[i];
         if (st == ST_NOANCHOR) {
-            V.anchor_pos[i] = -1; V.anchor_addr[i] = 0; V.flags[i] = 0; V.sort_key[i] = 1ull << 33;   // after every anchored read
+            V.anchor_pos[i] = -1; V.anchor_addr[i] = 0; V.flags[i] = 0; V.sort_key[i] = 1ull << 32;   // after every anchored read
             continue;
         }
         uint32_t pos = V.hit_pos[i];
@@ -453,7 +453,7 @@ __global__ void k_finalize_reads(ReadsDev R, DictDev D, ResolveDev V, uint64_t w
         uint32_t rev = revcomp(km, k) < km ? 1u : 0u;      // anchor != min(anchor, revcomp(anchor))
         V.anchor_pos[i] = (int32_t)pos; V.anchor_addr[i] = addr;
         V.flags[i] = (uint8_t)(rev | (st == ST_INSERTER ? 2u : 0u));
-        V.sort_key[i] = ((uint64_t)addr << 1) | rev;
+        V.sort_key[i] = addr;                              // both strands of an anchor walk together (k_walk)
     }
 }
 void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1) {
@@ -495,19 +495,17 @@ __device__ inline void walk_step(const BloomDev& B, const uint16_t* rv16, uint32
         if (cnt >= 1) { *ev_pos = (uint8_t)((EV_NT0 + nt) | EV_ERROR); follow = first; }
         else *ev_pos = (uint8_t)(EV_NT0 + nt);
     }
-    // AbstractDnaCoder::codeSeedBin, keeping the reverse complement alongside
-    if (right) {
-        kmer = ((kmer << 2) | (K)follow) & kmask_k;
-        rc = (rc >> 2) | ((K)(follow ^ 2u) << (2 * (k - 1)));
-    } else {
-        kmer = (kmer >> 2) | ((K)follow << (2 * (k - 1)));
-        rc = ((rc << 2) | (K)(follow ^ 2u)) & kmask_k;
-    }
+    // AbstractDnaCoder::codeSeedBin, keeping the reverse complement alongside (selects: see bloom_contains4)
+    const K f = (K)follow, fc = (K)(follow ^ 2u);
+    const K kr = ((kmer << 2) | f) & kmask_k, kl = (kmer >> 2) | (f << (2 * (k - 1)));
+    const K rr = (rc >> 2) | (fc << (2 * (k - 1))), rl = ((rc << 2) | fc) & kmask_k;
+    kmer = right ? kr : kl;
+    rc = right ? rr : rl;
 }
 
 template <typename K>
 __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
-                                             const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
+                                             const uint8_t* flags, const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
     __shared__ uint16_t rv16[256];
     load_rv16(rv16, rv16g);
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -524,40 +522,38 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
     const K anchor = kmer_at<K>(pk, (uint32_t)a, k);
     const K anchor_rc = revcomp(anchor, k);
 
+    // Left and right walks are independent (events are indexed by position), so their order is free: a read whose
+    // anchor is reverse-complemented walks right first.  All reads of an anchor, whatever their strand, then step
+    // through the same genome side at the same iteration and share the bloom sectors they probe.
+    const bool right_first = (flags[i] & 1u) != 0;
     // the read's 2-bit word (16 bases) and N-mask word (32 bases) stay in registers between reloads
     uint32_t pw = 0, pw_idx = 0xFFFFFFFFu, nw = 0, nw_idx = 0xFFFFFFFFu;
-    K kmer = anchor, rc = anchor_rc;
-    for (int32_t pos = a - 1; pos >= 0; pos--) {
-        if (((uint32_t)pos >> 4) != pw_idx) { pw_idx = (uint32_t)pos >> 4; pw = pk[pw_idx]; }
-        uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
-        if (hasN) {
-            if (((uint32_t)pos >> 5) != nw_idx) { nw_idx = (uint32_t)pos >> 5; nw = nm[nw_idx]; }
-            if ((nw >> (pos & 31)) & 1u) {                        // N: coded as 'A', nothing stored
-                kmer = kmer >> 2; rc = ((rc << 2) | (K)2u) & kmask_k;
-                continue;
+    for (uint32_t phase = 0; phase < 2; phase++) {
+        const bool right = (phase == 0) == right_first;
+        K kmer = anchor, rc = anchor_rc;
+        const uint32_t nsteps = right ? len - k - (uint32_t)a : (uint32_t)a;
+        for (uint32_t j = 0; j < nsteps; j++) {                       // one loop for both directions
+            const uint32_t pos = right ? (uint32_t)a + k + j : (uint32_t)a - 1 - j;
+            if ((pos >> 4) != pw_idx) { pw_idx = pos >> 4; pw = pk[pw_idx]; }
+            const uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
+            if (hasN) {
+                if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
+                if ((nw >> (pos & 31)) & 1u) {                        // N: coded as 'A', nothing stored
+                    const K kr = (kmer << 2) & kmask_k, kl = kmer >> 2;
+                    const K rr = (rc >> 2) | ((K)2u << (2 * (k - 1))), rl = ((rc << 2) | (K)2u) & kmask_k;
+                    kmer = right ? kr : kl; rc = right ? rr : rl;
+                    continue;
+                }
             }
+            walk_step<K>(B, rv16, k, kmask_k, kmer, rc, nt, right, ev + pos);
         }
-        walk_step<K>(B, rv16, k, kmask_k, kmer, rc, nt, false, ev + pos);
-    }
-    kmer = anchor; rc = anchor_rc;
-    for (uint32_t pos = (uint32_t)a + k; pos < len; pos++) {
-        if ((pos >> 4) != pw_idx) { pw_idx = pos >> 4; pw = pk[pw_idx]; }
-        uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
-        if (hasN) {
-            if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
-            if ((nw >> (pos & 31)) & 1u) {
-                kmer = (kmer << 2) & kmask_k; rc = (rc >> 2) | ((K)2u << (2 * (k - 1)));
-                continue;
-            }
-        }
-        walk_step<K>(B, rv16, k, kmask_k, kmer, rc, nt, true, ev + pos);
     }
 }
-void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos,
+void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos, const uint8_t* flags,
                  const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
     if (!n_walk) return;
     uint64_t g = (n_walk + 255) / 256;
-    DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, perm, n_walk, events));
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events));
 }
 
 // ================================================================================================

@@ -64,7 +64,7 @@ void launch_assign_addr(hipStream_t s, DictDev D, ResolveDev V, uint64_t w0, uin
 void launch_anchor_symbols(hipStream_t s, const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms);
 void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1);
 // ---- walk ----
-void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos,
+void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos, const uint8_t* flags,
                  const uint32_t* perm, uint64_t n_walk, uint8_t* events);
 // ---- symbols ----
 void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, uint32_t rpb, uint64_t first_block,
