@@ -311,3 +311,51 @@ def test_two_word_kmers_bit_exact(k):
     _full_compare(bases, off, k, 700, window=1000)
     bases, off = common.synthetic(1200, 100, 5000, seed=90 + k, ragged=True)
     _full_compare(bases, off, k, 500, window=64, batches=2)
+
+
+def test_c_abi_error_behaviour():
+    """status codes and messages instead of exceptions across the boundary (include/leon_dna.h)"""
+    import leon_amd
+    from leon_amd import capi
+    k, rpb = 31, 100
+    bases, off = common.synthetic(450, 120, 5000, seed=71)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ctx = _ctx(k, rpb, tai)
+    ctx.bloom_upload(bl.bits)
+    with pytest.raises(leon_amd.LeonDnaError) as e:                      # wrong bloom size
+        ctx.bloom_upload(bl.bits[:-1])
+    assert e.value.code == -1
+    # a sink that refuses the second block aborts the call with LEON_E_SINK
+    seen = []
+
+    def bad_sink(user, block_id, p, size, n_reads):
+        seen.append(block_id)
+        return 1 if block_id == 1 else 0
+    with pytest.raises(leon_amd.LeonDnaError) as e:
+        ctx.encode_batch(bases, off[:301], sink=capi.SINK(bad_sink))
+    assert e.value.code == -6 and seen == [0, 1]
+    ctx.close()
+    ctx = _ctx(k, rpb, tai)
+    ctx.bloom_upload(bl.bits)
+    ctx.next_read = 7                                                    # stream must be continued in order
+    with pytest.raises(leon_amd.LeonDnaError) as e:
+        ctx.encode_batch(bases, off[:101])
+    assert e.value.code == -4
+    ctx.next_read = 0
+    assert len(ctx.encode_batch(bases, off[:251])) == 3                  # 250 reads: the last block is partial ...
+    with pytest.raises(leon_amd.LeonDnaError) as e:                      # ... so no batch may follow
+        ctx.encode_batch(bases, off[250:351])
+    assert e.value.code == -4
+    with pytest.raises(leon_amd.LeonDnaError):                           # shard must be chosen before the first batch
+        ctx.set_shard(0, 2)
+    d1, n1 = ctx.finish()
+    d2, n2 = ctx.finish()                                                # idempotent
+    assert d1 == d2 and n1 == n2
+    with pytest.raises(leon_amd.LeonDnaError) as e:                      # no batch after finish
+        ctx.encode_batch(bases, off[:101])
+    assert e.value.code == -4
+    ctx.reset_stream()                                                   # a new file on the same context
+    ref = O.encode(bases, off, k, rpb, bl, trace=False)
+    assert [b[1] for b in ctx.encode_batch(bases, off)] == ref.blocks
+    assert ctx.finish()[0] == ref.anchor_dict
+    ctx.close()
