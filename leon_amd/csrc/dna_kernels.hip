@@ -246,55 +246,89 @@ __device__ inline int first_in_bloom(const BloomDev& B, const uint16_t* rv16, co
     return -1;
 }
 
+// 16-lane variant of canon_from_words: lanes gbase .. gbase+7 of each quarter-wave hold the dwords of that quarter's read
+template <typename K> __device__ inline K canon_from_words16(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k);
+template <> __device__ inline uint64_t canon_from_words16<uint64_t>(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k) {
+    const int d = (int)(gbase + (p >> 4) - (base >> 4));
+    const uint64_t km = kmer_from3((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1),
+                                   (uint32_t)__shfl((int)words, d + 2), p & 15, k);
+    const uint64_t rc = revcomp(km, k);
+    return rc < km ? rc : km;
+}
+template <> __device__ inline u128 canon_from_words16<u128>(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k) {
+    const int d = (int)(gbase + (p >> 4) - (base >> 4));             // p - base < 16: d - gbase <= 1, d + 4 - gbase <= 5 < 8
+    const u128 km = kmer_from5((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1), (uint32_t)__shfl((int)words, d + 2),
+                               (uint32_t)__shfl((int)words, d + 3), (uint32_t)__shfl((int)words, d + 4), p & 15, k);
+    const u128 rc = revcomp(km, k);
+    return rc < km ? rc : km;
+}
+
 // Pass A of a window: DnaEncoder::findExistingAnchor against the dictionary as it stood before the window,
-// else the candidate Leon::findAndInsertAnchor would insert.  One wave per read, one lane per k-mer.
+// else the candidate Leon::findAndInsertAnchor would insert.  Four reads per wave, 16 k-mer positions per read and
+// step: the first anchor sits ~20 positions into a read, so quarter-waves look up ~1.7x fewer k-mers than whole
+// waves would, and a wave keeps four independent reads' memory requests in flight.
 template <typename K>
 __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, const uint16_t* rv16g, DictDev D, ResolveDev V,
                                                     uint64_t w0, uint64_t w1, uint64_t first_global,
                                                     uint32_t* ulist, uint32_t* ucount) {
     __shared__ uint16_t rv16[256];
     load_rv16(rv16, rv16g);
-    uint32_t lane = lane_id(), k = R.k;
-    uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t i = w0 + wave; i < w1; i += nwaves) {
-        uint32_t len = R.len[i];
-        uint64_t g = first_global + i;
-        if (len < k) { if (lane == 0) V.status[i] = ST_NOANCHOR; continue; }
-        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
-        uint32_t nk = len - k + 1;
-        bool done = false;
-        for (uint32_t base = 0; base < nk; base += 64) {
-            uint32_t p = base + lane;
-            bool hit = false; uint32_t slot = 0xFFFFFFFFu;
-            const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
-            if (p < nk) {
-                slot = dict_find(D, cn);
-                hit = slot != 0xFFFFFFFFu && D.fin[slot] < g;
-            }
-            unsigned long long b = __ballot(hit);
-            if (b) {
-                uint32_t l = (uint32_t)__builtin_ctzll(b);
-                uint32_t hs = __shfl(slot, l);
-                if (lane == 0) { V.status[i] = ST_HIT; V.hit_pos[i] = base + l; V.hit_slot[i] = hs; }
-                done = true;
-                break;
-            }
-        }
-        if (done) continue;
+    const uint32_t lane = lane_id(), k = R.k;
+    const uint32_t grp = lane >> 4, l = lane & 15, gbase = grp * 16;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    enum : uint32_t { PH_LOOKUP = 0, PH_SEG_A = 1, PH_SEG_B = 2, PH_SEG_C = 3, PH_DONE = 4 };
+    for (uint64_t i0 = w0 + 4 * wave; i0 < w1; i0 += 4 * nwaves) {
+        const uint64_t i = i0 + grp;
+        const bool have = i < w1;
+        const uint32_t len = have ? R.len[i] : 0;
+        const uint64_t g = first_global + i;
+        const uint32_t* pk = R.packed + 2 * (have ? R.slot_off[i] : 0);
+        const uint32_t nk = len >= k ? len - k + 1 : 0;
         // Leon::findAndInsertAnchor scan order: [n/2, n/2+10), [0, n/2), [n/2+10, n)
-        uint32_t iMin = nk / 2, iMax = nk / 2 + 10;
-        if (iMax > nk) iMax = nk;
-        int cp = first_in_bloom<K>(B, rv16, pk, k, iMin, iMax, lane);
-        if (cp < 0) cp = first_in_bloom<K>(B, rv16, pk, k, 0, iMin, lane);
-        if (cp < 0) cp = first_in_bloom<K>(B, rv16, pk, k, iMax, nk, lane);
-        if (lane == 0) {
-            if (cp < 0) V.status[i] = ST_NOANCHOR;
-            else {
-                uint32_t slot = dict_find_or_insert<true>(D, canon_at<K>(pk, (uint32_t)cp, k));
-                atomicMin((unsigned long long*)&D.tent[slot], (unsigned long long)g);
-                V.status[i] = ST_UNRESOLVED; V.cand_pos[i] = (uint32_t)cp; V.cand_slot[i] = slot;
-                ulist[atomicAdd(ucount, 1u)] = (uint32_t)i;
+        const uint32_t iMin = nk / 2, iMax = nk / 2 + 10 > nk ? nk : nk / 2 + 10;
+        uint32_t phase = PH_LOOKUP, base = 0, limit = nk;
+        if (nk == 0) { phase = PH_DONE; if (have && l == 0) V.status[i] = ST_NOANCHOR; }
+        while (__any(phase != PH_DONE)) {
+            const bool active = phase != PH_DONE;
+            // a phase whose range is exhausted moves on (empty segments fall through in later iterations)
+            if (active && base >= limit) {
+                if (phase == PH_LOOKUP) { phase = PH_SEG_A; base = iMin; limit = iMax; }
+                else if (phase == PH_SEG_A) { phase = PH_SEG_B; base = 0; limit = iMin; }
+                else if (phase == PH_SEG_B) { phase = PH_SEG_C; base = iMax; limit = nk; }
+                else { phase = PH_DONE; if (l == 0) V.status[i] = ST_NOANCHOR; }
+            }
+            const bool run = phase != PH_DONE && base < limit;
+            const uint32_t p = base + l;
+            const bool valid = run && p < limit;
+            const uint32_t words = (run && l < 8) ? pk[(base >> 4) + l] : 0u;
+            const K cn = canon_from_words16<K>(words, gbase, base, valid ? p : (run ? limit - 1 : 0), k);   // all 64 lanes
+            bool hit = false; uint32_t slot = 0xFFFFFFFFu;
+            if (valid) {
+                if (phase == PH_LOOKUP) { slot = dict_find(D, cn); hit = slot != 0xFFFFFFFFu && D.fin[slot] < g; }
+                else hit = bloom_contains<K>(B, rv16, cn);
+            }
+            const unsigned long long bal = __ballot(hit);
+            const uint32_t gb = (uint32_t)(bal >> gbase) & 0xFFFFu;
+            bool want_insert = false; uint32_t cpos = 0;
+            if (run) {
+                if (gb) {
+                    const uint32_t f = (uint32_t)__builtin_ctz(gb);
+                    const uint32_t hs = __shfl(slot, (int)(gbase + f));
+                    if (phase == PH_LOOKUP) { if (l == 0) { V.status[i] = ST_HIT; V.hit_pos[i] = base + f; V.hit_slot[i] = hs; } }
+                    else { want_insert = (l == 0); cpos = base + f; }
+                    phase = PH_DONE;
+                } else base += 16;
+            }
+            // candidates go into the dictionary one quarter-wave at a time: with two-word keys an inserting lane may
+            // wait for another inserter, which must not be a lane of its own wave
+            for (uint32_t q = 0; q < 4; q++) {
+                if (want_insert && grp == q) {
+                    const uint32_t sl = dict_find_or_insert<true>(D, canon_at<K>(pk, cpos, k));
+                    atomicMin((unsigned long long*)&D.tent[sl], (unsigned long long)g);
+                    V.status[i] = ST_UNRESOLVED; V.cand_pos[i] = cpos; V.cand_slot[i] = sl;
+                    ulist[atomicAdd(ucount, 1u)] = (uint32_t)i;
+                }
             }
         }
     }
@@ -302,7 +336,7 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
 void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
                         uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount) {
     if (w1 <= w0) return;
-    DISPATCH_K(R.k, hipLaunchKernelGGL(k_lookup_cand<K>, dim3(grid_for(w1 - w0, 4, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_lookup_cand<K>, dim3(grid_for(w1 - w0, 16, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
                                        first_global, ulist, ucount));
 }
 
@@ -376,38 +410,51 @@ void launch_propose(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_globa
 }
 
 // After the window's fixpoint: findExistingAnchor's answer = FIRST position whose k-mer an earlier read owns.
+// Reads that hit the old dictionary at position h only re-check positions < h (this window's inserts); four reads
+// per wave, 16 positions per step, like k_lookup_cand.
 template <typename K>
 __global__ void __launch_bounds__(256) k_final_pos(ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t first_global) {
-    uint32_t lane = lane_id(), k = R.k;
-    uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t i = w0 + wave; i < w1; i += nwaves) {
-        uint8_t st = V.status[i];
-        if (st != ST_HIT && st != ST_HITNEW) continue;
-        uint64_t g = first_global + i;
-        uint32_t limit = st == ST_HIT ? V.hit_pos[i] : R.len[i] - k + 1;
-        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
-        for (uint32_t base = 0; base < limit; base += 64) {
-            uint32_t p = base + lane;
+    const uint32_t lane = lane_id(), k = R.k;
+    const uint32_t grp = lane >> 4, l = lane & 15, gbase = grp * 16;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i0 = w0 + 4 * wave; i0 < w1; i0 += 4 * nwaves) {
+        const uint64_t i = i0 + grp;
+        const bool have = i < w1;
+        const uint8_t st = have ? V.status[i] : (uint8_t)ST_NOANCHOR;
+        const bool mine = st == ST_HIT || st == ST_HITNEW;
+        const uint64_t g = first_global + i;
+        const uint32_t limit = !mine ? 0u : (st == ST_HIT ? V.hit_pos[i] : R.len[i] - k + 1);
+        const uint32_t* pk = R.packed + 2 * (mine ? R.slot_off[i] : 0);
+        uint32_t base = 0;
+        bool done = limit == 0;
+        while (__any(!done)) {
+            const bool run = !done;
+            const uint32_t p = base + l;
+            const bool valid = run && p < limit;
+            const uint32_t words = (run && l < 8) ? pk[(base >> 4) + l] : 0u;
+            const K cn = canon_from_words16<K>(words, gbase, base, valid ? p : (run ? limit - 1 : 0), k);
             bool hit = false; uint32_t slot = 0xFFFFFFFFu;
-            const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < limit ? p : limit - 1, k);
-            if (p < limit) {
+            if (valid) {
                 slot = dict_find(D, cn);
                 hit = slot != 0xFFFFFFFFu && D.fin[slot] < g;
             }
-            unsigned long long b = __ballot(hit);
-            if (b) {
-                uint32_t l = (uint32_t)__builtin_ctzll(b);
-                uint32_t hs = __shfl(slot, l);
-                if (lane == 0) { V.hit_pos[i] = base + l; V.hit_slot[i] = hs; }
-                break;
+            const unsigned long long bal = __ballot(hit);
+            const uint32_t gb = (uint32_t)(bal >> gbase) & 0xFFFFu;
+            if (run) {
+                if (gb) {
+                    const uint32_t f = (uint32_t)__builtin_ctz(gb);
+                    const uint32_t hs = __shfl(slot, (int)(gbase + f));
+                    if (l == 0) { V.hit_pos[i] = base + f; V.hit_slot[i] = hs; }
+                    done = true;
+                } else { base += 16; done = base >= limit; }
             }
         }
     }
 }
 void launch_final_pos(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t first_global) {
     if (w1 <= w0) return;
-    DISPATCH_K(R.k, hipLaunchKernelGGL(k_final_pos<K>, dim3(grid_for(w1 - w0, 4, 256 * 16)), dim3(256), 0, s, R, D, V, w0, w1, first_global));
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_final_pos<K>, dim3(grid_for(w1 - w0, 16, 256 * 16)), dim3(256), 0, s, R, D, V, w0, w1, first_global));
 }
 
 __global__ void k_ins_flags(ResolveDev V, uint64_t w0, uint64_t w1) {
