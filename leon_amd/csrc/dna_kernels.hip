@@ -527,13 +527,18 @@ void launch_anchor_symbols(hipStream_t s, const uint64_t* kmers, uint64_t n_anch
 // walk: DnaEncoder::encodeAnchorRead's two loops over buildBifurcationList.  One lane per read, reads taken
 // in anchor-sorted order so that neighbouring lanes probe the same bloom windows at the same step.
 // ================================================================================================
+// One extension step.  Every lane extends to the RIGHT on its own strand: a left walk over the read is a right walk
+// over the reverse complement (x = revcomp of the current k-mer, y = the k-mer), with the read base complemented.
+// The bloom is strand-symmetric, so contains4_left(kmer)[n] == contains4_right(revcomp(kmer))[n ^ 2]: the left-walking
+// lanes only swap the mask's bit pairs back.  One instruction stream for both directions, no duplicated arithmetic.
 template <typename K>
-__device__ inline void walk_step(const BloomDev& B, const uint16_t* rv16, uint32_t k, K kmask_k, K& kmer, K& rc,
-                                 uint32_t nt, bool right, uint8_t* ev_pos) {
-    uint32_t res4 = bloom_contains4<K>(B, rv16, kmer, rc, right);
-    uint32_t cnt = __popc(res4);
-    bool solid = (res4 >> nt) & 1u;
-    uint32_t first = res4 ? (uint32_t)__builtin_ctz(res4) : 0u;
+__device__ inline void walk_step(const BloomDev& B, const uint16_t* rv16, uint32_t k, K kmask_k, K& x, K& y,
+                                 uint32_t nt, bool left, uint8_t* ev_pos) {
+    uint32_t res4 = bloom_contains4<K>(B, rv16, x, y, true);
+    if (left) res4 = ((res4 >> 2) & 3u) | ((res4 & 3u) << 2);         // back to the read strand's base codes
+    const uint32_t cnt = __popc(res4);
+    const bool solid = (res4 >> nt) & 1u;
+    const uint32_t first = res4 ? (uint32_t)__builtin_ctz(res4) : 0u;
     uint32_t follow = nt;
     if (solid) {
         if (cnt == 2) *ev_pos = (uint8_t)(first == nt ? EV_BIN0 : EV_BIN1);
@@ -542,12 +547,10 @@ __device__ inline void walk_step(const BloomDev& B, const uint16_t* rv16, uint32
         if (cnt >= 1) { *ev_pos = (uint8_t)((EV_NT0 + nt) | EV_ERROR); follow = first; }
         else *ev_pos = (uint8_t)(EV_NT0 + nt);
     }
-    // AbstractDnaCoder::codeSeedBin, keeping the reverse complement alongside (selects: see bloom_contains4)
-    const K f = (K)follow, fc = (K)(follow ^ 2u);
-    const K kr = ((kmer << 2) | f) & kmask_k, kl = (kmer >> 2) | (f << (2 * (k - 1)));
-    const K rr = (rc >> 2) | (fc << (2 * (k - 1))), rl = ((rc << 2) | fc) & kmask_k;
-    kmer = right ? kr : kl;
-    rc = right ? rr : rl;
+    // AbstractDnaCoder::codeSeedBin on this lane's strand, keeping the other strand alongside
+    const uint32_t f = left ? follow ^ 2u : follow;
+    x = ((x << 2) | (K)f) & kmask_k;
+    y = (y >> 2) | ((K)(f ^ 2u) << (2 * (k - 1)));
 }
 
 template <typename K>
@@ -576,23 +579,23 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
     // the read's 2-bit word (16 bases) and N-mask word (32 bases) stay in registers between reloads
     uint32_t pw = 0, pw_idx = 0xFFFFFFFFu, nw = 0, nw_idx = 0xFFFFFFFFu;
     for (uint32_t phase = 0; phase < 2; phase++) {
-        const bool right = (phase == 0) == right_first;
-        K kmer = anchor, rc = anchor_rc;
-        const uint32_t nsteps = right ? len - k - (uint32_t)a : (uint32_t)a;
+        const bool left = (phase == 0) != right_first;
+        K x = left ? anchor_rc : anchor, y = left ? anchor : anchor_rc;          // x: the strand being extended rightwards
+        const uint32_t nsteps = left ? (uint32_t)a : len - k - (uint32_t)a;
         for (uint32_t j = 0; j < nsteps; j++) {                       // one loop for both directions
-            const uint32_t pos = right ? (uint32_t)a + k + j : (uint32_t)a - 1 - j;
+            const uint32_t pos = left ? (uint32_t)a - 1 - j : (uint32_t)a + k + j;
             if ((pos >> 4) != pw_idx) { pw_idx = pos >> 4; pw = pk[pw_idx]; }
             const uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
             if (hasN) {
                 if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
-                if ((nw >> (pos & 31)) & 1u) {                        // N: coded as 'A', nothing stored
-                    const K kr = (kmer << 2) & kmask_k, kl = kmer >> 2;
-                    const K rr = (rc >> 2) | ((K)2u << (2 * (k - 1))), rl = ((rc << 2) | (K)2u) & kmask_k;
-                    kmer = right ? kr : kl; rc = right ? rr : rl;
+                if ((nw >> (pos & 31)) & 1u) {                        // N: coded as 'A' on the read strand, nothing stored
+                    const uint32_t f = left ? 2u : 0u;
+                    x = ((x << 2) | (K)f) & kmask_k;
+                    y = (y >> 2) | ((K)(f ^ 2u) << (2 * (k - 1)));
                     continue;
                 }
             }
-            walk_step<K>(B, rv16, k, kmask_k, kmer, rc, nt, right, ev + pos);
+            walk_step<K>(B, rv16, k, kmask_k, x, y, nt, left, ev + pos);
         }
     }
 }

@@ -144,19 +144,17 @@ __device__ inline uint32_t bloom_window(const BloomDev& B, uint64_t bitpos) {
     __builtin_memcpy(&w, B.bits + (bitpos >> 3), 4);
     return w >> (bitpos & 7);
 }
-// contains4: pv4 packs the four canonical prefix+suffix values (4 bits each, neighbour nt in nibble nt)
+// contains4: pv4 packs the four canonical prefix+suffix values (4 bits each, neighbour nt in nibble nt).
+// Hash i of neighbour n sits at bit racine + key[i] + pv[n]: the same offset pv[n] inside every hash's window, so the
+// windows are ANDed first and the four bits are extracted once (the kernel is VALU-issue bound, not memory bound).
 __device__ inline uint32_t bloom_probe4(const BloomDev& B, const BloomKeys& Kk, uint32_t pv4) {
-    uint32_t alive = 15u;
+    uint32_t w = 0xFFFFFFFFu;
 #pragma unroll
     for (uint32_t i = 0; i < 10; i++) {
-        if (i < B.n_hash) {
-            uint32_t w = bloom_window(B, Kk.racine + Kk.key[i]);
-            uint32_t m = ((w >> (pv4 & 15)) & 1u) | (((w >> ((pv4 >> 4) & 15)) & 1u) << 1) |
-                         (((w >> ((pv4 >> 8) & 15)) & 1u) << 2) | (((w >> ((pv4 >> 12) & 15)) & 1u) << 3);
-            alive &= m;
-        }
+        if (i < B.n_hash) w &= bloom_window(B, Kk.racine + Kk.key[i]);
     }
-    return alive;
+    return ((w >> (pv4 & 15)) & 1u) | (((w >> ((pv4 >> 4) & 15)) & 1u) << 1) |
+           (((w >> ((pv4 >> 8) & 15)) & 1u) << 2) | (((w >> ((pv4 >> 12) & 15)) & 1u) << 3);
 }
 // BloomNeighborCoherent positions of one k-mer (insert / contains)
 template <typename K>
@@ -179,15 +177,16 @@ template <typename K>
 __device__ inline uint32_t bloom_contains4(const BloomDev& B, const uint16_t* rv16, K kmer, K rc, bool right) {
     const uint32_t k = B.k;
     const K mkm2 = kmask<K>(k - 2);
-    // right: elem = kmer[1..k-1] + X : middle = kmer[2..k-1], prefix = kmer[1], suffix varies
-    // left : elem = X + kmer[0..k-2] : middle = kmer[0..k-3], prefix varies, suffix = kmer[k-2]
-    // (selects, not branches: lanes walking in opposite directions stay in lockstep)
-    const K hpf = right ? (kmer & mkm2) : (kmer >> 4);
-    const K hpr = right ? (rc >> 4) : (rc & mkm2);
-    const uint32_t fixed = right ? ((uint32_t)(uint64_t)(kmer >> (2 * (k - 2))) & 3u) : ((uint32_t)(uint64_t)(kmer >> 2) & 3u);
-    const uint32_t fsh = right ? 2u : 0u, vsh = right ? 0u : 2u;       // (prefix << 2) | suffix with the varied base at vsh
-    const uint32_t f = fixed << fsh;
-    const uint32_t pv4 = cano2(f) | (cano2(f | (1u << vsh)) << 4) | (cano2(f | (2u << vsh)) << 8) | (cano2(f | (3u << vsh)) << 12);
+    K hpf, hpr; uint32_t pv4;
+    if (right) {          // elem = kmer[1..k-1] + X : middle = kmer[2..k-1], prefix = kmer[1], suffix varies
+        hpf = kmer & mkm2; hpr = rc >> 4;
+        const uint32_t p = (uint32_t)(uint64_t)(kmer >> (2 * (k - 2))) & 3u;
+        pv4 = cano2(p << 2) | (cano2((p << 2) | 1) << 4) | (cano2((p << 2) | 2) << 8) | (cano2((p << 2) | 3) << 12);
+    } else {              // elem = X + kmer[0..k-2] : middle = kmer[0..k-3], prefix varies, suffix = kmer[k-2]
+        hpf = kmer >> 4; hpr = rc & mkm2;
+        const uint32_t s = (uint32_t)(uint64_t)(kmer >> 2) & 3u;
+        pv4 = cano2(s) | (cano2(4 | s) << 4) | (cano2(8 | s) << 8) | (cano2(12 | s) << 12);
+    }
     BloomKeys Kk;
     bloom_keys<K>(B, rv16, hpf, hpr, Kk);
     return bloom_probe4(B, Kk, pv4);
