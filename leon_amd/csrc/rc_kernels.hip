@@ -156,19 +156,58 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
                     const uint32_t s_tot = (uint32_t)__builtin_amdgcn_readlane((int)v_tot, (int)j);
                     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)v_il, (int)j);
                     const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)v_ih, (int)j);
-                    // q = floor(range / tot): truncated multiply-high (at most 3 short), fixed up on the low word
-                    const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
-                    uint64_t q = (uint64_t)r1 * b1 + (((uint64_t)r1 * b0) >> 32) + (((uint64_t)r0 * b1) >> 32);
-                    uint32_t rem = r0 - (uint32_t)q * s_tot;            // true remainder < 4 * tot < 2^32
-                    uint32_t k = 0;
-                    if (rem >= 2 * s_tot) { k = 2; rem -= 2 * s_tot; }
-                    if (rem >= s_tot) k++;
-                    q += k;
-                    low += (uint64_t)s_lo * q;
-                    range = q * s_fr;
+                    // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
+                    // total < 2^30), fixed up on the low word; low += cumLow * q; range = q * freq.  Hand-scheduled on
+                    // the scalar unit: 29 instructions (the compiler's version of the same C was ~45 and went
+                    // through VALU compares).
+                    uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32), l0 = (uint32_t)low, l1 = (uint32_t)(low >> 32);
+                    uint32_t q0, q1, t0, t1, t2, t3;
+                    asm volatile(
+                        "s_mul_hi_u32 %[t0], %[r1], %[b0]\n\t"
+                        "s_mul_hi_u32 %[t1], %[r0], %[b1]\n\t"
+                        "s_mul_i32 %[q0], %[r1], %[b1]\n\t"
+                        "s_mul_hi_u32 %[q1], %[r1], %[b1]\n\t"
+                        "s_add_u32 %[q0], %[q0], %[t0]\n\t"
+                        "s_addc_u32 %[q1], %[q1], 0\n\t"
+                        "s_add_u32 %[q0], %[q0], %[t1]\n\t"
+                        "s_addc_u32 %[q1], %[q1], 0\n\t"
+                        "s_mul_i32 %[t0], %[q0], %[tot]\n\t"
+                        "s_sub_u32 %[t0], %[r0], %[t0]\n\t"              // remainder, < 4 * tot
+                        "s_lshl_b32 %[t1], %[tot], 1\n\t"
+                        "s_cmp_ge_u32 %[t0], %[t1]\n\t"
+                        "s_cselect_b32 %[t2], %[t1], 0\n\t"
+                        "s_cselect_b32 %[t3], 2, 0\n\t"
+                        "s_sub_u32 %[t0], %[t0], %[t2]\n\t"
+                        "s_cmp_ge_u32 %[t0], %[tot]\n\t"
+                        "s_addc_u32 %[t3], %[t3], 0\n\t"
+                        "s_add_u32 %[q0], %[q0], %[t3]\n\t"
+                        "s_addc_u32 %[q1], %[q1], 0\n\t"
+                        "s_mul_i32 %[t0], %[lo], %[q0]\n\t"              // low += cumLow * q
+                        "s_mul_hi_u32 %[t1], %[lo], %[q0]\n\t"
+                        "s_mul_i32 %[t2], %[lo], %[q1]\n\t"
+                        "s_add_u32 %[t1], %[t1], %[t2]\n\t"
+                        "s_add_u32 %[l0], %[l0], %[t0]\n\t"
+                        "s_addc_u32 %[l1], %[l1], %[t1]\n\t"
+                        "s_mul_hi_u32 %[t0], %[q0], %[fr]\n\t"           // range = q * freq
+                        "s_mul_i32 %[r1], %[q1], %[fr]\n\t"
+                        "s_mul_i32 %[r0], %[q0], %[fr]\n\t"
+                        "s_add_u32 %[r1], %[r1], %[t0]\n\t"
+                        : [r0] "+s"(r0), [r1] "+s"(r1), [l0] "+s"(l0), [l1] "+s"(l1), [q0] "=&s"(q0), [q1] "=&s"(q1),
+                          [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3)
+                        : [b0] "s"(b0), [b1] "s"(b1), [tot] "s"(s_tot), [lo] "s"(s_lo), [fr] "s"(s_fr)
+                        : "scc");
+                    range = ((uint64_t)r1 << 32) | r0;
+                    low = ((uint64_t)l1 << 32) | l0;
                     for (;;) {                                          // RangeEncoder::encode's while loop
-                        const uint32_t x = (uint32_t)((low ^ (low + range)) >> 32);
-                        if (x >= (1u << 24)) {
+                        uint32_t xh;                                    // high word of low ^ (low + range), on the scalar unit
+                        {
+                            uint32_t a0 = (uint32_t)low, a1 = (uint32_t)(low >> 32), c0 = (uint32_t)range, c1 = (uint32_t)(range >> 32), u0;
+                            asm volatile("s_add_u32 %[u0], %[a0], %[c0]\n\t"
+                                         "s_addc_u32 %[xh], %[a1], %[c1]\n\t"
+                                         "s_xor_b32 %[xh], %[xh], %[a1]\n\t"
+                                         : [u0] "=&s"(u0), [xh] "=&s"(xh) : [a0] "s"(a0), [a1] "s"(a1), [c0] "s"(c0), [c1] "s"(c1) : "scc");
+                        }
+                        if (xh >= (1u << 24)) {
                             if ((uint32_t)(range >> 32) >= (1u << 16)) break;
                             range = (0 - low) & (RC_BOTTOM - 1);
                         }
