@@ -25,6 +25,7 @@ K = 31
 L = 150
 N_HASH = 7
 BITS_PER_KMER = 12
+ABUNDANCE = 3
 RPB = 50000
 CHUNK = 1_000_000           # reads generated per torch call; also the unit of the rank partition
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s
@@ -68,24 +69,6 @@ def gen_reads_chunk(genome, chunk_id, n, err, device):
     return lut[codes.long()]
 
 
-def insert_genome_kmers(ctx, genome, k):
-    """bloom <- every canonical k-mer of the genome (stand-in for DSK's solid set at 30x, abundance >= 3)"""
-    G = genome.numel()
-    step = 32_000_000
-    for s in range(0, G - k + 1, step):
-        n = min(step, G - k + 1 - s)
-        c = genome[s:s + n + k - 1].to(torch.int64)
-        fwd = torch.zeros(n, dtype=torch.int64, device=genome.device)
-        rc = torch.zeros(n, dtype=torch.int64, device=genome.device)
-        for j in range(k):
-            fwd = (fwd << 2) | c[j:j + n]
-            rc |= (c[j:j + n] ^ 2) << (2 * j)
-        canon = torch.minimum(fwd, rc).contiguous()
-        torch.cuda.synchronize()
-        ctx.bloom_insert_device(canon.data_ptr(), n)
-        del c, fwd, rc, canon
-
-
 def walk_bytes_per_read(k):
     """algorithmic bytes of ONE read in the dominant kernel k_walk, SURVEY.md section 8(d)'s per-unit terms for it:
     the 2-bit read in, ONE 64-byte bloom line per extension step (L-k steps), the per-position event bytes out.
@@ -127,29 +110,6 @@ def main():
     n_local = (b1 - b0) * RPB                # reads this rank walks and codes (it resolves all n_total)
 
     genome = gen_genome(G, device)
-    tai = (G - K + 1) * BITS_PER_KMER
-    ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local)
-    ctx.set_shard(rank, world)
-    nbytes = ctx.bloom_nbytes
-    t_b = time.time()
-    if world == 1:
-        insert_genome_kmers(ctx, genome, K)
-        bcast_ms = 0.0
-    else:                                   # rank 0 builds, RCCL broadcast over xGMI, device to device
-        bits = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        if rank == 0:
-            insert_genome_kmers(ctx, genome, K)
-            ctx.bloom_download_device(bits.data_ptr(), nbytes)
-        torch.cuda.synchronize(); dist.barrier()
-        t0 = time.time()
-        dist.broadcast(bits, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.time() - t0) * 1e3
-        if rank != 0:
-            ctx.bloom_upload_device(bits.data_ptr(), nbytes)
-        del bits
-    bloom_s = time.time() - t_b
-
     # the whole read set on every rank (same seeds everywhere), generated chunk by chunk
     reads = torch.empty((n_total, L), dtype=torch.uint8, device=device)
     for c0 in range(0, (n_total + CHUNK - 1) // CHUNK):
@@ -160,6 +120,40 @@ def main():
     offsets = (torch.arange(n_total + 1, dtype=torch.int64, device=device) * L).contiguous()
     del genome
     torch.cuda.synchronize()
+
+    # bloom = the reads' solid k-mers (abundance >= 3, Leon's `-abundance 3`), counted on the device by rank 0
+    # (leon_kmer_solid_device, the DSK stand-in: outside the timed region, it is the step before the path)
+    t_b = time.time()
+    n_solid_t = torch.zeros(1, dtype=torch.int64, device=device)
+    d_solid = 0
+    if rank == 0:
+        d_solid, n_solid = capi.kmer_solid_device(reads.data_ptr(), offsets.data_ptr(), n_total, K, ABUNDANCE, device_id=local)
+        n_solid_t[0] = n_solid
+    count_s = time.time() - t_b
+    if world > 1:
+        dist.broadcast(n_solid_t, src=0)
+    n_solid = int(n_solid_t.item())
+    tai = n_solid * BITS_PER_KMER
+    ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local)
+    ctx.set_shard(rank, world)
+    nbytes = ctx.bloom_nbytes
+    bcast_ms = 0.0
+    if rank == 0:
+        ctx.bloom_insert_device(d_solid, n_solid)
+        capi.device_free(d_solid)
+    if world > 1:                           # RCCL broadcast of the bloom over xGMI, device to device
+        bits = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if rank == 0:
+            ctx.bloom_download_device(bits.data_ptr(), nbytes)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.time()
+        dist.broadcast(bits, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.time() - t0) * 1e3
+        if rank != 0:
+            ctx.bloom_upload_device(bits.data_ptr(), nbytes)
+        del bits
+    bloom_s = time.time() - t_b
 
     payload = [0, 0]
 
@@ -227,13 +221,14 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%d x %d bp synthetic reads, k=%d, genome %d bp (30x), 1%% substitutions, "
-                                   "bloom %d bits/k-mer x %d hashes built from the genome's k-mers"
-                                   % (n_total, L, K, G, BITS_PER_KMER, N_HASH),
+                                   "bloom %d bits/k-mer x %d hashes over the reads' %d solid k-mers (abundance >= %d, device counter)"
+                                   % (n_total, L, K, G, BITS_PER_KMER, N_HASH, n_solid, ABUNDANCE),
                        "reads": n_total, "read_len": L, "kmer_size": K, "reads_per_block": RPB,
                        "sharding": "bloom broadcast over RCCL; anchor resolution replicated on every rank (file-order "
                                    "dictionary, no exchange); walk + range coder on contiguous block ranges; "
                                    "dictionary stream on rank 0" if world > 1 else "single GPU",
-                       "bloom_bytes": nbytes, "bloom_bcast_ms": round(bcast_ms, 2), "bloom_build_s": round(bloom_s, 2)},
+                       "bloom_bytes": nbytes, "bloom_bcast_ms": round(bcast_ms, 2), "bloom_build_s": round(bloom_s, 2),
+                       "kmer_count_s": round(count_s, 2), "solid_kmers": n_solid},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},

@@ -112,6 +112,18 @@ int leon_dna_set_shard(leon_dna_ctx* ctx, uint32_t rank, uint32_t world);
  * payload stays owned by ctx until destroy. */
 int leon_dna_finish(leon_dna_ctx* ctx, const uint8_t** dict_payload, uint64_t* dict_size, uint64_t* n_anchors);
 
+/* -- the step BEFORE the path: solid k-mers of the reads, the set Leon::createBloom inserts (upstream DSK,
+ * SortingCountAlgorithm).  Canonical k-mers occurring at least min_abundance times; k-mers containing an N are skipped.
+ * Output: W words per k-mer (unordered across hash partitions).  histogram (optional, 256 entries): number of distinct
+ * k-mers by abundance, clipped at 255.  max_keys_per_pass: k-mers sorted at once (0 = 2^30).  Errors: leon_last_error(NULL). */
+int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads,
+                           uint32_t kmer_size, uint32_t min_abundance, uint64_t max_keys_per_pass,
+                           uint64_t** d_solid, uint64_t* n_solid, uint64_t* histogram);   /* *d_solid: leon_device_free */
+int leon_kmer_solid(int device_id, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t kmer_size,
+                    uint32_t min_abundance, uint64_t max_keys_per_pass, uint64_t* out, uint64_t out_cap, uint64_t* n_solid,
+                    uint64_t* histogram);
+void leon_device_free(void* d_ptr);
+
 /* Host-only helper (no GPU, no ctx): the dictionary stream leon_dna_finish returns for a given anchor list, i.e.
  * Leon::encodeInsertedAnchor over `kmers` in address order followed by the flush.  Used by the CPU tests. */
 int leon_host_anchor_dict_encode(const uint64_t* kmers, uint64_t n_anchors, uint32_t kmer_size, uint8_t* out,

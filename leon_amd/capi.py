@@ -65,6 +65,11 @@ _EXPORTS = {
     "leon_dna_finish": (C.c_int, [C.c_void_p, C.POINTER(_u8p), _u64p, _u64p]),
     "leon_dna_reset_stream": (C.c_int, [C.c_void_p]),
     "leon_dna_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "leon_kmer_solid_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
+                                          C.POINTER(C.c_void_p), _u64p, _u64p]),
+    "leon_kmer_solid": (C.c_int, [C.c_int, C.c_char_p, _u64p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _u64p, C.c_uint64,
+                                   _u64p, _u64p]),
+    "leon_device_free": (None, [C.c_void_p]),
     "leon_host_anchor_dict_encode": (C.c_int, [_u64p, C.c_uint64, C.c_uint32, _u8p, C.c_uint64, _u64p]),
     "leon_dna_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "leon_dna_trace_anchors": (C.c_int, [C.c_void_p, _i32p, _u32p, _u8p, C.c_uint64]),
@@ -115,6 +120,42 @@ def host_anchor_dict_encode(kmers, k):
     if rc:
         raise LeonDnaError(rc, "leon_host_anchor_dict_encode failed")
     return out[:size.value].tobytes()
+
+
+def kmer_solid(bases, offsets, k, min_abundance, device_id=0, with_histogram=False, max_keys_per_pass=0):
+    """solid canonical k-mers of the reads, counted on the device (host arrays in and out); flat uint64, kmer_words(k) each"""
+    lib = load_library()
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    if not isinstance(bases, (bytes, bytearray)):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).tobytes()
+    w = kmer_words(k)
+    hist = np.zeros(256, dtype=np.uint64)
+    ns = C.c_uint64()
+    cap = max(int(offsets[-1] - offsets[0]), 1)
+    out = np.zeros(cap * w, dtype=np.uint64)
+    rc = lib.leon_kmer_solid(device_id, bases, _ptr(offsets, _u64p), n, k, min_abundance, int(max_keys_per_pass),
+                             _ptr(out, _u64p), cap, C.byref(ns), _ptr(hist, _u64p))
+    if rc:
+        raise LeonDnaError(rc, (lib.leon_last_error(None) or b"").decode())
+    res = out[:ns.value * w].copy()
+    return (res, hist) if with_histogram else res
+
+
+def kmer_solid_device(d_bases_ptr, d_offsets_ptr, n_reads, k, min_abundance, device_id=0, max_keys_per_pass=0):
+    """device arrays in, device array out: returns (device pointer, n_solid); free with device_free()"""
+    lib = load_library()
+    p, ns = C.c_void_p(), C.c_uint64()
+    rc = lib.leon_kmer_solid_device(device_id, C.c_void_p(int(d_bases_ptr)), C.c_void_p(int(d_offsets_ptr)), int(n_reads), k,
+                                    min_abundance, int(max_keys_per_pass), C.byref(p), C.byref(ns), None)
+    if rc:
+        raise LeonDnaError(rc, (lib.leon_last_error(None) or b"").decode())
+    return p.value, ns.value
+
+
+def device_free(ptr):
+    if ptr:
+        load_library().leon_device_free(C.c_void_p(int(ptr)))
 
 
 class DnaEncodeContext:

@@ -19,6 +19,9 @@ using namespace leon;
 namespace {
 
 thread_local std::string g_create_error;
+}
+namespace leon { void set_create_error(const std::string& msg) { g_create_error = msg; } }
+namespace {
 
 struct DevBuf {
     void* p = nullptr;

@@ -1,0 +1,250 @@
+// kmer_kernels.hip -- solid k-mer counting on the device: the step right before the DNA encode path (upstream: DSK,
+// kmer/impl/SortingCountAlgorithm [RECALLED], whose solid k-mers Leon::createBloom inserts).  Sort-based: the canonical
+// k-mers of the reads are emitted in hash partitions that fit the device, each partition is radix-sorted (hipCUB), runs
+// of at least min_abundance equal k-mers are kept.  k-mers containing an N are skipped, as DSK does.
+#include "../../include/leon_dna.h"
+#include "kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace leon {
+void set_create_error(const std::string& msg);   // capi.hip: message behind leon_last_error(NULL)
+
+namespace {
+
+// k-mers of partition `part` (of n_parts, by hash) -> keys[], W words each, through a wave-aggregated cursor
+template <typename K>
+__global__ void __launch_bounds__(256) k_emit_kmers(ReadsDev R, uint32_t n_parts, uint32_t part, uint64_t* keys, uint64_t cap,
+                                                   unsigned long long* cursor, int* overflow) {
+    const uint32_t lane = lane_id(), k = R.k;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < R.n; i += nwaves) {
+        const uint32_t len = R.len[i];
+        if (len < k) continue;
+        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+        const uint32_t* nm = R.nmask + R.slot_off[i];
+        const bool hasN = R.n_count[i] != 0;
+        const uint32_t nk = len - k + 1;
+        for (uint32_t base = 0; base < nk; base += 64) {
+            const uint32_t p = base + lane;
+            bool valid = p < nk;
+            const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, valid ? p : nk - 1, k);
+            if (valid && hasN) {                              // any N in [p, p + k) ?
+                for (uint32_t d = p >> 5; d <= (p + k - 1) >> 5 && valid; d++) {
+                    uint32_t w = nm[d];
+                    const uint32_t lo = d == (p >> 5) ? (p & 31) : 0, hi = d == ((p + k - 1) >> 5) ? ((p + k - 1) & 31) : 31;
+                    const uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1)) & ~((1u << lo) - 1);
+                    if (w & m) valid = false;
+                }
+            }
+            if (valid && n_parts > 1) valid = (uint32_t)((key_hash(cn) >> 40) % n_parts) == part;
+            const unsigned long long b = __ballot(valid);
+            if (!b) continue;
+            unsigned long long start = 0;
+            if (lane == 0) start = atomicAdd(cursor, (unsigned long long)__popcll(b));
+            start = __shfl(start, 0);
+            if (valid) {
+                const uint64_t at = start + __popcll(b & ((1ull << lane) - 1));
+                if (at < cap) store_kmer(keys + at * KT<K>::W, cn);
+                else *overflow = 1;
+            }
+        }
+    }
+}
+
+__global__ void k_positions(const uint64_t* off, uint64_t n, uint32_t k, uint64_t* out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t len = off[i + 1] - off[i];
+        out[i] = len >= k ? len - k + 1 : 0;
+    }
+}
+// sorted keys -> flag the first element of every run of at least T equal keys; optional histogram of run lengths
+template <uint32_t W>
+__global__ void k_flag_runs(const uint64_t* keys, uint64_t n, uint32_t T, uint8_t* flags, unsigned long long* hist) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        auto eq = [&](uint64_t a, uint64_t b) { return keys[a * W] == keys[b * W] && (W == 1 || keys[a * W + 1] == keys[b * W + 1]); };
+        const bool head = i == 0 || !eq(i, i - 1);
+        uint8_t f = 0;
+        if (head) {
+            f = (i + T - 1 < n && eq(i, i + T - 1)) ? 1 : 0;
+            if (hist) {                                        // run length by doubling + binary search (runs are short)
+                uint64_t lo = i, step = 1;
+                while (lo + step < n && eq(i, lo + step)) { lo += step; step <<= 1; }
+                while (step > 1) { step >>= 1; if (lo + step < n && eq(i, lo + step)) lo += step; }
+                const uint64_t run = lo - i + 1;
+                atomicAdd(&hist[run > 255 ? 255 : run], 1ull);
+            }
+        }
+        flags[i] = f;
+    }
+}
+__global__ void k_split_words(const uint64_t* keys, uint64_t n, uint64_t* lo, uint64_t* hi) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { lo[i] = keys[2 * i]; hi[i] = keys[2 * i + 1]; }
+}
+__global__ void k_join_words(const uint64_t* lo, const uint64_t* hi, uint64_t n, uint64_t* keys) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { keys[2 * i] = lo[i]; keys[2 * i + 1] = hi[i]; }
+}
+struct Pair128 { uint64_t lo, hi; };
+
+struct Buf {
+    void* p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    ~Buf() { if (p) (void)hipFree(p); }
+    template <typename T> T* as() { return (T*)p; }
+};
+uint32_t grid(uint64_t n, uint32_t per = 256, uint32_t cap = 8192) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + per - 1) / per, cap)); }
+
+#define KCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_create_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LEON_E_HIP; } } while (0)
+
+}  // namespace
+}  // namespace leon
+
+using namespace leon;
+
+extern "C" {
+
+void leon_device_free(void* p) { if (p) (void)hipFree(p); }
+
+int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint32_t k,
+                           uint32_t min_abundance, uint64_t max_keys_per_pass, uint64_t** d_solid, uint64_t* n_solid,
+                           uint64_t* histogram) {
+    if (!d_solid || !n_solid || (n_reads && (!d_bases || !d_offsets))) return LEON_E_INVALID;
+    if (k < 3 || k > 63 || min_abundance < 1) { set_create_error("kmer_solid: need 3 <= k <= 63 and min_abundance >= 1"); return LEON_E_INVALID; }
+    *d_solid = nullptr; *n_solid = 0;
+    if (histogram) memset(histogram, 0, 256 * sizeof(uint64_t));
+    if (!n_reads) return LEON_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) { set_create_error("kmer_solid: no such HIP device"); return LEON_E_NO_DEVICE; }
+    KCHK(hipSetDevice(device_id));
+    hipStream_t s = nullptr;
+    const uint32_t W = kmer_words(k);
+    // ---- pack the reads once ----
+    Buf slot_off, packed, nmask, rlen, ncount, tmp, pos;
+    KCHK(slot_off.alloc((n_reads + 1) * 8));
+    launch_read_slots(s, d_offsets, n_reads, slot_off.as<uint64_t>());
+    size_t tb = 0;
+    KCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, slot_off.as<uint64_t>(), slot_off.as<uint64_t>(), n_reads + 1, s));
+    KCHK(tmp.alloc(tb));
+    KCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, slot_off.as<uint64_t>(), slot_off.as<uint64_t>(), n_reads + 1, s));
+    uint64_t n_slots = 0;
+    KCHK(hipMemcpy(&n_slots, slot_off.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
+    KCHK(packed.alloc((n_slots * 2 + 16) * 4)); KCHK(nmask.alloc((n_slots + 4) * 4)); KCHK(rlen.alloc(n_reads * 4)); KCHK(ncount.alloc(n_reads * 4));
+    KCHK(hipMemsetAsync(packed.as<uint32_t>() + n_slots * 2, 0, 64, s));
+    launch_pack(s, d_bases, d_offsets, slot_off.as<uint64_t>(), n_reads, packed.as<uint32_t>(), nmask.as<uint32_t>(), rlen.as<uint32_t>(), ncount.as<uint32_t>());
+    ReadsDev R{};
+    R.packed = packed.as<uint32_t>(); R.nmask = nmask.as<uint32_t>(); R.slot_off = slot_off.as<uint64_t>(); R.base_off = d_offsets;
+    R.len = rlen.as<uint32_t>(); R.n_count = ncount.as<uint32_t>(); R.n = n_reads; R.k = k;
+    // ---- how many k-mer positions, hence how many partitions ----
+    KCHK(pos.alloc((n_reads + 1) * 8));
+    hipLaunchKernelGGL(k_positions, dim3(grid(n_reads)), dim3(256), 0, s, d_offsets, n_reads, k, pos.as<uint64_t>());
+    Buf tmp2; size_t tb2 = 0;
+    KCHK(hipcub::DeviceReduce::Sum(nullptr, tb2, pos.as<uint64_t>(), pos.as<uint64_t>() + n_reads, n_reads, s));
+    KCHK(tmp2.alloc(tb2));
+    KCHK(hipcub::DeviceReduce::Sum(tmp2.p, tb2, pos.as<uint64_t>(), pos.as<uint64_t>() + n_reads, n_reads, s));
+    uint64_t total = 0;
+    KCHK(hipMemcpy(&total, pos.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
+    if (!total) return LEON_OK;
+    if (!max_keys_per_pass) max_keys_per_pass = 1ull << 30;
+    uint32_t n_parts = (uint32_t)((total + max_keys_per_pass - 1) / max_keys_per_pass);
+    if (n_parts < 1) n_parts = 1;
+    const uint64_t cap = n_parts == 1 ? total : (uint64_t)(total / n_parts * 1.15) + (1u << 20);
+    // ---- per-partition buffers ----
+    Buf keys, alt, alt2, alt3, flags, cursor, ovf, nsel, hist, sort_tmp, sel_tmp;
+    KCHK(keys.alloc(cap * 8 * W)); KCHK(alt.alloc(cap * 8 * W)); KCHK(flags.alloc(cap));
+    if (W == 2) { KCHK(alt2.alloc(cap * 8)); KCHK(alt3.alloc(cap * 8)); }
+    KCHK(cursor.alloc(8)); KCHK(ovf.alloc(4)); KCHK(nsel.alloc(8)); KCHK(hist.alloc(256 * 8));
+    KCHK(hipMemset(hist.p, 0, 256 * 8));
+    size_t st = 0, st2 = 0, sl = 0;
+    if (W == 1) { KCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, st, keys.as<uint64_t>(), alt.as<uint64_t>(), cap, 0, 2 * k, s)); }
+    else {
+        KCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, st, keys.as<uint64_t>(), alt.as<uint64_t>(), alt2.as<uint64_t>(), alt3.as<uint64_t>(), cap, 0, 64, s));
+        st2 = st;
+    }
+    KCHK(sort_tmp.alloc(std::max(st, st2)));
+    // the solid k-mers accumulate here (grown geometrically)
+    uint64_t out_cap = std::max<uint64_t>(total / 16, 1u << 20), out_n = 0;
+    uint64_t* out = nullptr;
+    KCHK(hipMalloc((void**)&out, out_cap * 8 * W));
+    auto fail_free = [&](int code) { if (out) (void)hipFree(out); return code; };
+#define KCHK2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_create_error(std::string(#call) + ": " + hipGetErrorString(e_)); return fail_free(LEON_E_HIP); } } while (0)
+    for (uint32_t part = 0; part < n_parts; part++) {
+        KCHK2(hipMemsetAsync(cursor.p, 0, 8, s)); KCHK2(hipMemsetAsync(ovf.p, 0, 4, s));
+        if (W == 1) hipLaunchKernelGGL(k_emit_kmers<uint64_t>, dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, keys.as<uint64_t>(), cap, cursor.as<unsigned long long>(), ovf.as<int>());
+        else hipLaunchKernelGGL(k_emit_kmers<u128>, dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, keys.as<uint64_t>(), cap, cursor.as<unsigned long long>(), ovf.as<int>());
+        uint64_t n = 0; int overflow = 0;
+        KCHK2(hipMemcpy(&n, cursor.p, 8, hipMemcpyDeviceToHost));
+        KCHK2(hipMemcpy(&overflow, ovf.p, 4, hipMemcpyDeviceToHost));
+        if (overflow || n > cap) { set_create_error("kmer_solid: a hash partition overflowed its buffer (very skewed k-mer spectrum); lower max_keys_per_pass"); return fail_free(LEON_E_OVERFLOW); }
+        if (!n) continue;
+        uint64_t* sorted = nullptr;
+        if (W == 1) {
+            KCHK2(hipcub::DeviceRadixSort::SortKeys(sort_tmp.p, st, keys.as<uint64_t>(), alt.as<uint64_t>(), n, 0, 2 * k, s));
+            sorted = alt.as<uint64_t>();
+        } else {                                              // 128-bit keys: LSD in two stable passes (low word, then high word)
+            uint64_t* lo = alt.as<uint64_t>(); uint64_t* hi = lo + cap;
+            hipLaunchKernelGGL(k_split_words, dim3(grid(n)), dim3(256), 0, s, keys.as<uint64_t>(), n, lo, hi);
+            KCHK2(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, st, lo, alt2.as<uint64_t>(), hi, alt3.as<uint64_t>(), n, 0, 64, s));     // by low
+            KCHK2(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, st, alt3.as<uint64_t>(), hi, alt2.as<uint64_t>(), lo, n, 0, 2 * k - 64 > 0 ? 2 * k - 64 : 1, s));   // by high (stable)
+            hipLaunchKernelGGL(k_join_words, dim3(grid(n)), dim3(256), 0, s, lo, hi, n, keys.as<uint64_t>());
+            sorted = keys.as<uint64_t>();
+        }
+        if (W == 1) hipLaunchKernelGGL(k_flag_runs<1>, dim3(grid(n)), dim3(256), 0, s, sorted, n, min_abundance, flags.as<uint8_t>(), histogram ? hist.as<unsigned long long>() : nullptr);
+        else hipLaunchKernelGGL(k_flag_runs<2>, dim3(grid(n)), dim3(256), 0, s, sorted, n, min_abundance, flags.as<uint8_t>(), histogram ? hist.as<unsigned long long>() : nullptr);
+        // compact the heads of solid runs behind what earlier partitions produced
+        uint64_t* dst = (sorted == keys.as<uint64_t>()) ? alt.as<uint64_t>() : keys.as<uint64_t>();
+        size_t need = 0;
+        if (W == 1) {
+            KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need, sorted, flags.as<uint8_t>(), dst, nsel.as<uint64_t>(), n, s));
+            if (need > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need)); sl = need; }
+            KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need, sorted, flags.as<uint8_t>(), dst, nsel.as<uint64_t>(), n, s));
+        } else {
+            KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need, (Pair128*)sorted, flags.as<uint8_t>(), (Pair128*)dst, nsel.as<uint64_t>(), n, s));
+            if (need > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need)); sl = need; }
+            KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need, (Pair128*)sorted, flags.as<uint8_t>(), (Pair128*)dst, nsel.as<uint64_t>(), n, s));
+        }
+        uint64_t ns = 0;
+        KCHK2(hipMemcpy(&ns, nsel.p, 8, hipMemcpyDeviceToHost));
+        if (out_n + ns > out_cap) {
+            uint64_t nc = std::max(out_cap * 2, out_n + ns);
+            uint64_t* bigger = nullptr;
+            KCHK2(hipMalloc((void**)&bigger, nc * 8 * W));
+            if (out_n) KCHK2(hipMemcpy(bigger, out, out_n * 8 * W, hipMemcpyDeviceToDevice));
+            (void)hipFree(out); out = bigger; out_cap = nc;
+        }
+        if (ns) KCHK2(hipMemcpy(out + out_n * W, dst, ns * 8 * W, hipMemcpyDeviceToDevice));
+        out_n += ns;
+    }
+    if (histogram) KCHK2(hipMemcpy(histogram, hist.p, 256 * 8, hipMemcpyDeviceToHost));
+    KCHK2(hipDeviceSynchronize());
+    *d_solid = out; *n_solid = out_n;
+    return LEON_OK;
+}
+
+int leon_kmer_solid(int device_id, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t k, uint32_t min_abundance,
+                    uint64_t max_keys_per_pass, uint64_t* out, uint64_t out_cap, uint64_t* n_solid, uint64_t* histogram) {
+    if (!n_solid || (n_reads && (!bases || !offsets))) return LEON_E_INVALID;
+    *n_solid = 0;
+    if (!n_reads) return LEON_OK;
+    if (hipSetDevice(device_id) != hipSuccess) { set_create_error("kmer_solid: no such HIP device"); return LEON_E_NO_DEVICE; }
+    const uint64_t nb = offsets[n_reads] - offsets[0];
+    std::vector<uint64_t> rel(n_reads + 1);
+    for (uint64_t i = 0; i <= n_reads; i++) rel[i] = offsets[i] - offsets[0];
+    Buf db, doff;
+    KCHK(db.alloc(nb + 64)); KCHK(doff.alloc((n_reads + 1) * 8));
+    KCHK(hipMemcpy(db.p, bases + offsets[0], nb, hipMemcpyHostToDevice));
+    KCHK(hipMemcpy(doff.p, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    uint64_t* d = nullptr;
+    int rc = leon_kmer_solid_device(device_id, db.as<uint8_t>(), doff.as<uint64_t>(), n_reads, k, min_abundance, max_keys_per_pass, &d, n_solid, histogram);
+    if (rc) return rc;
+    const uint32_t W = kmer_words(k);
+    if (out && *n_solid <= out_cap && *n_solid) KCHK(hipMemcpy(out, d, *n_solid * 8 * W, hipMemcpyDeviceToHost));
+    leon_device_free(d);
+    return (out && *n_solid > out_cap) ? LEON_E_OVERFLOW : LEON_OK;
+}
+
+}  // extern "C"

@@ -200,6 +200,28 @@ __device__ inline void load_rv16(uint16_t* lds, const uint16_t* g) {
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Wave-per-read kernels: the dwords covering k-mers [base, base+64) are loaded once (lane l < 12 holds dword
+// (base>>4)+l) and every lane assembles its k-mer with cross-lane reads instead of gathers.
+// Must be called by all 64 lanes (p is clamped by the caller).
+__device__ inline uint32_t pass_words(const uint32_t* pk, uint32_t base, uint32_t lane) {
+    return lane < 12 ? pk[(base >> 4) + lane] : 0u;
+}
+template <typename K> __device__ inline K canon_from_words(uint32_t words, uint32_t base, uint32_t p, uint32_t k);
+template <> __device__ inline uint64_t canon_from_words<uint64_t>(uint32_t words, uint32_t base, uint32_t p, uint32_t k) {
+    const int d = (int)((p >> 4) - (base >> 4));
+    const uint64_t km = kmer_from3((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1),
+                                   (uint32_t)__shfl((int)words, d + 2), p & 15, k);
+    const uint64_t rc = revcomp(km, k);
+    return rc < km ? rc : km;
+}
+template <> __device__ inline u128 canon_from_words<u128>(uint32_t words, uint32_t base, uint32_t p, uint32_t k) {
+    const int d = (int)((p >> 4) - (base >> 4));                     // d + 4 <= 8 < 12
+    const u128 km = kmer_from5((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1), (uint32_t)__shfl((int)words, d + 2),
+                               (uint32_t)__shfl((int)words, d + 3), (uint32_t)__shfl((int)words, d + 4), p & 15, k);
+    const u128 rc = revcomp(km, k);
+    return rc < km ? rc : km;
+}
+
 // k-mers cross the C-ABI as W 64-bit words each, low word first
 template <typename K> __device__ inline K load_kmer(const uint64_t* w);
 template <> __device__ inline uint64_t load_kmer<uint64_t>(const uint64_t* w) { return w[0]; }

@@ -25,12 +25,6 @@ int sink(void* user, uint64_t block_id, const uint8_t* payload, uint64_t size, u
     static_cast<Leon*>(user)->writeBlock(payload, size, (int)n_reads, block_id);
     return 0;
 }
-inline uint64_t revcomp(uint64_t x, unsigned k) {
-    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-    x = __builtin_bswap64(x) ^ 0xAAAAAAAAAAAAAAAAULL;
-    return x >> (64 - 2 * k);
-}
 // FASTA / FASTQ (plain text) -> sequences; stands in for gatb's Bank (out of scope)
 std::vector<Sequence> read_bank(const std::string& path) {
     std::ifstream in(path);
@@ -56,29 +50,6 @@ std::vector<Sequence> read_bank(const std::string& path) {
         }
     }
     return out;
-}
-// exact canonical k-mer counting by sorting: stands in for DSK (SortingCountAlgorithm), the step before the path
-std::vector<uint64_t> solid_kmers(const std::vector<Sequence>& seqs, unsigned k, unsigned min_abundance) {
-    std::vector<uint64_t> all;
-    const uint64_t mask = (k < 32 ? (1ULL << (2 * k)) : 0) - 1;
-    for (const Sequence& s : seqs) {
-        uint64_t km = 0; unsigned valid = 0;
-        for (char c : s.data) {
-            int code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'T' ? 2 : c == 'G' ? 3 : 4;
-            if (code == 4) { valid = 0; km = 0; continue; }
-            km = ((km << 2) | (uint64_t)code) & mask;
-            if (++valid >= k) { uint64_t rc = revcomp(km, k); all.push_back(rc < km ? rc : km); }
-        }
-    }
-    std::sort(all.begin(), all.end());
-    std::vector<uint64_t> solid;
-    for (size_t i = 0; i < all.size();) {
-        size_t j = i;
-        while (j < all.size() && all[j] == all[i]) j++;
-        if (j - i >= min_abundance) solid.push_back(all[i]);
-        i = j;
-    }
-    return solid;
 }
 template <typename T> void put(std::ofstream& o, T v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
 }  // namespace
@@ -143,16 +114,27 @@ void Leon::writeBlock(const uint8_t* data, uint64_t size, int encodedSequenceCou
 }
 
 void Leon::executeCompression() {
-    if (_kmerSize < 3 || _kmerSize > 31) throw Exception("-kmer-size must be < 32 in this CLI (the library takes k <= 63; the host k-mer counter is one-word)");
+    if (_kmerSize < 3 || _kmerSize > 63) throw Exception("-kmer-size must be in 3..63");
     std::vector<Sequence> bank = read_bank(_inputFilename);
-    std::vector<uint64_t> solid = solid_kmers(bank, (unsigned)_kmerSize, (unsigned)std::max(_abundance, 1));
-    const uint64_t tai = std::max<uint64_t>(solid.size() * 12, 1000);       // NBITS_PER_KMER = 12 [RECALLED]
+    // solid k-mers: counted on the device (leon_kmer_solid, the stand-in for DSK's SortingCountAlgorithm)
+    const uint32_t W = _kmerSize >= 32 ? 2 : 1;
+    std::string all_bases; std::vector<uint64_t> all_off(1, 0);
+    for (const Sequence& s : bank) { all_bases += s.data; all_off.push_back(all_bases.size()); }
+    std::vector<uint64_t> solid(std::max<size_t>(all_bases.size(), 1) * W);
+    uint64_t n_solid = 0;
+    {
+        int rc = leon_kmer_solid(0, reinterpret_cast<const uint8_t*>(all_bases.data()), all_off.data(), bank.size(), (uint32_t)_kmerSize,
+                                 (uint32_t)std::max(_abundance, 1), 0, solid.data(), all_bases.size(), &n_solid, nullptr);
+        if (rc != LEON_OK) throw Exception(std::string("leon_kmer_solid: ") + leon_last_error(nullptr));
+    }
+    solid.resize(n_solid * W);
+    const uint64_t tai = std::max<uint64_t>(n_solid * 12, 1000);           // NBITS_PER_KMER = 12 [RECALLED]
     leon_dna_cfg cfg = {};
     cfg.struct_size = sizeof(cfg);
     cfg.kmer_size = (uint32_t)_kmerSize; cfg.reads_per_block = READ_PER_BLOCK;
     cfg.bloom_n_hash = 7; cfg.bloom_block_nbits = 12; cfg.bloom_tai = tai; cfg.device_id = 0;
     check(nullptr, leon_dna_ctx_create(&cfg, &_ctx), "leon_dna_ctx_create");
-    check(_ctx, leon_dna_bloom_insert(_ctx, solid.data(), solid.size()), "leon_dna_bloom_insert");
+    check(_ctx, leon_dna_bloom_insert(_ctx, solid.data(), n_solid), "leon_dna_bloom_insert");
     {
         DnaEncoder enc(this);                       // upstream: Dispatcher::iterate(itSeq, DnaEncoder(this), READ_PER_BLOCK)
         for (Sequence& s : bank) enc(s);

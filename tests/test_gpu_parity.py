@@ -359,3 +359,28 @@ def test_c_abi_error_behaviour():
     assert [b[1] for b in ctx.encode_batch(bases, off)] == ref.blocks
     assert ctx.finish()[0] == ref.anchor_dict
     ctx.close()
+
+
+@pytest.mark.parametrize("k,min_ab,maxkeys", [(31, 3, 0), (31, 1, 50000), (21, 2, 0), (47, 3, 0), (63, 2, 40000)])
+def test_device_solid_kmer_counting(k, min_ab, maxkeys):
+    """leon_kmer_solid (sort-based counting on the device, hash partitions) == the oracle's exact counter, as a set;
+    then the bloom built from it and the stream encoded with it are the oracle's"""
+    from leon_amd import capi
+    bases, off = common.synthetic(2500, 150, 9000, seed=200 + k, n_rate=0.002, ragged=(k == 21))
+    exp = O.count_solid(bases, off, k, min_ab)
+    got, hist = capi.kmer_solid(bases, off, k, min_ab, with_histogram=True, max_keys_per_pass=maxkeys)
+    w = O.kwords(k)
+    assert len(got) == len(exp)
+    assert sorted(O.kmers_to_ints(got, k)) == sorted(O.kmers_to_ints(exp, k))
+    all1 = O.count_solid(bases, off, k, 1)
+    assert int(hist.sum()) == len(all1) // w                      # every distinct k-mer lands in one histogram bin
+    assert int(hist[min_ab:].sum()) == len(exp) // w
+    tai = max(len(got) // w * common.NB_BITS_PER_KMER, 1000)
+    bl = O.Bloom(tai, k)
+    bl.insert(exp)
+    ctx = _ctx(k, 800, tai)
+    ctx.bloom_insert(got)
+    assert np.array_equal(ctx.bloom_download(), bl.bits)
+    ref = O.encode(bases, off, k, 800, bl, trace=False)
+    assert [b[1] for b in ctx.encode_batch(bases, off)] == ref.blocks
+    ctx.close()
