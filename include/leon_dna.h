@@ -115,7 +115,7 @@ int leon_dna_finish(leon_dna_ctx* ctx, const uint8_t** dict_payload, uint64_t* d
 /* -- the step BEFORE the path: solid k-mers of the reads, the set Leon::createBloom inserts (upstream DSK,
  * SortingCountAlgorithm).  Canonical k-mers occurring at least min_abundance times; k-mers containing an N are skipped.
  * Output: W words per k-mer (unordered across hash partitions).  histogram (optional, 256 entries): number of distinct
- * k-mers by abundance, clipped at 255.  max_keys_per_pass: k-mers sorted at once (0 = 2^30).  Errors: leon_last_error(NULL). */
+ * k-mers by abundance, clipped at 255.  max_keys_per_pass: k-mers sorted at once (0 = sized from the free device memory).  Errors: leon_last_error(NULL). */
 int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads,
                            uint32_t kmer_size, uint32_t min_abundance, uint64_t max_keys_per_pass,
                            uint64_t** d_solid, uint64_t* n_solid, uint64_t* histogram);   /* *d_solid: leon_device_free */

@@ -149,7 +149,11 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     uint64_t total = 0;
     KCHK(hipMemcpy(&total, pos.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
     if (!total) return LEON_OK;
-    if (!max_keys_per_pass) max_keys_per_pass = 1ull << 30;
+    if (!max_keys_per_pass) {                                 // as many k-mers per pass as a third of the free HBM sorts in place
+        size_t free_b = 0, total_b = 0;
+        KCHK(hipMemGetInfo(&free_b, &total_b));
+        max_keys_per_pass = std::max<uint64_t>(1ull << 24, std::min<uint64_t>(1ull << 32, free_b / 3 / (8 * W * 2 + 1)));
+    }
     uint32_t n_parts = (uint32_t)((total + max_keys_per_pass - 1) / max_keys_per_pass);
     if (n_parts < 1) n_parts = 1;
     const uint64_t cap = n_parts == 1 ? total : (uint64_t)(total / n_parts * 1.15) + (1u << 20);
