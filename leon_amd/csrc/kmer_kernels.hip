@@ -16,44 +16,39 @@ void set_create_error(const std::string& msg);   // capi.hip: message behind leo
 
 namespace {
 
-// k-mers of partition `part` (of n_parts, by hash) -> keys[], W words each, through a wave-aggregated cursor
-template <typename K>
-__global__ void __launch_bounds__(256) k_emit_kmers(ReadsDev R, uint32_t n_parts, uint32_t part, uint64_t* keys, uint64_t cap,
-                                                   unsigned long long* cursor, int* overflow) {
+// k-mers of partition `part` (of n_parts, by hash).  EMIT = false: counts[i] = how many read i contributes;
+// EMIT = true: they are written at keys[start[i] ...] (start = exclusive scan of the counts): no atomics, exact sizes.
+template <typename K, bool EMIT>
+__global__ void __launch_bounds__(256) k_part_kmers(ReadsDev R, uint32_t n_parts, uint32_t part, uint64_t* counts_or_start, uint64_t* keys) {
     const uint32_t lane = lane_id(), k = R.k;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t i = wave; i < R.n; i += nwaves) {
         const uint32_t len = R.len[i];
-        if (len < k) continue;
-        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
-        const uint32_t* nm = R.nmask + R.slot_off[i];
-        const bool hasN = R.n_count[i] != 0;
-        const uint32_t nk = len - k + 1;
-        for (uint32_t base = 0; base < nk; base += 64) {
-            const uint32_t p = base + lane;
-            bool valid = p < nk;
-            const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, valid ? p : nk - 1, k);
-            if (valid && hasN) {                              // any N in [p, p + k) ?
-                for (uint32_t d = p >> 5; d <= (p + k - 1) >> 5 && valid; d++) {
-                    uint32_t w = nm[d];
-                    const uint32_t lo = d == (p >> 5) ? (p & 31) : 0, hi = d == ((p + k - 1) >> 5) ? ((p + k - 1) & 31) : 31;
-                    const uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1)) & ~((1u << lo) - 1);
-                    if (w & m) valid = false;
+        uint64_t at = EMIT ? counts_or_start[i] : 0;
+        if (len >= k) {
+            const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+            const uint32_t* nm = R.nmask + R.slot_off[i];
+            const bool hasN = R.n_count[i] != 0;
+            const uint32_t nk = len - k + 1;
+            for (uint32_t base = 0; base < nk; base += 64) {
+                const uint32_t p = base + lane;
+                bool valid = p < nk;
+                const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, valid ? p : nk - 1, k);
+                if (valid && hasN) {                          // any N in [p, p + k) ?
+                    for (uint32_t d = p >> 5; d <= (p + k - 1) >> 5 && valid; d++) {
+                        const uint32_t lo = d == (p >> 5) ? (p & 31) : 0, hi = d == ((p + k - 1) >> 5) ? ((p + k - 1) & 31) : 31;
+                        const uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1)) & ~((1u << lo) - 1);
+                        if (nm[d] & m) valid = false;
+                    }
                 }
-            }
-            if (valid && n_parts > 1) valid = (uint32_t)((key_hash(cn) >> 40) % n_parts) == part;
-            const unsigned long long b = __ballot(valid);
-            if (!b) continue;
-            unsigned long long start = 0;
-            if (lane == 0) start = atomicAdd(cursor, (unsigned long long)__popcll(b));
-            start = __shfl(start, 0);
-            if (valid) {
-                const uint64_t at = start + __popcll(b & ((1ull << lane) - 1));
-                if (at < cap) store_kmer(keys + at * KT<K>::W, cn);
-                else *overflow = 1;
+                if (valid && n_parts > 1) valid = (uint32_t)((key_hash(cn) >> 40) % n_parts) == part;
+                const unsigned long long b = __ballot(valid);
+                if (EMIT && valid) store_kmer(keys + (at + __popcll(b & ((1ull << lane) - 1))) * KT<K>::W, cn);
+                at += __popcll(b);
             }
         }
+        if (!EMIT && lane == 0) counts_or_start[i] = at;
     }
 }
 
@@ -156,12 +151,12 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     }
     uint32_t n_parts = (uint32_t)((total + max_keys_per_pass - 1) / max_keys_per_pass);
     if (n_parts < 1) n_parts = 1;
-    const uint64_t cap = n_parts == 1 ? total : (uint64_t)(total / n_parts * 1.15) + (1u << 20);
+    const uint64_t cap = n_parts == 1 ? total : (uint64_t)(total / n_parts * 1.25) + (1u << 20);
     // ---- per-partition buffers ----
-    Buf keys, alt, alt2, alt3, flags, cursor, ovf, nsel, hist, sort_tmp, sel_tmp;
+    Buf keys, alt, alt2, alt3, flags, nsel, hist, sort_tmp, sel_tmp;
     KCHK(keys.alloc(cap * 8 * W)); KCHK(alt.alloc(cap * 8 * W)); KCHK(flags.alloc(cap));
     if (W == 2) { KCHK(alt2.alloc(cap * 8)); KCHK(alt3.alloc(cap * 8)); }
-    KCHK(cursor.alloc(8)); KCHK(ovf.alloc(4)); KCHK(nsel.alloc(8)); KCHK(hist.alloc(256 * 8));
+    KCHK(nsel.alloc(8)); KCHK(hist.alloc(256 * 8));
     KCHK(hipMemset(hist.p, 0, 256 * 8));
     size_t st = 0, st2 = 0, sl = 0;
     if (W == 1) { KCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, st, keys.as<uint64_t>(), alt.as<uint64_t>(), cap, 0, 2 * k, s)); }
@@ -176,14 +171,23 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     KCHK(hipMalloc((void**)&out, out_cap * 8 * W));
     auto fail_free = [&](int code) { if (out) (void)hipFree(out); return code; };
 #define KCHK2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_create_error(std::string(#call) + ": " + hipGetErrorString(e_)); return fail_free(LEON_E_HIP); } } while (0)
+    size_t scan_tb = 0;
+    KCHK2(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tb, pos.as<uint64_t>(), pos.as<uint64_t>(), n_reads + 1, s));
+    Buf scan_tmp;
+    KCHK2(scan_tmp.alloc(scan_tb));
     for (uint32_t part = 0; part < n_parts; part++) {
-        KCHK2(hipMemsetAsync(cursor.p, 0, 8, s)); KCHK2(hipMemsetAsync(ovf.p, 0, 4, s));
-        if (W == 1) hipLaunchKernelGGL(k_emit_kmers<uint64_t>, dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, keys.as<uint64_t>(), cap, cursor.as<unsigned long long>(), ovf.as<int>());
-        else hipLaunchKernelGGL(k_emit_kmers<u128>, dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, keys.as<uint64_t>(), cap, cursor.as<unsigned long long>(), ovf.as<int>());
-        uint64_t n = 0; int overflow = 0;
-        KCHK2(hipMemcpy(&n, cursor.p, 8, hipMemcpyDeviceToHost));
-        KCHK2(hipMemcpy(&overflow, ovf.p, 4, hipMemcpyDeviceToHost));
-        if (overflow || n > cap) { set_create_error("kmer_solid: a hash partition overflowed its buffer (very skewed k-mer spectrum); lower max_keys_per_pass"); return fail_free(LEON_E_OVERFLOW); }
+        // count per read, scan, emit at exact offsets (pos[] is reused: n_reads + 1 entries)
+        KCHK2(hipMemsetAsync(pos.as<uint64_t>() + n_reads, 0, 8, s));
+        if (W == 1) hipLaunchKernelGGL((k_part_kmers<uint64_t, false>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), (uint64_t*)nullptr);
+        else hipLaunchKernelGGL((k_part_kmers<u128, false>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), (uint64_t*)nullptr);
+        KCHK2(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_tb, pos.as<uint64_t>(), pos.as<uint64_t>(), n_reads + 1, s));
+        uint64_t n = 0;
+        KCHK2(hipMemcpy(&n, pos.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
+        if (n > cap) { set_create_error("kmer_solid: a hash partition exceeds its buffer (very skewed k-mer spectrum); lower max_keys_per_pass"); return fail_free(LEON_E_OVERFLOW); }
+        if (n) {
+            if (W == 1) hipLaunchKernelGGL((k_part_kmers<uint64_t, true>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), keys.as<uint64_t>());
+            else hipLaunchKernelGGL((k_part_kmers<u128, true>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), keys.as<uint64_t>());
+        }
         if (!n) continue;
         uint64_t* sorted = nullptr;
         if (W == 1) {
