@@ -83,7 +83,7 @@ struct leon_dna_ctx {
     DevBuf in_bases, in_off, slot_off, packed, nmask, rlen, ncount;
     DevBuf status, hit_pos, hit_slot, cand_pos, cand_slot, anchor_pos, anchor_addr, flags, sort_key, ins_flag, rank;
     DevBuf ulist0, ulist1, counters, cub_tmp, sort_key2, perm, perm2, events, prev, sym_off, syms;
-    DevBuf blk_begin, out_off, out_size, rc_out, rc_scratch, dst_off, payload, errflag;
+    DevBuf blk_begin, out_off, out_size, rc_out, rc_scratch, dst_off, payload, errflag, nerr;
     void* h_payload = nullptr; size_t h_payload_cap = 0;
     uint64_t last_n = 0, last_bases = 0;
     leon_dna_stats stats{};
@@ -228,7 +228,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
                        &c->status, &c->hit_pos, &c->hit_slot, &c->cand_pos, &c->cand_slot, &c->anchor_pos, &c->anchor_addr,
                        &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
                        &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
-                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag };
+                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr };
     for (DevBuf* b : bufs) b->release();
     if (c->d_bloom) (void)hipFree(c->d_bloom);
     if (c->d_rv16) (void)hipFree(c->d_rv16);
@@ -503,10 +503,11 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     // ---- symbols ----
     HIPCHK(c, c->prev.ensure(n * 8));
     HIPCHK(c, c->sym_off.ensure((nl + 1) * 8));
+    HIPCHK(c, c->nerr.ensure(nl * 4));
     launch_prev_anchored(s, V.anchor_pos, n, rpb, lb0, nbl, c->prev.as<int64_t>());
     HIPCHK(c, hipMemsetAsync(c->sym_off.as<uint64_t>() + nl, 0, 8, s));
     launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(), r0, nl,
-                   c->sym_off.as<uint64_t>(), nullptr);
+                   c->sym_off.as<uint64_t>(), c->nerr.as<uint32_t>(), nullptr);
     HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
     if (int rc = ensure_cub(c, tmp_bytes)) return rc;
     HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
@@ -515,7 +516,7 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, c->syms.ensure(n_syms * 2 + 256));
     launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(), r0, nl,
-                   c->sym_off.as<uint64_t>(), c->syms.as<uint8_t>());
+                   c->sym_off.as<uint64_t>(), c->nerr.as<uint32_t>(), c->syms.as<uint8_t>());
     HIPCHK(c, c->blk_begin.ensure((nbl + 1) * 8)); HIPCHK(c, c->out_off.ensure((nbl + 1) * 8));
     HIPCHK(c, c->out_size.ensure(nbl * 8)); HIPCHK(c, c->dst_off.ensure((nbl + 1) * 8));
     launch_block_ranges(s, c->sym_off.as<uint64_t>(), nl, rpb, nbl, c->blk_begin.as<uint64_t>(), c->out_off.as<uint64_t>());

@@ -64,50 +64,46 @@ void launch_read_slots(hipStream_t s, const uint64_t* off, uint64_t n, uint64_t*
     hipLaunchKernelGGL(k_read_slots, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, off, n, slots);
 }
 
-// one wave per read; lane l packs bases [16l, 16l+16) of each 1024-base stretch
+// One LANE per read: the vector-memory pipeline costs ~64 cycles per wave-wide load instruction whatever the number of
+// active lanes, so 64 reads share each of the ~4 loads per 16 bases (a wave per read left 54 of 64 lanes idle).
 __global__ void __launch_bounds__(256) k_pack(const uint8_t* bases, const uint64_t* off, const uint64_t* slot_off, uint64_t n,
                                              uint32_t* packed, uint32_t* nmask, uint32_t* len_out, uint32_t* ncount) {
-    uint32_t lane = lane_id();
-    uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t r = wave; r < n; r += nwaves) {
-        uint64_t o = off[r];
-        uint32_t len = (uint32_t)(off[r + 1] - o);
-        uint64_t so = slot_off[r];
-        uint32_t ndw = (uint32_t)(slot_off[r + 1] - so) * 2;
-        const uint8_t* src = bases + o;
-        uint32_t nn = 0;
-        for (uint32_t dw = lane; dw < ndw; dw += 64) {          // ndw is even: lanes come in (even, odd) pairs
-            uint32_t word = 0, nb = 0;
-            const uint32_t j0 = dw * 16;
+    const uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t o = off[r];
+    const uint32_t len = (uint32_t)(off[r + 1] - o);
+    const uint64_t so = slot_off[r];
+    const uint32_t ndw = (uint32_t)(slot_off[r + 1] - so) * 2;
+    const uint8_t* src = bases + o;
+    uint32_t nn = 0, nb32 = 0;
+    for (uint32_t dw = 0; dw < ndw; dw++) {
+        uint32_t word = 0, nb = 0;
+        const uint32_t j0 = dw * 16;
 #pragma unroll
-            for (uint32_t q4 = 0; q4 < 4; q4++) {               // four (unaligned) dword loads of 4 bases each
-                uint32_t four = 0x41414141u;                    // "AAAA" past the end of the read
-                const uint32_t p0 = j0 + 4 * q4;
-                if (p0 + 4 <= len) __builtin_memcpy(&four, src + p0, 4);
-                else if (p0 < len) { for (uint32_t j = 0; p0 + j < len; j++) four = (four & ~(0xFFu << (8 * j))) | ((uint32_t)src[p0 + j] << (8 * j)); }
+        for (uint32_t q4 = 0; q4 < 4; q4++) {                   // four (unaligned) dword loads of 4 bases each
+            uint32_t four = 0x41414141u;                        // "AAAA" past the end of the read
+            const uint32_t p0 = j0 + 4 * q4;
+            if (p0 + 4 <= len) __builtin_memcpy(&four, src + p0, 4);
+            else if (p0 < len) { for (uint32_t j = 0; p0 + j < len; j++) four = (four & ~(0xFFu << (8 * j))) | ((uint32_t)src[p0 + j] << (8 * j)); }
 #pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint32_t c = (four >> (8 * j)) & 0xFFu;
-                    const bool valid = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
-                    const uint32_t code = valid ? ((c >> 1) & 3u) : 0u;
-                    word |= code << (30 - 2 * (4 * q4 + j));
-                    nb |= (valid ? 0u : 1u) << (4 * q4 + j);
-                }
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t c = (four >> (8 * j)) & 0xFFu;
+                const bool valid = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+                const uint32_t code = valid ? ((c >> 1) & 3u) : 0u;
+                word |= code << (30 - 2 * (4 * q4 + j));
+                nb |= (valid ? 0u : 1u) << (4 * q4 + j);
             }
-            packed[so * 2 + dw] = word;
-            uint32_t other = __shfl_down(nb, 1);
-            if ((dw & 1) == 0) nmask[so + (dw >> 1)] = nb | (other << 16);
-            nn += __popc(nb);
         }
-        for (int d = 32; d > 0; d >>= 1) nn += __shfl_xor(nn, d);
-        if (lane == 0) { len_out[r] = len; ncount[r] = nn; }
+        packed[so * 2 + dw] = word;
+        if (dw & 1) { nmask[so + (dw >> 1)] = nb32 | (nb << 16); } else nb32 = nb;
+        nn += __popc(nb);
     }
+    len_out[r] = len; ncount[r] = nn;
 }
 void launch_pack(hipStream_t s, const uint8_t* bases, const uint64_t* off, const uint64_t* slot_off, uint64_t n,
                  uint32_t* packed, uint32_t* nmask, uint32_t* len, uint32_t* ncount) {
     if (!n) return;
-    hipLaunchKernelGGL(k_pack, dim3(grid_for(n, 4, 256 * 64)), dim3(256), 0, s, bases, off, slot_off, n, packed, nmask, len, ncount);
+    hipLaunchKernelGGL(k_pack, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, bases, off, slot_off, n, packed, nmask, len, ncount);
 }
 
 
@@ -628,7 +624,7 @@ struct SymSink {
     uint8_t* p;           // nullptr: count only
     uint64_t n;
     __device__ inline void put(uint32_t model, uint32_t sym) {
-        if (p) { p[2 * n] = (uint8_t)model; p[2 * n + 1] = (uint8_t)sym; }
+        if (p) ((uint16_t*)p)[n] = (uint16_t)(model | (sym << 8));        // one store per symbol
         n++;
     }
     // CompressionUtils::encodeNumeric
@@ -648,9 +644,13 @@ struct SymSink {
     }
 };
 
+// EMIT = false: sym_off[li] = number of symbols of the read and n_err[li] = its number of error positions, from ONE
+// scan of the read's event bytes; EMIT = true: the symbols, written at syms + 2 * sym_off[li].  One lane per read; the
+// events are read as dwords (the memory pipeline charges per wave-wide instruction, not per byte).
+template <bool EMIT>
 __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr,
                                                 const uint8_t* flags, const int64_t* prev, const uint8_t* events,
-                                                uint64_t r0, uint64_t n_local, uint64_t* sym_off, uint8_t* syms) {
+                                                uint64_t r0, uint64_t n_local, uint64_t* sym_off, uint32_t* n_err, uint8_t* syms) {
     uint64_t li = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (li >= n_local) return;
     const uint64_t i = r0 + li;
@@ -659,16 +659,18 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
     const uint32_t* nm = R.nmask + R.slot_off[i];
     uint32_t nN = R.n_count[i];
     SymSink S;
-    S.p = syms ? syms + 2 * sym_off[li] : nullptr;
+    S.p = EMIT ? syms + 2 * sym_off[li] : nullptr;
     S.n = 0;
     int32_t a = anchor_pos[i];
     if (a < 0) {                                              // DnaEncoder::encodeNoAnchorRead
         S.put(M_READ_TYPE, 1);
         S.numeric(G_NOANCHOR_READSIZE, len);
-        for (uint32_t p = 0; p < len; p++) {
-            bool isN = nN && ((nm[p >> 5] >> (p & 31)) & 1u);
-            S.put(M_NOANCHOR_READ, isN ? 4u : base_at(pk, p));
-        }
+        if (EMIT) {
+            for (uint32_t p = 0; p < len; p++) {
+                bool isN = nN && ((nm[p >> 5] >> (p & 31)) & 1u);
+                S.put(M_NOANCHOR_READ, isN ? 4u : base_at(pk, p));
+            }
+        } else S.n += len;
     } else {                                                  // DnaEncoder::encodeAnchorRead
         int64_t q = prev[i];
         uint64_t pLen = 0, pPos = 0, pAddr = 0;
@@ -685,57 +687,75 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
             for (uint32_t p = 0; p < len; p++)
                 if ((nm[p >> 5] >> (p & 31)) & 1u) { S.numeric(G_NPOS, p - prevN); prevN = p; }
         }
-        // events are read four positions at a time (unaligned dword loads; the buffer is padded)
-        uint32_t nErr = 0;                                    // error positions, ascending
-        for (uint32_t p = 0; p < len; p += 4) {
-            uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
-            if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
-            nErr += __popc(w4 & 0x08080808u);
-        }
-        S.numeric(G_LEFT_ERROR, nErr);
-        if (nErr) {
-            uint32_t prevE = 0;
+        if (!EMIT) {
+            // one ascending scan: error positions (count + their numerics' sizes) and the number of bifurcation symbols
+            uint32_t nErr = 0, prevE = 0, nBif = 0;
             for (uint32_t p = 0; p < len; p += 4) {
                 uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
                 if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
+                if (!w4) continue;
+                const uint32_t c3 = w4 & 0x07070707u;
+                nBif += __popc((c3 | (c3 >> 1) | (c3 >> 2)) & 0x01010101u);
                 uint32_t e4 = w4 & 0x08080808u;
                 while (e4) {
-                    uint32_t q = p + ((uint32_t)__builtin_ctz(e4) >> 3);
-                    S.numeric(G_ERRPOS, q - prevE); prevE = q;
+                    uint32_t qq = p + ((uint32_t)__builtin_ctz(e4) >> 3);
+                    S.numeric(G_ERRPOS, qq - prevE); prevE = qq; nErr++;
                     e4 &= e4 - 1;
                 }
             }
-        }
-        // bifurcations: left walk (a-1 .. 0), then right walk (a+k .. len-1)
-        for (int32_t hi = a; hi > 0; hi -= 4) {               // positions hi-4 .. hi-1, descending
-            const int32_t lo4 = hi - 4;
-            uint32_t w4;
-            if (lo4 >= 0) __builtin_memcpy(&w4, ev + lo4, 4);
-            else { w4 = 0; for (int32_t q = 0; q < hi; q++) w4 |= (uint32_t)ev[q] << (8 * (q - lo4)); }
-            if ((w4 & 0x07070707u) == 0) continue;
-            for (int32_t j = 3; j >= 0; j--) {
-                const uint32_t cc = (w4 >> (8 * j)) & 7u;
-                if (cc >= EV_NT0) S.put(M_BIFURCATION, cc - EV_NT0); else if (cc) S.put(M_BIFURCATION_BINARY, cc - EV_BIN0);
+            S.numeric(G_LEFT_ERROR, nErr);
+            S.n += nBif;
+            n_err[li] = nErr;
+        } else {
+            const uint32_t nErr = n_err[li];                  // error positions, ascending
+            S.numeric(G_LEFT_ERROR, nErr);
+            if (nErr) {
+                uint32_t prevE = 0, left = nErr;
+                for (uint32_t p = 0; p < len && left; p += 4) {
+                    uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
+                    if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
+                    uint32_t e4 = w4 & 0x08080808u;
+                    while (e4) {
+                        uint32_t qq = p + ((uint32_t)__builtin_ctz(e4) >> 3);
+                        S.numeric(G_ERRPOS, qq - prevE); prevE = qq; left--;
+                        e4 &= e4 - 1;
+                    }
+                }
             }
-        }
-        for (uint32_t p = (uint32_t)a + k; p < len; p += 4) {
-            uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
-            if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
-            if ((w4 & 0x07070707u) == 0) continue;
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t cc = (w4 >> (8 * j)) & 7u;
-                if (cc >= EV_NT0) S.put(M_BIFURCATION, cc - EV_NT0); else if (cc) S.put(M_BIFURCATION_BINARY, cc - EV_BIN0);
+            // bifurcations: left walk (a-1 .. 0), then right walk (a+k .. len-1)
+            for (int32_t hi = a; hi > 0; hi -= 4) {           // positions hi-4 .. hi-1, descending
+                const int32_t lo4 = hi - 4;
+                uint32_t w4;
+                if (lo4 >= 0) __builtin_memcpy(&w4, ev + lo4, 4);
+                else { w4 = 0; for (int32_t qq = 0; qq < hi; qq++) w4 |= (uint32_t)ev[qq] << (8 * (qq - lo4)); }
+                if ((w4 & 0x07070707u) == 0) continue;
+                for (int32_t j = 3; j >= 0; j--) {
+                    const uint32_t cc = (w4 >> (8 * j)) & 7u;
+                    if (cc >= EV_NT0) S.put(M_BIFURCATION, cc - EV_NT0); else if (cc) S.put(M_BIFURCATION_BINARY, cc - EV_BIN0);
+                }
+            }
+            for (uint32_t p = (uint32_t)a + k; p < len; p += 4) {
+                uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
+                if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
+                if ((w4 & 0x07070707u) == 0) continue;
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t cc = (w4 >> (8 * j)) & 7u;
+                    if (cc >= EV_NT0) S.put(M_BIFURCATION, cc - EV_NT0); else if (cc) S.put(M_BIFURCATION_BINARY, cc - EV_BIN0);
+                }
             }
         }
     }
-    if (!syms) sym_off[li] = S.n;
+    if (!EMIT) sym_off[li] = S.n;
 }
 void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr, const uint8_t* flags,
-                    const int64_t* prev, const uint8_t* events, uint64_t r0, uint64_t n_local, uint64_t* sym_off, uint8_t* syms) {
+                    const int64_t* prev, const uint8_t* events, uint64_t r0, uint64_t n_local, uint64_t* sym_off, uint32_t* n_err,
+                    uint8_t* syms) {
     if (!n_local) return;
     uint64_t g = (n_local + 255) / 256;
-    hipLaunchKernelGGL(k_symbols, dim3((uint32_t)g), dim3(256), 0, s, R, anchor_pos, anchor_addr, flags, prev, events, r0, n_local,
-                       sym_off, syms);
+    if (syms) hipLaunchKernelGGL(k_symbols<true>, dim3((uint32_t)g), dim3(256), 0, s, R, anchor_pos, anchor_addr, flags, prev, events, r0, n_local,
+                                 sym_off, n_err, syms);
+    else hipLaunchKernelGGL(k_symbols<false>, dim3((uint32_t)g), dim3(256), 0, s, R, anchor_pos, anchor_addr, flags, prev, events, r0, n_local,
+                            sym_off, n_err, syms);
 }
 
 // per block: symbol range and output capacity offsets (3 bytes per symbol + 64 or more)

@@ -71,7 +71,8 @@ void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, 
                           uint64_t n_blocks, int64_t* prev);
 void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr,
                     const uint8_t* flags, const int64_t* prev, const uint8_t* events, uint64_t r0, uint64_t n_local,
-                    uint64_t* sym_off /*count or offsets, indexed from r0*/, uint8_t* syms /*nullptr = count pass*/);
+                    uint64_t* sym_off /*count or offsets, indexed from r0*/, uint32_t* n_err /*per read, from the count pass*/,
+                    uint8_t* syms /*nullptr = count pass*/);
 void launch_block_ranges(hipStream_t s, const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
                          uint64_t* blk_begin /*n_blocks+1*/, uint64_t* out_off /*n_blocks+1*/);
 // ---- range coder ----
