@@ -58,7 +58,7 @@ __global__ void k_iota(uint32_t* v, uint64_t n) {
 struct leon_dna_ctx {
     leon_dna_cfg cfg{};
     int device = 0;
-    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipStream_t stream = nullptr;
     std::string err;
     // bloom
     uint8_t* d_bloom = nullptr;
@@ -189,7 +189,6 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     } while (0)
     CREATE_CHK(hipSetDevice(c->device));
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CREATE_CHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
     // BloomCacheCoherent / BloomContainer geometry
     uint64_t blk = 1ull << cfg->bloom_block_nbits;
@@ -236,7 +235,6 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
     if (c->h_payload) (void)hipHostFree(c->h_payload);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
 }
 

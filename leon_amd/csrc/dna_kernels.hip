@@ -204,22 +204,6 @@ template <typename K> __device__ inline K canon_at(const uint32_t* pk, uint32_t 
     return rc < km ? rc : km;
 }
 
-// first position in [lo, hi) (scan order) whose canonical k-mer is in the bloom; -1 if none. Wave-uniform result.
-template <typename K>
-__device__ inline int first_in_bloom(const BloomDev& B, const uint16_t* rv16, const uint32_t* pk, uint32_t k,
-                                     uint32_t lo, uint32_t hi, uint32_t lane) {
-    for (uint32_t base = lo; base < hi; base += 64) {
-        uint32_t p = base + lane;
-        bool valid = p < hi;
-        const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, valid ? p : hi - 1, k);
-        bool c = false;
-        if (valid) c = bloom_contains<K>(B, rv16, cn);
-        unsigned long long b = __ballot(c);
-        if (b) return (int)(base + __builtin_ctzll(b));
-    }
-    return -1;
-}
-
 // 16-lane variant of canon_from_words: lanes gbase .. gbase+7 of each quarter-wave hold the dwords of that quarter's read
 template <typename K> __device__ inline K canon_from_words16(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k);
 template <> __device__ inline uint64_t canon_from_words16<uint64_t>(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k) {

@@ -8,7 +8,6 @@
 //     with one multiply-high by the precomputed reciprocal instead of a 64-bit division.
 // Counts are exactly Order0Model's cumulative counts (its rescale cannot trigger: MAX_RANGE = 2^48 total).
 #include "kernels.h"
-#include <cstdlib>
 
 namespace leon {
 
@@ -38,7 +37,7 @@ template <typename P> __device__ inline void model_init(P s, uint32_t lane, bool
 }
 
 
-template <int ABLATE, uint32_t RC_NSLOT>
+template <uint32_t RC_NSLOT>
 __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                                                   uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
                                                   uint32_t* scratch, int* err) {
@@ -68,8 +67,9 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
         uint8_t* dst = out + out_off[b];
         const uint64_t cap = out_off[b + 1] - out_off[b];
         bool overflow = false;
-        // modeler state (wave 1)
+        // modeler state (wave 1); the next tile's symbols are fetched one tile ahead (a global load costs ~2000 cycles)
         uint32_t nused = 0;
+        uint32_t raw_next = (wave == 1 && lane < (uint32_t)((s1 - s0) < 64 ? (s1 - s0) : 64)) ? sym16[s0 + lane] : 0xFFFFu;
         if (wave == 1) {                                       // AbstractDnaCoder::startBlock
             for (uint32_t m = 0; m < N_SMALL_MODELS; m++) model_init(&models[m * RC_SSTRIDE], lane, true);
             for (uint32_t i = lane; i < RC_NNUM; i += 64) slotmap[i] = 255;
@@ -78,12 +78,16 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
 
         for (uint64_t t = 0; t <= ntiles; t++) {
             if (wave == 1) {
-                if (t < ntiles && (ABLATE != 3 || t < 2)) {
+                if (t < ntiles) {
                     // =================== modeler: tile t -> ring[t & 1] ===================
                     const uint64_t base = s0 + t * 64;
                     const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
                     const bool act = lane < cnt;
-                    const uint32_t raw = act ? sym16[base + lane] : 0xFFFFu;
+                    const uint32_t raw = raw_next;
+                    {
+                        const uint64_t nb = base + 64;
+                        raw_next = (nb < s1 && lane < (uint32_t)((s1 - nb) < 64 ? (s1 - nb) : 64)) ? sym16[nb + lane] : 0xFFFFu;
+                    }
                     const uint32_t m = raw & 0xff, c = raw >> 8;
                     const uint32_t key = (m << 8) | c;
                     const bool numeric = act && m >= N_SMALL_MODELS;
@@ -121,7 +125,7 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
                     __builtin_amdgcn_wave_barrier();
                     // earlier symbols of the tile + Order0Model::update, symbol by symbol, branch-free
                     const uint32_t lowkey = m << 8;
-                    for (uint32_t i = 0; i < (ABLATE == 2 ? 0u : cnt); i++) {
+                    for (uint32_t i = 0; i < cnt; i++) {
                         const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);
                         const uint32_t mbi = (uint32_t)__builtin_amdgcn_readlane((int)mb, (int)i);
                         const uint32_t ci = ki & 0xff;
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
                 const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
                 uint32_t(*rg)[64] = ring[(t - 1) & 1];
                 const uint32_t v_lo = rg[0][lane], v_fr = rg[1][lane], v_tot = rg[2][lane], v_il = rg[3][lane], v_ih = rg[4][lane];
-                for (uint32_t j = 0; j < (ABLATE == 1 ? 1u : cnt); j++) {
+                for (uint32_t j = 0; j < cnt; j++) {
                     const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)v_lo, (int)j);
                     const uint32_t s_fr = (uint32_t)__builtin_amdgcn_readlane((int)v_fr, (int)j);
                     const uint32_t s_tot = (uint32_t)__builtin_amdgcn_readlane((int)v_tot, (int)j);
@@ -252,14 +256,10 @@ void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_be
                       const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err) {
     if (!n_blocks) return;
     uint32_t g = n_blocks > 65535 ? 65535u : (uint32_t)n_blocks;
-    static const int ablate = getenv("LEON_RC_ABLATE") ? atoi(getenv("LEON_RC_ABLATE")) : 0;   // timing experiments only
     const bool small = n_blocks > 256 * 5;                   // keep every block resident: 8 x 19.6 KB per CU
-#define RC_LAUNCH(A, N) hipLaunchKernelGGL((k_rc_encode<A, N>), dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
-    if (ablate == 1) RC_LAUNCH(1, RC_NSLOT_BIG);
-    else if (ablate == 2) RC_LAUNCH(2, RC_NSLOT_BIG);
-    else if (ablate == 3) RC_LAUNCH(3, RC_NSLOT_BIG);
-    else if (small) RC_LAUNCH(0, RC_NSLOT_SMALL);
-    else RC_LAUNCH(0, RC_NSLOT_BIG);
+#define RC_LAUNCH(N) hipLaunchKernelGGL((k_rc_encode<N>), dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
+    if (small) RC_LAUNCH(RC_NSLOT_SMALL);
+    else RC_LAUNCH(RC_NSLOT_BIG);
 #undef RC_LAUNCH
 }
 
