@@ -700,9 +700,16 @@ int leon_dna_anchor_kmers(leon_dna_ctx* c, uint64_t* kmers, uint64_t n) {
 // host-only: the dictionary stream of a list of anchors (what the worker thread produces); no GPU involved
 int leon_host_anchor_dict_encode(const uint64_t* kmers, uint64_t n, uint32_t k, uint8_t* out, uint64_t out_cap, uint64_t* size) {
     if ((!kmers && n) || !size || k < 1 || k > 63) return LEON_E_INVALID;
-    AnchorDictCoder coder;
+    // the same worker (chain thread + reciprocal helper thread) the contexts use, fed in a few batches
+    AnchorDictWorker worker(k);
     const uint32_t W = kmer_words(k);
-    for (uint64_t i = 0; i < n; i++) coder.encode_kmer(kmers + i * W, k);
+    const uint64_t step = std::max<uint64_t>(1, n / 3);
+    for (uint64_t i = 0; i < n; i += step) {
+        const uint64_t m = std::min(step, n - i);
+        worker.push(std::vector<uint64_t>(kmers + i * W, kmers + (i + m) * W));
+    }
+    worker.drain();
+    AnchorDictCoder& coder = worker.coder();
     coder.flush();
     *size = coder.size();
     if (coder.size() > out_cap) return LEON_E_OVERFLOW;
