@@ -134,7 +134,8 @@ def main():
         dist.broadcast(n_solid_t, src=0)
     n_solid = int(n_solid_t.item())
     tai = n_solid * BITS_PER_KMER
-    ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local)
+    ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local,
+                                    resolve_window=int(os.environ.get("LEON_RESOLVE_WINDOW", 0)))
     ctx.set_shard(rank, world)
     nbytes = ctx.bloom_nbytes
     bcast_ms = 0.0

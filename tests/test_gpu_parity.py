@@ -384,3 +384,15 @@ def test_device_solid_kmer_counting(k, min_ab, maxkeys):
     ref = O.encode(bases, off, k, 800, bl, trace=False)
     assert [b[1] for b in ctx.encode_batch(bases, off)] == ref.blocks
     ctx.close()
+
+
+def test_very_long_read_three_byte_numerics():
+    # one read longer than 65535 bases: read size / anchor-relative positions need three-byte numerics (numeric models [0..3])
+    import synth
+    g = synth.make_genome(90000, seed=5)
+    b1, off1 = synth.make_reads(g, 1, 70000, seed=6, err=0.001)
+    b2, off2 = synth.make_reads(g, 400, 300, seed=7, err=0.01, n_rate=0.001)
+    reads = [b2[int(off2[i]):int(off2[i + 1])].tobytes() for i in range(200)] + [b1.tobytes()] + \
+            [b2[int(off2[i]):int(off2[i + 1])].tobytes() for i in range(200, 400)]
+    bases, off = O.reads_to_arrays(reads)
+    _full_compare(bases, off, 31, 150, window=128)
