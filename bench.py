@@ -120,6 +120,12 @@ def main():
     offsets = (torch.arange(n_total + 1, dtype=torch.int64, device=device) * L).contiguous()
     del genome
     torch.cuda.synchronize()
+    if world > 1:                            # the replicated anchor resolution needs the SAME reads on every rank
+        chk = torch.stack([reads[::97].sum(dtype=torch.int64), reads[-1].sum(dtype=torch.int64)])
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN); dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo_, hi_):
+            raise SystemExit("rank %d: the synthetic read set differs between ranks" % rank)
 
     # bloom = the reads' solid k-mers (abundance >= 3, Leon's `-abundance 3`), counted on the device by rank 0
     # (leon_kmer_solid_device, the DSK stand-in: outside the timed region, it is the step before the path)
