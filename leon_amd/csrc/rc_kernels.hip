@@ -8,6 +8,7 @@
 //     with one multiply-high by the precomputed reciprocal instead of a 64-bit division.
 // Counts are exactly Order0Model's cumulative counts (its rescale cannot trigger: MAX_RANGE = 2^48 total).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace leon {
 
@@ -26,6 +27,12 @@ size_t rc_model_scratch_bytes(uint64_t n_blocks) {
     return (size_t)n_blocks * (RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE * sizeof(uint32_t);
 }
 
+// keep a wave-uniform 64-bit value in vector registers (so that arithmetic on it issues on the vector unit)
+__device__ inline void pin_v(uint64_t& x) {
+    uint32_t a = (uint32_t)x, b = (uint32_t)(x >> 32);
+    asm volatile("" : "+v"(a), "+v"(b));
+    x = ((uint64_t)b << 32) | a;
+}
 // A model keeps the cumulative count F(x) = H[x>>4] + Lw[x], x in 0..256 (F(256) = H[16] + the zero word).
 // Order0Model::clear: F(x) = x.
 template <typename P> __device__ inline void model_init(P s, uint32_t lane, bool small) {
@@ -37,7 +44,7 @@ template <typename P> __device__ inline void model_init(P s, uint32_t lane, bool
 }
 
 
-template <uint32_t RC_NSLOT>
+template <uint32_t RC_NSLOT, bool VCHAIN>
 __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                                                   uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
                                                   uint32_t* scratch, int* err) {
@@ -160,6 +167,36 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
                     const uint32_t s_tot = (uint32_t)__builtin_amdgcn_readlane((int)v_tot, (int)j);
                     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)v_il, (int)j);
                     const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)v_ih, (int)j);
+                    if (VCHAIN) {
+                        // The same chain on the VECTOR unit (every lane computes the same values): a CU has ONE scalar
+                        // unit for all its waves, and with 8 blocks resident per CU eight scalar chains queue on it.
+                        pin_v(range); pin_v(low);
+                        const uint32_t vr0 = (uint32_t)range, vr1 = (uint32_t)(range >> 32);
+                        uint64_t q = (uint64_t)vr1 * b1 + (((uint64_t)vr1 * b0) >> 32) + (((uint64_t)vr0 * b1) >> 32);
+                        const uint32_t rem0 = vr0 - (uint32_t)q * s_tot;          // true remainder < 4 * tot < 2^32
+                        const bool ge2 = rem0 >= 2 * s_tot;
+                        const uint32_t rem1 = rem0 - (ge2 ? 2 * s_tot : 0u);
+                        q += (ge2 ? 2u : 0u) + (rem1 >= s_tot ? 1u : 0u);
+                        low += (uint64_t)s_lo * q;
+                        range = q * s_fr;
+                        for (;;) {                                      // RangeEncoder::encode's while loop, uniform branches
+                            pin_v(range); pin_v(low);
+                            const uint32_t xh = (uint32_t)((low ^ (low + range)) >> 32);
+                            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)xh) >= (1u << 24)) {
+                                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(range >> 32)) >= (1u << 16)) break;
+                                range = (0 - low) & (RC_BOTTOM - 1);
+                            }
+                            acc = (acc << 8) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(low >> 56));
+                            nout++;
+                            if ((nout & 7) == 0) {
+                                if (nout <= cap) { if (lane == 0) *(uint64_t*)(dst + nout - 8) = __builtin_bswap64(acc); }
+                                else overflow = true;
+                            }
+                            range <<= 8;
+                            low <<= 8;
+                        }
+                        continue;
+                    }
                     // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
                     // total < 2^30), fixed up on the low word; low += cumLow * q; range = q * freq.  Hand-scheduled on
                     // the scalar unit: 29 instructions (the compiler's version of the same C was ~45 and went
@@ -230,7 +267,7 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
         }
         if (wave == 0) {
             for (int i = 0; i < 8; i++) {                               // RangeEncoder::flush
-                acc = (acc << 8) | (low >> 56);
+                acc = (acc << 8) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(low >> 56));
                 nout++;
                 if ((nout & 7) == 0) {
                     if (nout <= cap) { if (lane == 0) *(uint64_t*)(dst + nout - 8) = __builtin_bswap64(acc); }
@@ -257,9 +294,12 @@ void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_be
     if (!n_blocks) return;
     uint32_t g = n_blocks > 65535 ? 65535u : (uint32_t)n_blocks;
     const bool small = n_blocks > 256 * 5;                   // keep every block resident: 8 x 19.6 KB per CU
-#define RC_LAUNCH(N) hipLaunchKernelGGL((k_rc_encode<N>), dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
-    if (small) RC_LAUNCH(RC_NSLOT_SMALL);
-    else RC_LAUNCH(RC_NSLOT_BIG);
+    // scalar chain while a CU holds a block or two, vector chain once several blocks would queue on its one scalar unit
+    static const char* force = getenv("LEON_RC_CHAIN");       // "s" / "v": measurement override
+    const bool vchain = force ? force[0] == 'v' : n_blocks > 512;
+#define RC_LAUNCH(N, V) hipLaunchKernelGGL((k_rc_encode<N, V>), dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
+    if (small) { if (vchain) RC_LAUNCH(RC_NSLOT_SMALL, true); else RC_LAUNCH(RC_NSLOT_SMALL, false); }
+    else { if (vchain) RC_LAUNCH(RC_NSLOT_BIG, true); else RC_LAUNCH(RC_NSLOT_BIG, false); }
 #undef RC_LAUNCH
 }
 
