@@ -215,3 +215,27 @@ def test_two_word_kmers_roundtrip(k):
             assert d == bases[int(off[r + j]):int(off[r + j + 1])]
         r += nr
     assert r == 1500
+
+
+@pytest.mark.parametrize("k,nreads", [(31, 200), (15, 120), (33, 60)])
+def test_oracle_equals_independent_python_restatement(k, nreads):
+    """tests/py_leon.py restates the path from DESIGN.md's rules in pure Python; the C oracle must agree byte for byte
+    (blocks, dictionary stream, anchors, bloom bits)"""
+    import py_leon
+    if k == 31:
+        bases, off = common.toy_reads()
+    else:
+        bases, off = common.synthetic(nreads, 90, 1500, seed=300 + k, n_rate=0.004, err=0.02)
+    reads = [bases[int(off[i]):int(off[i + 1])].decode() for i in range(nreads)]
+    b2, off2 = O.reads_to_arrays(reads)
+    bl, solid, tai = common.make_bloom(b2, off2, k)
+    pb = py_leon.Bloom(tai, k)
+    for x in O.kmers_to_ints(solid, k):
+        pb.insert(x)
+    assert bytes(pb.bits) == bl.bits.tobytes()
+    rpb = 70
+    ref = O.encode(b2, off2, k, rpb, bl, trace=False)
+    blocks, dstream, anchors = py_leon.encode(reads, k, rpb, pb)
+    assert anchors == O.kmers_to_ints(ref.anchor_kmers, k)
+    assert blocks == ref.blocks
+    assert dstream == ref.anchor_dict
