@@ -5,6 +5,10 @@
 // window while the device resolves, walks and codes the read blocks (rc_kernels.hip codes those).
 #pragma once
 #include <stdint.h>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#define LEON_HOST_CHAIN_X86 1
+#endif
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -13,58 +17,71 @@
 
 namespace leon {
 
-// The dictionary stream's model total is 5 + t at symbol t, whatever the data: a helper thread runs ahead and hands
-// the chain floor((2^64-1)/(5+t)) in chunks, so the chain divides with one 64x64->128 multiply and a one-step fix-up
-// instead of a hardware division on its critical path (-15 % per symbol on an EPYC 9575F).
+// The dictionary stream's model total is 5 + t at symbol t, whatever the data: helper threads run ahead and hand the
+// chain, in chunks, the scaled reciprocal m(t) = floor((2^72 - 1) / d), d = 5 + t > 256.  With h = mulhi(x, m):
+// floor(256 x / d) = h or h + 1 when x < 2^56, and floor(x / d) = (h >> 8) or one more, "one more" having probability
+// < 2^-8 in both cases.  The chain so divides with one multiply (and an immediate shift) and checks the quotient in a
+// branch that is rarely taken, instead of waiting for a hardware division (4.1 -> ~2 ns per symbol on an EPYC 9575F
+// together with the branch-free renormalisation below).
 class ReciprocalStream {
 public:
     static constexpr uint64_t kChunk = 1ull << 18;
-    static constexpr uint32_t kBufs = 8;
+    static constexpr uint32_t kBufs = 12, kThreads = 3;         // one 128/64-bit division per symbol: ~3 threads keep ahead
     ReciprocalStream() { for (auto& b : buf_) b.resize(kChunk); }
     ~ReciprocalStream() { stop(); }
     void restart() {                                           // a new stream: t starts at 0 again
         stop();
-        produced_ = consumed_ = 0; quit_ = false;
-        th_ = std::thread([this] { run(); });
+        consumed_ = 0; quit_ = false;
+        for (auto& h : holds_) h = 0;
+        for (uint32_t j = 0; j < kThreads; j++) th_[j] = std::thread([this, j] { run(j); });
         running_ = true;
     }
     void stop() {
         if (!running_) return;
         { std::lock_guard<std::mutex> g(mu_); quit_ = true; }
         cv_.notify_all();
-        th_.join();
+        for (auto& t : th_) t.join();
         running_ = false;
     }
-    // reciprocals of chunk c (symbols c*kChunk ...); chunks are taken in increasing order, taking c releases c-1
+    // reciprocals of chunk c (symbols c*kChunk ...); chunks are taken in increasing order, taking c releases those before it
     const uint64_t* take(uint64_t c) {
         std::unique_lock<std::mutex> g(mu_);
         if (c > consumed_) { consumed_ = c; cv_.notify_all(); }
-        cv_.wait(g, [&] { return produced_ > c; });
+        cv_.wait(g, [&] { return holds_[c % kBufs] == c + 1; });
         return buf_[c % kBufs].data();
     }
+    static inline uint64_t reciprocal(uint64_t d) {            // floor((2^72 - 1) / d); 0 where it would not fit (d <= 256)
+        if (d <= 256) return 0;
+#ifdef LEON_HOST_CHAIN_X86
+        uint64_t q, r;
+        asm("divq %[d]" : "=a"(q), "=d"(r) : "a"(~0ull), "d"(255ull), [d] "r"(d) : "cc");
+        return q;
+#else
+        return (uint64_t)(((((unsigned __int128)255) << 64) | ~0ull) / d);
+#endif
+    }
 private:
-    void run() {
-        for (;;) {
-            uint64_t c;
+    void run(uint32_t j) {
+        for (uint64_t c = j;; c += kThreads) {
             {
                 std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&] { return quit_ || produced_ - consumed_ < kBufs; });
+                cv_.wait(g, [&] { return quit_ || c < consumed_ + kBufs; });   // the buffer's previous chunk is released
                 if (quit_) return;
-                c = produced_;
             }
             uint64_t* out = buf_[c % kBufs].data();
             const uint64_t t0 = c * kChunk;
-            for (uint64_t i = 0; i < kChunk; i++) out[i] = ~0ull / (5 + t0 + i);
-            { std::lock_guard<std::mutex> g(mu_); produced_ = c + 1; }
+            for (uint64_t i = 0; i < kChunk; i++) out[i] = reciprocal(5 + t0 + i);
+            { std::lock_guard<std::mutex> g(mu_); holds_[c % kBufs] = c + 1; }
             cv_.notify_all();
         }
     }
     std::vector<uint64_t> buf_[kBufs];
+    uint64_t holds_[kBufs] = {};                               // chunk index + 1 a buffer currently holds
     std::mutex mu_;
     std::condition_variable cv_;
-    uint64_t produced_ = 0, consumed_ = 0;
+    uint64_t consumed_ = 0;
     bool quit_ = false, running_ = false;
-    std::thread th_;
+    std::thread th_[kThreads];
 };
 
 // Order-0 adaptive model over {A,C,T,G,N} + carry-less 64-bit range coder, specialised for the dictionary
@@ -73,7 +90,7 @@ class AnchorDictCoder {
 public:
     AnchorDictCoder() { clear(); }
     void clear() {
-        low_ = 0; range_ = ~0ull; n_ = 0; buf_.clear(); w_ = 0; inv_ = nullptr; inv_chunk_ = ~0ull;
+        low_ = 0; range_ = ~0ull; n_ = 0; buf_.clear(); w_ = 0; inv_ = nullptr;
         for (int i = 0; i <= 5; i++) cum_[i] = i;              // Order0Model::clear: _charRanges[i] = i
     }
     void use_reciprocals(ReciprocalStream* r) { recips_ = r; }
@@ -81,31 +98,93 @@ public:
     // (LargeInt::toString order)
     inline void encode_kmer(const uint64_t* w, uint32_t k) {
         if (buf_.size() < w_ + 8 * (size_t)k + 16) buf_.resize(buf_.size() * 2 + 8 * (size_t)k + 4096);
+#ifdef LEON_HOST_CHAIN_X86
+        if (recips_ && n_ >= 256) { encode_kmer_chain(w, k); return; }     // (the scaled reciprocal needs a total above 256)
+#endif
         for (uint32_t i = 0; i < k; i++) {
             const uint32_t bit = 2 * (k - 1 - i);
             encode((uint32_t)(w[bit >> 6] >> (bit & 63)) & 3u);
         }
     }
     void flush() {                                             // RangeEncoder::flush
-        if (buf_.size() < w_ + 8) buf_.resize(w_ + 8);
+        if (buf_.size() < w_ + 24) buf_.resize(w_ + 24);
+        settle();
         for (int i = 0; i < 8; i++) { buf_[w_++] = (uint8_t)(low_ >> 56); low_ <<= 8; }
     }
     const uint8_t* data() const { return buf_.data(); }
     size_t size() const { return w_; }
     uint64_t symbols() const { return n_; }
 private:
-    // one symbol; the caller guarantees 8 bytes of room (a symbol emits at most 8)
-    inline void encode(uint32_t c) {
-        const uint64_t lo = cum_[c], fr = cum_[c + 1] - cum_[c], tot = cum_[5];
-        uint64_t q;
-        if (recips_) {                                         // floor(range / tot) = mulhi(range, floor((2^64-1)/tot)) or one more
-            const uint64_t ch = n_ / ReciprocalStream::kChunk;
-            if (ch != inv_chunk_) { inv_ = recips_->take(ch); inv_chunk_ = ch; }
-            q = (uint64_t)(((unsigned __int128)range_ * inv_[n_ % ReciprocalStream::kChunk]) >> 64);
-            q += (range_ - q * tot) >= tot;
-        } else q = range_ / tot;
-        low_ += lo * q;
-        range_ = q * fr;
+#ifdef LEON_HOST_CHAIN_X86
+    inline void encode_kmer_chain(const uint64_t* w, uint32_t k) {
+        // Latency-shaped chain.  The state carried from symbol to symbol is (low, range) BEFORE the renormalisation the
+        // previous symbol owes.  Its usual outcomes -- no byte, one byte -- are both formed and selected by conditional
+        // moves: with h = mulhi(range, m) the quotient is h >> 8 without the byte and h itself with it (range < 2^56
+        // there), so ONE multiply serves both.  The rare outcomes (two bytes at once, the carry-less coder's
+        // range < BOTTOM reset, a quotient one too small) leave through branches that are almost never taken.
+        // Loop-carried path: multiply-high, shift, select, multiply = ~9 cycles and no data-dependent branch, where
+        // the plain form has a division, a multiply and a ~25 %-taken renormalisation branch.  The model's cumulative
+        // counts live in two vector registers (one add each per symbol) and are read back through a small table.
+        alignas(16) static const uint64_t kInc[4][4] = {{1, 1, 1, 1}, {0, 1, 1, 1}, {0, 0, 1, 1}, {0, 0, 0, 1}};
+        alignas(16) uint64_t tbl[6] = {0, 0, cum_[1], cum_[2], cum_[3], cum_[4]};       // tbl[1 + c] = cum_[c]
+        __m128i ca = _mm_load_si128((const __m128i*)(tbl + 2)), cb = _mm_load_si128((const __m128i*)(tbl + 4));
+        unsigned __int128 x = k >= 32 ? (((unsigned __int128)w[1] << 64) | w[0]) : (unsigned __int128)w[0];
+        x <<= 128 - 2 * k;                                     // first base in the two highest bits
+        uint64_t L = low_, R = range_, n = n_;
+        uint8_t* p = buf_.data() + w_;
+        for (uint32_t done = 0; done < k;) {
+            const uint64_t off = n % ReciprocalStream::kChunk;
+            if (off == 0 || !inv_) inv_ = recips_->take(n / ReciprocalStream::kChunk);
+            const uint64_t* ip = inv_ + off;
+            const uint64_t left = ReciprocalStream::kChunk - off;
+            const uint32_t run = left < k - done ? (uint32_t)left : k - done;
+            uint64_t tot = 5 + n;
+            for (uint32_t i = 0; i < run; i++, tot++) {
+                const uint32_t c = (uint32_t)(x >> 126);
+                x <<= 2;
+                const uint64_t lo = tbl[1 + c], fr = tbl[2 + c] - lo, m = ip[i];
+                ca = _mm_add_epi64(ca, _mm_load_si128((const __m128i*)kInc[c]));       // Order0Model::update
+                cb = _mm_add_epi64(cb, _mm_load_si128((const __m128i*)kInc[c] + 1));
+                _mm_store_si128((__m128i*)(tbl + 2), ca);
+                _mm_store_si128((__m128i*)(tbl + 4), cb);
+                const uint64_t xr = L ^ (L + R);               // xr < TOP: the previous symbol owes (at least) one byte
+                uint64_t q;
+                // the branch-free form is valid for "no byte" and "exactly one byte" (the shifted test is xr << 8)
+                if (__builtin_expect((xr >> 48) == 0 || R < kBottom, 0)) {
+                    while ((L ^ (L + R)) < kTop || (R < kBottom && ((R = (0 - L) & (kBottom - 1)), true))) {
+                        *p++ = (uint8_t)(L >> 56);
+                        R <<= 8;
+                        L <<= 8;
+                    }
+                    q = (uint64_t)(((unsigned __int128)R * m) >> 64) >> 8;
+                } else {
+                    const uint64_t h = (uint64_t)(((unsigned __int128)R * m) >> 64);
+                    q = h >> 8;
+                    *p = (uint8_t)(L >> 56);
+                    // (q, R, L, p) = one byte ? (h, R << 8, L << 8, p + 1) : unchanged -- as conditional moves (a compiler
+                    // turns the selects back into the unpredictable branch this loop exists to avoid)
+                    asm("cmpq %[top], %[xr]\n\tcmovbq %[h], %[q]\n\tcmovbq %[R1], %[R]\n\tcmovbq %[L1], %[L]\n\tadcq $0, %[p]"
+                        : [q] "+r"(q), [R] "+r"(R), [L] "+r"(L), [p] "+r"(p)
+                        : [xr] "r"(xr), [top] "r"(kTop), [h] "r"(h), [R1] "r"(R << 8), [L1] "r"(L << 8)
+                        : "cc");
+                }
+                if (__builtin_expect(R - q * tot >= tot, 0)) {  // quotient one too small: probability < 2^-8
+                    asm volatile("" : "+r"(q));                // (keeps this a branch: as a select it would sit on the chain)
+                    q++;
+                }
+                R = q * fr;
+                L += q * lo;
+            }
+            done += run;
+            n += run;
+        }
+        w_ = (size_t)(p - buf_.data());
+        low_ = L; range_ = R; n_ = n;
+        cum_[1] = tbl[2]; cum_[2] = tbl[3]; cum_[3] = tbl[4]; cum_[4] = tbl[5]; cum_[5] = 5 + n;
+    }
+#endif
+    // the renormalisation the last symbol owes (the state is kept un-normalised between symbols, see encode_kmer)
+    inline void settle() {
         uint8_t* p = buf_.data() + w_;
         while ((low_ ^ (low_ + range_)) < kTop || (range_ < kBottom && ((range_ = (0 - low_) & (kBottom - 1)), true))) {
             *p++ = (uint8_t)(low_ >> 56);
@@ -113,6 +192,14 @@ private:
             low_ <<= 8;
         }
         w_ = (size_t)(p - buf_.data());
+    }
+    // one symbol, plain form (no reciprocal stream); the caller guarantees 16 bytes of room
+    inline void encode(uint32_t c) {
+        settle();
+        const uint64_t lo = cum_[c], fr = cum_[c + 1] - cum_[c], tot = cum_[5];
+        const uint64_t q = range_ / tot;
+        low_ += lo * q;
+        range_ = q * fr;
         for (uint32_t i = 1; i <= 5; i++) cum_[i] += (uint64_t)(i > c);    // Order0Model::update, branch-free
         n_++;                                                  // (its rescale needs 2^48 symbols: unreachable)
     }
@@ -122,7 +209,6 @@ private:
     size_t w_;
     ReciprocalStream* recips_ = nullptr;
     const uint64_t* inv_ = nullptr;
-    uint64_t inv_chunk_ = ~0ull;
 };
 
 // the worker that owns the coder: batches of anchor k-mers are queued in address order

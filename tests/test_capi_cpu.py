@@ -79,3 +79,31 @@ def test_host_anchor_dict_stream_matches_oracle(lib):
         exp = O.rc_encode_stream(np.ones(len(syms), dtype=np.uint8), syms, sizes)   # model 1: alphabet 5
         assert capi.host_anchor_dict_encode(kmers, k) == exp
         assert O.kmers_to_ints(O.decode_anchor_dict(exp, n, k), k) == ints
+
+
+@pytest.mark.parametrize("kind", ["polyA", "skewed", "two_letter", "uniform_long"])
+def test_host_anchor_dict_chain_rare_paths(lib, kind):
+    """the host chain's branch-free form covers 'no byte' / 'one byte' per symbol; skewed streams drive the other
+    outcomes (several bytes at once, the range < BOTTOM reset, quotient fix-up) and long ones cross many reciprocal chunks"""
+    import numpy as np
+    import oracle_lib as O
+    from leon_amd import capi
+    rng = np.random.default_rng(11)
+    k = 31
+    n = {"polyA": 40000, "skewed": 40000, "two_letter": 40000, "uniform_long": 200000}[kind]
+    if kind == "polyA":
+        syms = np.zeros(n * k, dtype=np.uint8)
+        syms[rng.integers(0, n * k, 50)] = 3
+    elif kind == "skewed":
+        syms = rng.choice(4, size=n * k, p=[0.97, 0.01, 0.01, 0.01]).astype(np.uint8)
+    elif kind == "two_letter":
+        syms = (rng.integers(0, 2, n * k) * 2).astype(np.uint8)
+    else:
+        syms = rng.integers(0, 4, n * k).astype(np.uint8)
+    s2 = syms.reshape(n, k).astype(np.uint64)
+    kmers = np.zeros(n, dtype=np.uint64)
+    for i in range(k):
+        kmers = (kmers << np.uint64(2)) | s2[:, i]
+    sizes = [2, 5, 5, 2, 3, 3, 3, 2] + [256] * 72
+    exp = O.rc_encode_stream(np.ones(len(syms), dtype=np.uint8), syms, sizes)
+    assert capi.host_anchor_dict_encode(kmers, k) == exp
