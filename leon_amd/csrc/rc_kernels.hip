@@ -8,6 +8,7 @@
 //     with one multiply-high by the precomputed reciprocal instead of a 64-bit division.
 // Counts are exactly Order0Model's cumulative counts (its rescale cannot trigger: MAX_RANGE = 2^48 total).
 #include "kernels.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace leon {
@@ -44,50 +45,74 @@ template <typename P> __device__ inline void model_init(P s, uint32_t lane, bool
 }
 
 
-template <uint32_t RC_NSLOT, bool VCHAIN>
-__global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
-                                                  uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
-                                                  uint32_t* scratch, int* err) {
-    __shared__ uint32_t models[RC_SMALL_WORDS + RC_NSLOT * RC_STRIDE];
-    __shared__ uint32_t ring[2][5][64];
-    __shared__ uint8_t slotmap[RC_NNUM];
+// One workgroup codes G blocks: waves 0..G-1 are the blocks' modelers, wave G is the coder and runs the G serial chains
+// in its lanes 0..G-1 (lane = block).  A chain step costs the same issue slots whether one lane or eight are active, so
+// a CU that holds 8 blocks runs ONE chain instruction stream instead of eight; the step itself is branch-free in the
+// usual cases (0..2 bytes leave, no range < BOTTOM reset) and falls back to RangeEncoder::encode's loop per lane otherwise.
+template <uint32_t G, uint32_t RC_NSLOT>
+__global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
+                                                            uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
+                                                            uint32_t* scratch, int* err) {
+    constexpr uint32_t MW = RC_SMALL_WORDS + RC_NSLOT * RC_STRIDE;
+    __shared__ uint32_t models_all[G * MW];
+    __shared__ uint32_t ring_all[G][2][5][64];
+    __shared__ uint8_t slotmap_all[G][RC_NNUM];
+    __shared__ uint32_t ntiles_s[G];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: keeps the coder chain on the scalar unit
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool is_coder = wave == G;
     // per-lane constants of the branch-free Order0Model::update: lanes 0..15 own Lw of the symbol's 16-block,
     // lanes 16..32 own H[0..16]
     const bool is_lw = lane < 16;
     const uint32_t upd_lane = is_lw ? lane : (lane < 33 ? lane - 16 : 0);
     const uint32_t upd_base = is_lw ? RC_LW + lane : upd_lane;
     const uint32_t upd_blkmask = is_lw ? ~0u : 0u;
+    uint32_t* models = models_all + (is_coder ? 0 : wave) * MW;
+    uint8_t* slotmap = slotmap_all[is_coder ? 0 : wave];
+    const uint16_t* sym16 = (const uint16_t*)syms;
 
-    for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        const uint64_t s0 = blk_begin[b], s1 = blk_begin[b + 1];
-        if (s1 - s0 >= RC_MAX_TOTAL - 256) {                    // totals must stay below 2^30 for the chain's 32-bit fix-up
-            if (threadIdx.x == 0) { atomicExch(err, 2); out_size[b] = 0; }
-            continue;
+    const uint64_t n_groups = (n_blocks + G - 1) / G;
+    for (uint64_t bg = blockIdx.x; bg < n_groups; bg += gridDim.x) {
+        // this thread's block: the wave's for a modeler, the lane's for the coder
+        const uint64_t b = bg * G + (is_coder ? lane : wave);
+        bool valid = (is_coder ? lane < G : true) && b < n_blocks;
+        uint64_t s0 = 0, s1 = 0;
+        if (valid) { s0 = blk_begin[b]; s1 = blk_begin[b + 1]; }
+        if (valid && s1 - s0 >= RC_MAX_TOTAL - 256) {            // totals must stay below 2^30 for the chain's 32-bit fix-up
+            if (is_coder || lane == 0) atomicExch(err, 2);
+            if (is_coder) out_size[b] = 0;
+            valid = false;
         }
-        const uint64_t ntiles = (s1 - s0 + 63) / 64;
-        const uint16_t* sym16 = (const uint16_t*)syms;
-        uint32_t* gmodels = scratch + b * (uint64_t)(RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE;
-        // coder state (wave 0)
-        uint64_t low = 0, range = ~0ull, nout = 0, acc = 0;
-        uint8_t* dst = out + out_off[b];
-        const uint64_t cap = out_off[b + 1] - out_off[b];
-        bool overflow = false;
-        // modeler state (wave 1); the next tile's symbols are fetched one tile ahead (a global load costs ~2000 cycles)
+        const uint32_t ntiles = valid ? (uint32_t)((s1 - s0 + 63) / 64) : 0;
+        if (!is_coder && lane == 0) ntiles_s[wave] = ntiles;
+        // coder state (wave G, lane = block)
+        uint64_t low = 0, range = ~0ull;
+        uint32_t nout = 0;
+        uint8_t* dst = nullptr;
+        uint64_t cap = 0;
+        uint32_t cap4 = 0;                                       // last cursor a 4-byte store may start at; stores clamp to it
+        if (is_coder && valid) {                                 // and the block reports overflow at its end (the cursor only grows)
+            dst = out + out_off[b]; cap = out_off[b + 1] - out_off[b];
+            cap4 = (uint32_t)(cap < 0xFFFFFFFFull ? cap : 0xFFFFFFFFull) - 4;
+        }
+        // modeler state; the next tile's symbols are fetched one tile ahead (a global load costs ~2000 cycles)
         uint32_t nused = 0;
-        uint32_t raw_next = (wave == 1 && lane < (uint32_t)((s1 - s0) < 64 ? (s1 - s0) : 64)) ? sym16[s0 + lane] : 0xFFFFu;
-        if (wave == 1) {                                       // AbstractDnaCoder::startBlock
+        uint32_t* gmodels = scratch + (valid ? b : 0) * (uint64_t)(RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE;
+        uint32_t raw_next = 0xFFFFu;
+        if (!is_coder && valid) {                                // AbstractDnaCoder::startBlock
+            raw_next = lane < (uint32_t)((s1 - s0) < 64 ? (s1 - s0) : 64) ? sym16[s0 + lane] : 0xFFFFu;
             for (uint32_t m = 0; m < N_SMALL_MODELS; m++) model_init(&models[m * RC_SSTRIDE], lane, true);
             for (uint32_t i = lane; i < RC_NNUM; i += 64) slotmap[i] = 255;
         }
         __syncthreads();
+        uint32_t T = 0;
+        for (uint32_t w = 0; w < G; w++) T = ntiles_s[w] > T ? ntiles_s[w] : T;
 
-        for (uint64_t t = 0; t <= ntiles; t++) {
-            if (wave == 1) {
+        for (uint32_t t = 0; t <= T; t++) {
+            if (!is_coder) {
                 if (t < ntiles) {
-                    // =================== modeler: tile t -> ring[t & 1] ===================
-                    const uint64_t base = s0 + t * 64;
+                    // =================== modeler: tile t -> ring[wave][t & 1] ===================
+                    const uint64_t base = s0 + (uint64_t)t * 64;
                     const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
                     const bool act = lane < cnt;
                     const uint32_t raw = raw_next;
@@ -150,140 +175,76 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
                         if (mbi & RC_GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
                     __builtin_amdgcn_wave_barrier();
-                    const uint64_t inv = ~0ull / (uint64_t)tot;        // per lane, off the serial chain
-                    uint32_t(*rg)[64] = ring[t & 1];
+                    const uint64_t inv = ~0ull / (uint64_t)tot;        // per lane, off the serial chains
+                    uint32_t(*rg)[64] = ring_all[wave][t & 1];
                     rg[0][lane] = lo; rg[1][lane] = hi - lo; rg[2][lane] = tot;
                     rg[3][lane] = (uint32_t)inv; rg[4][lane] = (uint32_t)(inv >> 32);
+                } else if (t < T) {
+                    // the group's longer blocks go on: records that leave a chain as it is (cumLow 0, freq = total = 1)
+                    uint32_t(*rg)[64] = ring_all[wave][t & 1];
+                    rg[0][lane] = 0; rg[1][lane] = 1; rg[2][lane] = 1; rg[3][lane] = ~0u; rg[4][lane] = ~0u;
                 }
             } else if (t > 0) {
-                // =================== coder: tile t-1 from ring[(t-1) & 1] ===================
-                const uint64_t base = s0 + (t - 1) * 64;
-                const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
-                uint32_t(*rg)[64] = ring[(t - 1) & 1];
-                const uint32_t v_lo = rg[0][lane], v_fr = rg[1][lane], v_tot = rg[2][lane], v_il = rg[3][lane], v_ih = rg[4][lane];
-                for (uint32_t j = 0; j < cnt; j++) {
-                    const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)v_lo, (int)j);
-                    const uint32_t s_fr = (uint32_t)__builtin_amdgcn_readlane((int)v_fr, (int)j);
-                    const uint32_t s_tot = (uint32_t)__builtin_amdgcn_readlane((int)v_tot, (int)j);
-                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)v_il, (int)j);
-                    const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)v_ih, (int)j);
-                    if (VCHAIN) {
-                        // The same chain on the VECTOR unit (every lane computes the same values): a CU has ONE scalar
-                        // unit for all its waves, and with 8 blocks resident per CU eight scalar chains queue on it.
-                        pin_v(range); pin_v(low);
-                        const uint32_t vr0 = (uint32_t)range, vr1 = (uint32_t)(range >> 32);
-                        uint64_t q = (uint64_t)vr1 * b1 + (((uint64_t)vr1 * b0) >> 32) + (((uint64_t)vr0 * b1) >> 32);
-                        const uint32_t rem0 = vr0 - (uint32_t)q * s_tot;          // true remainder < 4 * tot < 2^32
-                        const bool ge2 = rem0 >= 2 * s_tot;
-                        const uint32_t rem1 = rem0 - (ge2 ? 2 * s_tot : 0u);
-                        q += (ge2 ? 2u : 0u) + (rem1 >= s_tot ? 1u : 0u);
-                        low += (uint64_t)s_lo * q;
-                        range = q * s_fr;
-                        for (;;) {                                      // RangeEncoder::encode's while loop, uniform branches
-                            pin_v(range); pin_v(low);
-                            const uint32_t xh = (uint32_t)((low ^ (low + range)) >> 32);
-                            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)xh) >= (1u << 24)) {
-                                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(range >> 32)) >= (1u << 16)) break;
-                                range = (0 - low) & (RC_BOTTOM - 1);
+                // =================== coder: tile t-1 of every block of the group, lane = block ===================
+                // (symbols past a block's end are "leave as it is" records, so the 64 steps are uniform)
+                if (valid) {
+                    const uint32_t* rg = &ring_all[lane][(t - 1) & 1][0][0];
+                    uint32_t p_lo = rg[0], p_fr = rg[64], p_tot = rg[128], p_b0 = rg[192], p_b1 = rg[256];
+#pragma unroll 2
+                    for (uint32_t j = 0; j < 64; j++) {
+                        const uint32_t s_lo = p_lo, s_fr = p_fr, s_tot = p_tot, b0 = p_b0, b1 = p_b1;
+                        const uint32_t jn = (j + 1) & 63;                          // next step's record, fetched under this step
+                        p_lo = rg[jn]; p_fr = rg[64 + jn]; p_tot = rg[128 + jn]; p_b0 = rg[192 + jn]; p_b1 = rg[256 + jn];
+                        // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
+                        // total < 2^30), fixed up on the low word
+                        const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
+                        uint64_t q = (uint64_t)r1 * b1 + __umulhi(r1, b0);
+                        q += __umulhi(r0, b1);
+                        const uint32_t rem = r0 - (uint32_t)q * s_tot;              // true remainder < 4 * tot < 2^32
+                        const uint32_t t2 = s_tot << 1, t3 = t2 + s_tot;
+                        const uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
+                        q += e;
+                        const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
+                        const uint32_t s_hc = s_lo + s_fr;
+                        // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq)
+                        uint64_t top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
+                        low = (uint64_t)q0 * s_lo + low;            low += (uint64_t)(q1 * s_lo) << 32;
+                        range = (uint64_t)q0 * s_fr;                range += (uint64_t)(q1 * s_fr) << 32;
+                        // RangeEncoder::encode's while loop.  Usual case: low and low + range agree on their top 0..2
+                        // bytes and the shifted range stays >= BOTTOM: those bytes leave at once -- one unaligned 4-byte
+                        // store at the cursor (what lies past the cursor is overwritten by the stores that follow)
+                        const uint32_t lh = (uint32_t)(low >> 32);
+                        const uint32_t xh = lh ^ (uint32_t)(top >> 32);
+                        const uint32_t sh = (uint32_t)__builtin_clz(xh | 1u) & 24u;
+                        const uint64_t range_s = range << sh;
+                        const bool rare = xh < 256u || (uint32_t)(range_s >> 32) < (1u << 16);
+                        *(uint32_t*)(dst + (nout < cap4 ? nout : cap4)) = __builtin_bswap32(lh);
+                        uint64_t low_n = low << sh, range_n = range_s;
+                        uint32_t nout_n = nout + (sh >> 3);
+                        if (__builtin_expect(rare, 0)) {
+                            low_n = low; range_n = range; nout_n = nout;
+                            while ((low_n ^ (low_n + range_n)) < (1ull << 56) ||
+                                   (range_n < RC_BOTTOM && ((range_n = (0 - low_n) & (RC_BOTTOM - 1)), true))) {
+                                dst[nout_n < cap4 ? nout_n : cap4] = (uint8_t)(low_n >> 56);
+                                nout_n++;
+                                range_n <<= 8;
+                                low_n <<= 8;
                             }
-                            acc = (acc << 8) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(low >> 56));
-                            nout++;
-                            if ((nout & 7) == 0) {
-                                if (nout <= cap) { if (lane == 0) *(uint64_t*)(dst + nout - 8) = __builtin_bswap64(acc); }
-                                else overflow = true;
-                            }
-                            range <<= 8;
-                            low <<= 8;
                         }
-                        continue;
-                    }
-                    // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
-                    // total < 2^30), fixed up on the low word; low += cumLow * q; range = q * freq.  Hand-scheduled on
-                    // the scalar unit: 29 instructions (the compiler's version of the same C was ~45 and went
-                    // through VALU compares).
-                    uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32), l0 = (uint32_t)low, l1 = (uint32_t)(low >> 32);
-                    uint32_t q0, q1, t0, t1, t2, t3;
-                    asm volatile(
-                        "s_mul_hi_u32 %[t0], %[r1], %[b0]\n\t"
-                        "s_mul_hi_u32 %[t1], %[r0], %[b1]\n\t"
-                        "s_mul_i32 %[q0], %[r1], %[b1]\n\t"
-                        "s_mul_hi_u32 %[q1], %[r1], %[b1]\n\t"
-                        "s_add_u32 %[q0], %[q0], %[t0]\n\t"
-                        "s_addc_u32 %[q1], %[q1], 0\n\t"
-                        "s_add_u32 %[q0], %[q0], %[t1]\n\t"
-                        "s_addc_u32 %[q1], %[q1], 0\n\t"
-                        "s_mul_i32 %[t0], %[q0], %[tot]\n\t"
-                        "s_sub_u32 %[t0], %[r0], %[t0]\n\t"              // remainder, < 4 * tot
-                        "s_lshl_b32 %[t1], %[tot], 1\n\t"
-                        "s_cmp_ge_u32 %[t0], %[t1]\n\t"
-                        "s_cselect_b32 %[t2], %[t1], 0\n\t"
-                        "s_cselect_b32 %[t3], 2, 0\n\t"
-                        "s_sub_u32 %[t0], %[t0], %[t2]\n\t"
-                        "s_cmp_ge_u32 %[t0], %[tot]\n\t"
-                        "s_addc_u32 %[t3], %[t3], 0\n\t"
-                        "s_add_u32 %[q0], %[q0], %[t3]\n\t"
-                        "s_addc_u32 %[q1], %[q1], 0\n\t"
-                        "s_mul_i32 %[t0], %[lo], %[q0]\n\t"              // low += cumLow * q
-                        "s_mul_hi_u32 %[t1], %[lo], %[q0]\n\t"
-                        "s_mul_i32 %[t2], %[lo], %[q1]\n\t"
-                        "s_add_u32 %[t1], %[t1], %[t2]\n\t"
-                        "s_add_u32 %[l0], %[l0], %[t0]\n\t"
-                        "s_addc_u32 %[l1], %[l1], %[t1]\n\t"
-                        "s_mul_hi_u32 %[t0], %[q0], %[fr]\n\t"           // range = q * freq
-                        "s_mul_i32 %[r1], %[q1], %[fr]\n\t"
-                        "s_mul_i32 %[r0], %[q0], %[fr]\n\t"
-                        "s_add_u32 %[r1], %[r1], %[t0]\n\t"
-                        : [r0] "+s"(r0), [r1] "+s"(r1), [l0] "+s"(l0), [l1] "+s"(l1), [q0] "=&s"(q0), [q1] "=&s"(q1),
-                          [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3)
-                        : [b0] "s"(b0), [b1] "s"(b1), [tot] "s"(s_tot), [lo] "s"(s_lo), [fr] "s"(s_fr)
-                        : "scc");
-                    range = ((uint64_t)r1 << 32) | r0;
-                    low = ((uint64_t)l1 << 32) | l0;
-                    for (;;) {                                          // RangeEncoder::encode's while loop
-                        uint32_t xh;                                    // high word of low ^ (low + range), on the scalar unit
-                        {
-                            uint32_t a0 = (uint32_t)low, a1 = (uint32_t)(low >> 32), c0 = (uint32_t)range, c1 = (uint32_t)(range >> 32), u0;
-                            asm volatile("s_add_u32 %[u0], %[a0], %[c0]\n\t"
-                                         "s_addc_u32 %[xh], %[a1], %[c1]\n\t"
-                                         "s_xor_b32 %[xh], %[xh], %[a1]\n\t"
-                                         : [u0] "=&s"(u0), [xh] "=&s"(xh) : [a0] "s"(a0), [a1] "s"(a1), [c0] "s"(c0), [c1] "s"(c1) : "scc");
-                        }
-                        if (xh >= (1u << 24)) {
-                            if ((uint32_t)(range >> 32) >= (1u << 16)) break;
-                            range = (0 - low) & (RC_BOTTOM - 1);
-                        }
-                        acc = (acc << 8) | (low >> 56);
-                        nout++;
-                        if ((nout & 7) == 0) {
-                            if (nout <= cap) { if (lane == 0) *(uint64_t*)(dst + nout - 8) = __builtin_bswap64(acc); }
-                            else overflow = true;
-                        }
-                        range <<= 8;
-                        low <<= 8;
+                        low = low_n; range = range_n; nout = nout_n;
                     }
                 }
             }
             __syncthreads();
         }
-        if (wave == 0) {
+        if (is_coder && valid) {
             for (int i = 0; i < 8; i++) {                               // RangeEncoder::flush
-                acc = (acc << 8) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(low >> 56));
+                dst[nout < cap4 ? nout : cap4] = (uint8_t)(low >> 56);
                 nout++;
-                if ((nout & 7) == 0) {
-                    if (nout <= cap) { if (lane == 0) *(uint64_t*)(dst + nout - 8) = __builtin_bswap64(acc); }
-                    else overflow = true;
-                }
                 low <<= 8;
             }
-            const uint32_t tail = (uint32_t)(nout & 7);                 // bytes still in acc
-            if (tail) {
-                if (nout <= cap) { if (lane < tail) dst[nout - tail + lane] = (uint8_t)(acc >> (8 * (tail - 1 - lane))); }
-                else overflow = true;
-            }
-            if (lane == 0) {
-                out_size[b] = nout;
-                if (overflow) atomicExch(err, 1);
-            }
+            out_size[b] = nout;
+            if (nout > cap) atomicExch(err, 1);
         }
         __syncthreads();
     }
@@ -292,14 +253,18 @@ __global__ void __launch_bounds__(128) k_rc_encode(const uint8_t* syms, const ui
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint8_t* out,
                       const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err) {
     if (!n_blocks) return;
-    uint32_t g = n_blocks > 65535 ? 65535u : (uint32_t)n_blocks;
-    const bool small = n_blocks > 256 * 5;                   // keep every block resident: 8 x 19.6 KB per CU
-    // scalar chain while a CU holds a block or two, vector chain once several blocks would queue on its one scalar unit
-    static const char* force = getenv("LEON_RC_CHAIN");       // "s" / "v": measurement override
-    const bool vchain = force ? force[0] == 'v' : n_blocks > 512;
-#define RC_LAUNCH(N, V) hipLaunchKernelGGL((k_rc_encode<N, V>), dim3(g), dim3(128), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
-    if (small) { if (vchain) RC_LAUNCH(RC_NSLOT_SMALL, true); else RC_LAUNCH(RC_NSLOT_SMALL, false); }
-    else { if (vchain) RC_LAUNCH(RC_NSLOT_BIG, true); else RC_LAUNCH(RC_NSLOT_BIG, false); }
+    // blocks per workgroup: as few as keeps every block resident on the 256 CUs (LDS: 8 blocks of 19.6 KB per CU)
+    const uint64_t per_cu = (n_blocks + 255) / 256;
+    static const char* force = getenv("LEON_RC_GROUP");       // measurement override: blocks per workgroup
+    uint32_t G = per_cu <= 1 ? 1u : per_cu <= 2 ? 2u : per_cu <= 4 ? 4u : 8u;
+    if (force) { int v = atoi(force); if (v == 1 || v == 2 || v == 4 || v == 8) G = (uint32_t)v; }
+    const uint64_t n_groups = (n_blocks + G - 1) / G;
+    const uint32_t g = (uint32_t)std::min<uint64_t>(n_groups, 256ull * (8 / G));
+#define RC_LAUNCH(GG, N) hipLaunchKernelGGL((k_rc_encode<GG, N>), dim3(g), dim3(64 * (GG + 1)), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
+    if (G == 1) RC_LAUNCH(1, RC_NSLOT_BIG);
+    else if (G == 2) RC_LAUNCH(2, RC_NSLOT_BIG);
+    else if (G == 4) RC_LAUNCH(4, RC_NSLOT_BIG);
+    else RC_LAUNCH(8, RC_NSLOT_SMALL);
 #undef RC_LAUNCH
 }
 
