@@ -22,6 +22,7 @@ constexpr uint32_t RC_SMALL_WORDS = N_SMALL_MODELS * RC_SSTRIDE;
 constexpr uint32_t RC_NNUM = N_NUM_GROUPS * MODELS_PER_NUMERIC;   // 72
 constexpr uint32_t RC_GLOBAL = 0x80000000u;  // model lives in the global overflow area (more than RC_NSLOT numeric models)
 constexpr uint64_t RC_BOTTOM = 1ull << 48;
+constexpr uint32_t RC_RING = 65;
 constexpr uint32_t RC_MAX_TOTAL = 1u << 30;  // chain arithmetic assumes total < 2^30 (checked by the host per block)
 
 size_t rc_model_scratch_bytes(uint64_t n_blocks) {
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms,
                                                             uint32_t* scratch, int* err) {
     constexpr uint32_t MW = RC_SMALL_WORDS + RC_NSLOT * RC_STRIDE;
     __shared__ uint32_t models_all[G * MW];
-    __shared__ uint32_t ring_all[G][2][5][64];
+    __shared__ uint32_t ring_all[G][2][5][RC_RING];          // one spare entry per row: the coder prefetches record j + 1
     __shared__ uint8_t slotmap_all[G][RC_NNUM];
     __shared__ uint32_t ntiles_s[G];
     const uint32_t lane = threadIdx.x & 63;
@@ -155,33 +156,87 @@ __global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms,
                     }
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
-                    // earlier symbols of the tile + Order0Model::update, symbol by symbol, branch-free
-                    const uint32_t lowkey = m << 8;
-                    for (uint32_t i = 0; i < cnt; i++) {
-                        const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);
-                        const uint32_t mbi = (uint32_t)__builtin_amdgcn_readlane((int)mb, (int)i);
-                        const uint32_t ci = ki & 0xff;
-                        uint32_t dd = ki - lowkey;                      // < 256 <=> same model; then dd = c_i
-                        dd = lane > i ? dd : 0xFFFFFFFFu;
-                        lo += dd < c ? 1u : 0u;
-                        hi += dd <= c ? 1u : 0u;
-                        tot += dd < 256u ? 1u : 0u;
-                        const uint32_t thr = is_lw ? (ci & 15u) : (ci >> 4);
-                        const uint32_t idx = upd_base + ((ci & ~15u) & upd_blkmask);
-                        if (upd_lane > thr) {
-                            if (!(mbi & RC_GLOBAL)) (void)__hip_atomic_fetch_add(&models[mbi + idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            else (void)__hip_atomic_fetch_add(gmodels + (mbi & ~RC_GLOBAL) + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    // earlier symbols of the tile: lo += #(same model, smaller symbol), hi += #(same model, symbol <= mine),
+                    // tot += #(same model) over the lanes before this one -- 64 steps of a broadcast and three
+                    // compare/add-with-carry pairs; the lane mask "after lane i" is exec itself, shifted once per step
+                    // (one asm block, exec restored inside it)
+                    {
+                        const uint32_t lowkey = m << 8;
+                        uint32_t sk0, sk1, dd;
+                        uint64_t m1, m2, sav;
+                        asm volatile(
+                            "s_mov_b64 %[sav], exec\n\t"
+                            "v_readlane_b32 %[sk0], %[key], 0\n\t"
+                            "s_mov_b64 exec, -2\n\t"
+                            "s_nop 1\n\t"
+                            ".set rc_i, 0\n\t"
+                            ".rept 32\n\t"
+                            "v_sub_u32 %[dd], %[sk0], %[lowkey]\n\t"
+                            "v_readlane_b32 %[sk1], %[key], rc_i + 1\n\t"
+                            "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
+                            "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
+                            "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
+                            "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
+                            "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
+                            "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
+                            "s_lshl_b64 exec, exec, 1\n\t"
+                            "v_sub_u32 %[dd], %[sk1], %[lowkey]\n\t"
+                            "v_readlane_b32 %[sk0], %[key], (rc_i + 2) & 63\n\t"
+                            "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
+                            "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
+                            "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
+                            "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
+                            "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
+                            "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
+                            "s_lshl_b64 exec, exec, 1\n\t"
+                            ".set rc_i, rc_i + 2\n\t"
+                            ".endr\n\t"
+                            "s_mov_b64 exec, %[sav]\n\t"
+                            : [lo] "+v"(lo), [hi] "+v"(hi), [tot] "+v"(tot), [sk0] "=&s"(sk0), [sk1] "=&s"(sk1), [dd] "=&v"(dd),
+                              [m1] "=&s"(m1), [m2] "=&s"(m2), [sav] "=&s"(sav)
+                            : [key] "v"(key), [lowkey] "v"(lowkey), [c] "v"(c), [k256] "s"(256u)
+                            : "vcc");
+                        if (!act) { lo = 0; hi = 1; tot = 1; }         // past the block's end: a record that leaves the chain as it is
+                    }
+                    // Order0Model::update for the whole tile, lane = symbol: F(x) += 1 for x > c, i.e. H[k] for k > c >> 4
+                    // and Lw[x] for the x after c inside c's 16-block (adds of 0 where it does not apply: no exec juggling)
+                    {
+                        // (only the lanes an add applies to take part: same-address adds serialise in the LDS, and with 8
+                        // modelers per CU its atomic unit is the busiest part of the kernel.  A small model's total is
+                        // read from Lw[size], so its H[] is never touched)
+                        const bool in_lds = act && !(mb & RC_GLOBAL);
+                        uint32_t* mp = &models[in_lds ? mb : 0];
+                        const uint32_t h4 = (in_lds && numeric) ? c >> 4 : 64u;
+                        const uint32_t l4 = in_lds ? c & 15u : 64u, ymax = numeric ? 15u : small_model_size(m);
+                        uint32_t* lp = mp + RC_LW + (in_lds ? (c & ~15u) : 0u);
+#pragma unroll
+                        for (uint32_t k = 1; k <= 16; k++)
+                            if (k > h4) (void)__hip_atomic_fetch_add(&mp[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+                        for (uint32_t y = 1; y <= 15; y++)
+                            if (y > l4 && y <= ymax) (void)__hip_atomic_fetch_add(&lp[y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        // symbols of models that live in the global overflow area: one at a time, lanes 0..32 own the entries
+                        unsigned long long gl = __ballot(act && (mb & RC_GLOBAL));
+                        while (gl) {
+                            const uint32_t i = (uint32_t)__builtin_ctzll(gl);
+                            gl &= gl - 1;
+                            const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)i);
+                            const uint32_t mbi = (uint32_t)__builtin_amdgcn_readlane((int)mb, (int)i);
+                            const uint32_t thr = is_lw ? (ci & 15u) : (ci >> 4);
+                            const uint32_t idx = upd_base + ((ci & ~15u) & upd_blkmask);
+                            if (upd_lane > thr)
+                                (void)__hip_atomic_fetch_add(gmodels + (mbi & ~RC_GLOBAL) + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         }
-                        if (mbi & RC_GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
                     __builtin_amdgcn_wave_barrier();
                     const uint64_t inv = ~0ull / (uint64_t)tot;        // per lane, off the serial chains
-                    uint32_t(*rg)[64] = ring_all[wave][t & 1];
+                    uint32_t(*rg)[RC_RING] = ring_all[wave][t & 1];
                     rg[0][lane] = lo; rg[1][lane] = hi - lo; rg[2][lane] = tot;
                     rg[3][lane] = (uint32_t)inv; rg[4][lane] = (uint32_t)(inv >> 32);
                 } else if (t < T) {
                     // the group's longer blocks go on: records that leave a chain as it is (cumLow 0, freq = total = 1)
-                    uint32_t(*rg)[64] = ring_all[wave][t & 1];
+                    uint32_t(*rg)[RC_RING] = ring_all[wave][t & 1];
                     rg[0][lane] = 0; rg[1][lane] = 1; rg[2][lane] = 1; rg[3][lane] = ~0u; rg[4][lane] = ~0u;
                 }
             } else if (t > 0) {
@@ -189,12 +244,12 @@ __global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms,
                 // (symbols past a block's end are "leave as it is" records, so the 64 steps are uniform)
                 if (valid) {
                     const uint32_t* rg = &ring_all[lane][(t - 1) & 1][0][0];
-                    uint32_t p_lo = rg[0], p_fr = rg[64], p_tot = rg[128], p_b0 = rg[192], p_b1 = rg[256];
-#pragma unroll 2
+                    uint32_t p_lo = rg[0], p_fr = rg[RC_RING], p_tot = rg[2 * RC_RING], p_b0 = rg[3 * RC_RING], p_b1 = rg[4 * RC_RING];
+#pragma unroll 4
                     for (uint32_t j = 0; j < 64; j++) {
                         const uint32_t s_lo = p_lo, s_fr = p_fr, s_tot = p_tot, b0 = p_b0, b1 = p_b1;
-                        const uint32_t jn = (j + 1) & 63;                          // next step's record, fetched under this step
-                        p_lo = rg[jn]; p_fr = rg[64 + jn]; p_tot = rg[128 + jn]; p_b0 = rg[192 + jn]; p_b1 = rg[256 + jn];
+                        const uint32_t jn = j + 1;                                 // next step's record, fetched under this step
+                        p_lo = rg[jn]; p_fr = rg[RC_RING + jn]; p_tot = rg[2 * RC_RING + jn]; p_b0 = rg[3 * RC_RING + jn]; p_b1 = rg[4 * RC_RING + jn];
                         // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
                         // total < 2^30), fixed up on the low word
                         const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
@@ -202,7 +257,8 @@ __global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms,
                         q += __umulhi(r0, b1);
                         const uint32_t rem = r0 - (uint32_t)q * s_tot;              // true remainder < 4 * tot < 2^32
                         const uint32_t t2 = s_tot << 1, t3 = t2 + s_tot;
-                        const uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
+                        uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
+                        asm volatile("" : "+v"(e));                                 // (one 64-bit add, not three)
                         q += e;
                         const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
                         const uint32_t s_hc = s_lo + s_fr;
