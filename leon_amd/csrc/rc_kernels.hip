@@ -1,9 +1,9 @@
 // rc_kernels.hip -- block-parallel order-0 adaptive range coder (gatb RangeCoder.cpp: Order0Model,
 // RangeEncoder::encode / flush [RECALLED]).  The models reset per read block, so blocks are the only
-// independent streams the format has: one 2-wave workgroup per block, software-pipelined over tiles of 64 symbols.
-//   wave 1 (modeler, lane = symbol): every symbol's (cumLow, freq, total) from the model state at the tile start
-//     plus the earlier symbols of the tile, then Order0Model::update for the tile, then the reciprocal of total;
-//   wave 0 (coder, wave-uniform on the scalar unit): the serial chain
+// independent streams the format has.  A workgroup takes a group of up to 8 blocks, software-pipelined over tiles of 64 symbols:
+//   one modeler wave per block (lane = symbol): every symbol's (cumLow, freq, total) from the model state at the tile
+//     start plus the earlier symbols of the tile, then Order0Model::update for the tile, then the reciprocal of total;
+//   one coder wave per group (lane = block): the serial chains
 //     range /= total; low += cumLow*range; range *= freq; renormalise
 //     with one multiply-high by the precomputed reciprocal instead of a 64-bit division.
 // Counts are exactly Order0Model's cumulative counts (its rescale cannot trigger: MAX_RANGE = 2^48 total).
@@ -29,12 +29,6 @@ size_t rc_model_scratch_bytes(uint64_t n_blocks) {
     return (size_t)n_blocks * (RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE * sizeof(uint32_t);
 }
 
-// keep a wave-uniform 64-bit value in vector registers (so that arithmetic on it issues on the vector unit)
-__device__ inline void pin_v(uint64_t& x) {
-    uint32_t a = (uint32_t)x, b = (uint32_t)(x >> 32);
-    asm volatile("" : "+v"(a), "+v"(b));
-    x = ((uint64_t)b << 32) | a;
-}
 // A model keeps the cumulative count F(x) = H[x>>4] + Lw[x], x in 0..256 (F(256) = H[16] + the zero word).
 // Order0Model::clear: F(x) = x.
 template <typename P> __device__ inline void model_init(P s, uint32_t lane, bool small) {
@@ -46,12 +40,17 @@ template <typename P> __device__ inline void model_init(P s, uint32_t lane, bool
 }
 
 
-// One workgroup codes G blocks: waves 0..G-1 are the blocks' modelers, wave G is the coder and runs the G serial chains
+// Waves of a workgroup land on the CU's four SIMDs round-robin.  Wave 0 is the coder; the waves whose index is a multiple
+// of 4 would share its SIMD and stay idle (they only keep the barriers), so the chain never waits for a modeler's
+// vector instruction; the other waves are the modelers.
+__host__ __device__ constexpr uint32_t rc_waves(uint32_t g) { return g + 1 + (g - 1) / 3; }
+
+// One workgroup codes G blocks: G modeler waves, and one coder wave that runs the G serial chains
 // in its lanes 0..G-1 (lane = block).  A chain step costs the same issue slots whether one lane or eight are active, so
 // a CU that holds 8 blocks runs ONE chain instruction stream instead of eight; the step itself is branch-free in the
 // usual cases (0..2 bytes leave, no range < BOTTOM reset) and falls back to RangeEncoder::encode's loop per lane otherwise.
 template <uint32_t G, uint32_t RC_NSLOT>
-__global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
+__global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                                                             uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
                                                             uint32_t* scratch, int* err) {
     constexpr uint32_t MW = RC_SMALL_WORDS + RC_NSLOT * RC_STRIDE;
@@ -61,22 +60,23 @@ __global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms,
     __shared__ uint32_t ntiles_s[G];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const bool is_coder = wave == G;
+    const bool is_coder = wave == 0, is_idle = wave != 0 && (wave & 3u) == 0;
+    const uint32_t mi = is_coder || is_idle ? 0 : wave - 1 - (wave >> 2);     // the modeler's block inside the group
     // per-lane constants of the branch-free Order0Model::update: lanes 0..15 own Lw of the symbol's 16-block,
     // lanes 16..32 own H[0..16]
     const bool is_lw = lane < 16;
     const uint32_t upd_lane = is_lw ? lane : (lane < 33 ? lane - 16 : 0);
     const uint32_t upd_base = is_lw ? RC_LW + lane : upd_lane;
     const uint32_t upd_blkmask = is_lw ? ~0u : 0u;
-    uint32_t* models = models_all + (is_coder ? 0 : wave) * MW;
-    uint8_t* slotmap = slotmap_all[is_coder ? 0 : wave];
+    uint32_t* models = models_all + mi * MW;
+    uint8_t* slotmap = slotmap_all[mi];
     const uint16_t* sym16 = (const uint16_t*)syms;
 
     const uint64_t n_groups = (n_blocks + G - 1) / G;
     for (uint64_t bg = blockIdx.x; bg < n_groups; bg += gridDim.x) {
         // this thread's block: the wave's for a modeler, the lane's for the coder
-        const uint64_t b = bg * G + (is_coder ? lane : wave);
-        bool valid = (is_coder ? lane < G : true) && b < n_blocks;
+        const uint64_t b = bg * G + (is_coder ? lane : mi);
+        bool valid = (is_coder ? lane < G : !is_idle) && b < n_blocks;
         uint64_t s0 = 0, s1 = 0;
         if (valid) { s0 = blk_begin[b]; s1 = blk_begin[b + 1]; }
         if (valid && s1 - s0 >= RC_MAX_TOTAL - 256) {            // totals must stay below 2^30 for the chain's 32-bit fix-up
@@ -85,8 +85,8 @@ __global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms,
             valid = false;
         }
         const uint32_t ntiles = valid ? (uint32_t)((s1 - s0 + 63) / 64) : 0;
-        if (!is_coder && lane == 0) ntiles_s[wave] = ntiles;
-        // coder state (wave G, lane = block)
+        if (!is_coder && !is_idle && lane == 0) ntiles_s[mi] = ntiles;
+        // coder state (wave 0, lane = block)
         uint64_t low = 0, range = ~0ull;
         uint32_t nout = 0;
         uint8_t* dst = nullptr;
@@ -110,9 +110,10 @@ __global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms,
         for (uint32_t w = 0; w < G; w++) T = ntiles_s[w] > T ? ntiles_s[w] : T;
 
         for (uint32_t t = 0; t <= T; t++) {
-            if (!is_coder) {
+            if (is_idle) {
+            } else if (!is_coder) {
                 if (t < ntiles) {
-                    // =================== modeler: tile t -> ring[wave][t & 1] ===================
+                    // =================== modeler: tile t -> ring[mi][t & 1] ===================
                     const uint64_t base = s0 + (uint64_t)t * 64;
                     const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
                     const bool act = lane < cnt;
@@ -231,12 +232,12 @@ __global__ void __launch_bounds__(64 * (G + 1)) k_rc_encode(const uint8_t* syms,
                     }
                     __builtin_amdgcn_wave_barrier();
                     const uint64_t inv = ~0ull / (uint64_t)tot;        // per lane, off the serial chains
-                    uint32_t(*rg)[RC_RING] = ring_all[wave][t & 1];
+                    uint32_t(*rg)[RC_RING] = ring_all[mi][t & 1];
                     rg[0][lane] = lo; rg[1][lane] = hi - lo; rg[2][lane] = tot;
                     rg[3][lane] = (uint32_t)inv; rg[4][lane] = (uint32_t)(inv >> 32);
                 } else if (t < T) {
                     // the group's longer blocks go on: records that leave a chain as it is (cumLow 0, freq = total = 1)
-                    uint32_t(*rg)[RC_RING] = ring_all[wave][t & 1];
+                    uint32_t(*rg)[RC_RING] = ring_all[mi][t & 1];
                     rg[0][lane] = 0; rg[1][lane] = 1; rg[2][lane] = 1; rg[3][lane] = ~0u; rg[4][lane] = ~0u;
                 }
             } else if (t > 0) {
@@ -316,7 +317,7 @@ void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_be
     if (force) { int v = atoi(force); if (v == 1 || v == 2 || v == 4 || v == 8) G = (uint32_t)v; }
     const uint64_t n_groups = (n_blocks + G - 1) / G;
     const uint32_t g = (uint32_t)std::min<uint64_t>(n_groups, 256ull * (8 / G));
-#define RC_LAUNCH(GG, N) hipLaunchKernelGGL((k_rc_encode<GG, N>), dim3(g), dim3(64 * (GG + 1)), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
+#define RC_LAUNCH(GG, N) hipLaunchKernelGGL((k_rc_encode<GG, N>), dim3(g), dim3(64 * rc_waves(GG)), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
     if (G == 1) RC_LAUNCH(1, RC_NSLOT_BIG);
     else if (G == 2) RC_LAUNCH(2, RC_NSLOT_BIG);
     else if (G == 4) RC_LAUNCH(4, RC_NSLOT_BIG);
