@@ -94,13 +94,21 @@ public:
         for (int i = 0; i <= 5; i++) cum_[i] = i;              // Order0Model::clear: _charRanges[i] = i
     }
     void use_reciprocals(ReciprocalStream* r) { recips_ = r; }
-    // k-mer in the 2-bit code (w[0] low word, w[1] high word when k >= 32), first base in the highest bits
-    // (LargeInt::toString order)
-    inline void encode_kmer(const uint64_t* w, uint32_t k) {
-        if (buf_.size() < w_ + 8 * (size_t)k + 16) buf_.resize(buf_.size() * 2 + 8 * (size_t)k + 4096);
+    // `count` k-mers in the 2-bit code (W = 1 word per k-mer below k = 32, else low word then high word), first base in
+    // the highest bits (LargeInt::toString order)
+    void encode_kmers(const uint64_t* w, size_t count, uint32_t k) {
+        const uint32_t W = k >= 32 ? 2u : 1u;
 #ifdef LEON_HOST_CHAIN_X86
-        if (recips_ && n_ >= 256) { encode_kmer_chain(w, k); return; }     // (the scaled reciprocal needs a total above 256)
+        while (count && (!recips_ || n_ < 256)) { encode_kmer_plain(w, k); w += W; count--; }   // (the scaled reciprocal needs a total above 256)
+        if (!count) return;
+        if (W == 2) encode_chain<true>(w, count, k); else encode_chain<false>(w, count, k);
+#else
+        for (; count; count--, w += W) encode_kmer_plain(w, k);
 #endif
+    }
+    inline void encode_kmer(const uint64_t* w, uint32_t k) { encode_kmers(w, 1, k); }
+    inline void encode_kmer_plain(const uint64_t* w, uint32_t k) {
+        if (buf_.size() < w_ + 8 * (size_t)k + 16) buf_.resize(buf_.size() * 2 + 8 * (size_t)k + 4096);
         for (uint32_t i = 0; i < k; i++) {
             const uint32_t bit = 2 * (k - 1 - i);
             encode((uint32_t)(w[bit >> 6] >> (bit & 63)) & 3u);
@@ -116,8 +124,9 @@ public:
     uint64_t symbols() const { return n_; }
 private:
 #ifdef LEON_HOST_CHAIN_X86
-    inline void encode_kmer_chain(const uint64_t* w, uint32_t k) {
-        // Latency-shaped chain.  The state carried from symbol to symbol is (low, range) BEFORE the renormalisation the
+    // `count` k-mers through the latency-shaped chain; kTwo: k >= 32 (two words per k-mer)
+    template <bool kTwo> void encode_chain(const uint64_t* w, size_t count, uint32_t k) {
+        // The state carried from symbol to symbol is (low, range) BEFORE the renormalisation the
         // previous symbol owes.  Its usual outcomes -- no byte, one byte -- are both formed and selected by conditional
         // moves: with h = mulhi(range, m) the quotient is h >> 8 without the byte and h itself with it (range < 2^56
         // there), so ONE multiply serves both.  The rare outcomes (two bytes at once, the carry-less coder's
@@ -128,59 +137,65 @@ private:
         alignas(16) static const uint64_t kInc[4][4] = {{1, 1, 1, 1}, {0, 1, 1, 1}, {0, 0, 1, 1}, {0, 0, 0, 1}};
         alignas(16) uint64_t tbl[6] = {0, 0, cum_[1], cum_[2], cum_[3], cum_[4]};       // tbl[1 + c] = cum_[c]
         __m128i ca = _mm_load_si128((const __m128i*)(tbl + 2)), cb = _mm_load_si128((const __m128i*)(tbl + 4));
-        unsigned __int128 x = k >= 32 ? (((unsigned __int128)w[1] << 64) | w[0]) : (unsigned __int128)w[0];
-        x <<= 128 - 2 * k;                                     // first base in the two highest bits
-        uint64_t L = low_, R = range_, n = n_;
+        uint64_t L = low_, R = range_, tot = 5 + n_;          // the model's total IS the symbol index + 5
         uint8_t* p = buf_.data() + w_;
-        for (uint32_t done = 0; done < k;) {
-            const uint64_t off = n % ReciprocalStream::kChunk;
-            if (off == 0 || !inv_) inv_ = recips_->take(n / ReciprocalStream::kChunk);
-            const uint64_t* ip = inv_ + off;
-            const uint64_t left = ReciprocalStream::kChunk - off;
-            const uint32_t run = left < k - done ? (uint32_t)left : k - done;
-            uint64_t tot = 5 + n;
-            for (uint32_t i = 0; i < run; i++, tot++) {
-                const uint32_t c = (uint32_t)(x >> 126);
-                x <<= 2;
-                const uint64_t lo = tbl[1 + c], fr = tbl[2 + c] - lo, m = ip[i];
-                ca = _mm_add_epi64(ca, _mm_load_si128((const __m128i*)kInc[c]));       // Order0Model::update
-                cb = _mm_add_epi64(cb, _mm_load_si128((const __m128i*)kInc[c] + 1));
-                _mm_store_si128((__m128i*)(tbl + 2), ca);
-                _mm_store_si128((__m128i*)(tbl + 4), cb);
-                const uint64_t xr = L ^ (L + R);               // xr < TOP: the previous symbol owes (at least) one byte
-                uint64_t q;
-                // the branch-free form is valid for "no byte" and "exactly one byte" (the shifted test is xr << 8)
-                if (__builtin_expect((xr >> 48) == 0 || R < kBottom, 0)) {
-                    while ((L ^ (L + R)) < kTop || (R < kBottom && ((R = (0 - L) & (kBottom - 1)), true))) {
-                        *p++ = (uint8_t)(L >> 56);
-                        R <<= 8;
-                        L <<= 8;
-                    }
-                    q = (uint64_t)(((unsigned __int128)R * m) >> 64) >> 8;
-                } else {
-                    const uint64_t h = (uint64_t)(((unsigned __int128)R * m) >> 64);
-                    q = h >> 8;
-                    *p = (uint8_t)(L >> 56);
-                    // (q, R, L, p) = one byte ? (h, R << 8, L << 8, p + 1) : unchanged -- as conditional moves (a compiler
-                    // turns the selects back into the unpredictable branch this loop exists to avoid)
-                    asm("cmpq %[top], %[xr]\n\tcmovbq %[h], %[q]\n\tcmovbq %[R1], %[R]\n\tcmovbq %[L1], %[L]\n\tadcq $0, %[p]"
-                        : [q] "+r"(q), [R] "+r"(R), [L] "+r"(L), [p] "+r"(p)
-                        : [xr] "r"(xr), [top] "r"(kTop), [h] "r"(h), [R1] "r"(R << 8), [L1] "r"(L << 8)
-                        : "cc");
-                }
-                if (__builtin_expect(R - q * tot >= tot, 0)) {  // quotient one too small: probability < 2^-8
-                    asm volatile("" : "+r"(q));                // (keeps this a branch: as a select it would sit on the chain)
-                    q++;
-                }
-                R = q * fr;
-                L += q * lo;
+        for (size_t a = 0; a < count; a++, w += kTwo ? 2 : 1) {
+            if ((size_t)(buf_.data() + buf_.size() - p) < 8 * (size_t)k + 16) {
+                const size_t used = (size_t)(p - buf_.data());
+                buf_.resize(buf_.size() * 2 + 8 * (size_t)k + 4096);
+                p = buf_.data() + used;
             }
-            done += run;
-            n += run;
+            uint64_t x = w[0], xh = kTwo ? w[1] : 0;          // first base in the two highest bits of the (xh:)x register(s)
+            if (kTwo) { const uint32_t s = 128 - 2 * k; xh = s ? (xh << s) | (x >> (64 - s)) : xh; x <<= s; }
+            else x <<= 64 - 2 * k;
+            for (uint64_t tot_k = tot + k; tot < tot_k;) {
+                const uint64_t n = tot - 5, off = n % ReciprocalStream::kChunk;
+                if (off == 0 || !inv_) inv_ = recips_->take(n / ReciprocalStream::kChunk);
+                const uint64_t* ipb = inv_ + off - tot;        // ipb[tot] = the reciprocal of symbol n
+                const uint64_t left = ReciprocalStream::kChunk - off;
+                const uint64_t tot_e = left < tot_k - tot ? tot + left : tot_k;
+                for (; tot < tot_e; tot++) {
+                    uint32_t c;
+                    if (kTwo) { c = (uint32_t)(xh >> 62); xh = (xh << 2) | (x >> 62); x <<= 2; }
+                    else { c = (uint32_t)(x >> 62); x <<= 2; }
+                    const uint64_t lo = tbl[1 + c], fr = tbl[2 + c] - lo, m = ipb[tot];
+                    ca = _mm_add_epi64(ca, _mm_load_si128((const __m128i*)kInc[c]));       // Order0Model::update
+                    cb = _mm_add_epi64(cb, _mm_load_si128((const __m128i*)kInc[c] + 1));
+                    _mm_store_si128((__m128i*)(tbl + 2), ca);
+                    _mm_store_si128((__m128i*)(tbl + 4), cb);
+                    const uint64_t xr = L ^ (L + R);           // xr < TOP: the previous symbol owes (at least) one byte
+                    uint64_t q;
+                    // the branch-free form is valid for "no byte" and "exactly one byte" (the shifted test is xr << 8)
+                    if (__builtin_expect((xr >> 48) == 0 || R < kBottom, 0)) {
+                        while ((L ^ (L + R)) < kTop || (R < kBottom && ((R = (0 - L) & (kBottom - 1)), true))) {
+                            *p++ = (uint8_t)(L >> 56);
+                            R <<= 8;
+                            L <<= 8;
+                        }
+                        q = (uint64_t)(((unsigned __int128)R * m) >> 64) >> 8;
+                    } else {
+                        const uint64_t h = (uint64_t)(((unsigned __int128)R * m) >> 64);
+                        q = h >> 8;
+                        *p = (uint8_t)(L >> 56);
+                        // (q, R, L, p) = one byte ? (h, R << 8, L << 8, p + 1) : unchanged -- as conditional moves (a compiler
+                        // turns the selects back into the unpredictable branch this loop exists to avoid)
+                        asm("cmpq %[top], %[xr]\n\tcmovbq %[h], %[q]\n\tcmovbq %[R1], %[R]\n\tcmovbq %[L1], %[L]\n\tadcq $0, %[p]"
+                            : [q] "+r"(q), [R] "+r"(R), [L] "+r"(L), [p] "+r"(p)
+                            : [xr] "r"(xr), [top] "r"(kTop), [h] "r"(h), [R1] "r"(R << 8), [L1] "r"(L << 8)
+                            : "cc");
+                    }
+                    if (__builtin_expect(R - q * tot >= tot, 0)) {  // quotient one too small: probability < 2^-8
+                        asm volatile("" : "+r"(q));            // (keeps this a branch: as a select it would sit on the chain)
+                        q++;
+                    }
+                    R = q * fr;
+                    L += q * lo;
+                }
+            }
         }
         w_ = (size_t)(p - buf_.data());
-        low_ = L; range_ = R; n_ = n;
-        cum_[1] = tbl[2]; cum_[2] = tbl[3]; cum_[3] = tbl[4]; cum_[4] = tbl[5]; cum_[5] = 5 + n;
+        low_ = L; range_ = R; n_ = tot - 5;
+        cum_[1] = tbl[2]; cum_[2] = tbl[3]; cum_[3] = tbl[4]; cum_[4] = tbl[5]; cum_[5] = tot;
     }
 #endif
     // the renormalisation the last symbol owes (the state is kept un-normalised between symbols, see encode_kmer)
@@ -253,7 +268,7 @@ private:
                 q_.pop_front();
             }
             const uint32_t W = k_ >= 32 ? 2u : 1u;
-            for (size_t a = 0; a + W <= batch.size(); a += W) coder_.encode_kmer(batch.data() + a, k_);
+            coder_.encode_kmers(batch.data(), batch.size() / W, k_);
             {
                 std::lock_guard<std::mutex> g(mu_);
                 pending_--;
