@@ -174,8 +174,8 @@ def main():
         ctx.reset_stream()
         payload[0] = payload[1] = 0
         ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_total, sink=cb)
-        d, na = ctx.finish()
-        return len(d), na
+        d_size, na = ctx.finish(copy=False)                  # the stream stays in the context, as for a C caller
+        return d_size, na
 
     def sync():
         torch.cuda.synchronize()

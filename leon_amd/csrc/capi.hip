@@ -83,7 +83,7 @@ struct leon_dna_ctx {
     DevBuf in_bases, in_off, slot_off, packed, nmask, rlen, ncount;
     DevBuf status, hit_pos, hit_slot, cand_pos, cand_slot, anchor_pos, anchor_addr, flags, sort_key, ins_flag, rank;
     DevBuf ulist0, ulist1, counters, cub_tmp, sort_key2, perm, perm2, events, prev, sym_off, syms;
-    DevBuf blk_begin, out_off, out_size, rc_out, rc_scratch, dst_off, payload, errflag, nerr;
+    DevBuf blk_begin, out_off, out_size, rc_out, rc_scratch, dst_off, payload, errflag, nerr, wbits;
     void* h_payload = nullptr; size_t h_payload_cap = 0;
     uint64_t last_n = 0, last_bases = 0;
     leon_dna_stats stats{};
@@ -111,6 +111,7 @@ int dict_alloc(leon_dna_ctx* c, DictDev& D, uint64_t cap) {
     HIPCHK(c, hipMalloc((void**)&D.addr, cap * 4));
     D.mask = cap - 1;
     D.n_keys = c->d_nkeys;
+    D.wbits = c->wbits.as<uint32_t>();
     launch_dict_init(c->stream, D, cap, W);
     return LEON_OK;
 }
@@ -210,6 +211,7 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     CREATE_CHK(hipMemset(c->d_nkeys, 0, 8));
     CREATE_CHK(c->counters.ensure(64));
     CREATE_CHK(c->errflag.ensure(16));
+    CREATE_CHK(c->wbits.ensure((1ull << WBITS_LOG2) / 8));
     CREATE_CHK(hipStreamSynchronize(c->stream));
 #undef CREATE_CHK
     c->anchor_worker = new AnchorDictWorker(cfg->kmer_size);
@@ -227,7 +229,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
                        &c->status, &c->hit_pos, &c->hit_slot, &c->cand_pos, &c->cand_slot, &c->anchor_pos, &c->anchor_addr,
                        &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
                        &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
-                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr };
+                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits };
     for (DevBuf* b : bufs) b->release();
     if (c->d_bloom) (void)hipFree(c->d_bloom);
     if (c->d_rv16) (void)hipFree(c->d_rv16);
@@ -400,6 +402,7 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
         uint64_t w1 = std::min(n, w0 + W);
         if (int rc = dict_reserve(c, c->n_keys + (w1 - w0))) return rc;
         HIPCHK(c, hipMemsetAsync(counters, 0, 8, s));
+        HIPCHK(c, hipMemsetAsync(c->wbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
         launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters);
         uint32_t cnt = 0;
         HIPCHK(c, hipMemcpyAsync(&cnt, counters, 4, hipMemcpyDeviceToHost, s));

@@ -27,7 +27,9 @@ struct DictDev {
     uint32_t* addr;     // anchor address once assigned
     uint64_t mask;      // capacity - 1
     unsigned long long* n_keys;
+    uint32_t* wbits;    // 2^WBITS_LOG2-bit filter of the keys made final in the current resolution window (k_final_pos)
 };
+constexpr uint32_t WBITS_LOG2 = 26;
 
 enum : uint8_t { ST_NOANCHOR = 0, ST_HIT = 1, ST_UNRESOLVED = 2, ST_INSERTER = 3, ST_HITNEW = 4 };
 
