@@ -681,20 +681,36 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
             for (uint32_t p = 0; p < len; p++)
                 if ((nm[p >> 5] >> (p & 31)) & 1u) { S.numeric(G_NPOS, p - prevN); prevN = p; }
         }
+        // The event bytes are read 16 at a time (the memory pipeline charges per wave-wide instruction, not per byte), in
+        // chunks aligned to the read's first base; the buffer is padded, bytes past the read's end are masked off.
+        auto chunk = [&](uint32_t p0, uint32_t w[4]) {
+            __builtin_memcpy(w, ev + p0, 16);
+            if (p0 + 16 > len) {
+#pragma unroll
+                for (uint32_t d = 0; d < 4; d++) {
+                    const uint32_t q0 = p0 + 4 * d;
+                    w[d] = q0 >= len ? 0u : (q0 + 4 > len ? w[d] & (0xFFFFFFFFu >> (8 * (q0 + 4 - len))) : w[d]);
+                }
+            }
+        };
         if (!EMIT) {
             // one ascending scan: error positions (count + their numerics' sizes) and the number of bifurcation symbols
             uint32_t nErr = 0, prevE = 0, nBif = 0;
-            for (uint32_t p = 0; p < len; p += 4) {
-                uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
-                if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
-                if (!w4) continue;
-                const uint32_t c3 = w4 & 0x07070707u;
-                nBif += __popc((c3 | (c3 >> 1) | (c3 >> 2)) & 0x01010101u);
-                uint32_t e4 = w4 & 0x08080808u;
-                while (e4) {
-                    uint32_t qq = p + ((uint32_t)__builtin_ctz(e4) >> 3);
-                    S.numeric(G_ERRPOS, qq - prevE); prevE = qq; nErr++;
-                    e4 &= e4 - 1;
+            for (uint32_t p0 = 0; p0 < len; p0 += 16) {
+                uint32_t w[4];
+                chunk(p0, w);
+                if (!(w[0] | w[1] | w[2] | w[3])) continue;
+#pragma unroll
+                for (uint32_t d = 0; d < 4; d++) {
+                    const uint32_t w4 = w[d], p = p0 + 4 * d;
+                    const uint32_t c3 = w4 & 0x07070707u;
+                    nBif += __popc((c3 | (c3 >> 1) | (c3 >> 2)) & 0x01010101u);
+                    uint32_t e4 = w4 & 0x08080808u;
+                    while (e4) {
+                        uint32_t qq = p + ((uint32_t)__builtin_ctz(e4) >> 3);
+                        S.numeric(G_ERRPOS, qq - prevE); prevE = qq; nErr++;
+                        e4 &= e4 - 1;
+                    }
                 }
             }
             S.numeric(G_LEFT_ERROR, nErr);
@@ -705,35 +721,41 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
             S.numeric(G_LEFT_ERROR, nErr);
             if (nErr) {
                 uint32_t prevE = 0, left = nErr;
-                for (uint32_t p = 0; p < len && left; p += 4) {
-                    uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
-                    if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
-                    uint32_t e4 = w4 & 0x08080808u;
-                    while (e4) {
-                        uint32_t qq = p + ((uint32_t)__builtin_ctz(e4) >> 3);
-                        S.numeric(G_ERRPOS, qq - prevE); prevE = qq; left--;
-                        e4 &= e4 - 1;
+                for (uint32_t p0 = 0; p0 < len && left; p0 += 16) {
+                    uint32_t w[4];
+                    chunk(p0, w);
+#pragma unroll
+                    for (uint32_t d = 0; d < 4; d++) {
+                        uint32_t e4 = w[d] & 0x08080808u;
+                        while (e4) {
+                            uint32_t qq = p0 + 4 * d + ((uint32_t)__builtin_ctz(e4) >> 3);
+                            S.numeric(G_ERRPOS, qq - prevE); prevE = qq; left--;
+                            e4 &= e4 - 1;
+                        }
                     }
                 }
             }
             // bifurcations: left walk (a-1 .. 0), then right walk (a+k .. len-1)
-            for (int32_t hi = a; hi > 0; hi -= 4) {           // positions hi-4 .. hi-1, descending
-                const int32_t lo4 = hi - 4;
-                uint32_t w4;
-                if (lo4 >= 0) __builtin_memcpy(&w4, ev + lo4, 4);
-                else { w4 = 0; for (int32_t qq = 0; qq < hi; qq++) w4 |= (uint32_t)ev[qq] << (8 * (qq - lo4)); }
-                if ((w4 & 0x07070707u) == 0) continue;
-                for (int32_t j = 3; j >= 0; j--) {
-                    const uint32_t cc = (w4 >> (8 * j)) & 7u;
+            for (int32_t p0 = a > 0 ? ((a - 1) & ~15) : -16; p0 >= 0; p0 -= 16) {     // chunks descending, bytes descending
+                uint32_t w[4];
+                chunk((uint32_t)p0, w);
+                if (((w[0] | w[1] | w[2] | w[3]) & 0x07070707u) == 0) continue;
+#pragma unroll
+                for (int32_t j = 15; j >= 0; j--) {
+                    if (p0 + j >= a) continue;
+                    const uint32_t cc = (w[j >> 2] >> (8 * (j & 3))) & 7u;
                     if (cc >= EV_NT0) S.put(M_BIFURCATION, cc - EV_NT0); else if (cc) S.put(M_BIFURCATION_BINARY, cc - EV_BIN0);
                 }
             }
-            for (uint32_t p = (uint32_t)a + k; p < len; p += 4) {
-                uint32_t w4; __builtin_memcpy(&w4, ev + p, 4);
-                if (p + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (p + 4 - len));
-                if ((w4 & 0x07070707u) == 0) continue;
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint32_t cc = (w4 >> (8 * j)) & 7u;
+            const uint32_t rs = (uint32_t)a + k;
+            for (uint32_t p0 = rs & ~15u; p0 < len; p0 += 16) {
+                uint32_t w[4];
+                chunk(p0, w);
+                if (((w[0] | w[1] | w[2] | w[3]) & 0x07070707u) == 0) continue;
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++) {
+                    if (p0 + j < rs) continue;
+                    const uint32_t cc = (w[j >> 2] >> (8 * (j & 3))) & 7u;
                     if (cc >= EV_NT0) S.put(M_BIFURCATION, cc - EV_NT0); else if (cc) S.put(M_BIFURCATION_BINARY, cc - EV_BIN0);
                 }
             }
