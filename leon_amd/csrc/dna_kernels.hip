@@ -65,7 +65,7 @@ void launch_read_slots(hipStream_t s, const uint64_t* off, uint64_t n, uint64_t*
 }
 
 // One LANE per read: the vector-memory pipeline costs ~64 cycles per wave-wide load instruction whatever the number of
-// active lanes, so 64 reads share each of the ~4 loads per 16 bases (a wave per read left 54 of 64 lanes idle).
+// active lanes, so 64 reads share each load, and a load fetches 16 bases (a wave per read left 54 of 64 lanes idle).
 __global__ void __launch_bounds__(256) k_pack(const uint8_t* bases, const uint64_t* off, const uint64_t* slot_off, uint64_t n,
                                              uint32_t* packed, uint32_t* nmask, uint32_t* len_out, uint32_t* ncount) {
     const uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -79,12 +79,21 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t* bases, const uint64
     for (uint32_t dw = 0; dw < ndw; dw++) {
         uint32_t word = 0, nb = 0;
         const uint32_t j0 = dw * 16;
+        uint32_t fours[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};     // "AAAA" past the end of the read
+        if (j0 + 16 <= len) __builtin_memcpy(fours, src + j0, 16);                   // one (unaligned) 16-byte load
+        else {
 #pragma unroll
-        for (uint32_t q4 = 0; q4 < 4; q4++) {                   // four (unaligned) dword loads of 4 bases each
-            uint32_t four = 0x41414141u;                        // "AAAA" past the end of the read
-            const uint32_t p0 = j0 + 4 * q4;
-            if (p0 + 4 <= len) __builtin_memcpy(&four, src + p0, 4);
-            else if (p0 < len) { for (uint32_t j = 0; p0 + j < len; j++) four = (four & ~(0xFFu << (8 * j))) | ((uint32_t)src[p0 + j] << (8 * j)); }
+            for (uint32_t q4 = 0; q4 < 4; q4++) {
+                const uint32_t p0 = j0 + 4 * q4;
+                uint32_t four = 0x41414141u;
+                if (p0 + 4 <= len) __builtin_memcpy(&four, src + p0, 4);
+                else if (p0 < len) { for (uint32_t j = 0; p0 + j < len; j++) four = (four & ~(0xFFu << (8 * j))) | ((uint32_t)src[p0 + j] << (8 * j)); }
+                fours[q4] = four;
+            }
+        }
+#pragma unroll
+        for (uint32_t q4 = 0; q4 < 4; q4++) {
+            const uint32_t four = fours[q4];
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
                 const uint32_t c = (four >> (8 * j)) & 0xFFu;
