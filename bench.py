@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("LEON_BENCH_CPU_SAMPLE", 4_000_000)),
                     help="reads timed through the CPU restatement on rank 0 at N=1 (0 = skip)")
     ap.add_argument("--err", type=float, default=0.01)
+    ap.add_argument("--host-input", action="store_true",
+                    help="also time ONE step through leon_dna_encode_batch (reads in pageable host memory, PCIe included); "
+                         "reported as pcie_inclusive, never as value")
     return ap.parse_args()
 
 
@@ -218,6 +221,22 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(traffic) if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(walk_avg_ms, 3)}
 
+    pcie = None
+    if a.host_input and world == 1:
+        h_reads = reads.cpu().numpy()
+        h_off = offsets.cpu().numpy()
+        ctx.reset_stream()
+        payload[0] = payload[1] = 0
+        sync()
+        t0 = time.perf_counter()
+        ctx.encode_batch(h_reads, h_off, sink=cb)
+        ctx.finish(copy=False)
+        sync()
+        dt = time.perf_counter() - t0
+        pcie = {"value": round(n_total * L / 1e6 / dt, 1), "unit": "MB/s", "ms": round(dt * 1e3, 1),
+                "what": "one step through leon_dna_encode_batch: reads and offsets in pageable host memory, H2D inside the timed region"}
+        del h_reads, h_off
+
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         cpu = cpu_baseline(ctx, reads, min(a.cpu_sample, n_total))
@@ -238,6 +257,7 @@ def main():
                        "kmer_count_s": round(count_s, 2), "solid_kmers": n_solid},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "pcie_inclusive": pcie,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
                       "symbols": stage["n_symbols"], "resolve_rounds": stage["resolve_rounds"],

@@ -59,7 +59,7 @@ _EXPORTS = {
     "leon_dna_bloom_download_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "leon_dna_bloom_contains4": (C.c_int, [C.c_void_p, _u64p, C.c_uint64, C.c_int, _u8p]),
     "leon_dna_bloom_contains": (C.c_int, [C.c_void_p, _u64p, C.c_uint64, _u8p]),
-    "leon_dna_encode_batch": (C.c_int, [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, C.c_uint64, SINK, C.c_void_p]),
+    "leon_dna_encode_batch": (C.c_int, [C.c_void_p, C.c_void_p, _u64p, C.c_uint64, C.c_uint64, SINK, C.c_void_p]),
     "leon_dna_encode_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, SINK,
                                                 C.c_void_p]),
     "leon_dna_finish": (C.c_int, [C.c_void_p, C.POINTER(_u8p), _u64p, _u64p]),
@@ -258,11 +258,15 @@ class DnaEncodeContext:
         """bases: bytes / uint8 array, offsets: uint64[n+1].  Returns [(block_id, payload, n_reads)]."""
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
-        if not isinstance(bases, (bytes, bytearray)):
-            bases = np.ascontiguousarray(bases, dtype=np.uint8).tobytes()
+        if isinstance(bases, (bytes, bytearray)):
+            keep = (C.c_char * len(bases)).from_buffer_copy(bases) if isinstance(bases, bytes) else (C.c_char * len(bases)).from_buffer(bases)
+            ptr = C.cast(keep, C.c_void_p)
+        else:                                                   # a uint8 array is handed over in place (no copy)
+            keep = np.ascontiguousarray(bases, dtype=np.uint8)
+            ptr = C.c_void_p(keep.ctypes.data)
         blocks = []
         cb = sink if sink is not None else self._collect_sink(blocks)
-        self._chk(self.lib.leon_dna_encode_batch(self.h, bases, _ptr(offsets, _u64p), n, self.next_read, cb, None))
+        self._chk(self.lib.leon_dna_encode_batch(self.h, ptr, _ptr(offsets, _u64p), n, self.next_read, cb, None))
         self.next_read += n
         return blocks
 

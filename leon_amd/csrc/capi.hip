@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -88,6 +89,7 @@ struct leon_dna_ctx {
     uint64_t last_n = 0, last_bases = 0;
     leon_dna_stats stats{};
     hipEvent_t ev[12]{};
+    std::vector<hipEvent_t> pack_ev;             // pairs around the pack launches of a batch
 };
 
 namespace {
@@ -149,6 +151,15 @@ ReadsDev reads_view(leon_dna_ctx* c, const uint64_t* d_off, uint64_t n) {
     R.n = n; R.k = c->cfg.kmer_size;
     return R;
 }
+
+// leon_dna_encode_batch's upload of the caller's bases, group by group, on its own host thread: the device packs and
+// resolves a group while the next ones are still crossing PCIe
+struct Upload {
+    std::atomic<uint64_t> reads_done{0};                       // reads whose bases are in HBM
+    std::atomic<int> failed{0};
+    std::thread th;
+    ~Upload() { if (th.joinable()) th.join(); }
+};
 
 int ensure_cub(leon_dna_ctx* c, size_t bytes) { HIPCHK(c, c->cub_tmp.ensure(bytes)); return LEON_OK; }
 
@@ -236,6 +247,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
     if (c->d_nkeys) (void)hipFree(c->d_nkeys);
     if (c->h_payload) (void)hipHostFree(c->h_payload);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->pack_ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -334,8 +346,24 @@ int leon_dna_bloom_contains(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, 
 }
 
 // ------------------------------------------------------------------------------------------------ encode
+static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
+                             uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up);
+
 int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
                                  uint64_t first_read_index, leon_block_sink sink, void* user) {
+    return encode_batch_impl(c, d_bases, d_off, n, first_read_index, sink, user, nullptr);
+}
+
+// reads [0, group_end(a)) are packed (and, through the host entry point, uploaded) together: the first resolution window
+// alone, so that the device and the dictionary chain start at once, then groups of 8 windows (everything that is left
+// when the bases are in HBM already)
+static uint64_t group_end(uint64_t a, uint64_t n, uint64_t window, bool streamed) {
+    if (a == 0) return std::min(n, window);
+    return streamed ? std::min(n, a + 8 * window) : n;
+}
+
+static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
+                             uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up) {
     if (!c) return LEON_E_INVALID;
     if (c->finished) return fail(c, LEON_E_STATE, "encode_batch after finish");
     if (first_read_index != c->next_read) return fail(c, LEON_E_STATE, "first_read_index does not continue the stream");
@@ -374,14 +402,31 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     HIPCHK(c, c->rlen.ensure(n * 4));
     HIPCHK(c, c->ncount.ensure(n * 4));
     HIPCHK(c, hipMemsetAsync(c->packed.as<uint32_t>() + n_slots * 2, 0, 64, s));
-    // the first resolution window's reads are packed first, the rest after that window's kernels: the host thread that
-    // codes the dictionary stream (the longest single piece of a step) gets its first anchors ~25 ms earlier
-    const uint64_t n_first = std::min<uint64_t>(c->cfg.resolve_window, n);
-    auto pack_range = [&](uint64_t a, uint64_t b) {
+    // the first resolution window's reads are packed first, later groups right before their first window: the host thread
+    // that codes the dictionary stream (the longest single piece of a step) gets its first anchors ~25 ms earlier, and
+    // with host input the upload of a group overlaps the resolution of the groups before it
+    uint64_t packed_upto = 0;
+    uint32_t n_pack_ev = 0;
+    auto pack_group = [&]() -> int {
+        const uint64_t a = packed_upto, b = group_end(a, n, c->cfg.resolve_window, up != nullptr);
+        if (up) {
+            while (up->reads_done.load(std::memory_order_acquire) < b && !up->failed.load()) std::this_thread::yield();
+            if (up->failed.load()) return fail(c, LEON_E_HIP, "upload of the read bases failed");
+        }
+        if (c->pack_ev.size() < 2 * (size_t)(n_pack_ev + 1)) {
+            hipEvent_t e0, e1;
+            HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+            c->pack_ev.push_back(e0); c->pack_ev.push_back(e1);
+        }
+        HIPCHK(c, hipEventRecord(c->pack_ev[2 * n_pack_ev], s));
         launch_pack(s, d_bases, d_off + a, c->slot_off.as<uint64_t>() + a, b - a, c->packed.as<uint32_t>(), c->nmask.as<uint32_t>(),
                     c->rlen.as<uint32_t>() + a, c->ncount.as<uint32_t>() + a);
+        HIPCHK(c, hipEventRecord(c->pack_ev[2 * n_pack_ev + 1], s));
+        n_pack_ev++;
+        packed_upto = b;
+        return LEON_OK;
     };
-    pack_range(0, n_first);
+    if (int rc = pack_group()) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     ReadsDev R = reads_view(c, d_off, n);
 
@@ -458,11 +503,7 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
             c->n_anchors += n_new;
         }
         launch_finalize_reads(s, R, c->D, V, w0, w1);
-        if (w0 == 0 && n_first < n) {
-            HIPCHK(c, hipEventRecord(c->ev[9], s));
-            pack_range(n_first, n);
-            HIPCHK(c, hipEventRecord(c->ev[10], s));
-        }
+        if (w1 < n && packed_upto < std::min(n, w1 + W)) { if (int rc = pack_group()) return rc; }   // the next window's reads
         c->stats.resolve_windows++;
     }
     HIPCHK(c, hipGetLastError());
@@ -488,7 +529,7 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
     c->last_n = n; c->last_bases = nl_bases;
     if (nl == 0) {                                            // nothing of this batch is ours to encode
         HIPCHK(c, hipStreamSynchronize(s));
-        const float pack2 = n_first < n ? ms(9, 10) : 0.f;
+        float pack2 = 0; for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
         c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_total = ms(0, 2);
         c->next_read += n; c->next_block += n_blocks;
         return LEON_OK;
@@ -572,7 +613,8 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
 
     // ---- stats ----
     c->stats.n_symbols = n_syms; c->stats.payload_bytes = payload_bytes;
-    const float pack2 = n_first < n ? ms(9, 10) : 0.f;               // the part of the pack stage that ran inside the resolution loop
+    float pack2 = 0;                                                   // the part of the pack stage that ran inside the resolution loop
+    for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
     c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5);
     c->stats.ms_symbols = ms(5, 6); c->stats.ms_rangecoder = ms(6, 7); c->stats.ms_d2h = ms(7, 8); c->stats.ms_total = ms(0, 8);
     c->next_read += n;
@@ -595,15 +637,32 @@ int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t*
     if (!bases || !off) return fail(c, LEON_E_INVALID, "null argument");
     if (off[n] < off[0]) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
     HIPCHK(c, hipSetDevice(c->device));
-    uint64_t nb = off[n] - off[0];
+    const uint64_t nb = off[n] - off[0];
     HIPCHK(c, c->in_bases.ensure(nb + 64));
     HIPCHK(c, c->in_off.ensure((n + 1) * 8));
-    // the device copy is rebased so that offsets index it directly
-    std::vector<uint64_t> rel(n + 1);
-    for (uint64_t i = 0; i <= n; i++) rel[i] = off[i] - off[0];
-    HIPCHK(c, hipMemcpy(c->in_bases.p, bases + off[0], nb, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->in_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-    return leon_dna_encode_batch_device(c, c->in_bases.as<uint8_t>(), c->in_off.as<uint64_t>(), n, first_read_index, sink, user);
+    // offsets first (rebased on the device so that they index the device copy of the bases), then the bases group by
+    // group on an uploader thread while the device already works on the groups that have arrived
+    HIPCHK(c, hipMemcpy(c->in_off.p, off, (n + 1) * 8, hipMemcpyHostToDevice));
+    if (off[0]) {
+        launch_rebase_offsets(c->stream, c->in_off.as<uint64_t>(), n + 1, off[0]);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    Upload up;
+    const int dev = c->device;
+    uint8_t* dst = c->in_bases.as<uint8_t>();
+    const uint64_t window = c->cfg.resolve_window;
+    up.th = std::thread([&up, dev, dst, bases, off, n, window] {
+        if (hipSetDevice(dev) != hipSuccess) { up.failed.store(1); return; }
+        for (uint64_t a = 0; a < n;) {
+            const uint64_t b = group_end(a, n, window, true);
+            if (hipMemcpy(dst + (off[a] - off[0]), bases + off[a], off[b] - off[a], hipMemcpyHostToDevice) != hipSuccess) { up.failed.store(1); return; }
+            up.reads_done.store(b, std::memory_order_release);
+            a = b;
+        }
+    });
+    const int rc = encode_batch_impl(c, dst, c->in_off.as<uint64_t>(), n, first_read_index, sink, user, &up);
+    up.th.join();
+    return rc;
 }
 
 int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, uint64_t* n_anchors) {

@@ -60,6 +60,12 @@ __global__ void k_read_slots(const uint64_t* off, uint64_t n, uint64_t* slots) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x)
         slots[i] = i < n ? (off[i + 1] - off[i] + 31) / 32 : 0;
 }
+__global__ void k_rebase_offsets(uint64_t* off, uint64_t n, uint64_t base) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) off[i] -= base;
+}
+void launch_rebase_offsets(hipStream_t s, uint64_t* off, uint64_t n, uint64_t base) {
+    hipLaunchKernelGGL(k_rebase_offsets, dim3(grid_for(n, 256)), dim3(256), 0, s, off, n, base);
+}
 void launch_read_slots(hipStream_t s, const uint64_t* off, uint64_t n, uint64_t* slots) {
     hipLaunchKernelGGL(k_read_slots, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, off, n, slots);
 }
