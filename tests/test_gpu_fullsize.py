@@ -1,5 +1,5 @@
-"""-m gpu: BASELINE.json's single-GPU configuration #2 at FULL size (10 M x 150 bp, k = 31), checked through
-size-independent properties: decode(encode(x)) == x on sampled blocks (oracle decoder), run-to-run determinism,
+"""-m gpu: BASELINE.json's single-GPU configurations #2 and #3 at FULL size (10 M and 100 M x 150 bp, k = 31), checked
+through size-independent properties: decode(encode(x)) == x on sampled blocks (oracle decoder), run-to-run determinism,
 and shard-union == single stream via a checksum of block checksums."""
 import hashlib
 import os
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 K, L, RPB = 31, 150, 50000
-N_READS = int(os.environ.get("LEON_FULLSIZE_READS", 10_000_000))
+SIZES = [int(x) for x in os.environ.get("LEON_FULLSIZE_READS", "10000000,100000000").split(",")]
 
 
 def _checksum(blocks):
@@ -26,7 +26,8 @@ def _checksum(blocks):
     return h.hexdigest()
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("N_READS", SIZES)
+def test_full_size_properties(N_READS):
     import torch
     import bench
     import leon_amd
