@@ -129,6 +129,20 @@ void leon_device_free(void* d_ptr);
 int leon_host_anchor_dict_encode(const uint64_t* kmers, uint64_t n_anchors, uint32_t kmer_size, uint8_t* out,
                                  uint64_t out_cap, uint64_t* size);
 
+/* -- the inverse path: DnaDecoder::execute over read blocks, blocks in parallel on the device --
+ * Needs the bloom of the compressed file in ctx (leon_dna_bloom_upload).  anchors: the dictionary (n_anchors * W words,
+ * from leon_host_anchor_dict_decode).  payloads: the blocks' payloads back to back, payload_off[n_blocks + 1];
+ * block_n_reads / block_n_bases: reads and bases per block (the container's block table).  Output: the reads' bases back
+ * to back in block order (out_cap >= the sum of block_n_bases) and every read's length (sum of block_n_reads entries).
+ * LEON_E_INVALID with a message when a payload does not decode against this bloom / dictionary. */
+int leon_dna_decode_blocks(leon_dna_ctx* ctx, const uint64_t* anchors, uint64_t n_anchors, const uint8_t* payloads,
+                           const uint64_t* payload_off, const uint32_t* block_n_reads, const uint64_t* block_n_bases,
+                           uint64_t n_blocks, uint8_t* out_bases, uint64_t out_cap, uint32_t* out_len);
+/* Host-only (no GPU, no ctx): Leon::decodeAnchorDict, the inverse of the stream leon_dna_finish returns.
+ * out_kmers: n_anchors * W words. */
+int leon_host_anchor_dict_decode(const uint8_t* payload, uint64_t size, uint64_t n_anchors, uint32_t kmer_size,
+                                 uint64_t* out_kmers);
+
 /* Start a new output file on the same context: forgets the anchor dictionary, the dictionary stream and the
  * read/block counters (a fresh Leon object upstream); keeps the bloom and the device buffers. */
 int leon_dna_reset_stream(leon_dna_ctx* ctx);

@@ -62,6 +62,9 @@ _EXPORTS = {
     "leon_dna_encode_batch": (C.c_int, [C.c_void_p, C.c_void_p, _u64p, C.c_uint64, C.c_uint64, SINK, C.c_void_p]),
     "leon_dna_encode_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, SINK,
                                                 C.c_void_p]),
+    "leon_dna_decode_blocks": (C.c_int, [C.c_void_p, _u64p, C.c_uint64, _u8p, _u64p, _u32p, _u64p, C.c_uint64, _u8p, C.c_uint64,
+                                          _u32p]),
+    "leon_host_anchor_dict_decode": (C.c_int, [_u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]),
     "leon_dna_finish": (C.c_int, [C.c_void_p, C.POINTER(_u8p), _u64p, _u64p]),
     "leon_dna_reset_stream": (C.c_int, [C.c_void_p]),
     "leon_dna_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
@@ -105,6 +108,17 @@ def _ptr(a, t):
 def kmer_words(k):
     """64-bit words per k-mer at the C-ABI: 1 below k = 32, 2 from 32 to 63"""
     return 2 if k >= 32 else 1
+
+
+def anchor_dict_decode(payload, n_anchors, kmer_size):
+    """Leon::decodeAnchorDict on the host: the anchors' k-mers (n_anchors * W words) from the dictionary stream"""
+    lib = load_library()
+    out = np.zeros(max(n_anchors * kmer_words(kmer_size), 1), dtype=np.uint64)
+    buf = np.frombuffer(bytes(payload) + b"\0", dtype=np.uint8)
+    rc = lib.leon_host_anchor_dict_decode(_ptr(buf, _u8p), len(payload), n_anchors, kmer_size, _ptr(out, _u64p))
+    if rc:
+        raise LeonDnaError(rc, (lib.leon_last_error(None) or b"").decode())
+    return out[:n_anchors * kmer_words(kmer_size)]
 
 
 def host_anchor_dict_encode(kmers, k):
@@ -284,6 +298,28 @@ class DnaEncodeContext:
         p, sz, na = _u8p(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.leon_dna_finish(self.h, C.byref(p), C.byref(sz), C.byref(na)))
         return (C.string_at(p, sz.value) if copy else sz.value), na.value
+
+    def decode_blocks(self, anchors, blocks, block_n_bases):
+        """DnaDecoder over read blocks: blocks = [(block_id, payload, n_reads)] as the encoder's sink delivered them,
+        anchors = the dictionary (anchor_dict_decode), block_n_bases = bases per block.  Returns the list of reads (bytes)."""
+        blocks = sorted(blocks)
+        nb = len(blocks)
+        anchors = np.ascontiguousarray(anchors, dtype=np.uint64)
+        W = kmer_words(self.kmer_size)
+        pay = np.frombuffer(b"".join(b[1] for b in blocks) + b"\0", dtype=np.uint8)
+        off = np.zeros(nb + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(b[1]) for b in blocks], dtype=np.uint64)
+        nreads = np.array([b[2] for b in blocks], dtype=np.uint32)
+        nbases = np.ascontiguousarray(block_n_bases, dtype=np.uint64)
+        total, n_total = int(nbases.sum()), int(nreads.sum())
+        out = np.zeros(total + 1, dtype=np.uint8)
+        lens = np.zeros(n_total + 1, dtype=np.uint32)
+        self._chk(self.lib.leon_dna_decode_blocks(self.h, _ptr(anchors, _u64p), len(anchors) // W, _ptr(pay, _u8p), _ptr(off, _u64p),
+                                                  _ptr(nreads, _u32p), _ptr(nbases, _u64p), nb, _ptr(out, _u8p), total,
+                                                  _ptr(lens, _u32p)))
+        ends = np.cumsum(lens[:n_total], dtype=np.uint64)
+        raw = out[:total].tobytes()
+        return [raw[int(e) - int(l):int(e)] for e, l in zip(ends, lens[:n_total])]
 
     def set_shard(self, rank, world):
         self._chk(self.lib.leon_dna_set_shard(self.h, rank, world))

@@ -747,6 +747,68 @@ int leon_dna_get_stats(const leon_dna_ctx* c, leon_dna_stats* out) {
     return LEON_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ decode
+int leon_host_anchor_dict_decode(const uint8_t* payload, uint64_t size, uint64_t n_anchors, uint32_t k, uint64_t* out) {
+    if ((!payload && size) || (!out && n_anchors)) return fail(nullptr, LEON_E_INVALID, "null argument");
+    if (k < 3 || k > 63) return fail(nullptr, LEON_E_INVALID, "kmer_size must be in 3..63");
+    if (!decode_anchor_dict(payload, size, n_anchors, k, out)) return fail(nullptr, LEON_E_INVALID, "anchor dictionary stream does not decode");
+    return LEON_OK;
+}
+
+int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_anchors, const uint8_t* payloads,
+                           const uint64_t* payload_off, const uint32_t* block_n_reads, const uint64_t* block_n_bases,
+                           uint64_t n_blocks, uint8_t* out_bases, uint64_t out_cap, uint32_t* out_len) {
+    if (!c) return LEON_E_INVALID;
+    if (n_blocks == 0) return LEON_OK;
+    if (!payloads || !payload_off || !block_n_reads || !block_n_bases || !out_bases || !out_len || (!anchors && n_anchors))
+        return fail(c, LEON_E_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint32_t W = kmer_words(c->cfg.kmer_size);
+    std::vector<uint64_t> read0(n_blocks + 1, 0), out0(n_blocks + 1, 0);
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        if (payload_off[b + 1] < payload_off[b]) return fail(c, LEON_E_INVALID, "payload offsets are not monotonic");
+        read0[b + 1] = read0[b] + block_n_reads[b];
+        out0[b + 1] = out0[b] + block_n_bases[b];
+    }
+    if (out0[n_blocks] > out_cap) return fail(c, LEON_E_INVALID, "output capacity below the sum of block_n_bases");
+    const uint64_t pay_bytes = payload_off[n_blocks] - payload_off[0];
+    DevBuf d_anchors, d_pay, d_off, d_nreads, d_read0, d_out0, d_out, d_len, d_scr, d_err;
+    struct Release { std::vector<DevBuf*> v; ~Release() { for (DevBuf* b : v) b->release(); } } rel;
+    rel.v = { &d_anchors, &d_pay, &d_off, &d_nreads, &d_read0, &d_out0, &d_out, &d_len, &d_scr, &d_err };
+    HIPCHK(c, d_anchors.ensure(std::max<uint64_t>(n_anchors * W, 1) * 8));
+    HIPCHK(c, d_pay.ensure(pay_bytes + 1024));                 // the payload window reads up to 256 + 3 bytes past a block's end
+    HIPCHK(c, d_off.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_nreads.ensure(n_blocks * 4));
+    HIPCHK(c, d_read0.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_out0.ensure((n_blocks + 1) * 8));
+    HIPCHK(c, d_out.ensure(out0[n_blocks] + 64)); HIPCHK(c, d_len.ensure(std::max<uint64_t>(read0[n_blocks], 1) * 4));
+    HIPCHK(c, d_scr.ensure(decode_scratch_bytes(n_blocks))); HIPCHK(c, d_err.ensure(16));
+    std::vector<uint64_t> rel_off(n_blocks + 1);
+    for (uint64_t b = 0; b <= n_blocks; b++) rel_off[b] = payload_off[b] - payload_off[0];
+    if (n_anchors) HIPCHK(c, hipMemcpyAsync(d_anchors.p, anchors, n_anchors * W * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_pay.p, payloads + payload_off[0], pay_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync((uint8_t*)d_pay.p + pay_bytes, 0, 1024, s));
+    HIPCHK(c, hipMemcpyAsync(d_off.p, rel_off.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_nreads.p, block_n_reads, n_blocks * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_read0.p, read0.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_out0.p, out0.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(d_err.p, 0, 16, s));
+    launch_decode_blocks(s, c->B, c->d_rv16, d_anchors.as<uint64_t>(), n_anchors, d_pay.as<uint8_t>(), d_off.as<uint64_t>(),
+                         d_nreads.as<uint32_t>(), d_read0.as<uint64_t>(), d_out0.as<uint64_t>(), n_blocks, d_out.as<uint8_t>(),
+                         d_len.as<uint32_t>(), d_scr.as<uint32_t>(), d_err.as<int>());
+    HIPCHK(c, hipGetLastError());
+    int err[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(err, d_err.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (err[0]) {
+        const char* what = err[0] == 1 ? "anchor address or position out of range" : err[0] == 2 ? "more bases than the block table says"
+                                                                                                : "too many N / error positions in one read";
+        return fail(c, LEON_E_INVALID, std::string("block ") + std::to_string(err[1]) + " does not decode: " + what);
+    }
+    HIPCHK(c, hipMemcpy(out_bases, d_out.p, out0[n_blocks], hipMemcpyDeviceToHost));
+    if (read0[n_blocks]) HIPCHK(c, hipMemcpy(out_len, d_len.p, read0[n_blocks] * 4, hipMemcpyDeviceToHost));
+    return LEON_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ traces
 int leon_dna_trace_anchors(leon_dna_ctx* c, int32_t* pos, uint32_t* addr, uint8_t* flags, uint64_t n) {
     if (!c) return LEON_E_INVALID;

@@ -226,6 +226,37 @@ private:
     const uint64_t* inv_ = nullptr;
 };
 
+// The inverse of AnchorDictCoder (Leon::decodeAnchorDict / RangeDecoder on _anchorDictModel(5) [RECALLED]): one serial
+// chain again, on a host core.  k symbols per anchor, first base in the highest bits.  Returns false on a corrupt stream.
+inline bool decode_anchor_dict(const uint8_t* p, uint64_t n, uint64_t n_anchors, uint32_t k, uint64_t* out) {
+    constexpr uint64_t kTop = 1ull << 56, kBottom = 1ull << 48;
+    const uint32_t W = k >= 32 ? 2u : 1u;
+    uint64_t low = 0, range = ~0ull, code = 0, i = 0, cum[6] = {0, 1, 2, 3, 4, 5};
+    for (int b = 0; b < 8; b++) code = (code << 8) | (i < n ? p[i] : 0), i++;
+    for (uint64_t a = 0; a < n_anchors; a++) {
+        unsigned __int128 km = 0;
+        for (uint32_t j = 0; j < k; j++) {
+            range /= cum[5];
+            const uint64_t v = (code - low) / range;
+            uint32_t c = 4;
+            while (c > 0 && cum[c] > v) c--;
+            low += cum[c] * range;
+            range *= cum[c + 1] - cum[c];
+            while ((low ^ (low + range)) < kTop || (range < kBottom && ((range = (0 - low) & (kBottom - 1)), true))) {
+                code = (code << 8) | (i < n ? p[i] : 0); i++;
+                range <<= 8;
+                low <<= 8;
+            }
+            for (uint32_t x = c + 1; x <= 5; x++) cum[x]++;
+            if (c > 3) return false;                           // an N inside an anchor: not a stream this coder wrote
+            km = (km << 2) | c;
+        }
+        out[a * W] = (uint64_t)km;
+        if (W == 2) out[a * W + 1] = (uint64_t)(km >> 64);
+    }
+    return true;
+}
+
 // the worker that owns the coder: batches of anchor k-mers are queued in address order
 class AnchorDictWorker {
 public:

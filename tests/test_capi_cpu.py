@@ -107,3 +107,19 @@ def test_host_anchor_dict_chain_rare_paths(lib, kind):
     sizes = [2, 5, 5, 2, 3, 3, 3, 2] + [256] * 72
     exp = O.rc_encode_stream(np.ones(len(syms), dtype=np.uint8), syms, sizes)
     assert capi.host_anchor_dict_encode(kmers, k) == exp
+
+
+@pytest.mark.parametrize("k,n", [(31, 5000), (63, 1200), (9, 40), (31, 0)])
+def test_host_anchor_dict_decode_inverts_encode(lib, k, n):
+    """Leon::decodeAnchorDict on the host (the decoder's first step, no GPU): inverse of the dictionary stream, == oracle"""
+    import numpy as np
+    import oracle_lib as O
+    from leon_amd import capi
+    rng = np.random.default_rng(5)
+    ints = [(int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 1 << 62)) << 62)) & ((1 << (2 * k)) - 1) for _ in range(n)]
+    w = O.kwords(k)
+    kmers = np.array([[x & 0xFFFFFFFFFFFFFFFF, x >> 64][:w] for x in ints], dtype=np.uint64).reshape(-1)
+    stream = capi.host_anchor_dict_encode(kmers, k)
+    got = capi.anchor_dict_decode(stream, n, k)
+    assert np.array_equal(got, kmers)
+    assert O.kmers_to_ints(O.decode_anchor_dict(stream, n, k), k) == ints

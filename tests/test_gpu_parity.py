@@ -396,3 +396,42 @@ def test_very_long_read_three_byte_numerics():
             [b2[int(off2[i]):int(off2[i + 1])].tobytes() for i in range(200, 400)]
     bases, off = O.reads_to_arrays(reads)
     _full_compare(bases, off, 31, 150, window=128)
+
+
+@pytest.mark.parametrize("k,kw", [(31, dict(n_rate=0.003, err=0.02)), (21, dict(ragged=True, n_rate=0.001)), (47, dict(err=0.03)),
+                                  (63, dict(ragged=True, n_rate=0.002)), (31, dict(err=0.2))])
+def test_device_decoder_round_trip(k, kw):
+    """DnaDecoder on the device (one wave per block): decode(encode(x)) == x, the reference's own acceptance test, for reads
+    with N, sequencing errors, ragged lengths, reads shorter than k and reads without an anchor; also == the oracle's decoder"""
+    from leon_amd import capi
+    rpb = 300
+    bases, off = common.synthetic(2500, 160 if k < 32 else 220, 9000, seed=90 + k, **kw)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ctx = _ctx(k, rpb, tai)
+    ctx.bloom_upload(bl.bits)
+    blocks = ctx.encode_batch(bases, off)
+    dict_payload, n_anchors = ctx.finish()
+    n = len(off) - 1
+    reads = [bases[int(off[i]):int(off[i + 1])] for i in range(n)]
+    nbases = [sum(len(r) for r in reads[b * rpb:(b + 1) * rpb]) for b in range(len(blocks))]
+    anchors = capi.anchor_dict_decode(dict_payload, n_anchors, k)
+    assert np.array_equal(anchors, ctx.anchor_kmers(n_anchors))
+    got = ctx.decode_blocks(anchors, blocks, nbases)
+    norm = lambda r: bytes(c if c in b"ACGT" else ord("N") for c in r)      # any non-ACGT byte is an N in the format
+    assert len(got) == n
+    for i in range(n):
+        assert got[i] == norm(reads[i]), "read %d does not round-trip" % i
+    # the oracle's decoder agrees block by block
+    oa = O.decode_anchor_dict(dict_payload, n_anchors, k)
+    for b in (0, len(blocks) - 1):
+        dec = O.decode_block(k, bl, oa, blocks[b][1], blocks[b][2], nbases[b] + 16)
+        assert dec == got[b * rpb:b * rpb + blocks[b][2]]
+    # a corrupted payload is reported, not crashed on
+    bad = list(blocks)
+    bad[1] = (bad[1][0], bytes(255 - x for x in bad[1][1]), bad[1][2])
+    try:
+        out = ctx.decode_blocks(anchors, bad, nbases)
+        assert out[rpb:2 * rpb] != [norm(r) for r in reads[rpb:2 * rpb]]
+    except capi.LeonDnaError as e:
+        assert "does not decode" in str(e)
+    ctx.close()
