@@ -302,6 +302,13 @@ class DnaEncodeContext:
     def decode_blocks(self, anchors, blocks, block_n_bases):
         """DnaDecoder over read blocks: blocks = [(block_id, payload, n_reads)] as the encoder's sink delivered them,
         anchors = the dictionary (anchor_dict_decode), block_n_bases = bases per block.  Returns the list of reads (bytes)."""
+        out, lens = self.decode_blocks_raw(anchors, blocks, block_n_bases)
+        ends = np.cumsum(lens, dtype=np.uint64)
+        raw = out.tobytes()
+        return [raw[int(e) - int(l):int(e)] for e, l in zip(ends, lens)]
+
+    def decode_blocks_raw(self, anchors, blocks, block_n_bases):
+        """same, returning (bases back to back as a uint8 array, read lengths as a uint32 array)"""
         blocks = sorted(blocks)
         nb = len(blocks)
         anchors = np.ascontiguousarray(anchors, dtype=np.uint64)
@@ -317,9 +324,7 @@ class DnaEncodeContext:
         self._chk(self.lib.leon_dna_decode_blocks(self.h, _ptr(anchors, _u64p), len(anchors) // W, _ptr(pay, _u8p), _ptr(off, _u64p),
                                                   _ptr(nreads, _u32p), _ptr(nbases, _u64p), nb, _ptr(out, _u8p), total,
                                                   _ptr(lens, _u32p)))
-        ends = np.cumsum(lens[:n_total], dtype=np.uint64)
-        raw = out[:total].tobytes()
-        return [raw[int(e) - int(l):int(e)] for e, l in zip(ends, lens[:n_total])]
+        return out[:total], lens[:n_total]
 
     def set_shard(self, rank, world):
         self._chk(self.lib.leon_dna_set_shard(self.h, rank, world))

@@ -84,4 +84,20 @@ def test_full_size_properties(N_READS):
     for b in (0, 1, 100, 140, n_blocks - 1):               # 100: holds the N reads; 140: the garbage reads
         dec = O.decode_block(K, bl, anchors, blocks[b][1], RPB, RPB * L + 16)
         assert b"".join(dec) == host[b * RPB:(b + 1) * RPB].tobytes(), "block %d does not round-trip" % b
+    # (4) the device decoder (DnaDecoder, one wave per block) gives back every read of the file
+    import time
+    ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai)
+    ctx.bloom_upload(bits)
+    t0 = time.perf_counter()
+    anchors_dev = capi.anchor_dict_decode(d, na, K)
+    t1 = time.perf_counter()
+    out, lens = ctx.decode_blocks_raw(anchors_dev, blocks, [RPB * L] * n_blocks)
+    t2 = time.perf_counter()
+    ctx.close()
+    print("decode: dictionary %.2f s (host), %d blocks %.2f s (device) = %.1f MB/s" % (t1 - t0, n_blocks, t2 - t1, N_READS * L / 1e6 / (t2 - t1)))
+    assert np.array_equal(anchors_dev, np.asarray(anchors, dtype=np.uint64).reshape(-1))      # == the oracle's dictionary decoder
+    assert np.all(lens == L)
+    hn = host.reshape(-1).copy()
+    hn[~np.isin(hn, np.frombuffer(b"ACGT", dtype=np.uint8))] = ord("N")
+    assert np.array_equal(out, hn)
     capi.device_free(d_solid)
