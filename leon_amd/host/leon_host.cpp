@@ -1,9 +1,9 @@
 // leon_host.cpp -- see leon_host.hpp.  Host glue only: every byte of the DNA stream comes from libleon_dna.so.
 //
-// Interim container written by `-c` (little endian), until the .leon HDF5 layout row is built:
-//   "LEONDNA1" | u32 k | u32 reads_per_block | u64 n_reads | u64 n_blocks | u64 n_anchors | u64 dict_bytes |
+// Interim container written by `-c` and read by `-d` (little endian), until the .leon HDF5 layout row is built:
+//   "LEONDNA2" | u32 k | u32 reads_per_block | u64 n_reads | u64 n_blocks | u64 n_anchors | u64 dict_bytes |
 //   u64 bloom_tai | u64 bloom_bytes | u32 n_hash | u32 block_nbits |
-//   n_blocks x (u64 size, u64 n_reads) | dictionary stream | bloom bytes | block payloads
+//   n_blocks x (u64 size, u64 n_reads, u64 n_bases) | dictionary stream | bloom bytes | block payloads
 #include "leon_host.hpp"
 
 #include <algorithm>
@@ -150,11 +150,15 @@ void Leon::executeCompression() {
     _outputFilename = _inputFilename + ".leon";
     std::ofstream o(_outputFilename, std::ios::binary);
     if (!o) throw Exception("cannot write " + _outputFilename);
-    o.write("LEONDNA1", 8);
+    o.write("LEONDNA2", 8);
     put<uint32_t>(o, (uint32_t)_kmerSize); put<uint32_t>(o, READ_PER_BLOCK);
     put<uint64_t>(o, bank.size()); put<uint64_t>(o, _blockSizes.size() / 2); put<uint64_t>(o, n_anchors);
     put<uint64_t>(o, dict_size); put<uint64_t>(o, tai); put<uint64_t>(o, bloom_bytes); put<uint32_t>(o, 7); put<uint32_t>(o, 12);
-    o.write(reinterpret_cast<const char*>(_blockSizes.data()), (std::streamsize)(_blockSizes.size() * 8));
+    for (size_t b = 0; b < _blockSizes.size() / 2; b++) {          // block table; the bases per block let -d size its output
+        uint64_t nb = 0;
+        for (size_t r = b * READ_PER_BLOCK; r < std::min(bank.size(), (b + 1) * (size_t)READ_PER_BLOCK); r++) nb += bank[r].getDataSize();
+        put<uint64_t>(o, _blockSizes[2 * b]); put<uint64_t>(o, _blockSizes[2 * b + 1]); put<uint64_t>(o, nb);
+    }
     o.write(reinterpret_cast<const char*>(dict), (std::streamsize)dict_size);
     o.write(reinterpret_cast<const char*>(bloom.data()), (std::streamsize)bloom_bytes);
     o.write(reinterpret_cast<const char*>(_blocks.data()), (std::streamsize)_blocks.size());
@@ -165,8 +169,80 @@ void Leon::executeCompression() {
               << std::endl;
 }
 
+// ------------------------------------------------------------------------------------------------ DnaDecoder
+// upstream: DnaDecoder::execute() per block on the dispatcher's threads [RECALLED]; here every block at once on the device
+void DnaDecoder::execute(const std::vector<uint64_t>& anchors, const std::vector<uint8_t>& payloads, const std::vector<uint64_t>& payload_off,
+                         const std::vector<uint32_t>& block_reads, const std::vector<uint64_t>& block_bases,
+                         std::vector<uint8_t>& bases, std::vector<uint32_t>& lengths) {
+    uint64_t nb = 0, nr = 0;
+    for (uint64_t x : block_bases) nb += x;
+    for (uint32_t x : block_reads) nr += x;
+    bases.assign(nb + 1, 0);
+    lengths.assign(nr + 1, 0);
+    const uint32_t W = leon_->_kmerSize >= 32 ? 2 : 1;
+    check(leon_->_ctx, leon_dna_decode_blocks(leon_->_ctx, anchors.data(), anchors.size() / W, payloads.data(), payload_off.data(),
+                                              block_reads.data(), block_bases.data(), block_reads.size(), bases.data(), nb, lengths.data()),
+          "leon_dna_decode_blocks");
+    bases.resize(nb);
+    lengths.resize(nr);
+}
+
 void Leon::executeDecompression() {
-    throw Exception("decompression (-d) is not built in this round: DnaDecoder on the device is the next row (DESIGN.md section 11)");
+    std::ifstream in(_inputFilename, std::ios::binary);
+    if (!in) throw Exception("cannot open " + _inputFilename);
+    auto get = [&](void* p, size_t n) { if (!in.read(reinterpret_cast<char*>(p), (std::streamsize)n)) throw Exception("truncated container " + _inputFilename); };
+    char magic[8];
+    get(magic, 8);
+    if (std::memcmp(magic, "LEONDNA2", 8) != 0) throw Exception(_inputFilename + " is not a container written by this build's -c");
+    uint32_t k, rpb, n_hash, nbits; uint64_t n_reads, n_blocks, n_anchors, dict_bytes, tai, bloom_bytes;
+    get(&k, 4); get(&rpb, 4); get(&n_reads, 8); get(&n_blocks, 8); get(&n_anchors, 8); get(&dict_bytes, 8); get(&tai, 8);
+    get(&bloom_bytes, 8); get(&n_hash, 4); get(&nbits, 4);
+    if (n_blocks > (1ull << 32) || dict_bytes > (1ull << 40) || bloom_bytes > (1ull << 40)) throw Exception("implausible container header");
+    std::vector<uint64_t> table(3 * n_blocks);
+    if (n_blocks) get(table.data(), table.size() * 8);
+    std::vector<uint8_t> dict(dict_bytes + 1), bloom(bloom_bytes);
+    if (dict_bytes) get(dict.data(), dict_bytes);
+    if (bloom_bytes) get(bloom.data(), bloom_bytes);
+    std::vector<uint64_t> pay_off(n_blocks + 1, 0), block_bases(n_blocks);
+    std::vector<uint32_t> block_reads(n_blocks);
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        pay_off[b + 1] = pay_off[b] + table[3 * b];
+        block_reads[b] = (uint32_t)table[3 * b + 1];
+        block_bases[b] = table[3 * b + 2];
+    }
+    std::vector<uint8_t> payloads(pay_off[n_blocks] + 1);
+    if (pay_off[n_blocks]) get(payloads.data(), pay_off[n_blocks]);
+
+    _kmerSize = k;
+    leon_dna_cfg cfg = {};
+    cfg.struct_size = sizeof(cfg);
+    cfg.kmer_size = k; cfg.reads_per_block = rpb; cfg.bloom_n_hash = n_hash; cfg.bloom_block_nbits = nbits; cfg.bloom_tai = tai; cfg.device_id = 0;
+    check(nullptr, leon_dna_ctx_create(&cfg, &_ctx), "leon_dna_ctx_create");
+    check(_ctx, leon_dna_bloom_upload(_ctx, bloom.data(), bloom_bytes), "leon_dna_bloom_upload");
+    const uint32_t W = k >= 32 ? 2 : 1;
+    std::vector<uint64_t> anchors(std::max<uint64_t>(n_anchors * W, 1));
+    if (leon_host_anchor_dict_decode(dict.data(), dict_bytes, n_anchors, k, anchors.data()) != LEON_OK)
+        throw Exception(std::string("leon_host_anchor_dict_decode: ") + leon_last_error(nullptr));
+    anchors.resize(n_anchors * W);
+    std::vector<uint8_t> bases; std::vector<uint32_t> lengths;
+    DnaDecoder(this).execute(anchors, payloads, pay_off, block_reads, block_bases, bases, lengths);
+    if (lengths.size() != n_reads) throw Exception("the block table does not add up to the header's read count");
+
+    // output name: X.fastq.leon -> X.fastq.d (/root/reference/scripts/simple_test.sh:54,62).  Only the DNA stream exists in this
+    // build (no header / quality streams), so the output is the sequences, one per line, in file order.
+    std::string stem = _inputFilename;
+    if (stem.size() > 5 && stem.compare(stem.size() - 5, 5, ".leon") == 0) stem.resize(stem.size() - 5);
+    _outputFilename = stem + ".d";
+    std::ofstream o(_outputFilename, std::ios::binary);
+    if (!o) throw Exception("cannot write " + _outputFilename);
+    uint64_t at = 0;
+    for (uint32_t len : lengths) {
+        o.write(reinterpret_cast<const char*>(bases.data() + at), len);
+        o.put('\n');
+        at += len;
+    }
+    std::cout << "DNA stream: " << n_reads << " reads, " << at << " bases decoded from " << n_blocks << " blocks, written to "
+              << _outputFilename << std::endl;
 }
 
 }  // namespace leon_host

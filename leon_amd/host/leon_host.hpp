@@ -4,8 +4,9 @@
 //   DnaEncoder  : the functor handed one Sequence at a time (upstream Dispatcher::iterate(bank, DnaEncoder(this)) [RECALLED]);
 //                 here it batches whole blocks and calls leon_dna_encode_batch, its destructor flushes the last block;
 //   Exception   : gatb::core::system::Exception's getMessage() contract (/root/reference/src/main.cpp:46-49).
+//   DnaDecoder  : the inverse (`-d`), all blocks at once through leon_dna_decode_blocks.
 // Only the DNA stream is produced (headers, qualities, HDF5 are out of this round's scope: DESIGN.md section 11); the
-// output is an interim flat container documented in leon_host.cpp.
+// output of -c is an interim flat container documented in leon_host.cpp, -d writes the sequences one per line.
 #pragma once
 #include <stdint.h>
 #include <exception>
@@ -46,6 +47,17 @@ private:
     Leon* leon_;
     std::string bases_;
     std::vector<uint64_t> offsets_;
+};
+
+// upstream DnaDecoder::execute() decodes one block; this one hands all blocks to the device decoder at once
+class DnaDecoder {
+public:
+    explicit DnaDecoder(Leon* leon) : leon_(leon) {}
+    void execute(const std::vector<uint64_t>& anchors, const std::vector<uint8_t>& payloads, const std::vector<uint64_t>& payload_off,
+                 const std::vector<uint32_t>& block_reads, const std::vector<uint64_t>& block_bases,
+                 std::vector<uint8_t>& bases, std::vector<uint32_t>& lengths);
+private:
+    Leon* leon_;
 };
 
 class Leon {

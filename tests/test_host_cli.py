@@ -27,18 +27,19 @@ def test_cli_error_contract(leon_bin):
     r = subprocess.run([leon_bin, "-v"], capture_output=True, text=True)
     assert r.returncode == 1 and "C-ABI version" in r.stdout
     # main.cpp:46-49: exceptions become "EXCEPTION: <msg>" on stderr and EXIT_FAILURE
-    for args in (["-c"], ["-file", "x", "-c", "-d"], ["-file", "x", "-bogus"], ["-file", "x", "-d"]):
+    for args in (["-c"], ["-file", "x", "-c", "-d"], ["-file", "x", "-bogus"], ["-file", "/nonexistent/x.leon", "-d"]):
         r = subprocess.run([leon_bin] + args, capture_output=True, text=True)
         assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: "), (args, r.stderr)
 
 
 def _read_container(path):
     raw = open(path, "rb").read()
-    assert raw[:8] == b"LEONDNA1"
+    assert raw[:8] == b"LEONDNA2"
     k, rpb, n_reads, n_blocks, n_anchors, dict_bytes, tai, bloom_bytes, n_hash, nbits = struct.unpack_from("<IIQQQQQQII", raw, 8)
     o = 8 + struct.calcsize("<IIQQQQQQII")
-    table = struct.unpack_from("<%dQ" % (2 * n_blocks), raw, o)
-    o += 16 * n_blocks
+    table3 = struct.unpack_from("<%dQ" % (3 * n_blocks), raw, o)
+    table = [x for b in range(n_blocks) for x in table3[3 * b:3 * b + 2]]
+    o += 24 * n_blocks
     d = raw[o:o + dict_bytes]; o += dict_bytes
     bloom = raw[o:o + bloom_bytes]; o += bloom_bytes
     blocks = []
@@ -68,3 +69,31 @@ def test_cli_compress_toy_matches_oracle(leon_bin, tmp_path):
     anchors = O.decode_anchor_dict(c["dict"], c["n_anchors"], 31)
     dec = O.decode_block(31, bl, anchors, c["blocks"][0], c["nreads"][0], len(bases) + 16)
     assert b"".join(dec) == bases
+
+
+@pytest.mark.gpu
+def test_cli_round_trip(leon_bin, tmp_path):
+    """the reference's own acceptance test (scripts/simple_test.sh:51-62): compress, decompress, compare -- on the DNA stream"""
+    src = os.path.join(common.GOLDEN, "toy.fasta")
+    dst = str(tmp_path / "toy.fasta")
+    shutil.copy(src, dst)
+    r = subprocess.run([leon_bin, "-file", dst, "-c", "-kmer-size", "31", "-abundance", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([leon_bin, "-file", dst + ".leon", "-d"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = open(dst + ".d").read().split("\n")[:-1]             # X.fasta.leon -> X.fasta.d
+    want = [l.strip() for l in open(src) if l.strip() and not l.startswith(">")]
+    assert got == want
+    # a FASTQ with N and ragged lengths, k = 21
+    bases, off = common.synthetic(1200, 120, 5000, seed=5, n_rate=0.004, ragged=True, err=0.02)
+    fq = str(tmp_path / "x.fastq")
+    with open(fq, "w") as f:
+        for i in range(len(off) - 1):
+            s = bases[int(off[i]):int(off[i + 1])].decode()
+            f.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    r = subprocess.run([leon_bin, "-file", fq, "-c", "-kmer-size", "21", "-abundance", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([leon_bin, "-file", fq + ".leon", "-d"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = open(fq + ".d").read().split("\n")[:-1]
+    assert got == [bases[int(off[i]):int(off[i + 1])].decode() for i in range(len(off) - 1)]
