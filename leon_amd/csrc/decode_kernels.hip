@@ -223,15 +223,14 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
                     return (idx >= 0 && idx < cnt) ? (int64_t)__hip_atomic_load(list + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
                 };
                 int64_t nextN = cur(Npos, ni, (int64_t)nN), nextE = cur(Epos, ei, (int64_t)nErr);
-                for (; pos >= 0 && pos < (int64_t)len; pos += step) {
+                // One position: the decoded base goes out, the k-mer moves on by the base the GRAPH follows.
+                auto advance = [&](uint32_t res4) {
                     uint32_t nt_out, nt_seed;
                     if (pos == nextN) {                       // an N: 'A' in the k-mer, no probe, no symbol
                         ni += step; nextN = cur(Npos, ni, (int64_t)nN);
                         if (pos == nextE) { ei += step; nextE = cur(Epos, ei, (int64_t)nErr); }   // (never both, kept in step)
                         nt_out = 4; nt_seed = 0;
                     } else {
-                        const K rc = revcomp(kmer, k);
-                        const uint32_t res4 = bloom_contains4<K>(B, rv16, kmer, rc, dir == 1);
                         const uint32_t cnt = (uint32_t)__popc(res4);
                         const uint32_t first = res4 ? (uint32_t)__builtin_ctz(res4) : 0u;
                         if (pos == nextE) {                   // a recorded sequencing error: the true base, the graph's successor
@@ -250,6 +249,19 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
                     }
                     if (lane == 0) s[pos] = bin2nt(nt_out);
                     kmer = dir == 1 ? (((kmer << 2) | (K)nt_seed) & kmk) : ((kmer >> 2) | ((K)nt_seed << (2 * (k - 1))));
+                    pos += step;
+                    return nt_seed;
+                };
+                // Two positions per memory round trip: lane 0 probes the current k-mer, lanes 1..4 its four possible
+                // successors at the same time (the other lanes repeat lane 0's addresses, which costs no traffic), so
+                // when the first position is decided the probe of the k-mer it leads to is already there.
+                while (pos >= 0 && pos < (int64_t)len) {
+                    const uint32_t cand = (lane - 1) & 3u;
+                    K km = kmer;
+                    if (lane >= 1 && lane <= 4) km = dir == 1 ? (((kmer << 2) | (K)cand) & kmk) : ((kmer >> 2) | ((K)cand << (2 * (k - 1))));
+                    const uint32_t res = bloom_contains4<K>(B, rv16, km, revcomp(km, k), dir == 1);
+                    const uint32_t seed0 = advance((uint32_t)__builtin_amdgcn_readlane((int)res, 0));
+                    if (pos >= 0 && pos < (int64_t)len) (void)advance((uint32_t)__builtin_amdgcn_readlane((int)res, (int)(1 + seed0)));
                 }
             }
             if (lane == 0) for (uint64_t i = 0; i < nN; i++) {                                       // also inside the anchor
