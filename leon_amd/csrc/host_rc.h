@@ -228,20 +228,33 @@ private:
 
 // The inverse of AnchorDictCoder (Leon::decodeAnchorDict / RangeDecoder on _anchorDictModel(5) [RECALLED]): one serial
 // chain again, on a host core.  k symbols per anchor, first base in the highest bits.  Returns false on a corrupt stream.
+// range / total uses the encoder's reciprocal stream (the total is 5 + t here too); the decoder's second division,
+// (code - low) / range, is replaced by four multiplies: the symbol is the number of cumulative counts c with
+// c * range <= code - low.
 inline bool decode_anchor_dict(const uint8_t* p, uint64_t n, uint64_t n_anchors, uint32_t k, uint64_t* out) {
     constexpr uint64_t kTop = 1ull << 56, kBottom = 1ull << 48;
     const uint32_t W = k >= 32 ? 2u : 1u;
-    uint64_t low = 0, range = ~0ull, code = 0, i = 0, cum[6] = {0, 1, 2, 3, 4, 5};
+    uint64_t low = 0, range = ~0ull, code = 0, i = 0, t = 0, cum[6] = {0, 1, 2, 3, 4, 5};
     for (int b = 0; b < 8; b++) code = (code << 8) | (i < n ? p[i] : 0), i++;
+    ReciprocalStream recips;
+    const uint64_t* inv = nullptr;
+    if (n_anchors * (uint64_t)k > (1u << 16)) recips.restart();   // (not worth three threads for a handful of symbols)
+    const bool use_inv = n_anchors * (uint64_t)k > (1u << 16);
     for (uint64_t a = 0; a < n_anchors; a++) {
         unsigned __int128 km = 0;
-        for (uint32_t j = 0; j < k; j++) {
-            range /= cum[5];
-            const uint64_t v = (code - low) / range;
-            uint32_t c = 4;
-            while (c > 0 && cum[c] > v) c--;
-            low += cum[c] * range;
-            range *= cum[c + 1] - cum[c];
+        for (uint32_t j = 0; j < k; j++, t++) {
+            const uint64_t tot = 5 + t;
+            uint64_t r;
+            if (use_inv && t >= 256) {
+                const uint64_t off = t % ReciprocalStream::kChunk;
+                if (off == 0 || !inv) inv = recips.take(t / ReciprocalStream::kChunk);
+                r = (uint64_t)(((unsigned __int128)range * inv[off]) >> 64) >> 8;     // floor(range / tot) or one less
+                if (range - r * tot >= tot) r++;
+            } else r = range / tot;
+            const uint64_t d = code - low;
+            const uint32_t c = (uint32_t)(d >= r * cum[1]) + (uint32_t)(d >= r * cum[2]) + (uint32_t)(d >= r * cum[3]) + (uint32_t)(d >= r * cum[4]);
+            low += cum[c] * r;
+            range = r * (cum[c + 1] - cum[c]);
             while ((low ^ (low + range)) < kTop || (range < kBottom && ((range = (0 - low) & (kBottom - 1)), true))) {
                 code = (code << 8) | (i < n ? p[i] : 0); i++;
                 range <<= 8;
