@@ -21,8 +21,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-K = 31
-L = 150
+K = int(os.environ.get("LEON_BENCH_K", 31))          # 31 / 150: BASELINE's configurations 2-4; 63 / 250: configuration 5's read shape
+L = int(os.environ.get("LEON_BENCH_L", 150))
 N_HASH = 7
 BITS_PER_KMER = 12
 ABUNDANCE = 3
