@@ -159,22 +159,23 @@ __device__ inline uint32_t dict_find(const DictDev& D, u128 key) {
     }
 }
 template <typename K> __device__ inline uint32_t window_bit(K key) { return (uint32_t)(key_hash(key) >> (64 - WBITS_LOG2)); }
+// (`created` is set when the key was not there: the caller counts new keys, one atomic per wave where it matters)
 // ---- find or insert.  SPIN = true: called by ONE lane per wave (a lane may wait for another wave's insert to
 // complete); SPIN = false: the keys being inserted are all distinct (rehash), a locked slot is someone else's.
-template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDev& D, uint64_t key) {
+template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDev& D, uint64_t key, bool& created) {
     uint64_t slot = key_hash(key) & D.mask;
     for (;;) {
         uint64_t cur = D.keys[slot];
         if (cur == key) return (uint32_t)slot;
         if (cur == KEY_EMPTY) {
             uint64_t old = atomicCAS((unsigned long long*)&D.keys[slot], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-            if (old == KEY_EMPTY) { atomicAdd(D.n_keys, 1ull); return (uint32_t)slot; }
+            if (old == KEY_EMPTY) { created = true; return (uint32_t)slot; }
             if (old == key) return (uint32_t)slot;
         }
         slot = (slot + 1) & D.mask;
     }
 }
-template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDev& D, u128 key) {
+template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDev& D, u128 key, bool& created) {
     const uint64_t klo = (uint64_t)key, khi = (uint64_t)(key >> 64);
     uint64_t slot = key_hash(key) & D.mask;
     for (;;) {
@@ -185,7 +186,7 @@ template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDe
             if (hi == KEY_EMPTY) {                                       // ours: low word first, then publish the high word
                 __hip_atomic_store(&D.keys[2 * slot], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(phi, khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(D.n_keys, 1ull);
+                created = true;
                 return (uint32_t)slot;
             }
         }
@@ -206,7 +207,9 @@ template <> __device__ inline u128 dict_key<u128>(const DictDev& D, uint32_t slo
 template <typename K> __global__ void k_dict_rehash(DictDev from, uint64_t from_cap, DictDev to) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < from_cap; i += (uint64_t)gridDim.x * blockDim.x) {
         if (from.keys[i * KT<K>::W + (KT<K>::W - 1)] == KEY_EMPTY) continue;
-        uint32_t s = dict_find_or_insert<false>(to, dict_key<K>(from, (uint32_t)i));
+        bool created = false;
+        uint32_t s = dict_find_or_insert<false>(to, dict_key<K>(from, (uint32_t)i), created);
+        if (created) atomicAdd(to.n_keys, 1ull);
         to.fin[s] = from.fin[i]; to.tent[s] = IDX_INF; to.addr[s] = from.addr[i];
     }
 }
@@ -296,13 +299,26 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
             }
             // candidates go into the dictionary one quarter-wave at a time: with two-word keys an inserting lane may
             // wait for another inserter, which must not be a lane of its own wave
+            bool created = false;
+            uint32_t sl = 0;
             for (uint32_t q = 0; q < 4; q++) {
                 if (want_insert && grp == q) {
-                    const uint32_t sl = dict_find_or_insert<true>(D, canon_at<K>(pk, cpos, k));
+                    sl = dict_find_or_insert<true>(D, canon_at<K>(pk, cpos, k), created);
                     atomicMin((unsigned long long*)&D.tent[sl], (unsigned long long)g);
                     V.status[i] = ST_UNRESOLVED; V.cand_pos[i] = cpos; V.cand_slot[i] = sl;
-                    ulist[atomicAdd(ucount, 1u)] = (uint32_t)i;
                 }
+            }
+            // one atomic per wave on the window's two counters (in the first windows every read inserts: a million
+            // same-address atomics per launch were most of the kernel's time)
+            const unsigned long long wm = __ballot(want_insert);
+            if (wm) {
+                const uint32_t leader = (uint32_t)__builtin_ctzll(wm);
+                uint32_t first = 0;
+                if (lane == leader) first = atomicAdd(ucount, (uint32_t)__popcll(wm));
+                first = (uint32_t)__shfl((int)first, (int)leader);
+                if (want_insert) ulist[first + (uint32_t)__popcll(wm & ((1ull << lane) - 1))] = (uint32_t)i;
+                const unsigned long long cm = __ballot(created);
+                if (cm && lane == leader) atomicAdd(D.n_keys, (unsigned long long)__popcll(cm));
             }
         }
     }
