@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("LEON_BENCH_CPU_SAMPLE", 4_000_000)),
                     help="reads timed through the CPU restatement on rank 0 at N=1 (0 = skip)")
     ap.add_argument("--err", type=float, default=0.01)
+    ap.add_argument("--decode", action="store_true",
+                    help="also decode the whole file on the device (DnaDecoder, SURVEY 8f-1) and compare it with the input; "
+                         "reported as `decode`, never as value")
     ap.add_argument("--host-input", action="store_true",
                     help="also time ONE step through leon_dna_encode_batch (reads in pageable host memory, PCIe included); "
                          "reported as pcie_inclusive, never as value")
@@ -237,6 +240,25 @@ def main():
                 "what": "one step through leon_dna_encode_batch: reads and offsets in pageable host memory, H2D inside the timed region"}
         del h_reads, h_off
 
+    decode = None
+    if a.decode and world == 1:
+        kept = []
+        keep = capi.SINK(lambda user, bid, ptr, size, nreads: (kept.append((int(bid), bytes(ptr[:size]), int(nreads))), 0)[1])
+        ctx.reset_stream()
+        ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_total, sink=keep)
+        dstream, n_anchors = ctx.finish()
+        t0 = time.perf_counter()
+        anchors = capi.anchor_dict_decode(dstream, n_anchors, K)
+        t1 = time.perf_counter()
+        out_bases, out_lens = ctx.decode_blocks_raw(anchors, kept, [b[2] * L for b in kept])
+        t2 = time.perf_counter()
+        same = bool(np.array_equal(out_bases, reads.cpu().numpy().reshape(-1))) and bool(np.all(out_lens == L))
+        decode = {"value": round(n_total * L / 1e6 / (t2 - t0), 1), "unit": "MB/s", "dictionary_s": round(t1 - t0, 2),
+                  "blocks_s": round(t2 - t1, 2), "blocks_MBps": round(n_total * L / 1e6 / (t2 - t1), 1), "equals_input": same,
+                  "what": "leon_host_anchor_dict_decode (one host core) then leon_dna_decode_blocks (one wave per block), "
+                          "payloads in host memory, bases back in host memory"}
+        del kept, out_bases, out_lens
+
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         cpu = cpu_baseline(ctx, reads, min(a.cpu_sample, n_total))
@@ -258,6 +280,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "pcie_inclusive": pcie,
+            "decode": decode,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
                       "symbols": stage["n_symbols"], "resolve_rounds": stage["resolve_rounds"],
