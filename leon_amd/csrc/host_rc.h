@@ -251,16 +251,19 @@ inline bool decode_anchor_dict(const uint8_t* p, uint64_t n, uint64_t n_anchors,
                 r = (uint64_t)(((unsigned __int128)range * inv[off]) >> 64) >> 8;     // floor(range / tot) or one less
                 if (range - r * tot >= tot) r++;
             } else r = range / tot;
+            // the symbol is the number of cumulative counts c with c * r <= code - low; the five products also are the
+            // new low and range (no second multiply, no division)
             const uint64_t d = code - low;
-            const uint32_t c = (uint32_t)(d >= r * cum[1]) + (uint32_t)(d >= r * cum[2]) + (uint32_t)(d >= r * cum[3]) + (uint32_t)(d >= r * cum[4]);
-            low += cum[c] * r;
-            range = r * (cum[c + 1] - cum[c]);
+            uint64_t pp[6] = {0, r * cum[1], r * cum[2], r * cum[3], r * cum[4], r * tot};
+            const uint32_t c = (uint32_t)(d >= pp[1]) + (uint32_t)(d >= pp[2]) + (uint32_t)(d >= pp[3]) + (uint32_t)(d >= pp[4]);
+            low += pp[c];
+            range = pp[c + 1] - pp[c];
             while ((low ^ (low + range)) < kTop || (range < kBottom && ((range = (0 - low) & (kBottom - 1)), true))) {
                 code = (code << 8) | (i < n ? p[i] : 0); i++;
                 range <<= 8;
                 low <<= 8;
             }
-            for (uint32_t x = c + 1; x <= 5; x++) cum[x]++;
+            for (uint32_t x = 1; x <= 5; x++) cum[x] += (uint64_t)(x > c);     // Order0Model::update, branch-free
             if (c > 3) return false;                           // an N inside an anchor: not a stream this coder wrote
             km = (km << 2) | c;
         }
