@@ -357,8 +357,11 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
 // reads [0, group_end(a)) are packed (and, through the host entry point, uploaded) together: the first resolution window
 // alone, so that the device and the dictionary chain start at once, then groups of 8 windows (everything that is left
 // when the bases are in HBM already)
+// (the first window itself is short -- first_window() reads -- so that the first anchors reach the host chain, the longest
+// single piece of a step, a few milliseconds after the call starts; the result does not depend on where windows end)
+static uint64_t first_window(uint64_t window) { return std::min<uint64_t>(window, 1ull << 17); }
 static uint64_t group_end(uint64_t a, uint64_t n, uint64_t window, bool streamed) {
-    if (a == 0) return std::min(n, window);
+    if (a == 0) return std::min(n, first_window(window));
     return streamed ? std::min(n, a + 8 * window) : n;
 }
 
@@ -449,8 +452,8 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     size_t scan_tmp = 0;
     HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), W, s));
     if (int rc = ensure_cub(c, scan_tmp)) return rc;
-    for (uint64_t w0 = 0; w0 < n; w0 += W) {
-        uint64_t w1 = std::min(n, w0 + W);
+    for (uint64_t w0 = 0, w1 = 0; w0 < n; w0 = w1) {
+        w1 = std::min(n, w0 + (w0 == 0 ? first_window(W) : W));
         if (int rc = dict_reserve(c, c->n_keys + (w1 - w0))) return rc;
         HIPCHK(c, hipMemsetAsync(counters, 0, 8, s));
         HIPCHK(c, hipMemsetAsync(c->wbits.p, 0, (1ull << WBITS_LOG2) / 8, s));

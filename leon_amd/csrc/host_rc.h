@@ -10,6 +10,8 @@
 #define LEON_HOST_CHAIN_X86 1
 #endif
 #include <condition_variable>
+#include <cstdlib>
+#include <new>
 #include <deque>
 #include <mutex>
 #include <thread>
@@ -86,6 +88,27 @@ private:
 
 // Order-0 adaptive model over {A,C,T,G,N} + carry-less 64-bit range coder, specialised for the dictionary
 // stream (5 symbols, cumulative counts updated branch-free, output written through a raw cursor): ~4-5 ns/symbol.
+// the coder's output: grows by doubling, is never zero-filled, keeps its capacity from one stream to the next (a
+// 100 M-read file's stream is 110 MB: std::vector's resize would clear all of it again for every file)
+class ByteBuf {
+public:
+    ~ByteBuf() { free(p_); }
+    uint8_t* data() { return p_; }
+    const uint8_t* data() const { return p_; }
+    size_t size() const { return cap_; }
+    void clear() {}
+    void resize(size_t n) {                                    // grow only
+        if (n <= cap_) return;
+        uint8_t* q = (uint8_t*)realloc(p_, n);
+        if (!q) throw std::bad_alloc();
+        p_ = q; cap_ = n;
+    }
+    uint8_t& operator[](size_t i) { return p_[i]; }
+private:
+    uint8_t* p_ = nullptr;
+    size_t cap_ = 0;
+};
+
 class AnchorDictCoder {
 public:
     AnchorDictCoder() { clear(); }
@@ -220,7 +243,7 @@ private:
     }
     static constexpr uint64_t kTop = 1ull << 56, kBottom = 1ull << 48;
     uint64_t low_, range_, n_, cum_[6];
-    std::vector<uint8_t> buf_;
+    ByteBuf buf_;
     size_t w_;
     ReciprocalStream* recips_ = nullptr;
     const uint64_t* inv_ = nullptr;
