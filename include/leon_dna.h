@@ -68,7 +68,7 @@ typedef struct leon_dna_stats {
     /* HIP-event milliseconds of the last batch, measured on the library's own stream */
     float ms_pack, ms_resolve, ms_sort, ms_walk, ms_symbols, ms_rangecoder, ms_d2h, ms_total;
     uint32_t walk_launches, reserved;
-    float ms_anchor_wait, reserved2;   /* host ms leon_dna_finish waited for the dictionary-stream thread */
+    float ms_anchor_wait, ms_chain_busy;   /* host ms leon_dna_finish waited for the dictionary-stream thread; ms that thread spent coding */
 } leon_dna_stats;
 
 /* -- lifecycle (DnaEncoder ctor / dtor bracket one thread's work upstream) -- */

@@ -33,7 +33,7 @@ class Stats(C.Structure):
                [(n, C.c_float) for n in ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder",
                                          "ms_d2h", "ms_total")] + \
                [("walk_launches", C.c_uint32), ("reserved", C.c_uint32), ("ms_anchor_wait", C.c_float),
-                ("reserved2", C.c_float)]
+                ("ms_chain_busy", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}

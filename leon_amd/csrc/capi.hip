@@ -747,6 +747,7 @@ int leon_dna_get_stats(const leon_dna_ctx* c, leon_dna_stats* out) {
     *out = c->stats;
     out->n_anchors = c->n_anchors;
     out->ms_anchor_wait = (float)c->anchor_wait_ms;
+    out->ms_chain_busy = c->finished ? (float)c->anchor_worker->busy_ms() : 0.f;
     return LEON_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <emmintrin.h>
 #define LEON_HOST_CHAIN_X86 1
 #endif
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <new>
@@ -324,7 +325,8 @@ public:
         th_.join();
         running_ = false;
     }
-    void reset() { drain(); coder_.clear(); recips_.restart(); }
+    void reset() { drain(); coder_.clear(); recips_.restart(); busy_ms_ = 0; }
+    double busy_ms() const { return busy_ms_; }              // time spent coding since the last reset (read after drain())
     AnchorDictCoder& coder() { return coder_; }                // only after drain()
 private:
     void run() {
@@ -338,7 +340,9 @@ private:
                 q_.pop_front();
             }
             const uint32_t W = k_ >= 32 ? 2u : 1u;
+            const auto t0 = std::chrono::steady_clock::now();
             coder_.encode_kmers(batch.data(), batch.size() / W, k_);
+            busy_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             {
                 std::lock_guard<std::mutex> g(mu_);
                 pending_--;
@@ -353,6 +357,7 @@ private:
     std::condition_variable cv_, cv_done_;
     std::deque<std::vector<uint64_t>> q_;
     uint64_t pending_ = 0;
+    double busy_ms_ = 0;
     bool running_ = false, quit_ = false;
     std::thread th_;
 };
