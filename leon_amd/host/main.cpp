@@ -1,27 +1,39 @@
-// main.cpp -- same shape as /root/reference/src/main.cpp:37-51: version banner, Leon().run(argc, argv) in a try block,
-// "EXCEPTION: <msg>" on stderr and EXIT_FAILURE when the tool throws.
+// Command-line front of the host mirror.  Behaviour kept from the reference's entry point (/root/reference/src/main.cpp:37-51):
+//   * `-v` / `--version` print a banner and the process ends with EXIT_FAILURE (yes, failure: that is what upstream returns);
+//   * anything the tool throws is reported as "EXCEPTION: <message>" on stderr, exit status EXIT_FAILURE;
+//   * otherwise the tool parses its own arguments (Leon::run) and the process ends with EXIT_SUCCESS.
 #include <cstdlib>
-#include <cstring>
 #include <iostream>
+#include <string>
 
 #include "leon_host.hpp"
 
-static void displayVersion(std::ostream& os) {
-    os << "* * * * * * * * * * * * * * * * * * * * * *" << std::endl;
-    os << "* leon_amd DNA encode path, C-ABI version " << leon_dna_abi_version() << "  *" << std::endl;
-    os << "* * * * * * * * * * * * * * * * * * * * * *" << std::endl;
+namespace {
+
+bool wants_version(int argc, char** argv) {
+    if (argc < 2) return false;
+    const std::string first(argv[1]);
+    return first == "-v" || first == "--version";
 }
 
+int report(const leon_host::Exception& failure) {
+    std::cerr << "EXCEPTION: " << failure.getMessage() << std::endl;
+    return EXIT_FAILURE;
+}
+
+}  // namespace
+
 int main(int argc, char* argv[]) {
-    if (argc > 1 && (strcmp(argv[1], "--version") == 0 || strcmp(argv[1], "-v") == 0)) {
-        displayVersion(std::cout);
-        return EXIT_FAILURE;                  // the reference returns EXIT_FAILURE after the banner (main.cpp:40)
-    }
-    try {
-        leon_host::Leon().run(argc, argv);
-    } catch (leon_host::Exception& e) {
-        std::cerr << "EXCEPTION: " << e.getMessage() << std::endl;
+    if (wants_version(argc, argv)) {
+        const std::string rule(44, '*');
+        std::cout << rule << "\n* leon_amd DNA encode path, C-ABI version " << leon_dna_abi_version() << "\n" << rule << std::endl;
         return EXIT_FAILURE;
+    }
+    leon_host::Leon tool;
+    try {
+        tool.run(argc, argv);
+    } catch (const leon_host::Exception& failure) {
+        return report(failure);
     }
     return EXIT_SUCCESS;
 }
