@@ -777,15 +777,18 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     }
     if (out0[n_blocks] > out_cap) return fail(c, LEON_E_INVALID, "output capacity below the sum of block_n_bases");
     const uint64_t pay_bytes = payload_off[n_blocks] - payload_off[0];
-    DevBuf d_anchors, d_pay, d_off, d_nreads, d_read0, d_out0, d_out, d_len, d_scr, d_err;
+    DevBuf d_anchors, d_pay, d_off, d_nreads, d_read0, d_out0, d_out, d_len, d_scr, d_err, d_pool;
     struct Release { std::vector<DevBuf*> v; ~Release() { for (DevBuf* b : v) b->release(); } } rel;
-    rel.v = { &d_anchors, &d_pay, &d_off, &d_nreads, &d_read0, &d_out0, &d_out, &d_len, &d_scr, &d_err };
+    rel.v = { &d_anchors, &d_pay, &d_off, &d_nreads, &d_read0, &d_out0, &d_out, &d_len, &d_scr, &d_err, &d_pool };
     HIPCHK(c, d_anchors.ensure(std::max<uint64_t>(n_anchors * W, 1) * 8));
     HIPCHK(c, d_pay.ensure(pay_bytes + 1024));                 // the payload window reads up to 256 + 3 bytes past a block's end
     HIPCHK(c, d_off.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_nreads.ensure(n_blocks * 4));
     HIPCHK(c, d_read0.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_out0.ensure((n_blocks + 1) * 8));
     HIPCHK(c, d_out.ensure(out0[n_blocks] + 64)); HIPCHK(c, d_len.ensure(std::max<uint64_t>(read0[n_blocks], 1) * 4));
     HIPCHK(c, d_scr.ensure(decode_scratch_bytes(n_blocks))); HIPCHK(c, d_err.ensure(16));
+    // position lists longer than a block's own scratch (8192 N or error positions in ONE read) come from this pool
+    const uint64_t pool_words = std::min<uint64_t>(std::max<uint64_t>(out0[n_blocks] / 2, 1ull << 20), 1ull << 28);
+    HIPCHK(c, d_pool.ensure(pool_words * 4 + 16));
     std::vector<uint64_t> rel_off(n_blocks + 1);
     for (uint64_t b = 0; b <= n_blocks; b++) rel_off[b] = payload_off[b] - payload_off[0];
     if (n_anchors) HIPCHK(c, hipMemcpyAsync(d_anchors.p, anchors, n_anchors * W * 8, hipMemcpyHostToDevice, s));
@@ -796,9 +799,11 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     HIPCHK(c, hipMemcpyAsync(d_read0.p, read0.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_out0.p, out0.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemsetAsync(d_err.p, 0, 16, s));
+    HIPCHK(c, hipMemsetAsync((uint8_t*)d_pool.p + pool_words * 4, 0, 16, s));           // the pool's cursor lives behind it
     launch_decode_blocks(s, c->B, c->d_rv16, d_anchors.as<uint64_t>(), n_anchors, d_pay.as<uint8_t>(), d_off.as<uint64_t>(),
                          d_nreads.as<uint32_t>(), d_read0.as<uint64_t>(), d_out0.as<uint64_t>(), n_blocks, d_out.as<uint8_t>(),
-                         d_len.as<uint32_t>(), d_scr.as<uint32_t>(), d_err.as<int>());
+                         d_len.as<uint32_t>(), d_scr.as<uint32_t>(), d_pool.as<uint32_t>(),
+                         (unsigned long long*)((uint8_t*)d_pool.p + pool_words * 4), pool_words, d_err.as<int>());
     HIPCHK(c, hipGetLastError());
     int err[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(err, d_err.p, 8, hipMemcpyDeviceToHost, s));

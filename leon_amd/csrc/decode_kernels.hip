@@ -12,7 +12,8 @@
 namespace leon {
 
 constexpr uint32_t DC_NSLOT = 14;                          // numeric models in LDS (17 KB per block: every block resident)
-constexpr uint32_t DC_LIST_CAP = 8192;                     // N / error positions of ONE read (global scratch per block)
+constexpr uint32_t DC_LIST_CAP = 8192;                     // N / error positions of ONE read in the block's own scratch; longer
+                                                           // lists (a 70 kb read full of errors) come from a shared bump pool
 
 size_t decode_scratch_bytes(uint64_t n_blocks) {
     return (size_t)n_blocks * ((RC_NNUM - DC_NSLOT) * RC_STRIDE + 2 * DC_LIST_CAP) * sizeof(uint32_t);
@@ -136,7 +137,8 @@ template <typename K>
 __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors,
                                                      const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads,
                                                      const uint64_t* blk_read0, const uint64_t* blk_out0, uint64_t n_blocks,
-                                                     uint8_t* out, uint32_t* out_len, uint32_t* scratch, int* err) {
+                                                     uint8_t* out, uint32_t* out_len, uint32_t* scratch, uint32_t* pool,
+                                                     unsigned long long* pool_cursor, uint64_t pool_words, int* err) {
     __shared__ uint16_t rv16[256];
     __shared__ uint32_t models[RC_SMALL_WORDS + DC_NSLOT * RC_STRIDE];
     __shared__ uint8_t slotmap[RC_NNUM];
@@ -149,8 +151,8 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
         d.lane = lane; d.lds = models; d.slotmap = slotmap; d.nused = 0;
         uint32_t* blk_scratch = scratch + b * (uint64_t)((RC_NNUM - DC_NSLOT) * RC_STRIDE + 2 * DC_LIST_CAP);
         d.gmodels = blk_scratch;
-        uint32_t* Npos = blk_scratch + (RC_NNUM - DC_NSLOT) * RC_STRIDE;
-        uint32_t* Epos = Npos + DC_LIST_CAP;
+        uint32_t* const Nblk = blk_scratch + (RC_NNUM - DC_NSLOT) * RC_STRIDE;
+        uint32_t* const Eblk = Nblk + DC_LIST_CAP;
         d.p = payloads + pay_off[b]; d.n = pay_off[b + 1] - pay_off[b]; d.i = 0;
         d.low = 0; d.range = ~0ull; d.code = 0;
         __syncthreads();
@@ -164,6 +166,13 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
         const uint64_t wcap = blk_out0[b + 1];
         const uint64_t r0 = blk_read0[b];
         int fail = 0;
+        auto pool_alloc = [&](uint64_t cnt) -> uint32_t* {           // wave-uniform; never freed (rare, bounded by pool_words)
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(pool_cursor, (unsigned long long)cnt);
+            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+            return base + cnt <= pool_words ? pool + base : nullptr;
+        };
         for (uint32_t r = 0; r < blk_reads[b] && !fail; r++) {
             const uint32_t type = decode_sym(d, M_READ_TYPE);
             if (type == 1) {                                  // DnaDecoder::decodeNoAnchorRead
@@ -188,11 +197,15 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
             if (addr >= n_anchors || apos + k > len) { fail = 1; break; }
             if (w + len > wcap) { fail = 2; break; }
             const uint64_t nN = decode_numeric(d, G_NUMERIC);
-            if (nN > len || nN > DC_LIST_CAP) { fail = 3; break; }
+            if (nN > len) { fail = 3; break; }
+            uint32_t* Npos = nN > DC_LIST_CAP ? pool_alloc(nN) : Nblk;
+            if (!Npos) { fail = 3; break; }
             uint64_t pv = 0;
             for (uint64_t i = 0; i < nN; i++) { pv += decode_numeric(d, G_NPOS); if (lane == 0) Npos[i] = (uint32_t)pv; }
             const uint64_t nErr = decode_numeric(d, G_LEFT_ERROR);
-            if (nErr > len || nErr > DC_LIST_CAP) { fail = 3; break; }
+            if (nErr > len) { fail = 3; break; }
+            uint32_t* Epos = nErr > DC_LIST_CAP ? pool_alloc(nErr) : Eblk;
+            if (!Epos) { fail = 3; break; }
             pv = 0;
             for (uint64_t i = 0; i < nErr; i++) { pv += decode_numeric(d, G_ERRPOS); if (lane == 0) Epos[i] = (uint32_t)pv; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -277,13 +290,14 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
 
 void launch_decode_blocks(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors,
                           const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads, const uint64_t* blk_read0,
-                          const uint64_t* blk_out0, uint64_t n_blocks, uint8_t* out, uint32_t* out_len, uint32_t* scratch, int* err) {
+                          const uint64_t* blk_out0, uint64_t n_blocks, uint8_t* out, uint32_t* out_len, uint32_t* scratch,
+                          uint32_t* pool, unsigned long long* pool_cursor, uint64_t pool_words, int* err) {
     if (!n_blocks) return;
     const uint32_t g = (uint32_t)(n_blocks > 256 * 9 ? 256 * 9 : n_blocks);
     if (B.k >= 32) hipLaunchKernelGGL(k_decode_blocks<u128>, dim3(g), dim3(64), 0, s, B, rv16, anchors, n_anchors, payloads, pay_off, blk_reads,
-                                      blk_read0, blk_out0, n_blocks, out, out_len, scratch, err);
+                                      blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err);
     else hipLaunchKernelGGL(k_decode_blocks<uint64_t>, dim3(g), dim3(64), 0, s, B, rv16, anchors, n_anchors, payloads, pay_off, blk_reads,
-                            blk_read0, blk_out0, n_blocks, out, out_len, scratch, err);
+                            blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err);
 }
 
 }  // namespace leon

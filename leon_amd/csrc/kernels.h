@@ -89,6 +89,7 @@ void launch_gather_payload(hipStream_t s, const uint8_t* out, const uint64_t* ou
 size_t decode_scratch_bytes(uint64_t n_blocks);
 void launch_decode_blocks(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors,
                           const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads, const uint64_t* blk_read0,
-                          const uint64_t* blk_out0, uint64_t n_blocks, uint8_t* out, uint32_t* out_len, uint32_t* scratch, int* err);
+                          const uint64_t* blk_out0, uint64_t n_blocks, uint8_t* out, uint32_t* out_len, uint32_t* scratch,
+                          uint32_t* pool, unsigned long long* pool_cursor, uint64_t pool_words, int* err);
 
 }  // namespace leon

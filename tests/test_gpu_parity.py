@@ -435,3 +435,44 @@ def test_device_decoder_round_trip(k, kw):
     except capi.LeonDnaError as e:
         assert "does not decode" in str(e)
     ctx.close()
+
+
+def _decode_round_trip(reads, k, rpb, bloom=None):
+    from leon_amd import capi
+    bases, off = O.reads_to_arrays(reads)
+    bl, solid, tai = bloom if bloom is not None else common.make_bloom(bases, off, k)
+    ctx = _ctx(k, rpb, tai)
+    ctx.bloom_upload(bl.bits)
+    blocks = ctx.encode_batch(bases, off)
+    d, na = ctx.finish()
+    nbases = [sum(len(r) for r in reads[b * rpb:(b + 1) * rpb]) for b in range(len(blocks))]
+    got = ctx.decode_blocks(capi.anchor_dict_decode(d, na, k), blocks, nbases)
+    ctx.close()
+    norm = lambda r: bytes(c if c in b"ACGT" else ord("N") for c in r)
+    assert got == [norm(r) for r in reads]
+
+
+def test_device_decoder_edge_cases():
+    """the decoder on the inputs the encoder's edge-case test uses (reads shorter than k, all-N, empty, unanchorable, an empty
+    bloom) and on a 70 kb read with a fifth of its positions in error: more N / error positions than a block's own scratch
+    holds (8192), so its lists come from the shared pool"""
+    import synth
+    k = 31
+    bases, off = common.synthetic(2000, 150, 10000, seed=21)
+    bl = common.make_bloom(bases, off, k)
+    extra = [b"ACGT", b"A" * 31, b"N" * 50, b"ACGTTGCA" * 20, b"", b"ACGTNNNNACGT" * 10]
+    reads = [bases[int(off[i]):int(off[i + 1])] for i in range(300)]
+    mixed = []
+    for i, r in enumerate(reads):
+        mixed.append(r)
+        if i % 50 == 0:
+            mixed.append(extra[(i // 50) % len(extra)])
+    _decode_round_trip(mixed, k, 100, bloom=bl)
+    _decode_round_trip([reads[0]], k, 100, bloom=bl)
+    _decode_round_trip(mixed, k, 100, bloom=(O.Bloom(1000, k), None, 1000))
+    g = synth.make_genome(90000, seed=5)
+    b1, off1 = synth.make_reads(g, 1, 70000, seed=6, err=0.2, n_rate=0.15)
+    b2, off2 = synth.make_reads(g, 300, 300, seed=7, err=0.01)
+    rr = [b2[int(off2[i]):int(off2[i + 1])].tobytes() for i in range(150)] + [b1.tobytes()] + \
+         [b2[int(off2[i]):int(off2[i + 1])].tobytes() for i in range(150, 300)]
+    _decode_round_trip(rr, k, 120)
