@@ -58,26 +58,39 @@ template <bool GLB> __device__ inline void tinc(uint32_t* t, uint32_t idx) {
     else ((volatile uint32_t*)t)[idx] = ((volatile uint32_t*)t)[idx] + 1;
 }
 
+// floor(x / d) for d < 2^31: two rounds of a double-precision estimate (the generic 64-bit division is ~150 instructions
+// on this chain), then an exact fix-up
+__device__ inline uint64_t div_u64_u32(uint64_t x, uint32_t dv) {
+    const double inv = 1.0 / (double)dv;
+    uint64_t q = (uint64_t)((double)x * inv * 0.99999999999);          // never above the quotient (x < 2^64: q fits)
+    uint64_t rem = x - q * dv;                                          // < ~2^13 * dv + ...: a second, now exact-ish, round
+    const uint64_t q2 = (uint64_t)((double)rem * inv * 0.99999999999);
+    q += q2; rem -= q2 * dv;
+    while (rem >= dv) { q++; rem -= dv; }                               // at most a step or two
+    return q;
+}
+
 // RangeDecoder::nextByte on one model: the symbol, with the model updated (Order0Model::update)
 template <bool GLB> __device__ inline uint32_t decode_on(Dec& d, uint32_t* T, bool small, uint32_t size) {
     const uint32_t lane = d.lane;
     const uint32_t tot = small ? tld<GLB>(T, RC_LW + size) : tld<GLB>(T, 16);
-    const uint64_t r = d.range / tot;
-    uint64_t v64 = (d.code - d.low) / r;
-    const uint32_t v = v64 >= tot ? tot - 1 : (uint32_t)v64;
+    const uint64_t r = div_u64_u32(d.range, tot);
+    // RangeDecoder: value = (code - low) / r, symbol = the last c with F(c) <= value.  Equivalently the last c with
+    // F(c) * r <= code - low: every lane multiplies its own cumulative count, no second division (F(c) * r <= range).
+    const uint64_t dist = d.code - d.low;
     // level 1: the 16-block, F(16 j) = H[j]
     uint32_t j = 0, base = 0;
     if (!small) {
         const uint32_t h = lane < 16 ? tld<GLB>(T, lane) : 0xFFFFFFFFu;
-        const unsigned long long m1 = __ballot(lane < 16 && h <= v);
-        j = (uint32_t)__popcll(m1) - 1;                      // H[0] = 0 <= v
+        const unsigned long long m1 = __ballot(lane < 16 && (uint64_t)h * r <= dist);
+        j = m1 ? (uint32_t)__popcll(m1) - 1 : 0;             // H[0] = 0 passes
         base = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)j);
     }
     // level 2: inside the block, F(16 j + l) = H[j] + Lw[16 j + l]; a small model's Lw[size] is its total
     const uint32_t lim = small ? size : 16u;
     const uint32_t f = lane <= lim && (small || lane < 16) ? base + tld<GLB>(T, RC_LW + 16 * j + lane) : 0xFFFFFFFFu;
-    const unsigned long long m2 = __ballot(lane < lim && f <= v);
-    const uint32_t l = (uint32_t)__popcll(m2) - 1;
+    const unsigned long long m2 = __ballot(lane < lim && (uint64_t)f * r <= dist);
+    const uint32_t l = m2 ? (uint32_t)__popcll(m2) - 1 : 0;
     const uint32_t c = 16 * j + l;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)l);
     uint32_t hi;
