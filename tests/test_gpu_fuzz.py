@@ -1,0 +1,40 @@
+"""-m gpu: a seeded random sweep over the path's parameters -- k (one- and two-word k-mers), block size, bloom geometry
+(number of hashes, block bits), read length / raggedness / error and N rates, resolution window.  For every draw:
+the HIP encoder's bytes == the oracle's, and the device decoder gives the input back."""
+import random
+
+import pytest
+
+import common
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_parameter_sweep(chunk):
+    import leon_amd
+    from leon_amd import capi
+    rnd = random.Random(2024 + chunk)
+    for it in range(8):
+        k = rnd.choice([5, 9, 15, 21, 27, 31, 32, 33, 40, 47, 55, 63])
+        rpb = rnd.choice([1, 7, 50, 333, 1000])
+        n_hash, nbits = rnd.choice([1, 3, 7, 10]), rnd.choice([6, 9, 12, 14])
+        L = max(rnd.choice([k, k + 1, 40, 100, 151, 260]), 8)
+        n = rnd.choice([1, 17, 400, 1500])
+        kw = dict(err=rnd.choice([0, 0.01, 0.08]), n_rate=rnd.choice([0, 0.002, 0.05]), ragged=rnd.random() < 0.5)
+        what = dict(k=k, rpb=rpb, n_hash=n_hash, nbits=nbits, L=L, n=n, **kw)
+        bases, off = common.synthetic(n, L, rnd.choice([300, 3000, 20000]), seed=1000 * chunk + it, **kw)
+        bl, solid, tai = common.make_bloom(bases, off, k, rnd.choice([1, 2, 3]), n_hash, nbits)
+        ref = O.encode(bases, off, k, rpb, bl, trace=False)
+        ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=rpb, bloom_tai=tai, bloom_n_hash=n_hash,
+                                        bloom_block_nbits=nbits, resolve_window=rnd.choice([0, 16, 300]))
+        ctx.bloom_upload(bl.bits)
+        blocks = ctx.encode_batch(bases, off)
+        d, na = ctx.finish()
+        assert [b[1] for b in blocks] == ref.blocks and d == ref.anchor_dict and na == ref.n_anchors, what
+        reads = [bases[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+        nb = [sum(len(r) for r in reads[b * rpb:(b + 1) * rpb]) for b in range(len(blocks))]
+        got = ctx.decode_blocks(capi.anchor_dict_decode(d, na, k), blocks, nb)
+        assert got == [bytes(c if c in b"ACGT" else ord("N") for c in r) for r in reads], what
+        ctx.close()
