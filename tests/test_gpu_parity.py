@@ -357,7 +357,22 @@ def test_c_abi_error_behaviour():
     ctx.reset_stream()                                                   # a new file on the same context
     ref = O.encode(bases, off, k, rpb, bl, trace=False)
     assert [b[1] for b in ctx.encode_batch(bases, off)] == ref.blocks
-    assert ctx.finish()[0] == ref.anchor_dict
+    d, na = ctx.finish()
+    assert d == ref.anchor_dict
+    # the decode entry point: a block table that promises fewer bases than the payload holds, a dictionary stream that is
+    # not one, wrong anchors -- status codes and messages, no crash
+    blocks = [(i, b, nr) for i, (b, nr) in enumerate(zip(ref.blocks, ref.block_nreads))]
+    anchors = capi.anchor_dict_decode(d, na, k)
+    nb = [int(off[min(450, (b + 1) * rpb)] - off[b * rpb]) for b in range(len(blocks))]
+    assert len(ctx.decode_blocks(anchors, blocks, nb)) == 450
+    with pytest.raises(leon_amd.LeonDnaError) as e:
+        ctx.decode_blocks(anchors, blocks, [x - 5 for x in nb])
+    assert e.value.code == -1 and "does not decode" in str(e.value)
+    with pytest.raises(leon_amd.LeonDnaError) as e:
+        ctx.decode_blocks(anchors[:10], blocks, nb)
+    assert e.value.code == -1
+    with pytest.raises(leon_amd.LeonDnaError):
+        capi.anchor_dict_decode(bytes(255 - x for x in d), na, k)
     ctx.close()
 
 
