@@ -146,7 +146,7 @@ __device__ inline uint8_t bin2nt(uint32_t c) { return (uint8_t)("ACTGN"[c % 5]);
 
 // err[0]: 0 ok; otherwise 1 + the first failing block in err[1] (code: 1 address/position out of range, 2 output
 // overflow, 3 too many N / error positions in one read)
-template <typename K>
+template <typename K, bool DEEP>
 __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors,
                                                      const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads,
                                                      const uint64_t* blk_read0, const uint64_t* blk_out0, uint64_t n_blocks,
@@ -278,16 +278,25 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
                     pos += step;
                     return nt_seed;
                 };
-                // Two positions per memory round trip: lane 0 probes the current k-mer, lanes 1..4 its four possible
-                // successors at the same time (the other lanes repeat lane 0's addresses, which costs no traffic), so
-                // when the first position is decided the probe of the k-mer it leads to is already there.
+                // Two (DEEP: three) positions per memory round trip: lane 0 probes the current k-mer, lanes 1..4 its four
+                // possible successors, DEEP lanes 5..20 the sixteen k-mers two steps ahead (the other lanes repeat lane
+                // 0's addresses, which costs no traffic), so when a position is decided the probe of the k-mer it leads
+                // to is already there.  DEEP asks for 21 probe sets per round: only for files with few blocks, where
+                // the chip's random-sector rate is not the limit.
+                auto succ = [&](K x, uint32_t nt) -> K {
+                    return dir == 1 ? (((x << 2) | (K)nt) & kmk) : ((x >> 2) | ((K)nt << (2 * (k - 1))));
+                };
                 while (pos >= 0 && pos < (int64_t)len) {
-                    const uint32_t cand = (lane - 1) & 3u;
                     K km = kmer;
-                    if (lane >= 1 && lane <= 4) km = dir == 1 ? (((kmer << 2) | (K)cand) & kmk) : ((kmer >> 2) | ((K)cand << (2 * (k - 1))));
+                    if (lane >= 1 && lane <= 4) km = succ(kmer, (lane - 1) & 3u);
+                    if (DEEP && lane >= 5 && lane <= 20) km = succ(succ(kmer, ((lane - 5) >> 2) & 3u), (lane - 5) & 3u);
                     const uint32_t res = bloom_contains4<K>(B, rv16, km, revcomp(km, k), dir == 1);
                     const uint32_t seed0 = advance((uint32_t)__builtin_amdgcn_readlane((int)res, 0));
-                    if (pos >= 0 && pos < (int64_t)len) (void)advance((uint32_t)__builtin_amdgcn_readlane((int)res, (int)(1 + seed0)));
+                    if (pos >= 0 && pos < (int64_t)len) {
+                        const uint32_t seed1 = advance((uint32_t)__builtin_amdgcn_readlane((int)res, (int)(1 + seed0)));
+                        if (DEEP && pos >= 0 && pos < (int64_t)len)
+                            (void)advance((uint32_t)__builtin_amdgcn_readlane((int)res, (int)(5 + 4 * seed0 + seed1)));
+                    }
                 }
             }
             if (lane == 0) for (uint64_t i = 0; i < nN; i++) {                                       // also inside the anchor
@@ -307,10 +316,12 @@ void launch_decode_blocks(hipStream_t s, BloomDev B, const uint16_t* rv16, const
                           uint32_t* pool, unsigned long long* pool_cursor, uint64_t pool_words, int* err) {
     if (!n_blocks) return;
     const uint32_t g = (uint32_t)(n_blocks > 256 * 9 ? 256 * 9 : n_blocks);
-    if (B.k >= 32) hipLaunchKernelGGL(k_decode_blocks<u128>, dim3(g), dim3(64), 0, s, B, rv16, anchors, n_anchors, payloads, pay_off, blk_reads,
-                                      blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err);
-    else hipLaunchKernelGGL(k_decode_blocks<uint64_t>, dim3(g), dim3(64), 0, s, B, rv16, anchors, n_anchors, payloads, pay_off, blk_reads,
-                            blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err);
+    const bool deep = n_blocks <= 600;                       // 21 probe sets per round and wave: fine while few waves are in flight
+#define DC_LAUNCH(KT, D) hipLaunchKernelGGL((k_decode_blocks<KT, D>), dim3(g), dim3(64), 0, s, B, rv16, anchors, n_anchors, payloads, pay_off, \
+                                            blk_reads, blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err)
+    if (B.k >= 32) { if (deep) DC_LAUNCH(u128, true); else DC_LAUNCH(u128, false); }
+    else { if (deep) DC_LAUNCH(uint64_t, true); else DC_LAUNCH(uint64_t, false); }
+#undef DC_LAUNCH
 }
 
 }  // namespace leon
