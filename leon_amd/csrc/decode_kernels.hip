@@ -8,6 +8,7 @@
 // hides the memory latency of the bloom probes (one dependent probe set per decoded base).
 #include "kernels.h"
 #include "rc_model.h"
+#include <cstdlib>
 
 namespace leon {
 
@@ -281,8 +282,8 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
                 // Two (DEEP: three) positions per memory round trip: lane 0 probes the current k-mer, lanes 1..4 its four
                 // possible successors, DEEP lanes 5..20 the sixteen k-mers two steps ahead (the other lanes repeat lane
                 // 0's addresses, which costs no traffic), so when a position is decided the probe of the k-mer it leads
-                // to is already there.  DEEP asks for 21 probe sets per round: only for files with few blocks, where
-                // the chip's random-sector rate is not the limit.
+                // to is already there.  DEEP asks for 21 probe sets per round; with 2 000 waves in flight that is ~45 G sectors/s,
+                // still under the chip's random-sector rate.
                 auto succ = [&](K x, uint32_t nt) -> K {
                     return dir == 1 ? (((x << 2) | (K)nt) & kmk) : ((x >> 2) | ((K)nt << (2 * (k - 1))));
                 };
@@ -316,7 +317,8 @@ void launch_decode_blocks(hipStream_t s, BloomDev B, const uint16_t* rv16, const
                           uint32_t* pool, unsigned long long* pool_cursor, uint64_t pool_words, int* err) {
     if (!n_blocks) return;
     const uint32_t g = (uint32_t)(n_blocks > 256 * 9 ? 256 * 9 : n_blocks);
-    const bool deep = n_blocks <= 600;                       // 21 probe sets per round and wave: fine while few waves are in flight
+    static const char* force = getenv("LEON_DC_DEEP");       // measurement override
+    const bool deep = force ? force[0] == '1' : true;        // 21 probe sets per round and wave: measured better at 200 and at 2 000 blocks
 #define DC_LAUNCH(KT, D) hipLaunchKernelGGL((k_decode_blocks<KT, D>), dim3(g), dim3(64), 0, s, B, rv16, anchors, n_anchors, payloads, pay_off, \
                                             blk_reads, blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err)
     if (B.k >= 32) { if (deep) DC_LAUNCH(u128, true); else DC_LAUNCH(u128, false); }
