@@ -181,6 +181,13 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     if (cfg->bloom_n_hash < 1 || cfg->bloom_n_hash > 10) return fail(nullptr, LEON_E_INVALID, "bloom_n_hash must be in 1..10");
     if (cfg->bloom_block_nbits < 4 || cfg->bloom_block_nbits > 16)
         return fail(nullptr, LEON_E_INVALID, "bloom_block_nbits must be in 4..16");
+    {   // BloomNeighborCoherent's modulus tai' - 2 * blk must stay positive (bloom_tai = 0 makes tai a power of two, tai' = tai - 1
+        // < 2 * blk), and an absurd size is refused here rather than by hipMalloc
+        const uint64_t blk0 = 1ull << cfg->bloom_block_nbits;
+        uint64_t tai0 = cfg->bloom_tai + 2 * blk0;
+        if ((tai0 & (tai0 - 1)) == 0) tai0--;
+        if (tai0 <= 2 * blk0 || cfg->bloom_tai > (1ull << 46)) return fail(nullptr, LEON_E_INVALID, "bloom_tai out of range (1 .. 2^46 bits)");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, LEON_E_NO_DEVICE, "no HIP device: the DNA encode path has no CPU fallback");
@@ -208,7 +215,6 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     c->bloom_nchar = 1 + tai / 8;
     if ((tai & (tai - 1)) == 0) tai--;
     uint64_t reduced = tai - 2 * blk;
-    if (reduced == 0) { leon_dna_ctx_destroy(c); return fail(nullptr, LEON_E_INVALID, "bloom_tai too small"); }
     CREATE_CHK(hipMalloc((void**)&c->d_bloom, c->bloom_nchar + 16));
     CREATE_CHK(hipMemsetAsync(c->d_bloom, 0, c->bloom_nchar + 16, c->stream));
     uint16_t rv16[256];

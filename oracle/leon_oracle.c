@@ -149,6 +149,7 @@ static const uint8_t cano2[16] = { 0, 1, 2, 3, 4, 5, 3, 7, 8, 9, 0, 4, 9, 13, 1,
 
 lo_bloom* lo_bloom_new(uint64_t tai_bloom, uint32_t k, uint32_t n_hash, uint32_t block_nbits) {
     if (k < 3 || k > 63 || n_hash < 1 || n_hash > 10 || block_nbits < 4 || block_nbits > 16) return NULL;
+    if (tai_bloom == 0 || tai_bloom > (1ULL << 46)) return NULL;   /* the modulus tai - 2*blk would not be positive */
     rv_init();
     lo_bloom* b = (lo_bloom*)calloc(1, sizeof(*b));
     /* BloomCacheCoherent ctor: Bloom(tai_bloom + 2*(1<<block_nbits), nbHash) */

@@ -51,6 +51,11 @@ def test_config_validation_messages(lib):
         with pytest.raises(leon_amd.LeonDnaError) as e:
             leon_amd.DnaEncodeContext(bloom_tai=1000, **kw)
         assert e.value.code == -1
+    # bloom_tai = 0 would make BloomNeighborCoherent's modulus non-positive (every probe out of bounds): refused up front
+    for tai in (0, 1 << 50):
+        with pytest.raises(leon_amd.LeonDnaError) as e:
+            leon_amd.DnaEncodeContext(bloom_tai=tai)
+        assert e.value.code == -1 and "bloom_tai" in str(e.value)
 
 
 def test_product_does_not_touch_the_oracle():
