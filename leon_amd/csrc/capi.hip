@@ -398,14 +398,18 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     // ---- pack ----
     HIPCHK(c, c->slot_off.ensure((n + 1) * 8));
-    launch_read_slots(s, d_off, n, c->slot_off.as<uint64_t>());
+    HIPCHK(c, hipMemsetAsync(c->counters.as<uint32_t>() + 4, 0, 4, s));
+    launch_read_slots(s, d_off, n, c->slot_off.as<uint64_t>(), c->counters.as<uint32_t>() + 4);
     size_t tmp_bytes = 0;
     HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
     if (int rc = ensure_cub(c, tmp_bytes)) return rc;
     HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
     uint64_t n_slots = 0;
+    uint32_t bad_offsets = 0;
     HIPCHK(c, hipMemcpyAsync(&n_slots, c->slot_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&bad_offsets, c->counters.as<uint32_t>() + 4, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (bad_offsets) return fail(c, LEON_E_INVALID, "offsets are not monotonic (or a read is longer than 2^31 bases)");
     HIPCHK(c, c->packed.ensure((n_slots * 2 + 16) * 4));     // wave loads reach 12 dwords past a pass start
     HIPCHK(c, c->nmask.ensure((n_slots + 4) * 4));
     HIPCHK(c, c->rlen.ensure(n * 4));

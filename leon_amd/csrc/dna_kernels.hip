@@ -56,9 +56,15 @@ void launch_bloom_query(hipStream_t s, BloomDev B, const uint16_t* rv16, const u
 // ================================================================================================
 // pack: ASCII -> 2-bit words + N mask  (DnaEncoder::buildKmers replaces N by 'A' and remembers _Npos)
 // ================================================================================================
-__global__ void k_read_slots(const uint64_t* off, uint64_t n, uint64_t* slots) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x)
-        slots[i] = i < n ? (off[i + 1] - off[i] + 31) / 32 : 0;
+__global__ void k_read_slots(const uint64_t* off, uint64_t n, uint64_t* slots, uint32_t* bad) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t len = 0;
+        if (i < n) {
+            len = off[i + 1] - off[i];
+            if (off[i + 1] < off[i] || len >= (1ull << 31)) { atomicOr(bad, 1u); len = 0; }     // not an offsets array: refused by the caller
+        }
+        slots[i] = (len + 31) / 32;
+    }
 }
 __global__ void k_rebase_offsets(uint64_t* off, uint64_t n, uint64_t base) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) off[i] -= base;
@@ -66,8 +72,8 @@ __global__ void k_rebase_offsets(uint64_t* off, uint64_t n, uint64_t base) {
 void launch_rebase_offsets(hipStream_t s, uint64_t* off, uint64_t n, uint64_t base) {
     hipLaunchKernelGGL(k_rebase_offsets, dim3(grid_for(n, 256)), dim3(256), 0, s, off, n, base);
 }
-void launch_read_slots(hipStream_t s, const uint64_t* off, uint64_t n, uint64_t* slots) {
-    hipLaunchKernelGGL(k_read_slots, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, off, n, slots);
+void launch_read_slots(hipStream_t s, const uint64_t* off, uint64_t n, uint64_t* slots, uint32_t* bad) {
+    hipLaunchKernelGGL(k_read_slots, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, off, n, slots, bad);
 }
 
 // One LANE per read: the vector-memory pipeline costs ~64 cycles per wave-wide load instruction whatever the number of

@@ -47,7 +47,7 @@ void launch_bloom_query(hipStream_t s, BloomDev B, const uint16_t* rv16, const u
                         int mode /*0 contains, 1 contains4 left, 2 contains4 right*/, uint8_t* out);
 // ---- pack ----
 void launch_rebase_offsets(hipStream_t s, uint64_t* off, uint64_t n, uint64_t base);
-void launch_read_slots(hipStream_t s, const uint64_t* base_off, uint64_t n, uint64_t* slots);
+void launch_read_slots(hipStream_t s, const uint64_t* base_off, uint64_t n, uint64_t* slots, uint32_t* bad /*set when an offset pair is not a read*/);
 void launch_pack(hipStream_t s, const uint8_t* bases, const uint64_t* base_off, const uint64_t* slot_off, uint64_t n,
                  uint32_t* packed, uint32_t* nmask, uint32_t* len, uint32_t* n_count);
 // ---- anchor resolution ----

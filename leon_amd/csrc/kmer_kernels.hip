@@ -120,14 +120,20 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     const uint32_t W = kmer_words(k);
     // ---- pack the reads once ----
     Buf slot_off, packed, nmask, rlen, ncount, tmp, pos;
+    Buf bad;
     KCHK(slot_off.alloc((n_reads + 1) * 8));
-    launch_read_slots(s, d_offsets, n_reads, slot_off.as<uint64_t>());
+    KCHK(bad.alloc(4));
+    KCHK(hipMemsetAsync(bad.p, 0, 4, s));
+    launch_read_slots(s, d_offsets, n_reads, slot_off.as<uint64_t>(), bad.as<uint32_t>());
     size_t tb = 0;
     KCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, slot_off.as<uint64_t>(), slot_off.as<uint64_t>(), n_reads + 1, s));
     KCHK(tmp.alloc(tb));
     KCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, slot_off.as<uint64_t>(), slot_off.as<uint64_t>(), n_reads + 1, s));
     uint64_t n_slots = 0;
     KCHK(hipMemcpy(&n_slots, slot_off.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
+    uint32_t bad_offsets = 0;
+    KCHK(hipMemcpy(&bad_offsets, bad.p, 4, hipMemcpyDeviceToHost));
+    if (bad_offsets) { set_create_error("kmer_solid: offsets are not monotonic (or a read is longer than 2^31 bases)"); return LEON_E_INVALID; }
     KCHK(packed.alloc((n_slots * 2 + 16) * 4)); KCHK(nmask.alloc((n_slots + 4) * 4)); KCHK(rlen.alloc(n_reads * 4)); KCHK(ncount.alloc(n_reads * 4));
     KCHK(hipMemsetAsync(packed.as<uint32_t>() + n_slots * 2, 0, 64, s));
     launch_pack(s, d_bases, d_offsets, slot_off.as<uint64_t>(), n_reads, packed.as<uint32_t>(), nmask.as<uint32_t>(), rlen.as<uint32_t>(), ncount.as<uint32_t>());

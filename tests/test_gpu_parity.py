@@ -374,6 +374,16 @@ def test_c_abi_error_behaviour():
     with pytest.raises(leon_amd.LeonDnaError):
         capi.anchor_dict_decode(bytes(255 - x for x in d), na, k)
     ctx.close()
+    # offsets that are not an offsets array are refused before any kernel indexes with them
+    ctx = _ctx(k, rpb, tai)
+    ctx.bloom_upload(bl.bits)
+    bad = np.array(off[:101], dtype=np.uint64)
+    bad[50] = bad[52] + 7
+    with pytest.raises(leon_amd.LeonDnaError) as e:
+        ctx.encode_batch(bases, bad)
+    assert e.value.code == -1 and "monotonic" in str(e.value)
+    assert len(ctx.encode_batch(bases, off[:101])) == 1               # the context is still usable
+    ctx.close()
 
 
 @pytest.mark.parametrize("k,min_ab,maxkeys", [(31, 3, 0), (31, 1, 50000), (21, 2, 0), (47, 3, 0), (63, 2, 40000)])
