@@ -501,3 +501,20 @@ def test_device_decoder_edge_cases():
     rr = [b2[int(off2[i]):int(off2[i + 1])].tobytes() for i in range(150)] + [b1.tobytes()] + \
          [b2[int(off2[i]):int(off2[i + 1])].tobytes() for i in range(150, 300)]
     _decode_round_trip(rr, k, 120)
+
+
+def test_degenerate_batches():
+    """empty and near-empty inputs through both directions: only empty reads, a single one-base read, blocks made of reads
+    shorter than k, no reads at all"""
+    import leon_amd
+    k = 31
+    bl = (O.Bloom(1000, k), None, 1000)
+    _decode_round_trip([b""] * 7, k, 3, bloom=bl)
+    _decode_round_trip([b"A"], k, 5, bloom=bl)
+    _decode_round_trip([b"ACGTN" * 3, b"", b"T", b"NNNN"] * 5, k, 4, bloom=bl)
+    ctx = _ctx(k, 10, 1000)
+    assert ctx.encode_batch(b"", np.zeros(1, dtype=np.uint64)) == []
+    d, na = ctx.finish()
+    assert na == 0 and d == O.encode(b"", np.zeros(1, dtype=np.uint64), k, 10, bl[0], trace=False).anchor_dict
+    assert ctx.decode_blocks(np.zeros(0, dtype=np.uint64), [], []) == []
+    ctx.close()
