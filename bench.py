@@ -42,9 +42,13 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("LEON_BENCH_CPU_SAMPLE", 4_000_000)),
                     help="reads timed through the CPU restatement on rank 0 at N=1 (0 = skip)")
     ap.add_argument("--err", type=float, default=0.01)
+    ap.add_argument("--kmer-max-keys", type=int, default=0, help="k-mers sorted per pass by the solid k-mer counter (0 = sized by the library)")
     ap.add_argument("--decode", action="store_true",
                     help="also decode the whole file on the device (DnaDecoder, SURVEY 8f-1) and compare it with the input; "
                          "reported as `decode`, never as value")
+    ap.add_argument("--verify", action="store_true",
+                    help="one more UNTIMED step whose sink hashes every block: `verify.blocks_sha256` is a checksum of block "
+                         "checksums over the union of all ranks' blocks (equal for every world size), plus the dictionary stream's")
     ap.add_argument("--host-input", action="store_true",
                     help="also time ONE step through leon_dna_encode_batch (reads in pageable host memory, PCIe included); "
                          "reported as pcie_inclusive, never as value")
@@ -57,8 +61,9 @@ def gen_genome(G, device):
     return torch.randint(0, 4, (G,), dtype=torch.uint8, device=device, generator=g)   # gatb codes A0 C1 T2 G3
 
 
-def gen_reads_chunk(genome, chunk_id, n, err, device):
+def gen_reads_chunk(genome, chunk_id, n, err, device, L=None):
     """reads of chunk `chunk_id` (same bytes whatever the world size): uint8 [n, L] ASCII"""
+    L = L or globals()["L"]
     g = torch.Generator(device=device)
     g.manual_seed(43 + chunk_id)
     G = genome.numel()
@@ -139,7 +144,8 @@ def main():
     n_solid_t = torch.zeros(1, dtype=torch.int64, device=device)
     d_solid = 0
     if rank == 0:
-        d_solid, n_solid = capi.kmer_solid_device(reads.data_ptr(), offsets.data_ptr(), n_total, K, ABUNDANCE, device_id=local)
+        d_solid, n_solid = capi.kmer_solid_device(reads.data_ptr(), offsets.data_ptr(), n_total, K, ABUNDANCE, device_id=local,
+                                                  max_keys_per_pass=a.kmer_max_keys)
         n_solid_t[0] = n_solid
     count_s = time.time() - t_b
     if world > 1:
@@ -189,24 +195,62 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    times, walk_ms, stage = [], [], None
-    for _ in range(a.steps):
+    # the very first pass through the path in this process (whether it is a warm-up or a timed step): what `leon -c`,
+    # which encodes a file exactly once, sees -- allocations, code-object loads and all
+    cold_ms = [None]
+
+    def timed_step():
         sync()
         t0 = time.perf_counter()
-        dict_bytes, n_anchors = step()
+        r = step()
         sync()
-        times.append(time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
+        if cold_ms[0] is None:
+            cold_ms[0] = dt * 1e3
+        return r, dt
+
+    for _ in range(a.warmup):
+        timed_step()
+    times, walk_ms, dev_ms, stage = [], [], [], None
+    for _ in range(a.steps):
+        (dict_bytes, n_anchors), dt = timed_step()
+        times.append(dt)
         st = ctx.stats()
         walk_ms.append(st["ms_walk"])
+        dev_ms.append(st["ms_total"])
         stage = st
-    total_s = torch.tensor([sum(times)], dtype=torch.float64, device=device)
+    # max over ranks: whole step, device stages alone (HIP events on each rank's stream), cold first step
+    red = torch.tensor([sum(times), float(np.mean(dev_ms)), cold_ms[0]], dtype=torch.float64, device=device)
     if world > 1:
-        dist.all_reduce(total_s, op=dist.ReduceOp.MAX)
-    total_s = float(total_s.item())
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+    total_s, device_ms_max, cold_first_step_ms = float(red[0].item()), float(red[1].item()), float(red[2].item())
     ms_per_step = total_s / a.steps * 1e3
     value = n_total * L / 1e6 / (total_s / a.steps)
+
+    verify = None
+    if a.verify:
+        import hashlib
+        mine = []
+
+        def hsink(user, block_id, p, size, n_reads):
+            mine.append((int(block_id), hashlib.sha256(ctypes.string_at(p, size)).hexdigest(), int(n_reads)))
+            return 0
+        hcb = capi.SINK(hsink)
+        ctx.reset_stream()
+        ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_total, sink=hcb)
+        dstream, na_v = ctx.finish()
+        tables = [mine]
+        if world > 1:
+            tables = [None] * world
+            dist.all_gather_object(tables, mine)
+        if rank == 0:
+            from leon_amd.shard import merge_block_tables
+            h = hashlib.sha256()
+            for bid, digest, nr in merge_block_tables(tables):       # raises on a gap or a duplicate block
+                h.update(bytes.fromhex(digest) + bid.to_bytes(8, "little") + nr.to_bytes(4, "little"))
+            verify = {"blocks_sha256": h.hexdigest(), "n_blocks": sum(len(t) for t in tables),
+                      "dict_sha256": hashlib.sha256(dstream).hexdigest(), "n_anchors": int(na_v),
+                      "blocks_per_rank": [len(t) for t in tables]}
 
     # dominant kernel: k_walk, HIP events recorded on the library's launch stream around each launch
     walk_avg_ms = float(np.mean(walk_ms))
@@ -243,7 +287,7 @@ def main():
     decode = None
     if a.decode and world == 1:
         kept = []
-        keep = capi.SINK(lambda user, bid, ptr, size, nreads: (kept.append((int(bid), bytes(ptr[:size]), int(nreads))), 0)[1])
+        keep = capi.SINK(lambda user, bid, ptr, size, nreads: (kept.append((int(bid), ctypes.string_at(ptr, size), int(nreads))), 0)[1])
         ctx.reset_stream()
         ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_total, sink=keep)
         dstream, n_anchors = ctx.finish()
@@ -267,6 +311,11 @@ def main():
         out = {
             "metric": "compressed input MB/s (DNA encode path)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
+            "cold_first_step_ms": round(cold_first_step_ms, 2),
+            # the multi-GPU truth: the job also waits for the file-wide dictionary stream, one serial
+            # chain on a host core of rank 0 whatever N is; the device stages are what shards
+            "device_ms_max_over_ranks": round(device_ms_max, 2), "host_chain_ms": round(stage["ms_chain_busy"], 2),
+            "value_device_only": round(n_total * L / 1e6 / (device_ms_max * 1e-3), 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%d x %d bp synthetic reads, k=%d, genome %d bp (30x), 1%% substitutions, "
                                    "bloom %d bits/k-mer x %d hashes over the reads' %d solid k-mers (abundance >= %d, device counter)"
@@ -281,6 +330,7 @@ def main():
             "cpu_baseline": cpu,
             "pcie_inclusive": pcie,
             "decode": decode,
+            "verify": verify,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
                       "symbols": stage["n_symbols"], "resolve_rounds": stage["resolve_rounds"],

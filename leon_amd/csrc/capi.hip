@@ -10,6 +10,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -24,19 +25,33 @@ thread_local std::string g_create_error;
 namespace leon { void set_create_error(const std::string& msg) { g_create_error = msg; } }
 namespace {
 
+const bool g_trace_alloc = getenv("LEON_TRACE_ALLOC") != nullptr;   // measurement aid: device allocations of 1 ms or more on stderr
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
+        auto t0 = std::chrono::steady_clock::now();
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
+        if (g_trace_alloc) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms >= 1.0) fprintf(stderr, "[leon alloc] %.1f MB in %.1f ms\n", want / 1e6, ms);
+        }
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <typename T> T* as() const { return (T*)p; }
+};
+// a device buffer that lives for one call: released on every way out of the scope
+struct TmpBuf : DevBuf {
+    TmpBuf() = default;
+    TmpBuf(const TmpBuf&) = delete;
+    TmpBuf& operator=(const TmpBuf&) = delete;
+    ~TmpBuf() { release(); }
 };
 
 uint64_t splitmix_rv(uint32_t idx) {     // built-in simplehash16 table, see DESIGN.md "recalled constants"
@@ -80,6 +95,7 @@ struct leon_dna_ctx {
     uint64_t next_read = 0, next_block = 0;
     uint32_t shard_rank = 0, shard_world = 1;    // leon_dna_set_shard
     bool partial_seen = false, finished = false;
+    bool poisoned = false;                       // a batch failed after it had started to change the stream: LEON_E_STATE until reset_stream
     // batch buffers
     DevBuf in_bases, in_off, slot_off, packed, nmask, rlen, ncount;
     DevBuf status, hit_pos, hit_slot, cand_pos, cand_slot, anchor_pos, anchor_addr, flags, sort_key, ins_flag, rank;
@@ -105,24 +121,29 @@ int fail(leon_dna_ctx* c, int code, const std::string& msg) {
             return fail((c), LEON_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
     } while (0)
 
+void dict_free(DictDev& D) {
+    if (D.slots) (void)hipFree(D.slots);
+    if (D.tent && D.tstride == 1) (void)hipFree(D.tent);     // two-word keys keep tent inside the slots
+    if (D.addr) (void)hipFree(D.addr);
+    D = DictDev{};
+}
 int dict_alloc(leon_dna_ctx* c, DictDev& D, uint64_t cap) {
     const uint32_t W = kmer_words(c->cfg.kmer_size);
-    HIPCHK(c, hipMalloc((void**)&D.keys, cap * 8 * W));
-    HIPCHK(c, hipMalloc((void**)&D.fin, cap * 8));
-    HIPCHK(c, hipMalloc((void**)&D.tent, cap * 8));
-    HIPCHK(c, hipMalloc((void**)&D.addr, cap * 4));
+    D = DictDev{};
+    hipError_t e = hipMalloc((void**)&D.slots, cap * 16 * W);
+    if (e == hipSuccess && W == 1) { D.tstride = 1; e = hipMalloc((void**)&D.tent, cap * 8); }
+    if (e == hipSuccess) e = hipMalloc((void**)&D.addr, cap * 4);
+    if (e != hipSuccess) {                                    // nothing of a half-built table is kept
+        dict_free(D);
+        return fail(c, LEON_E_HIP, std::string("anchor dictionary allocation: ") + hipGetErrorString(e));
+    }
+    if (W == 2) { D.tent = D.slots + 3; D.tstride = 4; }
     D.mask = cap - 1;
     D.n_keys = c->d_nkeys;
     D.wbits = c->wbits.as<uint32_t>();
+    D.err = c->errflag.as<int>() + 2;
     launch_dict_init(c->stream, D, cap, W);
     return LEON_OK;
-}
-void dict_free(DictDev& D) {
-    if (D.keys) (void)hipFree(D.keys);
-    if (D.fin) (void)hipFree(D.fin);
-    if (D.tent) (void)hipFree(D.tent);
-    if (D.addr) (void)hipFree(D.addr);
-    D = DictDev{};
 }
 // capacity >= 4 * keys: the look-up kernels are bound by chains of dependent loads, not by the table footprint
 int dict_reserve(leon_dna_ctx* c, uint64_t keys) {
@@ -156,7 +177,8 @@ ReadsDev reads_view(leon_dna_ctx* c, const uint64_t* d_off, uint64_t n) {
 // resolves a group while the next ones are still crossing PCIe
 struct Upload {
     std::atomic<uint64_t> reads_done{0};                       // reads whose bases are in HBM
-    std::atomic<int> failed{0};
+    std::atomic<int> failed{0};                                // 1: a copy failed; 2: the offsets do not describe one buffer
+    std::atomic<int> cancel{0};                                // set by the caller when the batch has failed: stop copying
     std::thread th;
     ~Upload() { if (th.joinable()) th.join(); }
 };
@@ -228,6 +250,7 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     CREATE_CHK(hipMemset(c->d_nkeys, 0, 8));
     CREATE_CHK(c->counters.ensure(64));
     CREATE_CHK(c->errflag.ensure(16));
+    CREATE_CHK(hipMemsetAsync(c->errflag.p, 0, 16, c->stream));
     CREATE_CHK(c->wbits.ensure((1ull << WBITS_LOG2) / 8));
     CREATE_CHK(hipStreamSynchronize(c->stream));
 #undef CREATE_CHK
@@ -298,14 +321,11 @@ int leon_dna_bloom_insert(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n) {
     if (!c || (!kmers && n)) return LEON_E_INVALID;
     if (!n) return LEON_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    DevBuf tmp;
+    TmpBuf tmp;
     const uint64_t bytes = n * 8 * kmer_words(c->cfg.kmer_size);
     HIPCHK(c, tmp.ensure(bytes));
-    hipError_t e = hipMemcpy(tmp.p, kmers, bytes, hipMemcpyHostToDevice);
-    int rc = e == hipSuccess ? leon_dna_bloom_insert_device(c, tmp.as<uint64_t>(), n)
-                             : fail(c, LEON_E_HIP, std::string("bloom_insert H2D: ") + hipGetErrorString(e));
-    tmp.release();
-    return rc;
+    HIPCHK(c, hipMemcpy(tmp.p, kmers, bytes, hipMemcpyHostToDevice));
+    return leon_dna_bloom_insert_device(c, tmp.as<uint64_t>(), n);
 }
 int leon_dna_bloom_device_ptr(leon_dna_ctx* c, void** p, uint64_t* n) {
     if (!c || !p || !n) return LEON_E_INVALID;
@@ -332,7 +352,7 @@ static int bloom_query(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, int m
     if (!c || ((!kmers || !out) && n)) return LEON_E_INVALID;
     if (!n) return LEON_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    DevBuf dk, dout;
+    TmpBuf dk, dout;
     const uint64_t bytes = n * 8 * kmer_words(c->cfg.kmer_size);
     HIPCHK(c, dk.ensure(bytes));
     HIPCHK(c, dout.ensure(n));
@@ -341,7 +361,6 @@ static int bloom_query(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, int m
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, dout.p, n, hipMemcpyDeviceToHost));
-    dk.release(); dout.release();
     return LEON_OK;
 }
 int leon_dna_bloom_contains4(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, int right, uint8_t* out) {
@@ -355,9 +374,22 @@ int leon_dna_bloom_contains(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, 
 static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
                              uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up);
 
+// A batch that fails before it has touched the stream (bad arguments, bad offsets, call order) leaves the context as it was.
+// One that fails later -- a HIP error, an internal bound, the sink -- leaves the dictionary, the dictionary-stream thread
+// and the caller's block sequence part-way through the batch: the context is poisoned and every call on the stream
+// returns LEON_E_STATE until leon_dna_reset_stream starts a new one.
+static int encode_batch_guarded(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
+                                uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up) {
+    if (!c) return LEON_E_INVALID;
+    if (c->poisoned) return fail(c, LEON_E_STATE, "an earlier batch failed part-way: the stream is unusable until leon_dna_reset_stream");
+    const int rc = encode_batch_impl(c, d_bases, d_off, n, first_read_index, sink, user, up);
+    if (rc != LEON_OK && c->poisoned) c->err += " (stream poisoned: leon_dna_reset_stream to go on)";
+    return rc;
+}
+
 int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
                                  uint64_t first_read_index, leon_block_sink sink, void* user) {
-    return encode_batch_impl(c, d_bases, d_off, n, first_read_index, sink, user, nullptr);
+    return encode_batch_guarded(c, d_bases, d_off, n, first_read_index, sink, user, nullptr);
 }
 
 // reads [0, group_end(a)) are packed (and, through the host entry point, uploaded) together: the first resolution window
@@ -381,7 +413,6 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     if (!d_bases || !d_off || !sink) return fail(c, LEON_E_INVALID, "null argument");
     if (n > 0xFFFFFFF0ull) return fail(c, LEON_E_INVALID, "more than 2^32 reads in one batch");
     const uint32_t rpb = c->cfg.reads_per_block, k = c->cfg.kmer_size;
-    if (n % rpb) c->partial_seen = true;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->stats = leon_dna_stats{};
@@ -424,6 +455,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         const uint64_t a = packed_upto, b = group_end(a, n, c->cfg.resolve_window, up != nullptr);
         if (up) {
             while (up->reads_done.load(std::memory_order_acquire) < b && !up->failed.load()) std::this_thread::yield();
+            if (up->failed.load() == 2) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
             if (up->failed.load()) return fail(c, LEON_E_HIP, "upload of the read bases failed");
         }
         if (c->pack_ev.size() < 2 * (size_t)(n_pack_ev + 1)) {
@@ -462,6 +494,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     size_t scan_tmp = 0;
     HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), W, s));
     if (int rc = ensure_cub(c, scan_tmp)) return rc;
+    c->poisoned = true;             // from here on the dictionary and the dictionary stream change: cleared on success
     for (uint64_t w0 = 0, w1 = 0; w0 < n; w0 = w1) {
         w1 = std::min(n, w0 + (w0 == 0 ? first_window(W) : W));
         if (int rc = dict_reserve(c, c->n_keys + (w1 - w0))) return rc;
@@ -469,8 +502,14 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         HIPCHK(c, hipMemsetAsync(c->wbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
         launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters);
         uint32_t cnt = 0;
+        int dict_err = 0;
         HIPCHK(c, hipMemcpyAsync(&cnt, counters, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&dict_err, c->D.err, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        if (dict_err) {
+            HIPCHK(c, hipMemsetAsync(c->D.err, 0, 4, s));
+            return fail(c, LEON_E_STATE, "anchor dictionary: a two-word key stayed half-written (a stalled wave); batch abandoned");
+        }
         const uint32_t cnt0 = cnt;
         int cur = 0;
         while (cnt > 0) {
@@ -499,12 +538,12 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             if (c->n_anchors + n_new > 0xFFFFFFFFull) return fail(c, LEON_E_OVERFLOW, "more than 2^32 anchors");
             const uint64_t KW = kmer_words(k);                              // 64-bit words per anchor k-mer
             if ((c->n_anchors + n_new) * 8 * KW > c->anchor_kmers.cap) {      // grow, keeping what is there
-                DevBuf nb;
+                TmpBuf nb;
                 HIPCHK(c, nb.ensure(std::max<uint64_t>((c->n_anchors + n_new) * 2, 1024) * 8 * KW));
                 if (c->n_anchors) HIPCHK(c, hipMemcpyAsync(nb.p, c->anchor_kmers.p, c->n_anchors * 8 * KW, hipMemcpyDeviceToDevice, s));
                 HIPCHK(c, hipStreamSynchronize(s));
-                c->anchor_kmers.release();
-                c->anchor_kmers = nb;
+                std::swap(static_cast<DevBuf&>(nb).p, c->anchor_kmers.p);        // nb now holds the old buffer and releases it
+                std::swap(static_cast<DevBuf&>(nb).cap, c->anchor_kmers.cap);
             }
             launch_assign_addr(s, c->D, V, w0, w1, c->rank.as<uint32_t>(), c->n_anchors, c->anchor_kmers.as<uint64_t>(), k);
             if (n_new && c->shard_rank == 0 && !(c->cfg.flags & LEON_F_DICT_ON_DEVICE)) {   // the window's new anchors go straight to the host thread coding the dictionary stream
@@ -545,6 +584,8 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         float pack2 = 0; for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
         c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_total = ms(0, 2);
         c->next_read += n; c->next_block += n_blocks;
+        if (n % rpb) c->partial_seen = true;
+        c->poisoned = false;
         return LEON_OK;
     }
 
@@ -630,7 +671,6 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
     c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5);
     c->stats.ms_symbols = ms(5, 6); c->stats.ms_rangecoder = ms(6, 7); c->stats.ms_d2h = ms(7, 8); c->stats.ms_total = ms(0, 8);
-    c->next_read += n;
 
     // ---- Leon::writeBlock, in block order ----
     const uint8_t* hp = (const uint8_t*)c->h_payload;
@@ -638,7 +678,10 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         uint32_t nr = (uint32_t)std::min<uint64_t>(rpb, n - (lb0 + b) * rpb);
         if (sink(user, c->next_block + lb0 + b, hp + dst[b], sizes[b], nr)) return fail(c, LEON_E_SINK, "block sink returned non-zero");
     }
+    c->next_read += n;
     c->next_block += n_blocks;
+    if (n % rpb) c->partial_seen = true;
+    c->poisoned = false;
     (void)k;
     return LEON_OK;
 }
@@ -666,20 +709,25 @@ int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t*
     const uint64_t window = c->cfg.resolve_window;
     up.th = std::thread([&up, dev, dst, bases, off, n, window] {
         if (hipSetDevice(dev) != hipSuccess) { up.failed.store(1); return; }
-        for (uint64_t a = 0; a < n;) {
+        for (uint64_t a = 0; a < n && !up.cancel.load();) {
             const uint64_t b = group_end(a, n, window, true);
+            // every copy stays inside [off[0], off[n]) of the caller's buffer and of in_bases, whatever the entries between
+            // the group boundaries are (the device checks those one by one and refuses the batch)
+            if (off[a] < off[0] || off[b] < off[a] || off[b] > off[n]) { up.failed.store(2); return; }
             if (hipMemcpy(dst + (off[a] - off[0]), bases + off[a], off[b] - off[a], hipMemcpyHostToDevice) != hipSuccess) { up.failed.store(1); return; }
             up.reads_done.store(b, std::memory_order_release);
             a = b;
         }
     });
-    const int rc = encode_batch_impl(c, dst, c->in_off.as<uint64_t>(), n, first_read_index, sink, user, &up);
+    const int rc = encode_batch_guarded(c, dst, c->in_off.as<uint64_t>(), n, first_read_index, sink, user, &up);
+    if (rc != LEON_OK) up.cancel.store(1);
     up.th.join();
     return rc;
 }
 
 int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, uint64_t* n_anchors) {
     if (!c || !payload || !size || !n_anchors) return LEON_E_INVALID;
+    if (c->poisoned) return fail(c, LEON_E_STATE, "an earlier batch failed part-way: the stream is unusable until leon_dna_reset_stream");
     auto t0 = std::chrono::steady_clock::now();
     if (c->cfg.flags & LEON_F_DICT_ON_DEVICE) {
         if (!c->finished) {
@@ -688,7 +736,7 @@ int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, ui
                 HIPCHK(c, hipSetDevice(c->device));
                 hipStream_t s = c->stream;
                 const uint64_t nsym = c->n_anchors * c->cfg.kmer_size;
-                DevBuf dsyms, dbegin, doff, dsize, dout, dscr;
+                TmpBuf dsyms, dbegin, doff, dsize, dout, dscr;
                 HIPCHK(c, dsyms.ensure(nsym * 2 + 256)); HIPCHK(c, dbegin.ensure(16)); HIPCHK(c, doff.ensure(16)); HIPCHK(c, dsize.ensure(8));
                 const uint64_t begin[2] = { 0, nsym }, off[2] = { 0, ((3 * nsym + 7) & ~7ull) + 64 };
                 HIPCHK(c, dout.ensure(off[1] + 64)); HIPCHK(c, dscr.ensure(rc_model_scratch_bytes(1)));
@@ -706,7 +754,6 @@ int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, ui
                 if (errflag) return fail(c, LEON_E_OVERFLOW, "dictionary stream: device range coder bound hit");
                 c->dict_device_out.resize(sz);
                 if (sz) HIPCHK(c, hipMemcpy(c->dict_device_out.data(), dout.p, sz, hipMemcpyDeviceToHost));
-                dsyms.release(); dbegin.release(); doff.release(); dsize.release(); dout.release(); dscr.release();
             }
             c->finished = true;
         }
@@ -747,7 +794,7 @@ int leon_dna_reset_stream(leon_dna_ctx* c) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->n_keys = 0; c->n_anchors = 0;
-    c->next_read = 0; c->next_block = 0; c->partial_seen = false; c->finished = false;
+    c->next_read = 0; c->next_block = 0; c->partial_seen = false; c->finished = false; c->poisoned = false;
     c->last_n = 0; c->last_bases = 0;
     return LEON_OK;
 }
@@ -784,12 +831,11 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
         if (payload_off[b + 1] < payload_off[b]) return fail(c, LEON_E_INVALID, "payload offsets are not monotonic");
         read0[b + 1] = read0[b] + block_n_reads[b];
         out0[b + 1] = out0[b] + block_n_bases[b];
+        if (out0[b + 1] < out0[b] || out0[b + 1] > out_cap) return fail(c, LEON_E_INVALID, "output capacity below the sum of block_n_bases");
     }
     if (out0[n_blocks] > out_cap) return fail(c, LEON_E_INVALID, "output capacity below the sum of block_n_bases");
     const uint64_t pay_bytes = payload_off[n_blocks] - payload_off[0];
-    DevBuf d_anchors, d_pay, d_off, d_nreads, d_read0, d_out0, d_out, d_len, d_scr, d_err, d_pool;
-    struct Release { std::vector<DevBuf*> v; ~Release() { for (DevBuf* b : v) b->release(); } } rel;
-    rel.v = { &d_anchors, &d_pay, &d_off, &d_nreads, &d_read0, &d_out0, &d_out, &d_len, &d_scr, &d_err, &d_pool };
+    TmpBuf d_anchors, d_pay, d_off, d_nreads, d_read0, d_out0, d_out, d_len, d_scr, d_err, d_pool;
     HIPCHK(c, d_anchors.ensure(std::max<uint64_t>(n_anchors * W, 1) * 8));
     HIPCHK(c, d_pay.ensure(pay_bytes + 1024));                 // the payload window reads up to 256 + 3 bytes past a block's end
     HIPCHK(c, d_off.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_nreads.ensure(n_blocks * 4));
@@ -886,7 +932,7 @@ int leon_rc_encode_streams(leon_dna_ctx* c, const uint8_t* syms, const uint64_t*
         uint32_t m = syms[2 * i], v = syms[2 * i + 1];
         if (m >= N_MODELS || (m < N_SMALL_MODELS && v >= small_model_size(m))) return fail(c, LEON_E_INVALID, "bad symbol");
     }
-    DevBuf dsyms, dbegin, doff, dsize, dout, dscr;
+    TmpBuf dsyms, dbegin, doff, dsize, dout, dscr;
     HIPCHK(c, dsyms.ensure(n_syms * 2 + 256)); HIPCHK(c, dbegin.ensure((n_streams + 1) * 8)); HIPCHK(c, doff.ensure((n_streams + 1) * 8));
     HIPCHK(c, dsize.ensure(n_streams * 8)); HIPCHK(c, dscr.ensure(rc_model_scratch_bytes(n_streams)));
     std::vector<uint64_t> off(n_streams + 1);
@@ -912,7 +958,6 @@ int leon_rc_encode_streams(leon_dna_ctx* c, const uint8_t* syms, const uint64_t*
         if (e != hipSuccess) { rc = fail(c, LEON_E_HIP, hipGetErrorString(e)); break; }
         w += sizes[b];
     }
-    dsyms.release(); dbegin.release(); doff.release(); dsize.release(); dout.release(); dscr.release();
     return rc;
 }
 

@@ -141,6 +141,9 @@ __device__ inline uint64_t decode_numeric(Dec& d, uint32_t group) {
 __device__ inline uint64_t from_delta(uint32_t type, uint64_t prev, uint64_t delta) {
     return type == 0 ? delta : (type == 1 ? prev + delta : prev - delta);
 }
+// bounds on payload-derived values, written so that nothing wraps: w <= wcap always holds
+__host__ __device__ inline bool len_fits(uint64_t len, uint64_t w, uint64_t wcap) { return len < (1ull << 31) && len <= wcap - w; }
+__host__ __device__ inline bool anchor_fits(uint64_t apos, uint64_t len, uint32_t k) { return len >= k && apos <= len - k; }
 __device__ inline uint8_t bin2nt(uint32_t c) { return (uint8_t)("ACTGN"[c % 5]); }
 
 }  // namespace
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
             const uint32_t type = decode_sym(d, M_READ_TYPE);
             if (type == 1) {                                  // DnaDecoder::decodeNoAnchorRead
                 const uint64_t len = decode_numeric(d, G_NOANCHOR_READSIZE);
-                if (w + len > wcap) { fail = 2; break; }
+                if (!len_fits(len, w, wcap)) { fail = 2; break; }
                 for (uint64_t i = 0; i < len; i++) {
                     const uint32_t c = decode_sym(d, M_NOANCHOR_READ);
                     if (lane == 0) out[w + i] = bin2nt(c);
@@ -208,8 +211,9 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
             dt = decode_sym(d, M_ANCHORADDR_DT); dv = decode_numeric(d, G_ANCHOR_ADDRESS);
             const uint64_t addr = from_delta(dt, prevAddr, dv); prevAddr = addr;
             const uint32_t rev = decode_sym(d, M_ANCHOR_REVCOMP);
-            if (addr >= n_anchors || apos + k > len) { fail = 1; break; }
-            if (w + len > wcap) { fail = 2; break; }
+            // values from the payload: compared without sums that could wrap (a crafted delta of type 2 makes them ~2^64)
+            if (!len_fits(len, w, wcap)) { fail = 2; break; }
+            if (addr >= n_anchors || !anchor_fits(apos, len, k)) { fail = 1; break; }
             const uint64_t nN = decode_numeric(d, G_NUMERIC);
             if (nN > len) { fail = 3; break; }
             uint32_t* Npos = nN > DC_LIST_CAP ? pool_alloc(nN) : Nblk;
@@ -307,6 +311,7 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
             if (lane == 0) out_len[r0 + r] = (uint32_t)len;
             w += len;
         }
+        if (!fail && w != wcap) fail = 2;                    // the block table promised exactly wcap - blk_out0[b] bases
         if (fail && lane == 0) { if (atomicCAS(err, 0, fail) == 0) err[1] = (int)b; }
     }
 }

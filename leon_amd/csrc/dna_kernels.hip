@@ -130,37 +130,47 @@ void launch_pack(hipStream_t s, const uint8_t* bases, const uint64_t* off, const
 
 // ================================================================================================
 // anchor dictionary (Leon::anchorExist / findAndInsertAnchor with sequential, -nb-cores 1 semantics)
-// One-word keys: keys[slot], KEY_EMPTY when free.  Two-word keys: keys[2*slot] = low, keys[2*slot+1] = high word;
+// Slot layout (kernels.h DictDev): one-word keys { key, fin }, KEY_EMPTY when free; two-word keys { lo, hi, fin, tent },
 // the high word (< 2^62 for a real k-mer) doubles as the claim word: KEY_EMPTY free, KEY_LOCKED while the low word is written.
+// A look-up reads the key AND fin with one 16-byte load (one-word keys) or from the same 32-byte half sector.
 // ================================================================================================
+template <typename K> struct DS;
+template <> struct DS<uint64_t> { static constexpr uint32_t STRIDE = 2, CLAIM = 0, FIN = 1; };
+template <> struct DS<u128> { static constexpr uint32_t STRIDE = 4, CLAIM = 1, FIN = 2; };
+template <typename K> __device__ inline uint64_t* slot_ptr(const DictDev& D, uint64_t slot) { return D.slots + slot * DS<K>::STRIDE; }
+template <typename K> __device__ inline uint64_t* fin_ptr(const DictDev& D, uint64_t slot) { return slot_ptr<K>(D, slot) + DS<K>::FIN; }
+__device__ inline uint64_t* tent_ptr(const DictDev& D, uint64_t slot) { return D.tent + slot * D.tstride; }
+
 __global__ void k_dict_init(DictDev D, uint64_t cap, uint32_t W) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
-        D.keys[i * W] = KEY_EMPTY; if (W == 2) D.keys[i * 2 + 1] = KEY_EMPTY;
-        D.fin[i] = IDX_INF; D.tent[i] = IDX_INF; D.addr[i] = 0;
+        if (W == 2) { D.slots[4 * i] = KEY_EMPTY; D.slots[4 * i + 1] = KEY_EMPTY; D.slots[4 * i + 2] = IDX_INF; D.slots[4 * i + 3] = IDX_INF; }
+        else { D.slots[2 * i] = KEY_EMPTY; D.slots[2 * i + 1] = IDX_INF; D.tent[i] = IDX_INF; }
+        D.addr[i] = 0;
     }
 }
 void launch_dict_init(hipStream_t s, DictDev D, uint64_t cap, uint32_t W) {
     hipLaunchKernelGGL(k_dict_init, dim3(grid_for(cap, 256)), dim3(256), 0, s, D, cap, W);
 }
 
-// ---- look-up (any lane; 0xFFFFFFFF if absent).  A key being inserted by the running kernel may be missed: such a
-// key is only proposed (fin = INF), so missing it changes nothing.
-__device__ inline uint32_t dict_find(const DictDev& D, uint64_t key) {
+// ---- look-up (any lane; 0xFFFFFFFF if absent); fin = the slot's fin word as the same load saw it.  A key being inserted
+// by the running kernel may be missed: such a key is only proposed (fin = INF), so missing it changes nothing; a fin
+// older than a concurrent k_check store reads as "not final yet", which that round treats as blocked (tent <= the storer).
+__device__ inline uint32_t dict_find(const DictDev& D, uint64_t key, uint64_t& fin) {
     uint64_t slot = key_hash(key) & D.mask;
     for (;;) {
-        uint64_t cur = D.keys[slot];
-        if (cur == key) return (uint32_t)slot;
-        if (cur == KEY_EMPTY) return 0xFFFFFFFFu;
+        const ulonglong2 v = *(const ulonglong2*)(D.slots + 2 * slot);          // one 16-byte load: key and fin
+        if (v.x == key) { fin = v.y; return (uint32_t)slot; }
+        if (v.x == KEY_EMPTY) return 0xFFFFFFFFu;
         slot = (slot + 1) & D.mask;
     }
 }
-__device__ inline uint32_t dict_find(const DictDev& D, u128 key) {
+__device__ inline uint32_t dict_find(const DictDev& D, u128 key, uint64_t& fin) {
     const uint64_t klo = (uint64_t)key, khi = (uint64_t)(key >> 64);
     uint64_t slot = key_hash(key) & D.mask;
     for (;;) {
-        const uint64_t hi = D.keys[2 * slot + 1];
-        if (hi == KEY_EMPTY) return 0xFFFFFFFFu;
-        if (hi == khi && D.keys[2 * slot] == klo) return (uint32_t)slot;
+        const ulonglong2 v = *(const ulonglong2*)(D.slots + 4 * slot);          // { lo, hi }
+        if (v.y == KEY_EMPTY) return 0xFFFFFFFFu;
+        if (v.y == khi && v.x == klo) { fin = D.slots[4 * slot + 2]; return (uint32_t)slot; }   // same sector as the key
         slot = (slot + 1) & D.mask;
     }
 }
@@ -171,10 +181,11 @@ template <typename K> __device__ inline uint32_t window_bit(K key) { return (uin
 template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDev& D, uint64_t key, bool& created) {
     uint64_t slot = key_hash(key) & D.mask;
     for (;;) {
-        uint64_t cur = D.keys[slot];
+        uint64_t* pk = D.slots + 2 * slot;
+        uint64_t cur = *pk;
         if (cur == key) return (uint32_t)slot;
         if (cur == KEY_EMPTY) {
-            uint64_t old = atomicCAS((unsigned long long*)&D.keys[slot], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+            uint64_t old = atomicCAS((unsigned long long*)pk, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
             if (old == KEY_EMPTY) { created = true; return (uint32_t)slot; }
             if (old == key) return (uint32_t)slot;
         }
@@ -185,38 +196,44 @@ template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDe
     const uint64_t klo = (uint64_t)key, khi = (uint64_t)(key >> 64);
     uint64_t slot = key_hash(key) & D.mask;
     for (;;) {
-        uint64_t* phi = &D.keys[2 * slot + 1];
+        uint64_t* plo = D.slots + 4 * slot;
+        uint64_t* phi = plo + 1;
         uint64_t hi = __hip_atomic_load(phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (hi == KEY_EMPTY) {
             hi = atomicCAS((unsigned long long*)phi, (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_LOCKED);
             if (hi == KEY_EMPTY) {                                       // ours: low word first, then publish the high word
-                __hip_atomic_store(&D.keys[2 * slot], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(plo, klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(phi, khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 created = true;
                 return (uint32_t)slot;
             }
         }
         if (SPIN) {
-            for (uint32_t spin = 0; hi == KEY_LOCKED && spin < (1u << 20); spin++) {
+            // the other inserter is a lane of ANOTHER wave that is two stores away from publishing: it cannot be waiting for
+            // us.  Should the wait ever run out (a stalled wave), the batch is failed through D.err rather than probing on
+            // and inserting the same key twice.
+            uint32_t spin = 0;
+            for (; hi == KEY_LOCKED && spin < (1u << 22); spin++) {
                 __builtin_amdgcn_s_sleep(1);
                 hi = __hip_atomic_load(phi, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (hi == KEY_LOCKED) { atomicExch(D.err, 1); return (uint32_t)slot; }
         }
-        if (hi == khi && __hip_atomic_load(&D.keys[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == klo) return (uint32_t)slot;
+        if (hi == khi && __hip_atomic_load(plo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == klo) return (uint32_t)slot;
         slot = (slot + 1) & D.mask;
     }
 }
 template <typename K> __device__ inline K dict_key(const DictDev& D, uint32_t slot);
-template <> __device__ inline uint64_t dict_key<uint64_t>(const DictDev& D, uint32_t slot) { return D.keys[slot]; }
-template <> __device__ inline u128 dict_key<u128>(const DictDev& D, uint32_t slot) { return ((u128)D.keys[2 * (uint64_t)slot + 1] << 64) | D.keys[2 * (uint64_t)slot]; }
+template <> __device__ inline uint64_t dict_key<uint64_t>(const DictDev& D, uint32_t slot) { return D.slots[2 * (uint64_t)slot]; }
+template <> __device__ inline u128 dict_key<u128>(const DictDev& D, uint32_t slot) { return ((u128)D.slots[4 * (uint64_t)slot + 1] << 64) | D.slots[4 * (uint64_t)slot]; }
 
 template <typename K> __global__ void k_dict_rehash(DictDev from, uint64_t from_cap, DictDev to) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < from_cap; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (from.keys[i * KT<K>::W + (KT<K>::W - 1)] == KEY_EMPTY) continue;
+        if (from.slots[i * DS<K>::STRIDE + DS<K>::CLAIM] == KEY_EMPTY) continue;
         bool created = false;
         uint32_t s = dict_find_or_insert<false>(to, dict_key<K>(from, (uint32_t)i), created);
         if (created) atomicAdd(to.n_keys, 1ull);
-        to.fin[s] = from.fin[i]; to.tent[s] = IDX_INF; to.addr[s] = from.addr[i];
+        *fin_ptr<K>(to, s) = *fin_ptr<K>(from, i); *tent_ptr(to, s) = IDX_INF; to.addr[s] = from.addr[i];
     }
 }
 void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to, uint32_t k) {
@@ -288,7 +305,7 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
             const K cn = canon_from_words16<K>(words, gbase, base, valid ? p : (run ? limit - 1 : 0), k);   // all 64 lanes
             bool hit = false; uint32_t slot = 0xFFFFFFFFu;
             if (valid) {
-                if (phase == PH_LOOKUP) { slot = dict_find(D, cn); hit = slot != 0xFFFFFFFFu && D.fin[slot] < g; }
+                if (phase == PH_LOOKUP) { uint64_t fin = IDX_INF; slot = dict_find(D, cn, fin); hit = slot != 0xFFFFFFFFu && fin < g; }
                 else hit = bloom_contains<K>(B, rv16, cn);
             }
             const unsigned long long bal = __ballot(hit);
@@ -310,7 +327,7 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
             for (uint32_t q = 0; q < 4; q++) {
                 if (want_insert && grp == q) {
                     sl = dict_find_or_insert<true>(D, canon_at<K>(pk, cpos, k), created);
-                    atomicMin((unsigned long long*)&D.tent[sl], (unsigned long long)g);
+                    atomicMin((unsigned long long*)tent_ptr(D, sl), (unsigned long long)g);
                     V.status[i] = ST_UNRESOLVED; V.cand_pos[i] = cpos; V.cand_slot[i] = sl;
                 }
             }
@@ -357,10 +374,11 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
             bool f = false, t = false;
             const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
             if (p < nk) {
-                uint32_t slot = dict_find(D, cn);
+                uint64_t fin = IDX_INF;
+                uint32_t slot = dict_find(D, cn, fin);
                 if (slot != 0xFFFFFFFFu) {
-                    f = __hip_atomic_load(&D.fin[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g;
-                    t = D.tent[slot] < g;
+                    f = fin < g;
+                    t = *tent_ptr(D, slot) < g;
                 }
             }
             anyfin = __ballot(f) != 0;
@@ -372,7 +390,7 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
             else {
                 V.status[i] = ST_INSERTER;
                 const uint32_t slot = V.cand_slot[i];
-                __hip_atomic_store(&D.fin[slot], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(fin_ptr<K>(D, slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t wb = window_bit(dict_key<K>(D, slot));       // k_final_pos only looks up keys whose bit is set
                 atomicOr(&D.wbits[wb >> 5], 1u << (wb & 31));
             }
@@ -389,7 +407,7 @@ void launch_check(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t f
 __global__ void k_reset_tent(DictDev D, ResolveDev V, const uint32_t* list, const uint32_t* count) {
     uint32_t n = *count;
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x)
-        D.tent[V.cand_slot[list[e]]] = IDX_INF;
+        *tent_ptr(D, V.cand_slot[list[e]]) = IDX_INF;
 }
 void launch_reset_tent(hipStream_t s, DictDev D, ResolveDev V, const uint32_t* list, const uint32_t* count, uint32_t max_count) {
     if (!max_count) return;
@@ -399,7 +417,7 @@ __global__ void k_propose(DictDev D, ResolveDev V, uint64_t first_global, const 
     uint32_t n = *count;
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t i = list[e];
-        atomicMin((unsigned long long*)&D.tent[V.cand_slot[i]], (unsigned long long)(first_global + i));
+        atomicMin((unsigned long long*)tent_ptr(D, V.cand_slot[i]), (unsigned long long)(first_global + i));
     }
 }
 void launch_propose(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list,
@@ -440,8 +458,9 @@ __global__ void __launch_bounds__(256) k_final_pos(ReadsDev R, DictDev D, Resolv
                 // "not one of those" for nearly all of them without touching the dictionary
                 const uint32_t wb = window_bit(cn);
                 if ((D.wbits[wb >> 5] >> (wb & 31)) & 1u) {
-                    slot = dict_find(D, cn);
-                    hit = slot != 0xFFFFFFFFu && D.fin[slot] < g;
+                    uint64_t fin = IDX_INF;
+                    slot = dict_find(D, cn, fin);
+                    hit = slot != 0xFFFFFFFFu && fin < g;
                 }
             }
             const unsigned long long bal = __ballot(hit);

@@ -20,14 +20,19 @@ struct ReadsDev {
 };
 
 // anchor dictionary: open addressing, linear probing (replaces Leon::_anchorKmers, Hash16<kmer,u32>)
+// A slot is ONE aligned record, so a look-up and its `fin < g` test touch one 64-byte sector:
+//   one-word keys (k < 32):  16 bytes { key, fin };            tent[] beside it (only unresolved reads touch it)
+//   two-word keys (k >= 32): 32 bytes { key lo, key hi, fin, tent }   (the high word doubles as the claim word)
 struct DictDev {
-    uint64_t* keys;     // canonical k-mer (W words per slot) or KEY_EMPTY in the (high) word
-    uint64_t* fin;      // global index of the read that inserted the key, IDX_INF while only proposed
-    uint64_t* tent;     // smallest global read index currently proposing the key (per resolution round)
-    uint32_t* addr;     // anchor address once assigned
+    uint64_t* slots;    // key = canonical k-mer or KEY_EMPTY in the (high) word; fin = global index of the read that
+                        // inserted the key, IDX_INF while only proposed
+    uint64_t* tent;     // smallest global read index currently proposing the key (per resolution round), at
+    uint64_t tstride;   // tent[slot * tstride]: its own array for one-word keys, word 3 of the slot for two-word keys
+    uint32_t* addr;     // anchor address once assigned (read once per read, after the window's fixpoint)
     uint64_t mask;      // capacity - 1
     unsigned long long* n_keys;
     uint32_t* wbits;    // 2^WBITS_LOG2-bit filter of the keys made final in the current resolution window (k_final_pos)
+    int* err;           // set by a kernel that gave up waiting for another wave's half-written two-word key
 };
 constexpr uint32_t WBITS_LOG2 = 26;
 

@@ -10,7 +10,8 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-
                        os.path.join(here, "gather_ceiling.hip")])
 lib = ctypes.CDLL(so)
 lib.run_gather.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
-for table in (752 << 20, 8 << 30):
+tables = [int(x) << 20 for x in os.environ.get("LEON_GATHER_TABLES_MIB", "752,8192").split(",")]
+for table in tables:
     for dep in (0, 1):
         for blocks in (2048, 8192, 32768):
             iters = 256 if dep == 0 else 64

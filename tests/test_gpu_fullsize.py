@@ -1,6 +1,8 @@
-"""-m gpu: BASELINE.json's single-GPU configurations #2 and #3 at FULL size (10 M and 100 M x 150 bp, k = 31), checked
-through size-independent properties: decode(encode(x)) == x on sampled blocks (oracle decoder), run-to-run determinism,
-and shard-union == single stream via a checksum of block checksums."""
+"""-m gpu: BASELINE.json's single-GPU configurations #2 and #3 at FULL size (10 M and 100 M x 150 bp, k = 31) and
+configuration #5's workload (250 bp reads, k = 63: two-word k-mers) at the read count one GPU holds with the path's
+current buffers -- 40 M reads = 10 G bases (the configuration itself is 500 M reads over 8 GPUs: 62.5 M per GPU) --
+checked through size-independent properties: decode(encode(x)) == x on sampled blocks (oracle decoder), run-to-run
+determinism, shard-union == single stream via a checksum of block checksums, and the device decoder on every base."""
 import hashlib
 import os
 import sys
@@ -14,8 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-K, L, RPB = 31, 150, 50000
-SIZES = [int(x) for x in os.environ.get("LEON_FULLSIZE_READS", "10000000,100000000").split(",")]
+RPB = 50000
+# (reads, k, read length); LEON_FULLSIZE_CASES="n:k:L,..." overrides
+CASES = [tuple(int(v) for v in x.split(":")) for x in
+         os.environ.get("LEON_FULLSIZE_CASES", "10000000:31:150,100000000:31:150,40000000:63:250").split(",")]
 
 
 def _checksum(blocks):
@@ -26,8 +30,8 @@ def _checksum(blocks):
     return h.hexdigest()
 
 
-@pytest.mark.parametrize("N_READS", SIZES)
-def test_full_size_properties(N_READS):
+@pytest.mark.parametrize("N_READS,K,L", CASES, ids=["%dM_k%d_L%d" % (c[0] // 1000000, c[1], c[2]) for c in CASES])
+def test_full_size_properties(N_READS, K, L):
     import torch
     import bench
     import leon_amd
@@ -38,7 +42,7 @@ def test_full_size_properties(N_READS):
     reads = torch.empty((N_READS, L), dtype=torch.uint8, device=dev)
     for c0 in range((N_READS + bench.CHUNK - 1) // bench.CHUNK):
         lo, hi = c0 * bench.CHUNK, min(N_READS, (c0 + 1) * bench.CHUNK)
-        reads[lo:hi] = bench.gen_reads_chunk(genome, c0, bench.CHUNK, 0.01, dev)[:hi - lo]
+        reads[lo:hi] = bench.gen_reads_chunk(genome, c0, bench.CHUNK, 0.01, dev, L=L)[:hi - lo]
     # a few N and a block of garbage reads, so every branch of the path runs at size
     reads[123456, 40] = ord("N"); reads[5_000_001, 0:5] = ord("N")
     g = torch.Generator(device=dev); g.manual_seed(9)
@@ -79,7 +83,7 @@ def test_full_size_properties(N_READS):
     bl = O.Bloom(tai, K)
     bl.set_bits(bits)
     anchors = O.decode_anchor_dict(d, na, K)
-    assert len(anchors) == na
+    assert len(anchors) == na * O.kwords(K)
     host = reads.cpu().numpy()
     for b in (0, 1, 100, 140, n_blocks - 1):               # 100: holds the N reads; 140: the garbage reads
         dec = O.decode_block(K, bl, anchors, blocks[b][1], RPB, RPB * L + 16)
