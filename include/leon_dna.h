@@ -22,14 +22,18 @@
 extern "C" {
 #endif
 
-#define LEON_DNA_ABI_VERSION 1
+#define LEON_DNA_ABI_VERSION 2
 
 enum {
     LEON_OK = 0,
     LEON_E_INVALID = -1,     /* bad argument / configuration */
     LEON_E_NO_DEVICE = -2,   /* no usable HIP device (the product has no CPU path) */
     LEON_E_HIP = -3,         /* HIP runtime error, message carries hipGetErrorString */
-    LEON_E_STATE = -4,       /* call order violated (e.g. encode after finish) */
+    LEON_E_STATE = -4,       /* call order violated (e.g. encode after finish), or the stream is poisoned: a batch that
+                                failed after it had begun to change the stream (HIP error, internal bound, sink) leaves the
+                                dictionary and the caller's block sequence part-way through; every later call on the stream
+                                returns this code until leon_dna_reset_stream.  Batches refused for their arguments
+                                (LEON_E_INVALID, call order) leave the context untouched. */
     LEON_E_OVERFLOW = -5,    /* an internal device buffer bound was hit (reported, never silently truncated) */
     LEON_E_SINK = -6         /* the block sink returned non-zero */
 };
@@ -142,6 +146,34 @@ int leon_dna_decode_blocks(leon_dna_ctx* ctx, const uint64_t* anchors, uint64_t 
  * out_kmers: n_anchors * W words. */
 int leon_host_anchor_dict_decode(const uint8_t* payload, uint64_t size, uint64_t n_anchors, uint32_t kmer_size,
                                  uint64_t* out_kmers);
+
+/* -- the streams either side of the DNA stream --------------------------------------------------
+ * Header stream, Leon::startHeaderCompression's Dispatcher::iterate(bank, HeaderEncoder(this)) [RECALLED]: headers
+ * (text after '>' / '@', no newline) back to back with offsets[n_reads + 1], in file order; first_header: the file's
+ * first header, which every block starts from (AbstractHeaderCoder::startBlock; upstream stores it in the metadata).
+ * Same batching rules and sink contract as leon_dna_encode_batch; the header stream keeps its own read / block
+ * counters on the context and follows leon_dna_set_shard.  Record layout: DESIGN.md section 1.3. */
+int leon_header_encode_batch(leon_dna_ctx* ctx, const uint8_t* headers, const uint64_t* offsets, uint64_t n_reads,
+                             uint64_t first_read_index, const uint8_t* first_header, uint64_t first_header_len,
+                             leon_block_sink sink, void* user);
+int leon_header_encode_batch_device(leon_dna_ctx* ctx, const uint8_t* d_headers, const uint64_t* d_offsets, uint64_t n_reads,
+                                    uint64_t first_read_index, const uint8_t* first_header, uint64_t first_header_len,
+                                    leon_block_sink sink, void* user);
+/* Host-only (no GPU, no ctx): HeaderDecoder over read blocks, blocks in parallel on n_threads host threads (0 = all).
+ * out: the headers back to back in block order, out_off[total reads + 1]; *out_size = bytes needed (LEON_E_OVERFLOW when
+ * out_cap is smaller: call again with that capacity).  Errors: leon_last_error(NULL). */
+int leon_host_header_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
+                                   uint64_t n_blocks, const uint8_t* first_header, uint64_t first_header_len, uint8_t* out,
+                                   uint64_t out_cap, uint64_t* out_off, uint64_t* out_size, uint32_t n_threads);
+/* Quality stream, lossless form (`-lossless`): per read block the quality lines, each followed by '\n', through zlib
+ * (upstream deflates the block's buffered quality lines, Leon::writeBlockLena [RECALLED]).  Host-only, blocks in parallel
+ * on n_threads threads; blocks go to the sink in increasing id starting at first_block_id.  zlib_level: -1 = zlib default. */
+int leon_host_qual_encode_blocks(const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads, uint32_t reads_per_block,
+                                 int zlib_level, uint32_t n_threads, leon_block_sink sink, void* user, uint64_t first_block_id);
+/* inverse: block_n_bytes = quality bytes per block without the newlines; out_off[total reads + 1] */
+int leon_host_qual_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
+                                 const uint64_t* block_n_bytes, uint64_t n_blocks, uint8_t* out, uint64_t out_cap,
+                                 uint64_t* out_off, uint32_t n_threads);
 
 /* Start a new output file on the same context: forgets the anchor dictionary, the dictionary stream and the
  * read/block counters (a fresh Leon object upstream); keeps the bloom and the device buffers. */

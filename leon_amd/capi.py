@@ -79,6 +79,15 @@ _EXPORTS = {
     "leon_dna_trace_events": (C.c_int, [C.c_void_p, _u8p, C.c_uint64]),
     "leon_dna_anchor_kmers": (C.c_int, [C.c_void_p, _u64p, C.c_uint64]),
     "leon_rc_encode_streams": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_uint64, _u8p, C.c_uint64, _u64p]),
+    "leon_header_encode_batch": (C.c_int, [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64, SINK,
+                                            C.c_void_p]),
+    "leon_header_encode_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64,
+                                                   SINK, C.c_void_p]),
+    "leon_host_header_decode_blocks": (C.c_int, [_u8p, _u64p, _u32p, C.c_uint64, C.c_char_p, C.c_uint64, _u8p, C.c_uint64, _u64p,
+                                                  _u64p, C.c_uint32]),
+    "leon_host_qual_encode_blocks": (C.c_int, [C.c_char_p, _u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, SINK, C.c_void_p,
+                                                C.c_uint64]),
+    "leon_host_qual_decode_blocks": (C.c_int, [_u8p, _u64p, _u32p, _u64p, C.c_uint64, _u8p, C.c_uint64, _u64p, C.c_uint32]),
 }
 EXPORTED_SYMBOLS = tuple(_EXPORTS)
 _lib = None
@@ -134,6 +143,72 @@ def host_anchor_dict_encode(kmers, k):
     if rc:
         raise LeonDnaError(rc, "leon_host_anchor_dict_encode failed")
     return out[:size.value].tobytes()
+
+
+def _join_blocks(blocks):
+    """[(id, payload, n_reads)] -> (payload bytes array, offsets, n_reads array)"""
+    pay = np.frombuffer(b"".join(b[1] for b in blocks) + b"\0", dtype=np.uint8)
+    off = np.zeros(len(blocks) + 1, dtype=np.uint64)
+    if blocks:
+        off[1:] = np.cumsum([len(b[1]) for b in blocks])
+    nr = np.array([b[2] for b in blocks] or [0], dtype=np.uint32)
+    return pay, off, nr
+
+
+def host_header_decode_blocks(blocks, first_header, n_threads=0):
+    """HeaderDecoder on host threads (no GPU): blocks = [(id, payload, n_reads)] -> list of header bytes"""
+    lib = load_library()
+    if not blocks:
+        return []
+    pay, off, nr = _join_blocks(blocks)
+    total = int(nr[:len(blocks)].sum())
+    out_off = np.zeros(total + 1, dtype=np.uint64)
+    need = C.c_uint64()
+    cap = max(64, 64 * total)
+    for _ in range(2):
+        out = np.zeros(cap, dtype=np.uint8)
+        rc = lib.leon_host_header_decode_blocks(_ptr(pay, _u8p), _ptr(off, _u64p), _ptr(nr, _u32p), len(blocks), first_header,
+                                                len(first_header), _ptr(out, _u8p), cap, _ptr(out_off, _u64p), C.byref(need), n_threads)
+        if rc != -5:
+            break
+        cap = need.value
+    if rc:
+        raise LeonDnaError(rc, (lib.leon_last_error(None) or b"").decode())
+    raw = out.tobytes()
+    return [raw[int(out_off[i]):int(out_off[i + 1])] for i in range(total)]
+
+
+def host_qual_encode_blocks(quals, offsets, reads_per_block, zlib_level=-1, n_threads=0, first_block_id=0):
+    """lossless quality stream: [(id, zlib payload, n_reads)] per read block (host-only)"""
+    lib = load_library()
+    blocks = []
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+
+    def cb(user, block_id, payload, size, n_reads):
+        blocks.append((block_id, C.string_at(payload, size), n_reads))
+        return 0
+    rc = lib.leon_host_qual_encode_blocks(bytes(quals), _ptr(offsets, _u64p), len(offsets) - 1, reads_per_block, zlib_level, n_threads,
+                                          SINK(cb), None, first_block_id)
+    if rc:
+        raise LeonDnaError(rc, (lib.leon_last_error(None) or b"").decode())
+    return blocks
+
+
+def host_qual_decode_blocks(blocks, block_n_bytes, n_threads=0):
+    lib = load_library()
+    if not blocks:
+        return []
+    pay, off, nr = _join_blocks(blocks)
+    nb = np.ascontiguousarray(block_n_bytes, dtype=np.uint64)
+    total, cap = int(nr[:len(blocks)].sum()), int(nb.sum())
+    out = np.zeros(cap + 1, dtype=np.uint8)
+    out_off = np.zeros(total + 1, dtype=np.uint64)
+    rc = lib.leon_host_qual_decode_blocks(_ptr(pay, _u8p), _ptr(off, _u64p), _ptr(nr, _u32p), _ptr(nb, _u64p), len(blocks),
+                                          _ptr(out, _u8p), cap, _ptr(out_off, _u64p), n_threads)
+    if rc:
+        raise LeonDnaError(rc, (lib.leon_last_error(None) or b"").decode())
+    raw = out.tobytes()
+    return [raw[int(out_off[i]):int(out_off[i + 1])] for i in range(total)]
 
 
 def kmer_solid(bases, offsets, k, min_abundance, device_id=0, with_histogram=False, max_keys_per_pass=0):
@@ -197,6 +272,7 @@ class DnaEncodeContext:
         self.kmer_size, self.reads_per_block = kmer_size, reads_per_block
         self.bloom_tai, self.bloom_n_hash, self.bloom_block_nbits = int(bloom_tai), bloom_n_hash, bloom_block_nbits
         self.next_read = 0
+        self._hdr_next = 0
 
     def _chk(self, rc):
         if rc:
@@ -292,6 +368,21 @@ class DnaEncodeContext:
         self.next_read += int(n_reads)
         return blocks
 
+    def header_encode_batch(self, headers, first_header=None, sink=None):
+        """HeaderEncoder over a batch of header texts (list of bytes, file order) -> [(block_id, payload, n_reads)]"""
+        blob = b"".join(headers)
+        off = np.zeros(len(headers) + 1, dtype=np.uint64)
+        if headers:
+            off[1:] = np.cumsum([len(h) for h in headers])
+        if first_header is None:
+            first_header = headers[0] if headers else b""
+        blocks = []
+        cb = sink or self._collect_sink(blocks)
+        self._chk(self.lib.leon_header_encode_batch(self.h, blob, _ptr(off, _u64p), len(headers), self._hdr_next, first_header,
+                                                    len(first_header), cb, None))
+        self._hdr_next += len(headers)
+        return blocks
+
     def finish(self, copy=True):
         """(dictionary stream, number of anchors); copy=False returns its size instead of a bytes copy (the C caller
         gets a pointer into the context and writes from there: a 100 M-read file's stream is 110 MB)"""
@@ -330,6 +421,7 @@ class DnaEncodeContext:
         self._chk(self.lib.leon_dna_set_shard(self.h, rank, world))
 
     def reset_stream(self):
+        self._hdr_next = 0
         self._chk(self.lib.leon_dna_reset_stream(self.h))
         self.next_read = 0
 

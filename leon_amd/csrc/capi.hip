@@ -95,6 +95,9 @@ struct leon_dna_ctx {
     uint64_t next_read = 0, next_block = 0;
     uint32_t shard_rank = 0, shard_world = 1;    // leon_dna_set_shard
     bool partial_seen = false, finished = false;
+    uint64_t hdr_next_read = 0, hdr_next_block = 0;   // the header stream's own counters (leon_header_encode_batch)
+    bool hdr_partial_seen = false;
+    DevBuf hdr_first;
     bool poisoned = false;                       // a batch failed after it had started to change the stream: LEON_E_STATE until reset_stream
     // batch buffers
     DevBuf in_bases, in_off, slot_off, packed, nmask, rlen, ncount;
@@ -269,7 +272,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
                        &c->status, &c->hit_pos, &c->hit_slot, &c->cand_pos, &c->cand_slot, &c->anchor_pos, &c->anchor_addr,
                        &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
                        &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
-                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits };
+                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->hdr_first };
     for (DevBuf* b : bufs) b->release();
     if (c->d_bloom) (void)hipFree(c->d_bloom);
     if (c->d_rv16) (void)hipFree(c->d_rv16);
@@ -725,6 +728,129 @@ int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t*
     return rc;
 }
 
+
+// ------------------------------------------------------------------------------------------------ header stream
+// Leon::startHeaderCompression: Dispatcher::iterate(bank, HeaderEncoder(this)) [RECALLED].  Records of every header
+// against the previous one in parallel (hdr_kernels.hip), then the per-block chains on k_rc_encode with the header
+// stream's model set; blocks leave through the sink in increasing id, like the DNA stream's.
+static int header_batch_impl(leon_dna_ctx* c, const uint8_t* d_hdr, const uint64_t* d_off, uint64_t n, uint64_t first_read_index,
+                             const uint8_t* first_header, uint64_t first_len, leon_block_sink sink, void* user) {
+    if (!c) return LEON_E_INVALID;
+    if (first_read_index != c->hdr_next_read) return fail(c, LEON_E_STATE, "first_read_index does not continue the header stream");
+    if (c->hdr_partial_seen && n) return fail(c, LEON_E_STATE, "a batch with a partial block must be the last one");
+    if (n == 0) return LEON_OK;
+    if (!d_hdr || !d_off || !sink || (!first_header && first_len)) return fail(c, LEON_E_INVALID, "null argument");
+    if (n > 0xFFFFFFF0ull) return fail(c, LEON_E_INVALID, "more than 2^32 reads in one batch");
+    if (first_len >= (1ull << 31)) return fail(c, LEON_E_INVALID, "first header longer than 2^31 bytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint32_t rpb = c->cfg.reads_per_block;
+    const uint64_t n_blocks = (n + rpb - 1) / rpb;
+    // offsets must be an offsets array before anything indexes with them (headers below 2^31 bytes each)
+    HIPCHK(c, c->slot_off.ensure((n + 1) * 8));
+    HIPCHK(c, hipMemsetAsync(c->counters.as<uint32_t>() + 4, 0, 4, s));
+    launch_read_slots(s, d_off, n, c->slot_off.as<uint64_t>(), c->counters.as<uint32_t>() + 4);
+    uint32_t bad_offsets = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad_offsets, c->counters.as<uint32_t>() + 4, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (bad_offsets) return fail(c, LEON_E_INVALID, "offsets are not monotonic (or a header is longer than 2^31 bytes)");
+    // this rank's share: the same contiguous block range as the DNA stream's
+    uint64_t lb0 = 0, lb1 = n_blocks;
+    if (c->shard_world > 1) {
+        const uint64_t q = n_blocks / c->shard_world, rm = n_blocks % c->shard_world, rk = c->shard_rank;
+        lb0 = rk * q + std::min<uint64_t>(rk, rm);
+        lb1 = lb0 + q + (rk < rm ? 1 : 0);
+    }
+    const uint64_t nbl = lb1 - lb0;
+    const uint64_t r0 = std::min<uint64_t>(n, lb0 * rpb), r1 = std::min<uint64_t>(n, lb1 * rpb), nl = r1 - r0;
+    if (nl) {
+        HIPCHK(c, c->hdr_first.ensure(first_len + 16));
+        if (first_len) HIPCHK(c, hipMemcpyAsync(c->hdr_first.p, first_header, first_len, hipMemcpyHostToDevice, s));
+        HIPCHK(c, c->sym_off.ensure((nl + 1) * 8));
+        HIPCHK(c, hipMemsetAsync(c->sym_off.as<uint64_t>() + nl, 0, 8, s));
+        launch_hdr_symbols(s, d_hdr, d_off + r0, nl, rpb, c->hdr_first.as<uint8_t>(), (uint32_t)first_len, c->sym_off.as<uint64_t>(), nullptr);
+        size_t tmp_bytes = 0;
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
+        if (int rc = ensure_cub(c, tmp_bytes)) return rc;
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
+        uint64_t n_syms = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_syms, c->sym_off.as<uint64_t>() + nl, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, c->syms.ensure(n_syms * 2 + 256));
+        launch_hdr_symbols(s, d_hdr, d_off + r0, nl, rpb, c->hdr_first.as<uint8_t>(), (uint32_t)first_len, c->sym_off.as<uint64_t>(), c->syms.as<uint8_t>());
+        HIPCHK(c, c->blk_begin.ensure((nbl + 1) * 8)); HIPCHK(c, c->out_off.ensure((nbl + 1) * 8));
+        HIPCHK(c, c->out_size.ensure(nbl * 8)); HIPCHK(c, c->dst_off.ensure((nbl + 1) * 8));
+        launch_block_ranges(s, c->sym_off.as<uint64_t>(), nl, rpb, nbl, c->blk_begin.as<uint64_t>(), c->out_off.as<uint64_t>());
+        HIPCHK(c, c->rc_out.ensure(3 * n_syms + 72 * (nbl + 1)));
+        HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
+        HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
+        launch_rc_encode(s, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, c->rc_out.as<uint8_t>(), c->out_off.as<uint64_t>(),
+                         c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>(), SMALL_SIZES_HEADER);
+        HIPCHK(c, hipGetLastError());
+        std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
+        int errflag = 0;
+        HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, nbl * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (errflag) return fail(c, LEON_E_OVERFLOW, errflag == 2 ? "a header block has 2^30 symbols or more"
+                                                                  : "range coder output exceeded its 3 bytes/symbol bound");
+        for (uint64_t b = 0; b < nbl; b++) dst[b + 1] = dst[b] + sizes[b];
+        const uint64_t payload_bytes = dst[nbl];
+        HIPCHK(c, c->payload.ensure(payload_bytes + 16));
+        HIPCHK(c, hipMemcpyAsync(c->dst_off.p, dst.data(), (nbl + 1) * 8, hipMemcpyHostToDevice, s));
+        launch_gather_payload(s, c->rc_out.as<uint8_t>(), c->out_off.as<uint64_t>(), c->dst_off.as<uint64_t>(), c->out_size.as<uint64_t>(),
+                              nbl, c->payload.as<uint8_t>());
+        if (payload_bytes + 16 > c->h_payload_cap) {
+            if (c->h_payload) HIPCHK(c, hipHostFree(c->h_payload));
+            c->h_payload = nullptr; c->h_payload_cap = 0;
+            size_t want = payload_bytes + payload_bytes / 4 + 4096;
+            HIPCHK(c, hipHostMalloc(&c->h_payload, want, hipHostMallocDefault));
+            c->h_payload_cap = want;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_payload, c->payload.p, payload_bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const uint8_t* hp = (const uint8_t*)c->h_payload;
+        for (uint64_t b = 0; b < nbl; b++) {
+            const uint32_t nr = (uint32_t)std::min<uint64_t>(rpb, n - (lb0 + b) * rpb);
+            if (sink(user, c->hdr_next_block + lb0 + b, hp + dst[b], sizes[b], nr)) {
+                c->poisoned = true;                             // the caller holds part of the batch's blocks
+                return fail(c, LEON_E_SINK, "block sink returned non-zero (stream poisoned: leon_dna_reset_stream to go on)");
+            }
+        }
+    }
+    c->hdr_next_read += n;
+    c->hdr_next_block += n_blocks;
+    if (n % rpb) c->hdr_partial_seen = true;
+    return LEON_OK;
+}
+
+int leon_header_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_headers, const uint64_t* d_off, uint64_t n, uint64_t first_read_index,
+                                    const uint8_t* first_header, uint64_t first_header_len, leon_block_sink sink, void* user) {
+    if (!c) return LEON_E_INVALID;
+    if (c->poisoned) return fail(c, LEON_E_STATE, "an earlier batch failed part-way: the stream is unusable until leon_dna_reset_stream");
+    return header_batch_impl(c, d_headers, d_off, n, first_read_index, first_header, first_header_len, sink, user);
+}
+
+int leon_header_encode_batch(leon_dna_ctx* c, const uint8_t* headers, const uint64_t* off, uint64_t n, uint64_t first_read_index,
+                             const uint8_t* first_header, uint64_t first_header_len, leon_block_sink sink, void* user) {
+    if (!c) return LEON_E_INVALID;
+    if (n == 0) return leon_header_encode_batch_device(c, nullptr, nullptr, 0, first_read_index, first_header, first_header_len, sink, user);
+    if (!headers || !off) return fail(c, LEON_E_INVALID, "null argument");
+    if (off[n] < off[0]) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t nb = off[n] - off[0];
+    HIPCHK(c, c->in_bases.ensure(nb + 64));
+    HIPCHK(c, c->in_off.ensure((n + 1) * 8));
+    HIPCHK(c, hipMemcpy(c->in_off.p, off, (n + 1) * 8, hipMemcpyHostToDevice));
+    if (off[0]) {
+        launch_rebase_offsets(c->stream, c->in_off.as<uint64_t>(), n + 1, off[0]);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (nb) HIPCHK(c, hipMemcpy(c->in_bases.p, headers + off[0], nb, hipMemcpyHostToDevice));
+    return leon_header_encode_batch_device(c, c->in_bases.as<uint8_t>(), c->in_off.as<uint64_t>(), n, first_read_index, first_header,
+                                           first_header_len, sink, user);
+}
+
 int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, uint64_t* n_anchors) {
     if (!c || !payload || !size || !n_anchors) return LEON_E_INVALID;
     if (c->poisoned) return fail(c, LEON_E_STATE, "an earlier batch failed part-way: the stream is unusable until leon_dna_reset_stream");
@@ -795,6 +921,7 @@ int leon_dna_reset_stream(leon_dna_ctx* c) {
     }
     c->n_keys = 0; c->n_anchors = 0;
     c->next_read = 0; c->next_block = 0; c->partial_seen = false; c->finished = false; c->poisoned = false;
+    c->hdr_next_read = 0; c->hdr_next_block = 0; c->hdr_partial_seen = false;
     c->last_n = 0; c->last_bases = 0;
     return LEON_OK;
 }

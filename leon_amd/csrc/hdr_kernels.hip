@@ -1,0 +1,133 @@
+// hdr_kernels.hip -- the header stream's symbols (gatb HeaderCoder.cpp HeaderEncoder [RECALLED lo]).
+// Upstream codes headers per read block through the same RangeCoder, field by field against the previous header (the
+// file's FIRST header at the start of every block, AbstractHeaderCoder::startBlock).  What a header contributes to the
+// stream depends on the previous header's TEXT only, never on coder state, so the records of all headers of a batch
+// are produced in parallel -- one lane per header, count pass / scan / emit pass like k_symbols -- and the per-block
+// serial part is left to k_rc_encode (rc_kernels.hip) with this stream's model set.  The record layout is the one
+// oracle/leon_oracle.c states; tests compare payload bytes with the oracle.
+#include "kernels.h"
+
+namespace leon {
+
+namespace {
+
+struct HField { uint32_t len, tok; uint32_t sep; bool has_sep; uint32_t kind, zeros; uint64_t value; };
+enum : uint32_t { HK_ASCII = 0, HK_NUM = 1, HK_ZERO_ONLY = 2, HK_ZERO_NUM = 3 };
+
+__device__ inline bool h_isalnum(uint32_t c) { return (c - '0') < 10u || ((c | 32u) - 'a') < 26u; }
+
+// the field starting at h[pos] (pos < len): an alphanumeric run plus the one separator byte after it, classified in the same pass
+__device__ inline HField h_field(const uint8_t* h, uint32_t len, uint32_t pos) {
+    HField f; f.sep = 0; f.has_sep = false; f.kind = HK_ASCII; f.zeros = 0; f.value = 0;
+    uint32_t e = pos, z = 0, sig = 0;
+    bool digits = true, lead = true;
+    uint64_t v = 0;
+    while (e < len) {
+        const uint32_t c = h[e];
+        if (!h_isalnum(c)) { f.has_sep = true; f.sep = c; break; }
+        const uint32_t d = c - '0';
+        if (d < 10u) {
+            if (lead && d == 0) z++; else { lead = false; if (sig < 18) v = v * 10 + d; sig++; }
+        } else digits = false;
+        e++;
+    }
+    f.tok = e - pos;
+    f.len = f.tok + (f.has_sep ? 1u : 0u);
+    if (digits && f.tok > 0 && !(f.has_sep && f.sep == 0)) {
+        if (f.tok == 1 || z == 0) { if (f.tok <= 18) { f.kind = HK_NUM; f.value = f.tok == 1 ? (uint64_t)(h[pos] - '0') : v; } }
+        else if (z == f.tok) { f.kind = HK_ZERO_ONLY; f.zeros = z; }
+        else if (sig <= 18) { f.kind = HK_ZERO_NUM; f.zeros = z; f.value = v; }
+    }
+    return f;
+}
+
+struct HSink {
+    uint16_t* p;          // nullptr: count only
+    uint64_t n;
+    __device__ inline void put(uint32_t model, uint32_t sym) { if (p) p[n] = (uint16_t)(model | (sym << 8)); n++; }
+    __device__ inline void numeric(uint64_t v) {                    // CompressionUtils::encodeNumeric on _numericModels
+        uint32_t bc = 1;
+        while (bc < 8 && (v >> (8 * bc)) != 0) bc++;
+        put(HM_NUMERIC0, bc);
+        for (uint32_t b = 0; b < bc; b++) put(HM_NUMERIC0 + 1 + b, (uint32_t)(v >> (8 * b)) & 0xff);
+    }
+    __device__ inline void count(uint32_t model, uint64_t x) {
+        if (x < 255) put(model, (uint32_t)x); else { put(model, 255); numeric(x - 255); }
+    }
+};
+
+}  // namespace
+
+// EMIT = false: sym_off[i] = number of symbols of header i; EMIT = true: the symbols at syms + 2 * sym_off[i].
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_hdr_symbols(const uint8_t* hdr, const uint64_t* off, uint64_t n, uint32_t rpb,
+                                                    const uint8_t* first, uint32_t first_len, uint64_t* sym_off, uint8_t* syms) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* cur = hdr + off[i];
+    const uint32_t lc = (uint32_t)(off[i + 1] - off[i]);
+    const bool block_start = i % rpb == 0;                          // AbstractHeaderCoder::startBlock: previous = the file's first header
+    const uint8_t* prev = block_start ? first : hdr + off[i - 1];
+    const uint32_t lp = block_start ? first_len : (uint32_t)(off[i] - off[i - 1]);
+    HSink S;
+    S.p = EMIT ? (uint16_t*)syms + sym_off[i] : nullptr;
+    S.n = 0;
+    uint32_t pc = 0, pp = 0, fi = 0, fprev = 0;
+    while (pc < lc) {
+        const HField c = h_field(cur, lc, pc);
+        const bool have_p = pp < lp;
+        HField p; p.len = 0; p.kind = HK_ASCII; p.sep = 0; p.has_sep = false; p.value = 0; p.tok = 0; p.zeros = 0;
+        uint32_t col = 0;
+        bool same = false;
+        if (have_p) {
+            p = h_field(prev, lp, pp);
+            const uint32_t m = c.len < p.len ? c.len : p.len;
+            while (col < m && cur[pc + col] == prev[pp + col]) col++;
+            same = col == c.len && c.len == p.len;
+            fprev++;
+        }
+        if (!same) {
+            if (c.kind == HK_NUM) {
+                if (have_p && p.kind == HK_NUM && p.has_sep == c.has_sep && p.sep == c.sep && p.value != c.value) {
+                    const bool up = c.value > p.value;
+                    S.put(HM_TYPE, up ? H_FIELD_DELTA : H_FIELD_DELTA_2);
+                    S.count(HM_FIELD_INDEX, fi);
+                    S.numeric(up ? c.value - p.value : p.value - c.value);
+                } else {
+                    S.put(HM_TYPE, H_FIELD_NUMERIC);
+                    S.count(HM_FIELD_INDEX, fi);
+                    S.numeric(c.value);
+                    S.put(HM_ASCII, c.has_sep ? c.sep : 0u);
+                }
+            } else if (c.kind != HK_ASCII) {
+                S.put(HM_TYPE, c.kind == HK_ZERO_ONLY ? H_FIELD_ZERO_ONLY : H_FIELD_ZERO_AND_NUMERIC);
+                S.count(HM_FIELD_INDEX, fi);
+                S.count(HM_ZERO, c.zeros);
+                if (c.kind == HK_ZERO_NUM) S.numeric(c.value);
+                S.put(HM_ASCII, c.has_sep ? c.sep : 0u);
+            } else {
+                S.put(HM_TYPE, H_FIELD_ASCII);
+                S.count(HM_FIELD_INDEX, fi);
+                S.count(HM_FIELD_COLUMN, col);
+                S.count(HM_MIS_SIZE, c.len - col);
+                if (EMIT) { for (uint32_t j = col; j < c.len; j++) S.put(HM_ASCII, cur[pc + j]); }
+                else S.n += c.len - col;
+            }
+        }
+        pc += c.len; pp += p.len; fi++;
+    }
+    while (pp < lp) { pp += h_field(prev, lp, pp).len; fprev++; }
+    if (fi >= fprev) S.put(HM_TYPE, H_END_MATCH);
+    else { S.put(HM_TYPE, H_END); S.count(HM_FIELD_INDEX, fi); }
+    if (!EMIT) sym_off[i] = S.n;
+}
+
+void launch_hdr_symbols(hipStream_t s, const uint8_t* hdr, const uint64_t* off, uint64_t n, uint32_t rpb, const uint8_t* first,
+                        uint32_t first_len, uint64_t* sym_off, uint8_t* syms) {
+    if (!n) return;
+    const uint32_t g = (uint32_t)((n + 255) / 256);
+    if (syms) hipLaunchKernelGGL(k_hdr_symbols<true>, dim3(g), dim3(256), 0, s, hdr, off, n, rpb, first, first_len, sym_off, syms);
+    else hipLaunchKernelGGL(k_hdr_symbols<false>, dim3(g), dim3(256), 0, s, hdr, off, n, rpb, first, first_len, sym_off, syms);
+}
+
+}  // namespace leon

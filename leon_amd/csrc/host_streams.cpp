@@ -1,0 +1,289 @@
+// host_streams.cpp -- the host-side entry points of the C-ABI that need no GPU:
+//   * HeaderDecoder over read blocks (gatb HeaderCoder.cpp [RECALLED lo]; record layout: DESIGN.md section 1.3), blocks in
+//     parallel on host threads: inside a block every header is rebuilt from the one before it, so a block is one serial
+//     chain, and `-d` has as many chains as the file has blocks;
+//   * the quality stream in its lossless form (`-lossless`): per read block, the qualities joined by '\n' through zlib
+//     (upstream: DnaEncoder buffers the block's quality lines and deflates them, Leon::writeBlockLena [RECALLED med]).
+// Nothing here is on the DNA encode path; these are the streams either side of it.
+#include "../../include/leon_dna.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace leon { void set_create_error(const std::string& msg); }
+
+namespace {
+
+int fail(int code, const std::string& msg) { leon::set_create_error(msg); return code; }
+
+template <typename F> void parallel_blocks(uint64_t n_blocks, uint32_t n_threads, F&& f) {
+    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    n_threads = (uint32_t)std::min<uint64_t>(n_threads, std::max<uint64_t>(n_blocks, 1));
+    std::atomic<uint64_t> next{0};
+    auto work = [&] { for (uint64_t b; (b = next.fetch_add(1)) < n_blocks;) f(b); };
+    if (n_threads <= 1) { work(); return; }
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < n_threads; t++) th.emplace_back(work);
+    for (auto& t : th) t.join();
+}
+
+// ---- Order0Model with the two-level layout of the device coder (F(x) = H[x >> 4] + Lw[x]): update touches <= 31 words ----
+struct Model256 {
+    uint32_t H[17], Lw[257];
+    uint32_t size;
+    void init(uint32_t n) { size = n; for (uint32_t x = 0; x <= 256; x++) Lw[x] = x < 256 ? (x & 15u) : 0u; for (uint32_t j = 0; j <= 16; j++) H[j] = 16 * j; }
+    uint32_t F(uint32_t x) const { return H[x >> 4] + Lw[x]; }
+    uint32_t total() const { return F(size); }
+    uint32_t find(uint64_t value) const {                    // last c < size with F(c) <= value
+        uint32_t j = 0;
+        const uint32_t jmax = (size - 1) >> 4;
+        while (j < jmax && H[j + 1] <= value) j++;
+        uint32_t c = 16 * j;
+        const uint32_t cmax = std::min(size - 1, 16 * j + 15);
+        while (c < cmax && F(c + 1) <= value) c++;
+        return c;
+    }
+    void update(uint32_t c) {                                // Order0Model::update: F(x) += 1 for x > c
+        for (uint32_t x = c + 1; x <= (c | 15u); x++) Lw[x]++;
+        for (uint32_t j = (c >> 4) + 1; j <= 16; j++) H[j]++;
+    }
+};
+struct RangeDecoder {
+    uint64_t low = 0, range = ~0ull, code = 0;
+    const uint8_t* p; uint64_t n, i = 0;
+    RangeDecoder(const uint8_t* p_, uint64_t n_) : p(p_), n(n_) { for (int k = 0; k < 8; k++) code = (code << 8) | byte(); }
+    uint8_t byte() { return i < n ? p[i++] : 0; }
+    uint32_t next(Model256& m) {
+        range /= m.total();
+        const uint32_t c = m.find((code - low) / range);
+        low += (uint64_t)m.F(c) * range;
+        range *= (uint64_t)(m.F(c + 1) - m.F(c));
+        while ((low ^ (low + range)) < (1ull << 56) || (range < (1ull << 48) && ((range = (0 - low) & ((1ull << 48) - 1)), true))) {
+            code = (code << 8) | byte();
+            range <<= 8;
+            low <<= 8;
+        }
+        m.update(c);
+        return c;
+    }
+};
+
+enum { H_END = 1, H_END_MATCH, H_FIELD_ASCII, H_FIELD_NUMERIC, H_FIELD_DELTA, H_FIELD_DELTA_2, H_FIELD_ZERO_ONLY, H_FIELD_ZERO_AND_NUMERIC, H_TYPE_COUNT };
+
+struct HeaderModels {
+    Model256 type, field_index, field_column, mis_size, ascii, zero, numeric[9];
+    HeaderModels() {
+        type.init(H_TYPE_COUNT); field_index.init(256); field_column.init(256); mis_size.init(256); ascii.init(256); zero.init(256);
+        for (auto& m : numeric) m.init(256);
+    }
+};
+uint64_t decode_numeric(RangeDecoder& d, HeaderModels& M) {
+    uint32_t bc = d.next(M.numeric[0]);
+    if (bc > 8) bc = 8;
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < bc; i++) v |= (uint64_t)d.next(M.numeric[i + 1]) << (8 * i);
+    return v;
+}
+uint64_t decode_count(RangeDecoder& d, HeaderModels& M, Model256& m) {
+    const uint64_t x = d.next(m);
+    return x < 255 ? x : 255 + decode_numeric(d, M);
+}
+inline bool is_alnum(uint8_t c) { return (uint8_t)(c - '0') < 10 || (uint8_t)((c | 32) - 'a') < 26; }
+struct Field { uint64_t len = 0; bool numeric = false, has_sep = false; uint8_t sep = 0; uint64_t value = 0; };
+// the field of h starting at pos: token + one separator; numeric = digits without a leading zero, 1..18 of them
+Field field_at(const uint8_t* h, uint64_t len, uint64_t pos) {
+    Field f;
+    uint64_t e = pos;
+    bool digits = true;
+    while (e < len && is_alnum(h[e])) { digits = digits && (uint8_t)(h[e] - '0') < 10; e++; }
+    const uint64_t tok = e - pos;
+    if (e < len) { f.has_sep = true; f.sep = h[e]; e++; }
+    f.len = e - pos;
+    if (digits && tok >= 1 && tok <= 18 && (tok == 1 || h[pos] != '0') && !(f.has_sep && f.sep == 0)) {
+        f.numeric = true;
+        for (uint64_t i = pos; i < pos + tok; i++) f.value = f.value * 10 + (uint64_t)(h[i] - '0');
+    }
+    return f;
+}
+
+// one block; out receives the headers back to back, off[n + 1] (relative to out); false when the payload does not decode
+bool decode_header_block(const uint8_t* payload, uint64_t size, uint32_t n, const uint8_t* first, uint64_t first_len,
+                         std::string& out, std::vector<uint64_t>& off) {
+    RangeDecoder d(payload, size);
+    HeaderModels* Mp = new HeaderModels();
+    HeaderModels& M = *Mp;
+    struct Free { HeaderModels* p; ~Free() { delete p; } } fr{Mp};
+    out.clear(); off.assign(1, 0);
+    std::string prev(reinterpret_cast<const char*>(first), first_len), cur;
+    const uint64_t max_header = 1ull << 31;
+    for (uint32_t r = 0; r < n; r++) {
+        cur.clear();
+        const uint8_t* ph = reinterpret_cast<const uint8_t*>(prev.data());
+        const uint64_t lp = prev.size();
+        uint64_t pp = 0, nf = 0;
+        auto copy_prev_until = [&](uint64_t limit) {             // fields nf .. limit-1 are the previous header's
+            while (nf < limit && pp < lp) { const Field p = field_at(ph, lp, pp); cur.append(prev, pp, p.len); pp += p.len; nf++; }
+        };
+        for (;;) {
+            const uint32_t t = d.next(M.type);
+            if (t == H_END_MATCH) { copy_prev_until(~0ull); break; }
+            if (t == H_END) {
+                const uint64_t f = decode_count(d, M, M.field_index);
+                if (f < nf) return false;
+                copy_prev_until(f);
+                if (nf != f) return false;
+                break;
+            }
+            if (t < H_FIELD_ASCII || t >= H_TYPE_COUNT) return false;
+            const uint64_t idx = decode_count(d, M, M.field_index);
+            if (idx < nf) return false;
+            copy_prev_until(idx);
+            if (nf != idx) return false;
+            Field p;
+            const bool have_p = pp < lp;
+            const uint64_t p0 = pp;
+            if (have_p) { p = field_at(ph, lp, pp); pp += p.len; }
+            if (t == H_FIELD_ASCII) {
+                const uint64_t col = decode_count(d, M, M.field_column), sz = decode_count(d, M, M.mis_size);
+                if (col > p.len || sz > max_header || cur.size() + col + sz > max_header) return false;
+                cur.append(prev, p0, col);
+                for (uint64_t j = 0; j < sz; j++) cur.push_back((char)d.next(M.ascii));
+            } else {
+                uint64_t v = 0, z = 0; uint8_t sep = 0; bool has_sep = false;
+                if (t == H_FIELD_DELTA || t == H_FIELD_DELTA_2) {
+                    const uint64_t dv = decode_numeric(d, M);
+                    if (!have_p || !p.numeric) return false;
+                    v = t == H_FIELD_DELTA ? p.value + dv : p.value - dv;
+                    sep = p.sep; has_sep = p.has_sep;
+                } else {
+                    if (t != H_FIELD_NUMERIC) z = decode_count(d, M, M.zero);
+                    if (t != H_FIELD_ZERO_ONLY) v = decode_numeric(d, M);
+                    sep = (uint8_t)d.next(M.ascii); has_sep = sep != 0;
+                }
+                if (z > max_header || cur.size() + z > max_header) return false;
+                cur.append(z, '0');
+                if (t != H_FIELD_ZERO_ONLY) cur += std::to_string(v);
+                if (has_sep) cur.push_back((char)sep);
+            }
+            nf++;
+        }
+        out += cur;
+        off.push_back(out.size());
+        prev.swap(cur);
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int leon_host_header_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads, uint64_t n_blocks,
+                                   const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap,
+                                   uint64_t* out_off, uint64_t* out_size, uint32_t n_threads) {
+    if (!out_size || (n_blocks && (!payloads || !payload_off || !block_n_reads || !out_off)) || (!first_header && first_header_len))
+        return fail(LEON_E_INVALID, "null argument");
+    *out_size = 0;
+    if (!n_blocks) return LEON_OK;
+    for (uint64_t b = 0; b < n_blocks; b++)
+        if (payload_off[b + 1] < payload_off[b]) return fail(LEON_E_INVALID, "payload offsets are not monotonic");
+    std::vector<std::string> texts(n_blocks);
+    std::vector<std::vector<uint64_t>> offs(n_blocks);
+    std::atomic<int64_t> bad{-1};
+    parallel_blocks(n_blocks, n_threads, [&](uint64_t b) {
+        if (!decode_header_block(payloads + payload_off[b], payload_off[b + 1] - payload_off[b], block_n_reads[b], first_header,
+                                 first_header_len, texts[b], offs[b])) {
+            int64_t expect = -1;
+            bad.compare_exchange_strong(expect, (int64_t)b);
+        }
+    });
+    if (bad.load() >= 0) return fail(LEON_E_INVALID, "header block " + std::to_string(bad.load()) + " does not decode");
+    uint64_t w = 0, r = 0;
+    for (uint64_t b = 0; b < n_blocks; b++) w += texts[b].size();
+    *out_size = w;
+    if (w > out_cap || !out) return fail(LEON_E_OVERFLOW, "header output needs " + std::to_string(w) + " bytes");
+    w = 0;
+    out_off[0] = 0;
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        if (!texts[b].empty()) memcpy(out + w, texts[b].data(), texts[b].size());
+        for (size_t i = 1; i < offs[b].size(); i++) out_off[++r] = w + offs[b][i];
+        w += texts[b].size();
+    }
+    return LEON_OK;
+}
+
+// ---- quality stream, lossless: one zlib stream per read block over the block's quality lines, each followed by '\n' ----
+int leon_host_qual_encode_blocks(const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads, uint32_t reads_per_block,
+                                 int zlib_level, uint32_t n_threads, leon_block_sink sink, void* user, uint64_t first_block_id) {
+    if ((n_reads && (!quals || !offsets)) || !sink || !reads_per_block) return fail(LEON_E_INVALID, "null argument");
+    if (zlib_level < -1 || zlib_level > 9) return fail(LEON_E_INVALID, "zlib level must be in -1..9");
+    const uint64_t n_blocks = (n_reads + reads_per_block - 1) / reads_per_block;
+    for (uint64_t i = 0; i < n_reads; i++)
+        if (offsets[i + 1] < offsets[i]) return fail(LEON_E_INVALID, "offsets are not monotonic");
+    std::vector<std::vector<uint8_t>> outs(n_blocks);
+    std::atomic<int> zerr{0};
+    parallel_blocks(n_blocks, n_threads, [&](uint64_t b) {
+        const uint64_t r0 = b * reads_per_block, r1 = std::min<uint64_t>(n_reads, r0 + reads_per_block);
+        std::vector<uint8_t> text;
+        text.reserve((size_t)(offsets[r1] - offsets[r0] + (r1 - r0)));
+        for (uint64_t r = r0; r < r1; r++) {
+            text.insert(text.end(), quals + offsets[r], quals + offsets[r + 1]);
+            text.push_back('\n');
+        }
+        uLongf cap = compressBound((uLong)text.size());
+        outs[b].resize(cap);
+        if (compress2(outs[b].data(), &cap, text.data(), (uLong)text.size(), zlib_level) != Z_OK) zerr.store(1);
+        outs[b].resize(cap);
+    });
+    if (zerr.load()) return fail(LEON_E_INVALID, "zlib compress2 failed");
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        const uint32_t nr = (uint32_t)std::min<uint64_t>(reads_per_block, n_reads - b * reads_per_block);
+        if (sink(user, first_block_id + b, outs[b].data(), outs[b].size(), nr)) return fail(LEON_E_SINK, "block sink returned non-zero");
+    }
+    return LEON_OK;
+}
+
+int leon_host_qual_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
+                                 const uint64_t* block_n_bytes, uint64_t n_blocks, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
+                                 uint32_t n_threads) {
+    if (n_blocks && (!payloads || !payload_off || !block_n_reads || !block_n_bytes || !out || !out_off)) return fail(LEON_E_INVALID, "null argument");
+    if (!n_blocks) return LEON_OK;
+    // block_n_bytes: quality bytes per block WITHOUT the newlines (what the container's block table records)
+    std::vector<uint64_t> o0(n_blocks + 1, 0), r0(n_blocks + 1, 0);
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        if (payload_off[b + 1] < payload_off[b]) return fail(LEON_E_INVALID, "payload offsets are not monotonic");
+        o0[b + 1] = o0[b] + block_n_bytes[b];
+        r0[b + 1] = r0[b] + block_n_reads[b];
+        if (o0[b + 1] < o0[b] || o0[b + 1] > out_cap) return fail(LEON_E_INVALID, "output capacity below the sum of block_n_bytes");
+    }
+    std::atomic<int64_t> bad{-1};
+    parallel_blocks(n_blocks, n_threads, [&](uint64_t b) {
+        std::vector<uint8_t> text((size_t)(block_n_bytes[b] + block_n_reads[b]));
+        uLongf got = (uLongf)text.size();
+        bool ok = uncompress(text.data(), &got, payloads + payload_off[b], (uLong)(payload_off[b + 1] - payload_off[b])) == Z_OK && got == text.size();
+        uint64_t w = o0[b], r = r0[b], at = 0;
+        if (ok && b == 0) out_off[0] = 0;
+        for (uint32_t i = 0; ok && i < block_n_reads[b]; i++) {
+            const uint8_t* nl = (const uint8_t*)memchr(text.data() + at, '\n', text.size() - at);
+            if (!nl) { ok = false; break; }
+            const uint64_t len = (uint64_t)(nl - (text.data() + at));
+            if (w + len > o0[b + 1]) { ok = false; break; }
+            memcpy(out + w, text.data() + at, len);
+            w += len; at += len + 1;
+            out_off[++r] = w;
+        }
+        if (ok && (w != o0[b + 1] || at != text.size())) ok = false;
+        if (!ok) { int64_t expect = -1; bad.compare_exchange_strong(expect, (int64_t)b); }
+    });
+    if (bad.load() >= 0) return fail(LEON_E_INVALID, "quality block " + std::to_string(bad.load()) + " does not decode");
+    return LEON_OK;
+}
+
+}  // extern "C"

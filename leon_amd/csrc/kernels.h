@@ -84,8 +84,13 @@ void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const 
 void launch_block_ranges(hipStream_t s, const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
                          uint64_t* blk_begin /*n_blocks+1*/, uint64_t* out_off /*n_blocks+1*/);
 // ---- range coder ----
+// small_sizes: alphabet sizes of the small models, a nibble per model id (SMALL_SIZES_DNA / SMALL_SIZES_HEADER)
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
-                      uint8_t* out, const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err);
+                      uint8_t* out, const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err,
+                      uint32_t small_sizes = SMALL_SIZES_DNA);
+// ---- header stream (HeaderEncoder): records of every header against the previous one ----
+void launch_hdr_symbols(hipStream_t s, const uint8_t* hdr, const uint64_t* off, uint64_t n, uint32_t rpb, const uint8_t* first,
+                        uint32_t first_len, uint64_t* sym_off /*count or offsets*/, uint8_t* syms /*nullptr = count pass*/);
 size_t rc_model_scratch_bytes(uint64_t n_blocks);
 void launch_gather_payload(hipStream_t s, const uint8_t* out, const uint64_t* out_off, const uint64_t* dst_off,
                            const uint64_t* sizes, uint64_t n_blocks, uint8_t* dst);

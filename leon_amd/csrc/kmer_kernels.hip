@@ -150,10 +150,14 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     uint64_t total = 0;
     KCHK(hipMemcpy(&total, pos.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
     if (!total) return LEON_OK;
-    if (!max_keys_per_pass) {                                 // as many k-mers per pass as a third of the free HBM sorts in place
+    if (!max_keys_per_pass) {
+        // 2^30 k-mers per pass (17-34 GB of sort buffers), less when a third of the free HBM does not hold them.  NOT "as
+        // many as fit": the driver wipes freed VRAM at ~55 GB/s before handing it out again, so a counter that took and
+        // returned 200 GB made the first allocation of the encode path wait 3.8 s (profiles/README.md, round 2), and
+        // passes of 2^30 keys sort no slower than one of 2^32.
         size_t free_b = 0, total_b = 0;
         KCHK(hipMemGetInfo(&free_b, &total_b));
-        max_keys_per_pass = std::max<uint64_t>(1ull << 24, std::min<uint64_t>(1ull << 32, free_b / 3 / (8 * W * 2 + 1)));
+        max_keys_per_pass = std::max<uint64_t>(1ull << 24, std::min<uint64_t>(1ull << 30, free_b / 3 / (8 * W * 2 + 1)));
     }
     uint32_t n_parts = (uint32_t)((total + max_keys_per_pass - 1) / max_keys_per_pass);
     if (n_parts < 1) n_parts = 1;

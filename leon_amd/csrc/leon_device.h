@@ -25,13 +25,25 @@ enum : uint32_t {
     N_NUM_GROUPS = 8, MODELS_PER_NUMERIC = 9,
     N_MODELS = N_SMALL_MODELS + N_NUM_GROUPS * MODELS_PER_NUMERIC   // 80
 };
+// alphabet sizes of the small models, one nibble per model id: the DNA stream's and the header stream's sets
+constexpr uint32_t SMALL_SIZES_DNA = 0x23332552u;
+constexpr uint32_t SMALL_SIZES_HEADER = 0x22222229u;
+__host__ __device__ inline uint32_t small_size_of(uint32_t sizes, uint32_t m) { return (sizes >> (4 * m)) & 15u; }
 __host__ __device__ inline uint32_t small_model_size(uint32_t m) {
     // readType 2, noAnchorRead 5, bifurcation 5, binary 2, three delta-type models 3, revcomp 2
-    return (0x23332552u >> (4 * m)) & 15u;
+    return (SMALL_SIZES_DNA >> (4 * m)) & 15u;
 }
 __host__ __device__ inline uint32_t numeric_model_id(uint32_t group, uint32_t idx) {
     return N_SMALL_MODELS + group * MODELS_PER_NUMERIC + idx;
 }
+
+// ---- the header stream's model set (AbstractHeaderCoder's Order0Model members [RECALLED]) and record types ----
+// One small model (the record type, 9 symbols) and 14 256-symbol models; ids in the space k_rc_encode is given.
+enum : uint32_t {
+    HM_TYPE = 0, HM_FIELD_INDEX = 8, HM_FIELD_COLUMN = 9, HM_MIS_SIZE = 10, HM_ASCII = 11, HM_ZERO = 12, HM_NUMERIC0 = 13,   // .. 21
+    H_END = 1, H_END_MATCH = 2, H_FIELD_ASCII = 3, H_FIELD_NUMERIC = 4, H_FIELD_DELTA = 5, H_FIELD_DELTA_2 = 6,
+    H_FIELD_ZERO_ONLY = 7, H_FIELD_ZERO_AND_NUMERIC = 8, H_TYPE_COUNT = 9
+};
 
 // event byte written by the walk per read position
 enum : uint8_t { EV_BIN0 = 1, EV_BIN1 = 2, EV_NT0 = 3, EV_ERROR = 8 };

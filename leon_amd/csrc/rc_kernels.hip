@@ -30,7 +30,7 @@ __host__ __device__ constexpr uint32_t rc_waves(uint32_t g) { return g + 1 + (g 
 template <uint32_t G, uint32_t RC_NSLOT>
 __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                                                             uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
-                                                            uint32_t* scratch, int* err) {
+                                                            uint32_t* scratch, int* err, uint32_t small_sizes) {
     constexpr uint32_t MW = RC_SMALL_WORDS + RC_NSLOT * RC_STRIDE;
     __shared__ uint32_t models_all[G * MW];
     __shared__ uint32_t ring_all[G][2][5][RC_RING];          // one spare entry per row: the coder prefetches record j + 1
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                     uint32_t mb = 0;
                     if (act) mb = !numeric ? m * RC_SSTRIDE
                                            : (slot < RC_NSLOT ? RC_SMALL_WORDS + slot * RC_STRIDE : (RC_GLOBAL | ((slot - RC_NSLOT) * RC_STRIDE)));
-                    const uint32_t tot_idx = numeric ? 16u : RC_LW + small_model_size(m);
+                    const uint32_t tot_idx = numeric ? 16u : RC_LW + small_size_of(small_sizes, m);
                     __builtin_amdgcn_wave_barrier();
                     // counts at the tile start
                     uint32_t lo = 0, hi = 1, tot = 1;
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                         const bool in_lds = act && !(mb & RC_GLOBAL);
                         uint32_t* mp = &models[in_lds ? mb : 0];
                         const uint32_t h4 = (in_lds && numeric) ? c >> 4 : 64u;
-                        const uint32_t l4 = in_lds ? c & 15u : 64u, ymax = numeric ? 15u : small_model_size(m);
+                        const uint32_t l4 = in_lds ? c & 15u : 64u, ymax = numeric ? 15u : small_size_of(small_sizes, m);
                         uint32_t* lp = mp + RC_LW + (in_lds ? (c & ~15u) : 0u);
 #pragma unroll
                         for (uint32_t k = 1; k <= 16; k++)
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
 }
 
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint8_t* out,
-                      const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err) {
+                      const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err, uint32_t small_sizes) {
     if (!n_blocks) return;
     // blocks per workgroup: as few as keeps every block resident on the 256 CUs (LDS: 8 blocks of 19.6 KB per CU)
     const uint64_t per_cu = (n_blocks + 255) / 256;
@@ -295,7 +295,7 @@ void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_be
     if (force) { int v = atoi(force); if (v == 1 || v == 2 || v == 4 || v == 8) G = (uint32_t)v; }
     const uint64_t n_groups = (n_blocks + G - 1) / G;
     const uint32_t g = (uint32_t)std::min<uint64_t>(n_groups, 256ull * (8 / G));
-#define RC_LAUNCH(GG, N) hipLaunchKernelGGL((k_rc_encode<GG, N>), dim3(g), dim3(64 * rc_waves(GG)), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err)
+#define RC_LAUNCH(GG, N) hipLaunchKernelGGL((k_rc_encode<GG, N>), dim3(g), dim3(64 * rc_waves(GG)), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err, small_sizes)
     if (G == 1) RC_LAUNCH(1, RC_NSLOT_BIG);
     else if (G == 2) RC_LAUNCH(2, RC_NSLOT_BIG);
     else if (G == 4) RC_LAUNCH(4, RC_NSLOT_BIG);

@@ -1,0 +1,93 @@
+#include "bank.hpp"
+#include "leon_host.hpp"
+
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include <cstring>
+
+namespace leon_host {
+
+Bank::Bank(const std::string& path) : path_(path), buf_(1 << 20) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) throw Exception("cannot open " + path);
+    file_bytes_ = (uint64_t)st.st_size;
+    gz_ = gzopen(path.c_str(), "rb");
+    if (!gz_) throw Exception("cannot open " + path);
+    gzbuffer((gzFile)gz_, 1 << 20);
+}
+Bank::~Bank() { if (gz_) gzclose((gzFile)gz_); }
+
+// one line without its terminator ("\n" or "\r\n"); false at the end of the file
+bool Bank::getline(std::string& line) {
+    line.clear();
+    bool any = false;
+    for (;;) {
+        if (buf_pos_ == buf_len_) {
+            const int got = gzread((gzFile)gz_, buf_.data(), (unsigned)buf_.size());
+            if (got < 0) { int e = 0; throw Exception(std::string("read error in ") + path_ + ": " + gzerror((gzFile)gz_, &e)); }
+            if (got == 0) break;
+            buf_pos_ = 0; buf_len_ = (size_t)got;
+        }
+        const char* p = buf_.data() + buf_pos_;
+        const char* nl = (const char*)memchr(p, '\n', buf_len_ - buf_pos_);
+        any = true;
+        if (nl) { line.append(p, (size_t)(nl - p)); buf_pos_ += (size_t)(nl - p) + 1; break; }
+        line.append(p, buf_len_ - buf_pos_);
+        buf_pos_ = buf_len_;
+    }
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    return any;
+}
+
+bool Bank::isFastq() {
+    if (!decided_) {
+        std::string l;
+        while (getline(l)) {
+            if (l.empty()) continue;
+            pending_ = l; have_pending_ = true;
+            fastq_ = l[0] == '@';
+            if (l[0] != '@' && l[0] != '>') throw Exception(path_ + " is neither FASTA nor FASTQ (first record starts with '" + l.substr(0, 1) + "')");
+            break;
+        }
+        decided_ = true;
+    }
+    return fastq_;
+}
+
+uint64_t Bank::next(ReadBatch& b, uint64_t max_reads) {
+    isFastq();
+    uint64_t n = 0;
+    std::string line;
+    auto take = [&](std::string& l) -> bool {
+        if (have_pending_) { l.swap(pending_); have_pending_ = false; return true; }
+        return getline(l);
+    };
+    while (n < max_reads) {
+        if (!take(line)) break;
+        if (line.empty()) continue;
+        if (fastq_) {
+            if (line[0] != '@') throw Exception("malformed FASTQ record " + std::to_string(n_read_ + 1) + " in " + path_);
+            b.headers.append(line, 1, std::string::npos);
+            std::string seq, plus, qual;
+            if (!getline(seq) || !getline(plus) || !getline(qual)) throw Exception("truncated FASTQ record in " + path_);
+            if (plus.empty() || plus[0] != '+') throw Exception("malformed FASTQ record " + std::to_string(n_read_ + 1) + " in " + path_);
+            if (qual.size() != seq.size()) throw Exception("FASTQ record " + std::to_string(n_read_ + 1) + " of " + path_ + ": quality and sequence lengths differ");
+            b.bases += seq; b.quals += qual;
+        } else {
+            if (line[0] != '>') throw Exception("FASTA data before the first header in " + path_);
+            b.headers.append(line, 1, std::string::npos);
+            while (getline(line)) {                                  // sequence lines up to the next header
+                if (!line.empty() && line[0] == '>') { pending_ = line; have_pending_ = true; break; }
+                b.bases += line;
+            }
+        }
+        b.header_off.push_back(b.headers.size());
+        b.base_off.push_back(b.bases.size());
+        b.qual_off.push_back(b.quals.size());
+        n++; n_read_++;
+    }
+    return n;
+}
+
+}  // namespace leon_host

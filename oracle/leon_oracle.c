@@ -7,6 +7,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 /* ------------------------------------------------------------------------------------------ */
 /* small growable byte / word vectors                                                         */
@@ -848,4 +849,222 @@ int lo_rc_decode_stream(const uint8_t* payload, uint64_t size, const uint8_t* mo
     for (uint64_t i = 0; i < n; i++) out[i] = dec_next(&d, &m[models[i]]);
     free(m);
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* HeaderCoder.cpp (AbstractHeaderCoder / HeaderEncoder / HeaderDecoder) [RECALLED lo]          */
+/*                                                                                            */
+/* What is recalled of upstream: headers are coded per read block through the same RangeCoder,  */
+/* field by field against the previous header (the FIRST header of the file, stored in plain in */
+/* the metadata, at the start of every block: AbstractHeaderCoder::startBlock); a header is    */
+/* cut into fields at non-alphanumeric bytes; record types HEADER_END = 1, HEADER_END_MATCH,    */
+/* FIELD_ASCII, FIELD_NUMERIC, FIELD_DELTA, FIELD_DELTA_2, FIELD_ZERO_ONLY,                    */
+/* FIELD_ZERO_AND_NUMERIC; models _typeModel, _fieldIndexModel, _fieldColumnModel,             */
+/* _misSizeModel, _asciiModel, _numericModels (encodeNumeric), _zeroModel.  The exact record    */
+/* layout below is this restatement's own definition in that shape;     */
+/* like the rest of the oracle it is pinned by round trip and by a second implementation        */
+/* (tests/py_header.py), not by reference output.                                               */
+/*                                                                                            */
+/* Rules.  A field = a maximal (possibly empty) run of [0-9A-Za-z] plus the ONE separator byte  */
+/* that follows it (the last field may end with the header); the fields concatenate to the     */
+/* header.  Field i of the current header is compared with field i of the previous one; equal   */
+/* bytes cost nothing.  A differing (or new) field is one record: type on _typeModel, the      */
+/* field index as a count on _fieldIndexModel, then                                            */
+/*   token = digits without a leading zero (1..18 digits), separator not NUL:                  */
+/*       previous field of the same kind with the same separator -> FIELD_DELTA (value greater,  */
+/*       numeric(value - prev)) or FIELD_DELTA_2 (numeric(prev - value));                      */
+/*       otherwise FIELD_NUMERIC: numeric(value), separator on _asciiModel (0 = none);         */
+/*   token = z >= 2 zeros only -> FIELD_ZERO_ONLY: count(z) on _zeroModel, separator;          */
+/*   token = z >= 1 zeros then 1..18 digits -> FIELD_ZERO_AND_NUMERIC: count(z), numeric, sep;  */
+/*   anything else -> FIELD_ASCII: count(col) on _fieldColumnModel, col = common prefix with    */
+/*       the previous field, count(size - col) on _misSizeModel, the remaining bytes on         */
+/*       _asciiModel.                                                                          */
+/* count(x) on a 256-symbol model: x < 255 as itself, else 255 followed by numeric(x - 255).    */
+/* End of header: HEADER_END_MATCH when it has at least as many fields as the previous one,    */
+/* else HEADER_END followed by count(number of fields) on _fieldIndexModel.                     */
+/* ------------------------------------------------------------------------------------------ */
+enum { HEADER_END = 1, HEADER_END_MATCH, FIELD_ASCII, FIELD_NUMERIC, FIELD_DELTA, FIELD_DELTA_2, FIELD_ZERO_ONLY,
+       FIELD_ZERO_AND_NUMERIC, HEADER_TYPE_COUNT };
+/* model ids of the (model, symbol) trace: the id space the device range coder is given for this stream */
+enum { HM_TYPE = 0, HM_FIELD_INDEX = 8, HM_FIELD_COLUMN = 9, HM_MIS_SIZE = 10, HM_ASCII = 11, HM_ZERO = 12, HM_NUMERIC0 = 13 };
+
+typedef struct {
+    o0model type, field_index, field_column, mis_size, ascii, zero;
+    nummodel numeric;
+} hdrmodels;
+static void hm_start_block(hdrmodels* h) {                    /* AbstractHeaderCoder::startBlock */
+    m_init(&h->type, HEADER_TYPE_COUNT); m_init(&h->field_index, 256); m_init(&h->field_column, 256);
+    m_init(&h->mis_size, 256); m_init(&h->ascii, 256); m_init(&h->zero, 256); nm_init(&h->numeric);
+}
+typedef struct { const uint8_t* p; uint32_t len, tok; uint8_t sep, has_sep, kind; uint32_t zeros; uint64_t value; } hfield;
+enum { HK_ASCII = 0, HK_NUM = 1, HK_ZERO_ONLY = 2, HK_ZERO_NUM = 3 };
+static inline int h_isalnum(uint8_t c) { return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'); }
+/* the field starting at h[pos] (pos < len) */
+static hfield h_field(const uint8_t* h, uint64_t len, uint64_t pos) {
+    hfield f; memset(&f, 0, sizeof f);
+    uint64_t e = pos;
+    while (e < len && h_isalnum(h[e])) e++;
+    f.p = h + pos; f.tok = (uint32_t)(e - pos);
+    if (e < len) { f.has_sep = 1; f.sep = h[e]; e++; }
+    f.len = (uint32_t)(e - pos);
+    f.kind = HK_ASCII;
+    int digits = f.tok > 0;
+    for (uint32_t i = 0; i < f.tok && digits; i++) digits = f.p[i] >= '0' && f.p[i] <= '9';
+    if (digits && !(f.has_sep && f.sep == 0)) {
+        uint32_t z = 0;
+        while (z < f.tok && f.p[z] == '0') z++;
+        if (f.tok == 1 || z == 0) { if (f.tok <= 18) f.kind = HK_NUM; }
+        else if (z == f.tok) { f.kind = HK_ZERO_ONLY; f.zeros = z; }
+        else if (f.tok - z <= 18) { f.kind = HK_ZERO_NUM; f.zeros = z; }
+        if (f.kind == HK_NUM || f.kind == HK_ZERO_NUM)
+            for (uint32_t i = f.zeros; i < f.tok; i++) f.value = f.value * 10 + (uint64_t)(f.p[i] - '0');
+    }
+    return f;
+}
+typedef struct { rcenc* e; hdrmodels* m; bytevec* trace; } hsink;
+static void h_put(hsink* s, o0model* m, uint32_t id, uint8_t c) {
+    enc_encode(s->e, m, c);
+    if (s->trace) { bv_push(s->trace, (uint8_t)id); bv_push(s->trace, c); }
+}
+static void h_numeric(hsink* s, uint64_t v) {
+    int bc = byte_count(v);
+    h_put(s, &s->m->numeric.m[0], HM_NUMERIC0, (uint8_t)bc);
+    for (int i = 0; i < bc; i++) h_put(s, &s->m->numeric.m[i + 1], HM_NUMERIC0 + 1 + (uint32_t)i, (uint8_t)((v >> (8 * i)) & 0xff));
+}
+static void h_count(hsink* s, o0model* m, uint32_t id, uint64_t x) {
+    if (x < 255) h_put(s, m, id, (uint8_t)x);
+    else { h_put(s, m, id, 255); h_numeric(s, x - 255); }
+}
+static void h_encode_header(hsink* s, const uint8_t* cur, uint64_t lc, const uint8_t* prev, uint64_t lp) {
+    uint64_t pc = 0, pp = 0, i = 0, fprev = 0;
+    hdrmodels* M = s->m;
+    while (pc < lc) {
+        hfield c = h_field(cur, lc, pc);
+        int have_p = pp < lp;
+        hfield p; memset(&p, 0, sizeof p);
+        if (have_p) { p = h_field(prev, lp, pp); pp += p.len; fprev++; }
+        if (!(have_p && p.len == c.len && memcmp(p.p, c.p, c.len) == 0)) {
+            if (c.kind == HK_NUM) {
+                if (have_p && p.kind == HK_NUM && p.has_sep == c.has_sep && p.sep == c.sep && p.value != c.value) {
+                    int up = c.value > p.value;
+                    h_put(s, &M->type, HM_TYPE, up ? FIELD_DELTA : FIELD_DELTA_2);
+                    h_count(s, &M->field_index, HM_FIELD_INDEX, i);
+                    h_numeric(s, up ? c.value - p.value : p.value - c.value);
+                } else {
+                    h_put(s, &M->type, HM_TYPE, FIELD_NUMERIC);
+                    h_count(s, &M->field_index, HM_FIELD_INDEX, i);
+                    h_numeric(s, c.value);
+                    h_put(s, &M->ascii, HM_ASCII, c.has_sep ? c.sep : 0);
+                }
+            } else if (c.kind == HK_ZERO_ONLY || c.kind == HK_ZERO_NUM) {
+                h_put(s, &M->type, HM_TYPE, c.kind == HK_ZERO_ONLY ? FIELD_ZERO_ONLY : FIELD_ZERO_AND_NUMERIC);
+                h_count(s, &M->field_index, HM_FIELD_INDEX, i);
+                h_count(s, &M->zero, HM_ZERO, c.zeros);
+                if (c.kind == HK_ZERO_NUM) h_numeric(s, c.value);
+                h_put(s, &M->ascii, HM_ASCII, c.has_sep ? c.sep : 0);
+            } else {
+                uint32_t col = 0;
+                if (have_p) while (col < c.len && col < p.len && c.p[col] == p.p[col]) col++;
+                h_put(s, &M->type, HM_TYPE, FIELD_ASCII);
+                h_count(s, &M->field_index, HM_FIELD_INDEX, i);
+                h_count(s, &M->field_column, HM_FIELD_COLUMN, col);
+                h_count(s, &M->mis_size, HM_MIS_SIZE, c.len - col);
+                for (uint32_t j = col; j < c.len; j++) h_put(s, &M->ascii, HM_ASCII, c.p[j]);
+            }
+        }
+        pc += c.len; i++;
+    }
+    while (pp < lp) { hfield p = h_field(prev, lp, pp); pp += p.len; fprev++; }
+    if (i >= fprev) h_put(s, &M->type, HM_TYPE, HEADER_END_MATCH);
+    else { h_put(s, &M->type, HM_TYPE, HEADER_END); h_count(s, &M->field_index, HM_FIELD_INDEX, i); }
+}
+
+/* one block of n headers (text without the leading '>' / '@'); first = the file's first header.
+ * payload (malloc'ed, lo_free) and, when trace != NULL, the (model id, symbol) pairs in coding order */
+int lo_header_encode_block(const char* headers, const uint64_t* off, uint64_t n, const char* first, uint64_t first_len,
+                           uint8_t** payload, uint64_t* size, uint8_t** trace, uint64_t* trace_size) {
+    rcenc e; memset(&e, 0, sizeof e); enc_clear(&e);
+    hdrmodels* M = (hdrmodels*)malloc(sizeof(hdrmodels));
+    hm_start_block(M);
+    bytevec tr; memset(&tr, 0, sizeof tr);
+    hsink s = { &e, M, trace ? &tr : NULL };
+    const uint8_t* prev = (const uint8_t*)first; uint64_t lp = first_len;
+    for (uint64_t r = 0; r < n; r++) {
+        const uint8_t* cur = (const uint8_t*)headers + off[r]; uint64_t lc = off[r + 1] - off[r];
+        h_encode_header(&s, cur, lc, prev, lp);
+        prev = cur; lp = lc;
+    }
+    enc_flush(&e);
+    free(M);
+    *payload = e.buf.p; *size = e.buf.n;
+    if (trace) { *trace = tr.p; *trace_size = tr.n; }
+    return 0;
+}
+void lo_free(void* p) { free(p); }
+
+static uint64_t hd_count(rcdec* d, hdrmodels* M, o0model* m) {
+    uint64_t x = dec_next(d, m);
+    return x < 255 ? x : 255 + decode_numeric(d, &M->numeric);
+}
+/* HeaderDecoder over one block: the n headers back to back in out, out_off[n + 1]; returns the bytes written or -1 */
+int64_t lo_header_decode_block(const uint8_t* payload, uint64_t size, uint64_t n, const char* first, uint64_t first_len,
+                               char* out, uint64_t out_cap, uint64_t* out_off) {
+    rcdec d; dec_init(&d, payload, size);
+    hdrmodels* M = (hdrmodels*)malloc(sizeof(hdrmodels));
+    hm_start_block(M);
+    const uint8_t* prev = (const uint8_t*)first; uint64_t lp = first_len;
+    uint64_t w = 0;
+    int64_t rc = 0;
+    out_off[0] = 0;
+    for (uint64_t r = 0; r < n && rc == 0; r++) {
+        uint64_t start = w, pp = 0, nf = 0;                      /* pp: read cursor in prev, nf: fields written so far */
+        #define HD_COPY_PREV_UNTIL(limit)                                                        \
+            while (nf < (limit) && pp < lp) { hfield p = h_field(prev, lp, pp);                  \
+                if (w + p.len > out_cap) { rc = -1; break; }                                     \
+                memcpy(out + w, p.p, p.len); w += p.len; pp += p.len; nf++; }
+        for (;;) {
+            uint8_t t = dec_next(&d, &M->type);
+            if (t == HEADER_END_MATCH) { HD_COPY_PREV_UNTIL(~0ull); break; }
+            if (t == HEADER_END) { uint64_t f = hd_count(&d, M, &M->field_index); if (f < nf) rc = -1; else { HD_COPY_PREV_UNTIL(f); if (nf != f) rc = -1; } break; }
+            if (t < FIELD_ASCII || t >= HEADER_TYPE_COUNT) { rc = -1; break; }
+            uint64_t idx = hd_count(&d, M, &M->field_index);
+            if (idx < nf) { rc = -1; break; }
+            HD_COPY_PREV_UNTIL(idx);
+            if (rc || nf != idx) { rc = -1; break; }
+            hfield p; memset(&p, 0, sizeof p);
+            int have_p = pp < lp;
+            if (have_p) { p = h_field(prev, lp, pp); pp += p.len; }
+            char tmp[64]; int tl = 0;
+            if (t == FIELD_ASCII) {
+                uint64_t col = hd_count(&d, M, &M->field_column), sz = hd_count(&d, M, &M->mis_size);
+                if (col > p.len || w + col + sz > out_cap || col + sz < col) { rc = -1; break; }
+                if (col) memcpy(out + w, p.p, col);
+                w += col;
+                for (uint64_t j = 0; j < sz; j++) out[w++] = (char)dec_next(&d, &M->ascii);
+            } else {
+                uint64_t v = 0, z = 0; uint8_t sep; int has_sep;
+                if (t == FIELD_DELTA || t == FIELD_DELTA_2) {
+                    uint64_t dv = decode_numeric(&d, &M->numeric);
+                    if (!have_p || p.kind != HK_NUM) { rc = -1; break; }
+                    v = t == FIELD_DELTA ? p.value + dv : p.value - dv;
+                    sep = p.sep; has_sep = p.has_sep;
+                } else {
+                    if (t != FIELD_NUMERIC) z = hd_count(&d, M, &M->zero);
+                    if (t != FIELD_ZERO_ONLY) v = decode_numeric(&d, &M->numeric);
+                    sep = dec_next(&d, &M->ascii); has_sep = sep != 0;
+                }
+                if (t != FIELD_ZERO_ONLY) tl = snprintf(tmp, sizeof tmp, "%llu", (unsigned long long)v);
+                if (w + z + (uint64_t)tl + 1 > out_cap || z > out_cap) { rc = -1; break; }
+                memset(out + w, '0', z); w += z;
+                memcpy(out + w, tmp, (size_t)tl); w += (uint64_t)tl;
+                if (has_sep) out[w++] = (char)sep;
+            }
+            nf++;
+        }
+        #undef HD_COPY_PREV_UNTIL
+        out_off[r + 1] = w;
+        prev = (const uint8_t*)out + start; lp = w - start;
+    }
+    free(M);
+    return rc ? rc : (int64_t)w;
 }

@@ -16,6 +16,7 @@
  *   tools/compression/RangeCoder.{hpp,cpp}   Order0Model, RangeEncoder, RangeDecoder
  *   tools/compression/CompressionUtils.hpp   encodeNumeric / decodeNumeric / getDeltaValue
  *   tools/compression/DnaCoder.{hpp,cpp}     AbstractDnaCoder, DnaEncoder, DnaDecoder
+ *   tools/compression/HeaderCoder.{hpp,cpp}  AbstractHeaderCoder, HeaderEncoder, HeaderDecoder (row f3)
  *   tools/compression/Leon.{hpp,cpp}         anchorExist, findAndInsertAnchor, encodeInsertedAnchor,
  *                                            nt2bin/bin2nt, READ_PER_BLOCK
  *   tools/collections/impl/Bloom.hpp         HashFunctors, Bloom, BloomCacheCoherent,
@@ -85,6 +86,15 @@ int lo_decode_anchor_dict(const uint8_t* payload, uint64_t size, uint64_t n_anch
 int64_t lo_decode_block(uint32_t k, const lo_bloom* bloom, const uint64_t* anchors, uint64_t n_anchors,
                         const uint8_t* payload, uint64_t size, uint32_t n_reads,
                         char* out, uint64_t out_cap, uint32_t* out_len);
+
+/* ---- header stream (HeaderEncoder / HeaderDecoder, one read block per call; rules in leon_oracle.c) ----
+ * headers: the blocks' header texts back to back (no leading '>' / '@', no newline), off[n + 1]; first: the file's first
+ * header (AbstractHeaderCoder::startBlock starts every block from it).  payload / trace are malloc'ed: lo_free. */
+int     lo_header_encode_block(const char* headers, const uint64_t* off, uint64_t n, const char* first, uint64_t first_len,
+                               uint8_t** payload, uint64_t* size, uint8_t** trace, uint64_t* trace_size);
+int64_t lo_header_decode_block(const uint8_t* payload, uint64_t size, uint64_t n, const char* first, uint64_t first_len,
+                               char* out, uint64_t out_cap, uint64_t* out_off);
+void    lo_free(void* p);
 
 /* ---- exact k-mer counting helper for tests (stands in for DSK) ---- */
 /* returns the number of distinct canonical k-mers with count >= min_abundance; fills out (may be NULL) */

@@ -61,6 +61,10 @@ def _load():
         "lo_decode_block": (C.c_int64, [C.c_uint32, C.c_void_p, u64p, C.c_uint64, u8p, C.c_uint64, C.c_uint32,
                                         C.c_char_p, C.c_uint64, u32p]),
         "lo_count_solid": (C.c_uint64, [C.c_char_p, u64p, C.c_uint64, C.c_uint32, C.c_uint32, u64p, C.c_uint64]),
+        "lo_header_encode_block": (C.c_int, [C.c_char_p, u64p, C.c_uint64, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), u64p,
+                                             C.POINTER(C.c_void_p), u64p]),
+        "lo_header_decode_block": (C.c_int64, [u8p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u64p]),
+        "lo_free": (None, [C.c_void_p]),
         "lo_rc_new": (C.c_void_p, []),
         "lo_rc_free": (None, [C.c_void_p]),
         "lo_rc_encode_stream": (C.c_int, [C.c_void_p, u8p, u8p, C.c_uint64, u32p, C.c_uint32]),
@@ -265,3 +269,30 @@ def rc_decode_stream(payload, models, model_sizes):
     lib.lo_rc_decode_stream(_p(buf, u8p), len(buf), _p(models, u8p), _p(out, u8p), len(models), _p(sizes, u32p),
                             len(sizes))
     return out
+
+
+def header_encode_block(headers, first, with_trace=False):
+    """HeaderEncoder over one block: list of bytes -> payload bytes (and the (model id, symbol) trace as an (n, 2) array)"""
+    blob, off = reads_to_arrays(headers)
+    pay, tr = C.c_void_p(), C.c_void_p()
+    sz, tsz = C.c_uint64(), C.c_uint64()
+    lib.lo_header_encode_block(blob, _p(off, u64p), len(headers), first, len(first), C.byref(pay), C.byref(sz),
+                               C.byref(tr) if with_trace else None, C.byref(tsz))
+    payload = C.string_at(pay, sz.value) if sz.value else b""
+    lib.lo_free(pay)
+    if not with_trace:
+        return payload
+    trace = np.frombuffer(C.string_at(tr, tsz.value), dtype=np.uint8).reshape(-1, 2).copy() if tsz.value else np.zeros((0, 2), np.uint8)
+    lib.lo_free(tr)
+    return payload, trace
+
+
+def header_decode_block(payload, n, first, max_bytes):
+    buf = np.frombuffer(payload, dtype=np.uint8)
+    out = C.create_string_buffer(int(max_bytes) + 1)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    w = lib.lo_header_decode_block(_p(buf, u8p), len(buf), n, first, len(first), out, int(max_bytes), _p(off, u64p))
+    if w < 0:
+        raise ValueError("header block does not decode")
+    raw = out.raw[:w]
+    return [raw[int(off[i]):int(off[i + 1])] for i in range(n)]
