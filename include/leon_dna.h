@@ -117,7 +117,7 @@ int leon_dna_set_shard(leon_dna_ctx* ctx, uint32_t rank, uint32_t world);
 int leon_dna_finish(leon_dna_ctx* ctx, const uint8_t** dict_payload, uint64_t* dict_size, uint64_t* n_anchors);
 
 /* -- the step BEFORE the path: solid k-mers of the reads, the set Leon::createBloom inserts (upstream DSK,
- * SortingCountAlgorithm).  Canonical k-mers occurring at least min_abundance times; k-mers containing an N are skipped.
+ * SortingCountAlgorithm).  Canonical k-mers occurring at least min_abundance times (0 = automatic threshold, see leon_kmer_auto_cutoff); k-mers containing an N are skipped.
  * Output: W words per k-mer (unordered across hash partitions).  histogram (optional, 256 entries): number of distinct
  * k-mers by abundance, clipped at 255.  max_keys_per_pass: k-mers sorted at once (0 = sized from the free device memory).  Errors: leon_last_error(NULL). */
 int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads,
@@ -127,6 +127,17 @@ int leon_kmer_solid(int device_id, const uint8_t* bases, const uint64_t* offsets
                     uint32_t min_abundance, uint64_t max_keys_per_pass, uint64_t* out, uint64_t out_cap, uint64_t* n_solid,
                     uint64_t* histogram);
 void leon_device_free(void* d_ptr);
+/* min_abundance = 0 in the two calls above means "automatic" (Leon's default, /root/reference/README.md:54): the threshold
+ * this function derives from the abundance spectrum (first local minimum, never below 2; 2 when there is no valley).
+ * histogram: 256 entries as returned above.  Host-only. */
+int leon_kmer_auto_cutoff(const uint64_t* histogram, uint32_t* cutoff);
+/* plain device memory for callers that keep their reads resident in HBM (the host mirror's -c does): errors through
+ * leon_last_error(NULL) */
+int leon_device_count(int* n_devices);
+int leon_device_alloc(int device_id, uint64_t bytes, void** d_ptr);
+int leon_device_upload(int device_id, void* d_dst, const void* src, uint64_t bytes);
+int leon_device_copy(int device_id, void* d_dst, const void* d_src, uint64_t bytes);
+int leon_device_download(int device_id, void* dst, const void* d_src, uint64_t bytes);
 
 /* Host-only helper (no GPU, no ctx): the dictionary stream leon_dna_finish returns for a given anchor list, i.e.
  * Leon::encodeInsertedAnchor over `kmers` in address order followed by the flush.  Used by the CPU tests. */
@@ -165,6 +176,13 @@ int leon_header_encode_batch_device(leon_dna_ctx* ctx, const uint8_t* d_headers,
 int leon_host_header_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
                                    uint64_t n_blocks, const uint8_t* first_header, uint64_t first_header_len, uint8_t* out,
                                    uint64_t out_cap, uint64_t* out_off, uint64_t* out_size, uint32_t n_threads);
+/* Quality stream, lossy form (Leon's default, /root/reference/README.md:55): DnaEncoder::storeSolidCoverageInfo + smoothQuals
+ * [RECALLED]: a quality becomes '@' where at least two of the read's solid k-mers (in the bloom of ctx) span the position, or
+ * where it is above '@'; reads shorter than k are left alone.  quals: one byte per base, same offsets as the bases, rewritten
+ * in place; what comes out then goes through leon_host_qual_encode_blocks like the lossless form. */
+int leon_qual_smooth_batch(leon_dna_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads, uint8_t* quals);
+int leon_qual_smooth_batch_device(leon_dna_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads,
+                                  uint8_t* d_quals);   /* d_quals[j] belongs to base d_bases[d_offsets[0] + j] */
 /* Quality stream, lossless form (`-lossless`): per read block the quality lines, each followed by '\n', through zlib
  * (upstream deflates the block's buffered quality lines, Leon::writeBlockLena [RECALLED]).  Host-only, blocks in parallel
  * on n_threads threads; blocks go to the sink in increasing id starting at first_block_id.  zlib_level: -1 = zlib default. */

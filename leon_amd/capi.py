@@ -85,6 +85,14 @@ _EXPORTS = {
                                                    SINK, C.c_void_p]),
     "leon_host_header_decode_blocks": (C.c_int, [_u8p, _u64p, _u32p, C.c_uint64, C.c_char_p, C.c_uint64, _u8p, C.c_uint64, _u64p,
                                                   _u64p, C.c_uint32]),
+    "leon_qual_smooth_batch": (C.c_int, [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _u8p]),
+    "leon_qual_smooth_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "leon_kmer_auto_cutoff": (C.c_int, [_u64p, _u32p]),
+    "leon_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "leon_device_alloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "leon_device_upload": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "leon_device_copy": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "leon_device_download": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "leon_host_qual_encode_blocks": (C.c_int, [C.c_char_p, _u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, SINK, C.c_void_p,
                                                 C.c_uint64]),
     "leon_host_qual_decode_blocks": (C.c_int, [_u8p, _u64p, _u32p, _u64p, C.c_uint64, _u8p, C.c_uint64, _u64p, C.c_uint32]),
@@ -209,6 +217,17 @@ def host_qual_decode_blocks(blocks, block_n_bytes, n_threads=0):
         raise LeonDnaError(rc, (lib.leon_last_error(None) or b"").decode())
     raw = out.tobytes()
     return [raw[int(out_off[i]):int(out_off[i + 1])] for i in range(total)]
+
+
+def kmer_auto_cutoff(histogram):
+    lib = load_library()
+    h = np.ascontiguousarray(histogram, dtype=np.uint64)
+    assert len(h) == 256
+    out = C.c_uint32()
+    rc = lib.leon_kmer_auto_cutoff(_ptr(h, _u64p), C.byref(out))
+    if rc:
+        raise LeonDnaError(rc, "leon_kmer_auto_cutoff failed")
+    return out.value
 
 
 def kmer_solid(bases, offsets, k, min_abundance, device_id=0, with_histogram=False, max_keys_per_pass=0):
@@ -382,6 +401,14 @@ class DnaEncodeContext:
                                                     len(first_header), cb, None))
         self._hdr_next += len(headers)
         return blocks
+
+    def qual_smooth_batch(self, bases, offsets, quals):
+        """DnaEncoder::smoothQuals (lossy qualities) over a batch: returns the smoothed quality bytes (same offsets)"""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        q = np.frombuffer(bytes(quals), dtype=np.uint8).copy()
+        if len(offsets) > 1:
+            self._chk(self.lib.leon_qual_smooth_batch(self.h, bytes(bases), _ptr(offsets, _u64p), len(offsets) - 1, _ptr(q, _u8p)))
+        return q.tobytes()
 
     def finish(self, copy=True):
         """(dictionary stream, number of anchors); copy=False returns its size instead of a bytes copy (the C caller

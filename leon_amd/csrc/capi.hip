@@ -851,6 +851,67 @@ int leon_header_encode_batch(leon_dna_ctx* c, const uint8_t* headers, const uint
                                            first_header_len, sink, user);
 }
 
+// ------------------------------------------------------------------------------------------------ quality stream (lossy)
+// DnaEncoder::smoothQuals over a batch: the reads are packed as for the encode path, then one wave per read rewrites the
+// qualities in place (hdr_kernels.hip k_qual_smooth).  Needs the file's bloom in the context.
+int leon_qual_smooth_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n, uint8_t* d_quals) {
+    if (!c) return LEON_E_INVALID;
+    if (n == 0) return LEON_OK;
+    if (!d_bases || !d_off || !d_quals) return fail(c, LEON_E_INVALID, "null argument");
+    if (n > 0xFFFFFFF0ull) return fail(c, LEON_E_INVALID, "more than 2^32 reads in one batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIPCHK(c, c->slot_off.ensure((n + 1) * 8));
+    HIPCHK(c, hipMemsetAsync(c->counters.as<uint32_t>() + 4, 0, 4, s));
+    launch_read_slots(s, d_off, n, c->slot_off.as<uint64_t>(), c->counters.as<uint32_t>() + 4);
+    size_t tmp_bytes = 0;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
+    if (int rc = ensure_cub(c, tmp_bytes)) return rc;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
+    uint64_t n_slots = 0;
+    uint32_t bad_offsets = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_slots, c->slot_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&bad_offsets, c->counters.as<uint32_t>() + 4, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (bad_offsets) return fail(c, LEON_E_INVALID, "offsets are not monotonic (or a read is longer than 2^31 bases)");
+    HIPCHK(c, c->packed.ensure((n_slots * 2 + 16) * 4));
+    HIPCHK(c, c->nmask.ensure((n_slots + 4) * 4));
+    HIPCHK(c, c->rlen.ensure(n * 4));
+    HIPCHK(c, c->ncount.ensure(n * 4));
+    HIPCHK(c, hipMemsetAsync(c->packed.as<uint32_t>() + n_slots * 2, 0, 64, s));
+    launch_pack(s, d_bases, d_off, c->slot_off.as<uint64_t>(), n, c->packed.as<uint32_t>(), c->nmask.as<uint32_t>(), c->rlen.as<uint32_t>(),
+                c->ncount.as<uint32_t>());
+    launch_qual_smooth(s, reads_view(c, d_off, n), c->B, c->d_rv16, d_quals);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    return LEON_OK;
+}
+
+int leon_qual_smooth_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t* off, uint64_t n, uint8_t* quals) {
+    if (!c) return LEON_E_INVALID;
+    if (n == 0) return LEON_OK;
+    if (!bases || !off || !quals) return fail(c, LEON_E_INVALID, "null argument");
+    if (off[n] < off[0]) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t nb = off[n] - off[0];
+    TmpBuf dq;
+    HIPCHK(c, c->in_bases.ensure(nb + 64));
+    HIPCHK(c, c->in_off.ensure((n + 1) * 8));
+    HIPCHK(c, dq.ensure(nb + 64));
+    HIPCHK(c, hipMemcpy(c->in_off.p, off, (n + 1) * 8, hipMemcpyHostToDevice));
+    if (off[0]) {
+        launch_rebase_offsets(c->stream, c->in_off.as<uint64_t>(), n + 1, off[0]);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (nb) {
+        HIPCHK(c, hipMemcpy(c->in_bases.p, bases + off[0], nb, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(dq.p, quals + off[0], nb, hipMemcpyHostToDevice));
+    }
+    if (int rc = leon_qual_smooth_batch_device(c, c->in_bases.as<uint8_t>(), c->in_off.as<uint64_t>(), n, dq.as<uint8_t>())) return rc;
+    if (nb) HIPCHK(c, hipMemcpy(quals + off[0], dq.p, nb, hipMemcpyDeviceToHost));
+    return LEON_OK;
+}
+
 int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, uint64_t* n_anchors) {
     if (!c || !payload || !size || !n_anchors) return LEON_E_INVALID;
     if (c->poisoned) return fail(c, LEON_E_STATE, "an earlier batch failed part-way: the stream is unusable until leon_dna_reset_stream");

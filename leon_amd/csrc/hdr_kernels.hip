@@ -4,7 +4,7 @@
 // stream depends on the previous header's TEXT only, never on coder state, so the records of all headers of a batch
 // are produced in parallel -- one lane per header, count pass / scan / emit pass like k_symbols -- and the per-block
 // serial part is left to k_rc_encode (rc_kernels.hip) with this stream's model set.  The record layout is the one
-// oracle/leon_oracle.c states; tests compare payload bytes with the oracle.
+// DESIGN.md section 1.3 states; the tests compare payload bytes with the CPU restatement of the same rules.
 #include "kernels.h"
 
 namespace leon {
@@ -128,6 +128,59 @@ void launch_hdr_symbols(hipStream_t s, const uint8_t* hdr, const uint64_t* off, 
     const uint32_t g = (uint32_t)((n + 255) / 256);
     if (syms) hipLaunchKernelGGL(k_hdr_symbols<true>, dim3(g), dim3(256), 0, s, hdr, off, n, rpb, first, first_len, sym_off, syms);
     else hipLaunchKernelGGL(k_hdr_symbols<false>, dim3(g), dim3(256), 0, s, hdr, off, n, rpb, first, first_len, sym_off, syms);
+}
+
+}  // namespace leon
+
+// ================================================================================================
+// quality stream, lossy form (the default without -lossless): DnaEncoder::storeSolidCoverageInfo + smoothQuals
+// [RECALLED med].  cover[i] = number of the read's k-mers that are in the bloom (canonical, N read as 'A') and span
+// position i; a quality becomes '@' where cover[i] >= 2 (_smoothing_threshold) or where it is above '@' (truncation);
+// reads shorter than k are left as they are.  One wave per read, lane = k-mer position (64 per step): the solid flags
+// of a step are one ballot, and a position's coverage is a popcount over the k flags that span it.
+// ================================================================================================
+namespace leon {
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_qual_smooth(ReadsDev R, BloomDev B, const uint16_t* rv16g, uint8_t* quals) {
+    __shared__ uint16_t rv16[256];
+    load_rv16(rv16, rv16g);
+    const uint32_t lane = lane_id(), k = R.k;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < R.n; i += nwaves) {
+        const uint32_t len = R.len[i];
+        if (len < k) continue;
+        const uint32_t nk = len - k + 1;
+        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+        uint8_t* q = quals + (R.base_off[i] - R.base_off[0]);
+        unsigned long long prev = 0;                              // solid flags of k-mer positions [base - 64, base)
+        for (uint32_t base = 0; base < len; base += 64) {
+            const uint32_t p = base + lane;
+            bool solid = false;
+            const uint32_t kb = base < nk ? base : ((nk - 1) & ~63u);    // past the last k-mer only the coverage counts go on
+            const K cn = canon_from_words<K>(pass_words(pk, kb, lane), kb, p < nk ? p : nk - 1, k);
+            if (p < nk) solid = bloom_contains<K>(B, rv16, cn);
+            const unsigned long long cur = __ballot(solid);
+            if (p < len) {
+                // k-mer positions spanning p: [p - k + 1, p] = bits [lane + 65 - k, lane + 64] of the 128 flags prev:cur
+                const unsigned __int128 both = ((unsigned __int128)cur << 64) | prev;
+                const uint32_t lo = lane + 65 - k;                // k <= 63: lo >= 2
+                const unsigned __int128 win = (both >> lo) & ((((unsigned __int128)1) << k) - 1);
+                const uint32_t cover = (uint32_t)__popcll((unsigned long long)win) + (uint32_t)__popcll((unsigned long long)(win >> 64));
+                const uint8_t c = q[p];
+                if (cover >= 2u || c > (uint8_t)'@') q[p] = (uint8_t)'@';
+            }
+            prev = cur;
+        }
+    }
+}
+void launch_qual_smooth(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, uint8_t* quals) {
+    if (!R.n) return;
+    uint64_t g = (R.n + 3) / 4;
+    if (g > 256 * 16) g = 256 * 16;
+    if (R.k >= 32) hipLaunchKernelGGL(k_qual_smooth<u128>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, quals);
+    else hipLaunchKernelGGL(k_qual_smooth<uint64_t>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, quals);
 }
 
 }  // namespace leon

@@ -95,6 +95,8 @@ size_t rc_model_scratch_bytes(uint64_t n_blocks);
 void launch_gather_payload(hipStream_t s, const uint8_t* out, const uint64_t* out_off, const uint64_t* dst_off,
                            const uint64_t* sizes, uint64_t n_blocks, uint8_t* dst);
 
+// ---- quality stream, lossy form: DnaEncoder::smoothQuals over packed reads, quals in place (indexed like the bases) ----
+void launch_qual_smooth(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, uint8_t* quals);
 // ---- decoder (DnaDecoder) ----
 size_t decode_scratch_bytes(uint64_t n_blocks);
 void launch_decode_blocks(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors,

@@ -60,7 +60,7 @@ __global__ void k_positions(const uint64_t* off, uint64_t n, uint32_t k, uint64_
 }
 // sorted keys -> flag the first element of every run of at least T equal keys; optional histogram of run lengths
 template <uint32_t W>
-__global__ void k_flag_runs(const uint64_t* keys, uint64_t n, uint32_t T, uint8_t* flags, unsigned long long* hist) {
+__global__ void k_flag_runs(const uint64_t* keys, uint64_t n, uint32_t T, uint8_t* flags, unsigned long long* hist, uint8_t* runlen) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         auto eq = [&](uint64_t a, uint64_t b) { return keys[a * W] == keys[b * W] && (W == 1 || keys[a * W + 1] == keys[b * W + 1]); };
         const bool head = i == 0 || !eq(i, i - 1);
@@ -73,10 +73,14 @@ __global__ void k_flag_runs(const uint64_t* keys, uint64_t n, uint32_t T, uint8_
                 while (step > 1) { step >>= 1; if (lo + step < n && eq(i, lo + step)) lo += step; }
                 const uint64_t run = lo - i + 1;
                 atomicAdd(&hist[run > 255 ? 255 : run], 1ull);
+                if (runlen) runlen[i] = (uint8_t)(run > 255 ? 255 : run);
             }
         }
         flags[i] = f;
     }
+}
+__global__ void k_flag_at_least(const uint8_t* counts, uint64_t n, uint32_t T, uint8_t* flags) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) flags[i] = counts[i] >= T ? 1 : 0;
 }
 __global__ void k_split_words(const uint64_t* keys, uint64_t n, uint64_t* lo, uint64_t* hi) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { lo[i] = keys[2 * i]; hi[i] = keys[2 * i + 1]; }
@@ -105,11 +109,65 @@ extern "C" {
 
 void leon_device_free(void* p) { if (p) (void)hipFree(p); }
 
+int leon_device_count(int* n_devices) {
+    if (!n_devices) return LEON_E_INVALID;
+    *n_devices = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { set_create_error("no usable HIP device"); return LEON_E_NO_DEVICE; }
+    *n_devices = n;
+    return LEON_OK;
+}
+int leon_device_alloc(int device_id, uint64_t bytes, void** d_ptr) {
+    if (!d_ptr) return LEON_E_INVALID;
+    *d_ptr = nullptr;
+    KCHK(hipSetDevice(device_id));
+    KCHK(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return LEON_OK;
+}
+int leon_device_upload(int device_id, void* d_dst, const void* src, uint64_t bytes) {
+    if (bytes && (!d_dst || !src)) return LEON_E_INVALID;
+    KCHK(hipSetDevice(device_id));
+    if (bytes) KCHK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return LEON_OK;
+}
+int leon_device_copy(int device_id, void* d_dst, const void* d_src, uint64_t bytes) {
+    if (bytes && (!d_dst || !d_src)) return LEON_E_INVALID;
+    KCHK(hipSetDevice(device_id));
+    if (bytes) KCHK(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+    return LEON_OK;
+}
+
+int leon_device_download(int device_id, void* dst, const void* d_src, uint64_t bytes) {
+    if (bytes && (!dst || !d_src)) return LEON_E_INVALID;
+    KCHK(hipSetDevice(device_id));
+    if (bytes) KCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return LEON_OK;
+}
+
+// The abundance threshold Leon uses when `-abundance` is absent ("default: automatic", /root/reference/README.md:54; upstream
+// asks DSK for `-abundance-min auto` [RECALLED]): the first local minimum of the abundance spectrum -- the valley between the
+// sequencing-error k-mers (abundance 1, 2, ...) and the genomic ones around the coverage -- never below 2, and 2 when the
+// spectrum has no valley (coverage too low to separate them).  histogram[a] = distinct k-mers of abundance a, a = 255 and more
+// in the last entry.  Host-only.
+int leon_kmer_auto_cutoff(const uint64_t* histogram, uint32_t* cutoff) {
+    if (!histogram || !cutoff) return LEON_E_INVALID;
+    *cutoff = 2;
+    uint32_t last = 0;
+    for (uint32_t a = 1; a < 256; a++) if (histogram[a]) last = a;
+    for (uint32_t a = 1; a < last; a++)                          // the spectrum stops falling at a: k-mers seen a times or more are kept
+        if (histogram[a + 1] >= histogram[a]) { *cutoff = a < 2 ? 2 : a; break; }
+    return LEON_OK;
+}
+
 int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint32_t k,
                            uint32_t min_abundance, uint64_t max_keys_per_pass, uint64_t** d_solid, uint64_t* n_solid,
                            uint64_t* histogram) {
     if (!d_solid || !n_solid || (n_reads && (!d_bases || !d_offsets))) return LEON_E_INVALID;
-    if (k < 3 || k > 63 || min_abundance < 1) { set_create_error("kmer_solid: need 3 <= k <= 63 and min_abundance >= 1"); return LEON_E_INVALID; }
+    if (k < 3 || k > 63) { set_create_error("kmer_solid: need 3 <= k <= 63"); return LEON_E_INVALID; }
+    // min_abundance 0 = automatic (Leon's default, /root/reference/README.md:54): k-mers seen twice or more are kept with their
+    // abundance while the partitions go by, the threshold comes from the whole spectrum (leon_kmer_auto_cutoff), then they are filtered
+    const bool automatic = min_abundance == 0;
+    if (automatic) min_abundance = 2;
     *d_solid = nullptr; *n_solid = 0;
     if (histogram) memset(histogram, 0, 256 * sizeof(uint64_t));
     if (!n_reads) return LEON_OK;
@@ -163,8 +221,9 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     if (n_parts < 1) n_parts = 1;
     const uint64_t cap = n_parts == 1 ? total : (uint64_t)(total / n_parts * 1.25) + (1u << 20);
     // ---- per-partition buffers ----
-    Buf keys, alt, alt2, alt3, flags, nsel, hist, sort_tmp, sel_tmp;
+    Buf keys, alt, alt2, alt3, flags, nsel, hist, sort_tmp, sel_tmp, runlen, runsel;
     KCHK(keys.alloc(cap * 8 * W)); KCHK(alt.alloc(cap * 8 * W)); KCHK(flags.alloc(cap));
+    if (automatic) { KCHK(runlen.alloc(cap)); KCHK(runsel.alloc(cap)); }
     if (W == 2) { KCHK(alt2.alloc(cap * 8)); KCHK(alt3.alloc(cap * 8)); }
     KCHK(nsel.alloc(8)); KCHK(hist.alloc(256 * 8));
     KCHK(hipMemset(hist.p, 0, 256 * 8));
@@ -178,9 +237,12 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     // the solid k-mers accumulate here (grown geometrically)
     uint64_t out_cap = std::max<uint64_t>(total / 16, 1u << 20), out_n = 0;
     uint64_t* out = nullptr;
+    uint8_t* out_cnt = nullptr;                               // automatic: abundance (clipped at 255) of every kept k-mer
     KCHK(hipMalloc((void**)&out, out_cap * 8 * W));
-    auto fail_free = [&](int code) { if (out) (void)hipFree(out); return code; };
+    auto fail_free = [&](int code) { if (out) (void)hipFree(out); if (out_cnt) (void)hipFree(out_cnt); return code; };
+    const bool want_hist = histogram != nullptr || automatic;
 #define KCHK2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_create_error(std::string(#call) + ": " + hipGetErrorString(e_)); return fail_free(LEON_E_HIP); } } while (0)
+    if (automatic) KCHK2(hipMalloc((void**)&out_cnt, out_cap));
     size_t scan_tb = 0;
     KCHK2(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tb, pos.as<uint64_t>(), pos.as<uint64_t>(), n_reads + 1, s));
     Buf scan_tmp;
@@ -211,8 +273,8 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
             hipLaunchKernelGGL(k_join_words, dim3(grid(n)), dim3(256), 0, s, lo, hi, n, keys.as<uint64_t>());
             sorted = keys.as<uint64_t>();
         }
-        if (W == 1) hipLaunchKernelGGL(k_flag_runs<1>, dim3(grid(n)), dim3(256), 0, s, sorted, n, min_abundance, flags.as<uint8_t>(), histogram ? hist.as<unsigned long long>() : nullptr);
-        else hipLaunchKernelGGL(k_flag_runs<2>, dim3(grid(n)), dim3(256), 0, s, sorted, n, min_abundance, flags.as<uint8_t>(), histogram ? hist.as<unsigned long long>() : nullptr);
+        if (W == 1) hipLaunchKernelGGL(k_flag_runs<1>, dim3(grid(n)), dim3(256), 0, s, sorted, n, min_abundance, flags.as<uint8_t>(), want_hist ? hist.as<unsigned long long>() : nullptr, runlen.as<uint8_t>());
+        else hipLaunchKernelGGL(k_flag_runs<2>, dim3(grid(n)), dim3(256), 0, s, sorted, n, min_abundance, flags.as<uint8_t>(), want_hist ? hist.as<unsigned long long>() : nullptr, runlen.as<uint8_t>());
         // compact the heads of solid runs behind what earlier partitions produced
         uint64_t* dst = (sorted == keys.as<uint64_t>()) ? alt.as<uint64_t>() : keys.as<uint64_t>();
         size_t need = 0;
@@ -225,6 +287,12 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
             if (need > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need)); sl = need; }
             KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need, (Pair128*)sorted, flags.as<uint8_t>(), (Pair128*)dst, nsel.as<uint64_t>(), n, s));
         }
+        if (automatic) {                                        // the same heads' run lengths, in the same order
+            size_t need2 = 0;
+            KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need2, runlen.as<uint8_t>(), flags.as<uint8_t>(), runsel.as<uint8_t>(), nsel.as<uint64_t>(), n, s));
+            if (need2 > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need2)); sl = need2; }
+            KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need2, runlen.as<uint8_t>(), flags.as<uint8_t>(), runsel.as<uint8_t>(), nsel.as<uint64_t>(), n, s));
+        }
         uint64_t ns = 0;
         KCHK2(hipMemcpy(&ns, nsel.p, 8, hipMemcpyDeviceToHost));
         if (out_n + ns > out_cap) {
@@ -232,13 +300,47 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
             uint64_t* bigger = nullptr;
             KCHK2(hipMalloc((void**)&bigger, nc * 8 * W));
             if (out_n) KCHK2(hipMemcpy(bigger, out, out_n * 8 * W, hipMemcpyDeviceToDevice));
-            (void)hipFree(out); out = bigger; out_cap = nc;
+            (void)hipFree(out); out = bigger;
+            if (automatic) {
+                uint8_t* bc = nullptr;
+                KCHK2(hipMalloc((void**)&bc, nc));
+                if (out_n) KCHK2(hipMemcpy(bc, out_cnt, out_n, hipMemcpyDeviceToDevice));
+                (void)hipFree(out_cnt); out_cnt = bc;
+            }
+            out_cap = nc;
         }
         if (ns) KCHK2(hipMemcpy(out + out_n * W, dst, ns * 8 * W, hipMemcpyDeviceToDevice));
+        if (ns && automatic) KCHK2(hipMemcpy(out_cnt + out_n, runsel.p, ns, hipMemcpyDeviceToDevice));
         out_n += ns;
     }
-    if (histogram) KCHK2(hipMemcpy(histogram, hist.p, 256 * 8, hipMemcpyDeviceToHost));
+    uint64_t h_hist[256] = {0};
+    if (want_hist) KCHK2(hipMemcpy(h_hist, hist.p, 256 * 8, hipMemcpyDeviceToHost));
+    if (histogram) memcpy(histogram, h_hist, sizeof h_hist);
+    if (automatic && out_n) {
+        uint32_t cutoff = 2;
+        (void)leon_kmer_auto_cutoff(h_hist, &cutoff);
+        if (cutoff > 2) {                                       // drop what is below the spectrum's own threshold
+            Buf f2, kept;
+            KCHK2(f2.alloc(out_n)); KCHK2(kept.alloc(out_n * 8 * W));
+            hipLaunchKernelGGL(k_flag_at_least, dim3(grid(out_n)), dim3(256), 0, s, out_cnt, out_n, cutoff, f2.as<uint8_t>());
+            size_t need3 = 0;
+            if (W == 1) {
+                KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need3, out, f2.as<uint8_t>(), kept.as<uint64_t>(), nsel.as<uint64_t>(), out_n, s));
+                if (need3 > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need3)); sl = need3; }
+                KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need3, out, f2.as<uint8_t>(), kept.as<uint64_t>(), nsel.as<uint64_t>(), out_n, s));
+            } else {
+                KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need3, (Pair128*)out, f2.as<uint8_t>(), (Pair128*)kept.p, nsel.as<uint64_t>(), out_n, s));
+                if (need3 > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need3)); sl = need3; }
+                KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need3, (Pair128*)out, f2.as<uint8_t>(), (Pair128*)kept.p, nsel.as<uint64_t>(), out_n, s));
+            }
+            uint64_t nk = 0;
+            KCHK2(hipMemcpy(&nk, nsel.p, 8, hipMemcpyDeviceToHost));
+            if (nk) KCHK2(hipMemcpy(out, kept.p, nk * 8 * W, hipMemcpyDeviceToDevice));
+            out_n = nk;
+        }
+    }
     KCHK2(hipDeviceSynchronize());
+    if (out_cnt) (void)hipFree(out_cnt);
     *d_solid = out; *n_solid = out_n;
     return LEON_OK;
 }

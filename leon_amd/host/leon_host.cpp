@@ -1,16 +1,31 @@
-// leon_host.cpp -- see leon_host.hpp.  Host glue only: every byte of the DNA stream comes from libleon_dna.so.
+// leon_host.cpp -- see leon_host.hpp.  Host glue only: the DNA and header streams come from libleon_dna.so's HIP path.
 //
-// Interim container written by `-c` and read by `-d` (little endian), until the .leon HDF5 layout row is built:
-//   "LEONDNA2" | u32 k | u32 reads_per_block | u64 n_reads | u64 n_blocks | u64 n_anchors | u64 dict_bytes |
-//   u64 bloom_tai | u64 bloom_bytes | u32 n_hash | u32 block_nbits |
-//   n_blocks x (u64 size, u64 n_reads, u64 n_bases) | dictionary stream | bloom bytes | block payloads
+// -c, one pass over the input (bank.hpp), batch by batch:
+//      headers  -> leon_header_encode_batch            -> leon/header/block_<i>
+//      bases    -> appended to a device-resident copy of the reads (never all of it on the host)
+//      qualities (-lossless) -> leon_host_qual_encode_blocks (zlib on host threads) -> leon/qual/block_<i>
+//    then: solid k-mers of the resident reads (leon_kmer_solid_device, automatic threshold unless -abundance) -> bloom ->
+//      leon_dna_encode_batch_device over the resident reads -> leon/dna/block_<i>, anchor dictionary, bloom, tables;
+//      lossy qualities (the default) need the bloom: a second pass over the file smooths them on the device
+//      (leon_qual_smooth_batch_device) before the same zlib blocks.
+// -d, block group by block group: leon_dna_decode_blocks (device), leon_host_header_decode_blocks,
+//      leon_host_qual_decode_blocks, records written as FASTA / FASTQ text.
 #include "leon_host.hpp"
 
+#include "bank.hpp"
+#include "leon_container.hpp"
+
+#include <zlib.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 namespace leon_host {
 
@@ -18,231 +33,552 @@ const char* Leon::STR_COMPRESS = "-c";
 const char* Leon::STR_DECOMPRESS = "-d";
 
 namespace {
+
+using namespace layout;
+
 void check(leon_dna_ctx* ctx, int rc, const char* what) {
     if (rc != LEON_OK) throw Exception(std::string(what) + ": " + leon_last_error(ctx));
 }
-int sink(void* user, uint64_t block_id, const uint8_t* payload, uint64_t size, uint32_t n_reads) {
-    static_cast<Leon*>(user)->writeBlock(payload, size, (int)n_reads, block_id);
-    return 0;
+bool ends_with(const std::string& s, const std::string& suffix) {
+    return s.size() >= suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0;
 }
-// FASTA / FASTQ (plain text) -> sequences; stands in for gatb's Bank (out of scope)
-std::vector<Sequence> read_bank(const std::string& path) {
-    std::ifstream in(path);
-    if (!in) throw Exception("cannot open " + path);
-    std::vector<Sequence> out;
-    std::string line;
-    bool fastq = false, first = true;
-    while (std::getline(in, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (line.empty()) continue;
-        if (first) { fastq = line[0] == '@'; first = false; }
-        if (fastq) {
-            Sequence s; s.comment = line.substr(1);
-            if (!std::getline(in, s.data)) break;
-            std::string plus;
-            if (!std::getline(in, plus) || !std::getline(in, s.quality)) throw Exception("truncated FASTQ record in " + path);
-            s.index = out.size(); out.push_back(std::move(s));
-        } else if (line[0] == '>') {
-            Sequence s; s.comment = line.substr(1); s.index = out.size(); out.push_back(std::move(s));
-        } else {
-            if (out.empty()) throw Exception("FASTA data before the first header in " + path);
-            out.back().data += line;
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+struct CtxDeleter { void operator()(leon_dna_ctx* c) const { if (c) leon_dna_ctx_destroy(c); } };
+typedef std::unique_ptr<leon_dna_ctx, CtxDeleter> CtxPtr;
+
+CtxPtr make_ctx(uint32_t k, uint64_t tai, int device, uint32_t n_hash = 7, uint32_t block_nbits = 12, uint32_t rpb = Leon::READ_PER_BLOCK) {
+    leon_dna_cfg cfg = {};
+    cfg.struct_size = sizeof(cfg);
+    cfg.kmer_size = k; cfg.reads_per_block = rpb;
+    cfg.bloom_n_hash = n_hash; cfg.bloom_block_nbits = block_nbits; cfg.bloom_tai = tai; cfg.device_id = device;
+    leon_dna_ctx* c = nullptr;
+    check(nullptr, leon_dna_ctx_create(&cfg, &c), "leon_dna_ctx_create");
+    return CtxPtr(c);
+}
+
+// One stream's blocks on their way into the container (Leon::writeBlock / writeBlockLena).  Blocks of one stream come from
+// one thread in increasing id, or -- DNA blocks of a multi-GPU run -- from one thread per GPU with disjoint ids.
+struct StreamWriter {
+    Container* out = nullptr;
+    std::mutex* mu = nullptr;
+    const char* group = nullptr;
+    std::vector<uint64_t> sizes, reads;          // per block id
+    uint64_t bytes = 0;
+    std::string error;
+    static int sink(void* user, uint64_t block_id, const uint8_t* payload, uint64_t size, uint32_t n_reads) {
+        StreamWriter* w = static_cast<StreamWriter*>(user);
+        try {
+            std::lock_guard<std::mutex> g(*w->mu);
+            if (block_id >= w->sizes.size()) { w->sizes.resize(block_id + 1, ~0ull); w->reads.resize(block_id + 1, 0); }
+            if (w->sizes[block_id] != ~0ull) throw Exception("block " + std::to_string(block_id) + " arrived twice");
+            w->out->putBytes(Container::blockPath(w->group, block_id), payload, size);
+            w->sizes[block_id] = size; w->reads[block_id] = n_reads; w->bytes += size;
+            return 0;
+        } catch (const std::exception& e) {        // no exception may cross the C boundary
+            w->error = e.what();
+            return 1;
         }
     }
-    return out;
+    void complete(uint64_t n_blocks, const char* what) const {
+        if (sizes.size() != n_blocks) throw Exception(std::string(what) + ": " + std::to_string(sizes.size()) + " blocks written, " + std::to_string(n_blocks) + " expected");
+        for (uint64_t s : sizes) if (s == ~0ull) throw Exception(std::string(what) + ": a block is missing");
+    }
+};
+void check_sink(leon_dna_ctx* ctx, int rc, const StreamWriter& w, const char* what) {
+    if (rc == LEON_E_SINK && !w.error.empty()) throw Exception(std::string(what) + ": " + w.error);
+    check(ctx, rc, what);
 }
-template <typename T> void put(std::ofstream& o, T v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
-}  // namespace
 
-// ------------------------------------------------------------------------------------------------ DnaEncoder
-DnaEncoder::DnaEncoder(Leon* leon) : leon_(leon), offsets_(1, 0) {}
-DnaEncoder::DnaEncoder(const DnaEncoder& o) : leon_(o.leon_), offsets_(1, 0) {}
-DnaEncoder::~DnaEncoder() {
-    try { flush(); } catch (...) {}
+// the reads' bases, resident in HBM on one device: appended batch by batch, offsets kept on the host until the pass ends
+struct DeviceReads {
+    int device = 0;
+    uint8_t* d_bases = nullptr;
+    uint64_t* d_off = nullptr;
+    uint64_t cap = 0, n_bases = 0;
+    ~DeviceReads() { leon_device_free(d_bases); leon_device_free(d_off); }
+    void reserve(uint64_t need) {
+        if (need <= cap) return;
+        const uint64_t nc = std::max<uint64_t>(need + need / 4, 1ull << 26);
+        void* p = nullptr;
+        check(nullptr, leon_device_alloc(device, nc + 64, &p), "leon_device_alloc");
+        if (n_bases) check(nullptr, leon_device_copy(device, p, d_bases, n_bases), "leon_device_copy");
+        leon_device_free(d_bases);
+        d_bases = static_cast<uint8_t*>(p); cap = nc;
+    }
+    void append(const std::string& bases) {
+        reserve(n_bases + bases.size());
+        check(nullptr, leon_device_upload(device, d_bases + n_bases, bases.data(), bases.size()), "leon_device_upload");
+        n_bases += bases.size();
+    }
+    void set_offsets(const std::vector<uint64_t>& off) {
+        void* p = nullptr;
+        check(nullptr, leon_device_alloc(device, off.size() * 8, &p), "leon_device_alloc");
+        d_off = static_cast<uint64_t*>(p);
+        check(nullptr, leon_device_upload(device, d_off, off.data(), off.size() * 8), "leon_device_upload");
+    }
+};
+
+int device_for(int gpu_index) {
+    // LEON_SHARE_GPU=1 lets a multi-GPU run rehearse on fewer devices (ranks wrap around); otherwise -gpus must fit
+    static const char* share = getenv("LEON_SHARE_GPU");
+    static const int n_dev = [] { int n = 0; return leon_device_count(&n) == LEON_OK ? n : 0; }();
+    if (n_dev <= 0) throw Exception("no HIP device: the DNA encode path has no CPU fallback");
+    if (gpu_index >= n_dev && !(share && share[0] == '1')) throw Exception("-gpus " + std::to_string(gpu_index + 1) + " asked, " + std::to_string(n_dev) + " device(s) present");
+    return gpu_index % n_dev;
 }
-void DnaEncoder::operator()(Sequence& s) {
-    bases_.append(s.getDataBuffer(), s.getDataSize());
-    offsets_.push_back(bases_.size());
-    if (offsets_.size() - 1 == leon_->_batchReads) flush();
-}
-void DnaEncoder::flush() {
-    const uint64_t n = offsets_.size() - 1;
-    if (!n) return;
-    check(leon_->_ctx, leon_dna_encode_batch(leon_->_ctx, reinterpret_cast<const uint8_t*>(bases_.data()), offsets_.data(), n,
-                                             leon_->_nextRead, sink, leon_), "leon_dna_encode_batch");
-    leon_->_nextRead += n;
-    bases_.clear();
-    offsets_.assign(1, 0);
-}
+
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------ Leon
 Leon::Leon() {}
-Leon::~Leon() { if (_ctx) leon_dna_ctx_destroy(_ctx); }
+Leon::~Leon() {}
 
 void Leon::run(int argc, char* argv[]) {
-    for (int i = 1; i < argc; i++) {
-        std::string a = argv[i];
-        auto need = [&](const char* flag) -> std::string {
-            if (i + 1 >= argc) throw Exception(std::string("option ") + flag + " needs a value");
-            return argv[++i];
-        };
-        if (a == "-file") _inputFilename = need("-file");
-        else if (a == STR_COMPRESS) _compress = true;
-        else if (a == STR_DECOMPRESS) _decompress = true;
-        else if (a == "-kmer-size") _kmerSize = (size_t)std::stoul(need("-kmer-size"));
-        else if (a == "-abundance") _abundance = std::stoi(need("-abundance"));
-        else if (a == "-nb-cores") (void)need("-nb-cores");          // accepted; the device replaces the thread pool
-        else if (a == "-gpus") _gpus = std::stoi(need("-gpus"));
-        else if (a == "-verbose") _verbose = std::stoi(need("-verbose")) != 0;
-        else if (a == "-lossless" || a == "-seq-only" || a == "-noheader" || a == "-noqual") {}   // other streams: not built
-        else throw Exception("unknown option " + a);
+    try {
+        for (int i = 1; i < argc; i++) {
+            std::string a = argv[i];
+            auto need = [&](const char* flag) -> std::string {
+                if (i + 1 >= argc) throw Exception(std::string("option ") + flag + " needs a value");
+                return argv[++i];
+            };
+            auto number = [&](const char* flag) -> long {
+                const std::string v = need(flag);
+                size_t used = 0;
+                long x = 0;
+                try { x = std::stol(v, &used); } catch (const std::exception&) { used = 0; }
+                if (used != v.size() || v.empty()) throw Exception(std::string("option ") + flag + ": '" + v + "' is not a number");
+                return x;
+            };
+            if (a == "-file") _inputFilename = need("-file");
+            else if (a == STR_COMPRESS) _compress = true;
+            else if (a == STR_DECOMPRESS) _decompress = true;
+            else if (a == "-kmer-size") _kmerSize = (size_t)number("-kmer-size");
+            else if (a == "-abundance") { _abundance = (int)number("-abundance"); if (_abundance < 1) throw Exception("-abundance must be at least 1"); }
+            else if (a == "-nb-cores") _nbCores = (int)std::max<long>(0, number("-nb-cores"));
+            else if (a == "-gpus") { _gpus = (int)number("-gpus"); if (_gpus < 1 || _gpus > 64) throw Exception("-gpus must be in 1..64"); }
+            else if (a == "-verbose") _verbose = number("-verbose") != 0;
+            else if (a == "-lossless") _lossless = true;
+            else if (a == "-seq-only") _seqOnly = true;
+            else if (a == "-noheader") _noHeader = true;
+            else if (a == "-noqual") _noQual = true;
+            else if (a == "-test-file") _testFile = true;
+            else throw Exception("unknown option " + a);
+        }
+        if (_inputFilename.empty()) throw Exception("option -file is mandatory");
+        if (_compress == _decompress) throw Exception("choose one of -c (compress) or -d (decompress)");
+        if (_seqOnly) _noHeader = _noQual = true;             // "same as -noheader -noqual", /root/reference/README.md:56
+        execute();
+    } catch (const Exception&) {
+        throw;
+    } catch (const std::exception& e) {                        // bad_alloc and friends follow the EXCEPTION: contract too
+        throw Exception(e.what());
     }
-    if (_inputFilename.empty()) throw Exception("option -file is mandatory");
-    if (_compress == _decompress) throw Exception("choose one of -c (compress) or -d (decompress)");
-    execute();
 }
 
 void Leon::execute() {
     if (_compress) executeCompression(); else executeDecompression();
 }
 
-void Leon::writeBlock(const uint8_t* data, uint64_t size, int encodedSequenceCount, uint64_t blockID) {
-    if (blockID != _blockSizes.size() / 2) throw Exception("blocks arrived out of order");
-    _blocks.insert(_blocks.end(), data, data + size);
-    _blockSizes.push_back(size);
-    _blockSizes.push_back((uint64_t)encodedSequenceCount);
-}
-
+// ------------------------------------------------------------------------------------------------ -c
 void Leon::executeCompression() {
     if (_kmerSize < 3 || _kmerSize > 63) throw Exception("-kmer-size must be in 3..63");
-    std::vector<Sequence> bank = read_bank(_inputFilename);
-    // solid k-mers: counted on the device (leon_kmer_solid, the stand-in for DSK's SortingCountAlgorithm)
-    const uint32_t W = _kmerSize >= 32 ? 2 : 1;
-    std::string all_bases; std::vector<uint64_t> all_off(1, 0);
-    for (const Sequence& s : bank) { all_bases += s.data; all_off.push_back(all_bases.size()); }
-    std::vector<uint64_t> solid(std::max<size_t>(all_bases.size(), 1) * W);
-    uint64_t n_solid = 0;
-    {
-        int rc = leon_kmer_solid(0, reinterpret_cast<const uint8_t*>(all_bases.data()), all_off.data(), bank.size(), (uint32_t)_kmerSize,
-                                 (uint32_t)std::max(_abundance, 1), 0, solid.data(), all_bases.size(), &n_solid, nullptr);
-        if (rc != LEON_OK) throw Exception(std::string("leon_kmer_solid: ") + leon_last_error(nullptr));
-    }
-    solid.resize(n_solid * W);
-    const uint64_t tai = std::max<uint64_t>(n_solid * 12, 1000);           // NBITS_PER_KMER = 12 [RECALLED]
-    leon_dna_cfg cfg = {};
-    cfg.struct_size = sizeof(cfg);
-    cfg.kmer_size = (uint32_t)_kmerSize; cfg.reads_per_block = READ_PER_BLOCK;
-    cfg.bloom_n_hash = 7; cfg.bloom_block_nbits = 12; cfg.bloom_tai = tai; cfg.device_id = 0;
-    check(nullptr, leon_dna_ctx_create(&cfg, &_ctx), "leon_dna_ctx_create");
-    check(_ctx, leon_dna_bloom_insert(_ctx, solid.data(), n_solid), "leon_dna_bloom_insert");
-    {
-        DnaEncoder enc(this);                       // upstream: Dispatcher::iterate(itSeq, DnaEncoder(this), READ_PER_BLOCK)
-        for (Sequence& s : bank) enc(s);
-    }                                               // ~DnaEncoder flushes the last (partial) block
-    const uint8_t* dict = nullptr; uint64_t dict_size = 0, n_anchors = 0;
-    check(_ctx, leon_dna_finish(_ctx, &dict, &dict_size, &n_anchors), "leon_dna_finish");
-    uint64_t bloom_bytes = 0;
-    check(_ctx, leon_dna_bloom_nbytes(_ctx, &bloom_bytes), "leon_dna_bloom_nbytes");
-    std::vector<uint8_t> bloom(bloom_bytes);
-    check(_ctx, leon_dna_bloom_download(_ctx, bloom.data(), bloom_bytes), "leon_dna_bloom_download");
-
-    // output name: strip nothing, append ".leon" (data/toy.fasta -> data/toy.fasta.leon, /root/reference/INSTALL:21-23)
-    _outputFilename = _inputFilename + ".leon";
-    std::ofstream o(_outputFilename, std::ios::binary);
-    if (!o) throw Exception("cannot write " + _outputFilename);
-    o.write("LEONDNA2", 8);
-    put<uint32_t>(o, (uint32_t)_kmerSize); put<uint32_t>(o, READ_PER_BLOCK);
-    put<uint64_t>(o, bank.size()); put<uint64_t>(o, _blockSizes.size() / 2); put<uint64_t>(o, n_anchors);
-    put<uint64_t>(o, dict_size); put<uint64_t>(o, tai); put<uint64_t>(o, bloom_bytes); put<uint32_t>(o, 7); put<uint32_t>(o, 12);
-    for (size_t b = 0; b < _blockSizes.size() / 2; b++) {          // block table; the bases per block let -d size its output
-        uint64_t nb = 0;
-        for (size_t r = b * READ_PER_BLOCK; r < std::min(bank.size(), (b + 1) * (size_t)READ_PER_BLOCK); r++) nb += bank[r].getDataSize();
-        put<uint64_t>(o, _blockSizes[2 * b]); put<uint64_t>(o, _blockSizes[2 * b + 1]); put<uint64_t>(o, nb);
-    }
-    o.write(reinterpret_cast<const char*>(dict), (std::streamsize)dict_size);
-    o.write(reinterpret_cast<const char*>(bloom.data()), (std::streamsize)bloom_bytes);
-    o.write(reinterpret_cast<const char*>(_blocks.data()), (std::streamsize)_blocks.size());
-    uint64_t n_bases = 0;
-    for (const Sequence& s : bank) n_bases += s.getDataSize();
-    std::cout << "DNA stream: " << bank.size() << " reads, " << n_bases << " bases -> " << (_blocks.size() + dict_size)
-              << " bytes (" << n_anchors << " anchors, " << _blockSizes.size() / 2 << " blocks), written to " << _outputFilename
-              << std::endl;
-}
-
-// ------------------------------------------------------------------------------------------------ DnaDecoder
-// upstream: DnaDecoder::execute() per block on the dispatcher's threads [RECALLED]; here every block at once on the device
-void DnaDecoder::execute(const std::vector<uint64_t>& anchors, const std::vector<uint8_t>& payloads, const std::vector<uint64_t>& payload_off,
-                         const std::vector<uint32_t>& block_reads, const std::vector<uint64_t>& block_bases,
-                         std::vector<uint8_t>& bases, std::vector<uint32_t>& lengths) {
-    uint64_t nb = 0, nr = 0;
-    for (uint64_t x : block_bases) nb += x;
-    for (uint32_t x : block_reads) nr += x;
-    bases.assign(nb + 1, 0);
-    lengths.assign(nr + 1, 0);
-    const uint32_t W = leon_->_kmerSize >= 32 ? 2 : 1;
-    check(leon_->_ctx, leon_dna_decode_blocks(leon_->_ctx, anchors.data(), anchors.size() / W, payloads.data(), payload_off.data(),
-                                              block_reads.data(), block_bases.data(), block_reads.size(), bases.data(), nb, lengths.data()),
-          "leon_dna_decode_blocks");
-    bases.resize(nb);
-    lengths.resize(nr);
-}
-
-void Leon::executeDecompression() {
-    std::ifstream in(_inputFilename, std::ios::binary);
-    if (!in) throw Exception("cannot open " + _inputFilename);
-    auto get = [&](void* p, size_t n) { if (!in.read(reinterpret_cast<char*>(p), (std::streamsize)n)) throw Exception("truncated container " + _inputFilename); };
-    char magic[8];
-    get(magic, 8);
-    if (std::memcmp(magic, "LEONDNA2", 8) != 0) throw Exception(_inputFilename + " is not a container written by this build's -c");
-    uint32_t k, rpb, n_hash, nbits; uint64_t n_reads, n_blocks, n_anchors, dict_bytes, tai, bloom_bytes;
-    get(&k, 4); get(&rpb, 4); get(&n_reads, 8); get(&n_blocks, 8); get(&n_anchors, 8); get(&dict_bytes, 8); get(&tai, 8);
-    get(&bloom_bytes, 8); get(&n_hash, 4); get(&nbits, 4);
-    if (n_blocks > (1ull << 32) || dict_bytes > (1ull << 40) || bloom_bytes > (1ull << 40)) throw Exception("implausible container header");
-    std::vector<uint64_t> table(3 * n_blocks);
-    if (n_blocks) get(table.data(), table.size() * 8);
-    std::vector<uint8_t> dict(dict_bytes + 1), bloom(bloom_bytes);
-    if (dict_bytes) get(dict.data(), dict_bytes);
-    if (bloom_bytes) get(bloom.data(), bloom_bytes);
-    std::vector<uint64_t> pay_off(n_blocks + 1, 0), block_bases(n_blocks);
-    std::vector<uint32_t> block_reads(n_blocks);
-    for (uint64_t b = 0; b < n_blocks; b++) {
-        pay_off[b + 1] = pay_off[b] + table[3 * b];
-        block_reads[b] = (uint32_t)table[3 * b + 1];
-        block_bases[b] = table[3 * b + 2];
-    }
-    std::vector<uint8_t> payloads(pay_off[n_blocks] + 1);
-    if (pay_off[n_blocks]) get(payloads.data(), pay_off[n_blocks]);
-
-    _kmerSize = k;
-    leon_dna_cfg cfg = {};
-    cfg.struct_size = sizeof(cfg);
-    cfg.kmer_size = k; cfg.reads_per_block = rpb; cfg.bloom_n_hash = n_hash; cfg.bloom_block_nbits = nbits; cfg.bloom_tai = tai; cfg.device_id = 0;
-    check(nullptr, leon_dna_ctx_create(&cfg, &_ctx), "leon_dna_ctx_create");
-    check(_ctx, leon_dna_bloom_upload(_ctx, bloom.data(), bloom_bytes), "leon_dna_bloom_upload");
-    const uint32_t W = k >= 32 ? 2 : 1;
-    std::vector<uint64_t> anchors(std::max<uint64_t>(n_anchors * W, 1));
-    if (leon_host_anchor_dict_decode(dict.data(), dict_bytes, n_anchors, k, anchors.data()) != LEON_OK)
-        throw Exception(std::string("leon_host_anchor_dict_decode: ") + leon_last_error(nullptr));
-    anchors.resize(n_anchors * W);
-    std::vector<uint8_t> bases; std::vector<uint32_t> lengths;
-    DnaDecoder(this).execute(anchors, payloads, pay_off, block_reads, block_bases, bases, lengths);
-    if (lengths.size() != n_reads) throw Exception("the block table does not add up to the header's read count");
-
-    // output name: X.fastq.leon -> X.fastq.d (/root/reference/scripts/simple_test.sh:54,62).  Only the DNA stream exists in this
-    // build (no header / quality streams), so the output is the sequences, one per line, in file order.
+    const auto t_start = std::chrono::steady_clock::now();
+    const uint32_t k = (uint32_t)_kmerSize, rpb = READ_PER_BLOCK;
+    Bank bank(_inputFilename);
+    const bool fastq = bank.isFastq();
+    const bool keep_header = !_noHeader, keep_qual = fastq && !_noQual;
+    // X.fastq.gz -> X.fastq.leon, data/toy.fasta -> data/toy.fasta.leon (/root/reference/scripts/simple_test.sh:51,54, INSTALL:21-23)
     std::string stem = _inputFilename;
-    if (stem.size() > 5 && stem.compare(stem.size() - 5, 5, ".leon") == 0) stem.resize(stem.size() - 5);
+    if (ends_with(stem, ".gz")) stem.resize(stem.size() - 3);
+    _outputFilename = stem + ".leon";
+    const std::string tmp_name = _outputFilename + ".tmp";     // renamed at the very end: a failed run leaves no .leon behind
+    struct TmpGuard { std::string p; bool keep = false; ~TmpGuard() { if (!keep) std::remove(p.c_str()); } } guard{tmp_name};
+    Container out(tmp_name, Container::CREATE);
+    std::mutex out_mu;
+    StreamWriter wh, wd, wq;
+    wh.out = wd.out = wq.out = &out; wh.mu = wd.mu = wq.mu = &out_mu;
+    wh.group = GROUP_HEADER; wd.group = GROUP_DNA; wq.group = GROUP_QUAL;
+
+    // ---- the pass over the file ----
+    const int n_gpus = _gpus;
+    std::vector<std::unique_ptr<DeviceReads>> store;
+    for (int g = 0; g < n_gpus; g++) { store.emplace_back(new DeviceReads()); store.back()->device = device_for(g); }
+    CtxPtr hdr_ctx;
+    if (keep_header) hdr_ctx = make_ctx(k, 1000, store[0]->device);
+    std::vector<uint64_t> offsets(1, 0);                         // base offsets of every read, absolute in the resident copy
+    std::string first_header;
+    uint64_t n_reads = 0, header_bytes = 0, qual_bytes = 0;
+    const uint64_t batch_reads = 64ull * rpb;
+    ReadBatch batch;
+    for (;;) {
+        batch.clear();
+        const uint64_t got = bank.next(batch, batch_reads);
+        if (!got) break;
+        if (n_reads == 0) first_header.assign(batch.headers, 0, batch.header_off[1]);
+        if (keep_header) {
+            check_sink(hdr_ctx.get(), leon_header_encode_batch(hdr_ctx.get(), reinterpret_cast<const uint8_t*>(batch.headers.data()), batch.header_off.data(), got, n_reads,
+                                                               reinterpret_cast<const uint8_t*>(first_header.data()), first_header.size(), StreamWriter::sink, &wh),
+                       wh, "leon_header_encode_batch");
+            header_bytes += batch.headers.size();
+        }
+        if (keep_qual && _lossless) {
+            int rc = leon_host_qual_encode_blocks(reinterpret_cast<const uint8_t*>(batch.quals.data()), batch.qual_off.data(), got, rpb, -1, (uint32_t)_nbCores,
+                                                  StreamWriter::sink, &wq, n_reads / rpb);
+            check_sink(nullptr, rc, wq, "leon_host_qual_encode_blocks");
+        }
+        qual_bytes += batch.quals.size();
+        for (auto& st : store) st->append(batch.bases);
+        for (uint64_t i = 1; i <= got; i++) offsets.push_back(offsets[n_reads] + batch.base_off[i]);
+        n_reads += got;
+        if (got < batch_reads) break;                            // the partial batch is the last one
+    }
+    const uint64_t n_blocks = (n_reads + rpb - 1) / rpb, n_bases = offsets.back();
+    for (auto& st : store) st->set_offsets(offsets);
+    hdr_ctx.reset();
+    const double t_parse = seconds_since(t_start);
+
+    // ---- solid k-mers -> bloom (Leon::executeCompression: DSK, then createBloom) ----
+    const auto t_count = std::chrono::steady_clock::now();
+    uint64_t hist[256] = {0};
+    uint64_t* d_solid = nullptr; uint64_t n_solid = 0;
+    if (n_reads) {
+        int rc = leon_kmer_solid_device(store[0]->device, store[0]->d_bases, store[0]->d_off, n_reads, k, (uint32_t)std::max(_abundance, 0), 0, &d_solid, &n_solid, hist);
+        if (rc != LEON_OK) throw Exception(std::string("leon_kmer_solid_device: ") + leon_last_error(nullptr));
+    }
+    struct SolidGuard { uint64_t* p; ~SolidGuard() { leon_device_free(p); } } solid_guard{d_solid};
+    uint32_t abundance = (uint32_t)_abundance;
+    if (_abundance == 0) (void)leon_kmer_auto_cutoff(hist, &abundance);
+    const uint64_t tai = std::max<uint64_t>(n_solid * 12, 1000);         // NBITS_PER_KMER = 12 [RECALLED]
+    std::vector<CtxPtr> ctx;
+    for (int g = 0; g < n_gpus; g++) {
+        ctx.push_back(make_ctx(k, tai, store[g]->device));
+        check(ctx[g].get(), leon_dna_set_shard(ctx[g].get(), (uint32_t)g, (uint32_t)n_gpus), "leon_dna_set_shard");
+    }
+    check(ctx[0].get(), leon_dna_bloom_insert_device(ctx[0].get(), d_solid, n_solid), "leon_dna_bloom_insert_device");
+    uint64_t bloom_bytes = 0;
+    check(ctx[0].get(), leon_dna_bloom_nbytes(ctx[0].get(), &bloom_bytes), "leon_dna_bloom_nbytes");
+    std::vector<uint8_t> bloom(bloom_bytes);
+    check(ctx[0].get(), leon_dna_bloom_download(ctx[0].get(), bloom.data(), bloom_bytes), "leon_dna_bloom_download");
+    for (int g = 1; g < n_gpus; g++) check(ctx[g].get(), leon_dna_bloom_upload(ctx[g].get(), bloom.data(), bloom_bytes), "leon_dna_bloom_upload");
+    const double t_bloom = seconds_since(t_count);
+
+    // ---- the DNA stream: Dispatcher::iterate(bank, DnaEncoder(this)) upstream, the device path here ----
+    const auto t_dna = std::chrono::steady_clock::now();
+    const uint64_t batch_blocks = n_blocks <= 2400 ? std::max<uint64_t>(n_blocks, 1) : 1000;     // whole file at once up to 120 M reads
+    std::vector<std::string> gpu_error(n_gpus);
+    auto encode_on = [&](int g) {
+        try {
+            for (uint64_t b0 = 0; b0 < n_blocks; b0 += batch_blocks) {
+                const uint64_t r0 = b0 * rpb, r1 = std::min<uint64_t>(n_reads, (b0 + batch_blocks) * rpb);
+                int rc = leon_dna_encode_batch_device(ctx[g].get(), store[g]->d_bases, store[g]->d_off + r0, r1 - r0, r0, StreamWriter::sink, &wd);
+                check_sink(ctx[g].get(), rc, wd, "leon_dna_encode_batch_device");
+            }
+        } catch (const std::exception& e) { gpu_error[g] = e.what(); }
+    };
+    if (n_gpus == 1) encode_on(0);
+    else {
+        std::vector<std::thread> th;
+        for (int g = 0; g < n_gpus; g++) th.emplace_back(encode_on, g);
+        for (auto& t : th) t.join();
+    }
+    for (const std::string& e : gpu_error) if (!e.empty()) throw Exception(e);
+    const uint8_t* dict = nullptr; uint64_t dict_size = 0, n_anchors = 0;
+    check(ctx[0].get(), leon_dna_finish(ctx[0].get(), &dict, &dict_size, &n_anchors), "leon_dna_finish");
+    for (int g = 1; g < n_gpus; g++) { const uint8_t* d; uint64_t ds, na; check(ctx[g].get(), leon_dna_finish(ctx[g].get(), &d, &ds, &na), "leon_dna_finish"); }
+    const double t_encode = seconds_since(t_dna);
+
+    // ---- lossy qualities (the default): smoothed against the bloom on the device, then the same zlib blocks ----
+    if (keep_qual && !_lossless) {
+        Bank again(_inputFilename);
+        uint64_t r = 0;
+        void* d_q = nullptr; uint64_t d_q_cap = 0;
+        struct QGuard { void** p; ~QGuard() { leon_device_free(*p); } } qg{&d_q};
+        for (;;) {
+            batch.clear();
+            const uint64_t got = again.next(batch, batch_reads);
+            if (!got) break;
+            if (r + got > n_reads || batch.bases.size() != offsets[r + got] - offsets[r]) throw Exception(_inputFilename + " changed while it was being compressed");
+            if (batch.quals.size() > d_q_cap) {
+                leon_device_free(d_q); d_q = nullptr;
+                d_q_cap = batch.quals.size() + batch.quals.size() / 8 + 64;
+                check(nullptr, leon_device_alloc(store[0]->device, d_q_cap, &d_q), "leon_device_alloc");
+            }
+            check(nullptr, leon_device_upload(store[0]->device, d_q, batch.quals.data(), batch.quals.size()), "leon_device_upload");
+            check(ctx[0].get(), leon_qual_smooth_batch_device(ctx[0].get(), store[0]->d_bases, store[0]->d_off + r, got, static_cast<uint8_t*>(d_q)),
+                  "leon_qual_smooth_batch_device");
+            check(nullptr, leon_device_download(store[0]->device, &batch.quals[0], d_q, batch.quals.size()), "leon_device_download");
+            int rc = leon_host_qual_encode_blocks(reinterpret_cast<const uint8_t*>(batch.quals.data()), batch.qual_off.data(), got, rpb, -1, (uint32_t)_nbCores,
+                                                  StreamWriter::sink, &wq, r / rpb);
+            check_sink(nullptr, rc, wq, "leon_host_qual_encode_blocks");
+            r += got;
+            if (got < batch_reads) break;
+        }
+        if (r != n_reads) throw Exception(_inputFilename + " changed while it was being compressed");
+    }
+
+    // ---- tables and metadata ----
+    wd.complete(n_blocks, "DNA stream");
+    if (keep_header) wh.complete(n_blocks, "header stream");
+    if (keep_qual) wq.complete(n_blocks, "quality stream");
+    std::vector<uint64_t> table;
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        const uint64_t r0 = b * rpb, r1 = std::min<uint64_t>(n_reads, r0 + rpb);
+        table.push_back(wd.sizes[b]); table.push_back(wd.reads[b]); table.push_back(offsets[r1] - offsets[r0]);
+    }
+    out.putU64(DS_DNA_TABLE, table.data(), table.size());
+    if (keep_header) {
+        table.clear();
+        for (uint64_t b = 0; b < n_blocks; b++) { table.push_back(wh.sizes[b]); table.push_back(wh.reads[b]); }
+        out.putU64(DS_HEADER_TABLE, table.data(), table.size());
+        out.putBytes(DS_FIRST_HEADER, first_header.data(), first_header.size());
+    }
+    if (keep_qual) {
+        table.clear();
+        for (uint64_t b = 0; b < n_blocks; b++) {
+            const uint64_t r0 = b * rpb, r1 = std::min<uint64_t>(n_reads, r0 + rpb);
+            table.push_back(wq.sizes[b]); table.push_back(wq.reads[b]); table.push_back(offsets[r1] - offsets[r0]);
+        }
+        out.putU64(DS_QUAL_TABLE, table.data(), table.size());
+    }
+    out.putBytes(DS_ANCHOR_DICT, dict, dict_size);
+    out.putBytes(DS_BLOOM_BITS, bloom.data(), bloom.size());
+    const uint8_t info = (uint8_t)((fastq ? 0 : INFO_FASTA) | (keep_header ? 0 : INFO_NO_HEADER) | (keep_qual ? 0 : INFO_NO_QUAL) | (_lossless ? INFO_LOSSLESS : 0));
+    out.putBytes(DS_INFOBYTE, &info, 1);
+    uint64_t params[PARAM_COUNT] = {0};
+    params[P_VERSION_MAJOR] = 1; params[P_VERSION_MINOR] = 1; params[P_VERSION_PATCH] = 0;       // Leon 1.1.0, /root/reference/CMakeLists.txt:9-11
+    params[P_KMER_SIZE] = k; params[P_READS_PER_BLOCK] = rpb; params[P_N_READS] = n_reads; params[P_N_ANCHORS] = n_anchors;
+    params[P_ABUNDANCE] = abundance; params[P_BLOOM_TAI] = tai; params[P_BLOOM_N_HASH] = 7; params[P_BLOOM_BLOCK_NBITS] = 12;
+    params[P_TOTAL_BASES] = n_bases; params[P_FASTA_LINE_WIDTH] = 0;
+    out.putU64(DS_PARAMS, params, PARAM_COUNT);
+    out.close();
+    if (std::rename(tmp_name.c_str(), _outputFilename.c_str()) != 0) throw Exception("cannot write " + _outputFilename);
+    guard.keep = true;
+
+    const uint64_t dna_bytes = wd.bytes + dict_size;
+    std::cout << "DNA stream: " << n_reads << " reads, " << n_bases << " bases -> " << dna_bytes << " bytes (" << n_anchors << " anchors, "
+              << n_blocks << " blocks, abundance threshold " << abundance << (_abundance ? "" : " (automatic)") << ", " << n_solid << " solid k-mers)\n";
+    if (keep_header) std::cout << "header stream: " << header_bytes << " bytes -> " << wh.bytes << " bytes\n";
+    if (keep_qual) std::cout << "quality stream (" << (_lossless ? "lossless" : "lossy") << "): " << qual_bytes << " bytes -> " << wq.bytes << " bytes\n";
+    std::cout << "written to " << _outputFilename << std::endl;
+    if (_verbose)
+        std::cout << "time: parse + headers" << (keep_qual && _lossless ? " + qualities " : " ") << t_parse << " s, k-mer counting + bloom " << t_bloom
+                  << " s, DNA encode " << t_encode << " s, total " << seconds_since(t_start) << " s" << std::endl;
+}
+
+// ------------------------------------------------------------------------------------------------ -d
+void Leon::executeDecompression() {
+    const auto t_start = std::chrono::steady_clock::now();
+    Container in(_inputFilename, Container::READ);
+    const std::vector<uint8_t> infov = in.getBytes(DS_INFOBYTE);
+    const std::vector<uint64_t> params = in.getU64(DS_PARAMS);
+    if (infov.size() != 1 || params.size() < PARAM_COUNT) throw Exception(_inputFilename + ": metadata is not what this build writes");
+    const uint8_t info = infov[0];
+    const bool fasta_in = info & INFO_FASTA, has_header = !(info & INFO_NO_HEADER), has_qual = !(info & INFO_NO_QUAL);
+    const uint64_t k = params[P_KMER_SIZE], rpb = params[P_READS_PER_BLOCK], n_reads = params[P_N_READS], n_anchors = params[P_N_ANCHORS];
+    const uint64_t tai = params[P_BLOOM_TAI], n_hash = params[P_BLOOM_N_HASH], nbits = params[P_BLOOM_BLOCK_NBITS], total_bases = params[P_TOTAL_BASES];
+    if (params[P_VERSION_MAJOR] != 1) throw Exception(_inputFilename + " was written by an incompatible version");
+    if (k < 3 || k > 63 || rpb == 0 || rpb > (1u << 30) || n_hash < 1 || n_hash > 10 || nbits < 4 || nbits > 16 || n_anchors > (1ull << 32) ||
+        n_reads > (1ull << 40) || total_bases > (1ull << 46))
+        throw Exception(_inputFilename + ": implausible parameters in the metadata");
+    _kmerSize = (size_t)k;
+    const uint64_t n_blocks = (n_reads + rpb - 1) / rpb;
+    const uint32_t W = k >= 32 ? 2 : 1;
+    // block tables, checked against the header's totals before anything is sized from them
+    const std::vector<uint64_t> tdna = in.getU64(DS_DNA_TABLE);
+    if (tdna.size() != 3 * n_blocks) throw Exception(_inputFilename + ": the DNA block table does not match the read count");
+    uint64_t sum_reads = 0, sum_bases = 0;
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        if (tdna[3 * b + 1] > rpb || tdna[3 * b + 2] > total_bases - sum_bases) throw Exception(_inputFilename + ": the DNA block table does not add up");
+        sum_reads += tdna[3 * b + 1]; sum_bases += tdna[3 * b + 2];
+    }
+    if (sum_reads != n_reads || sum_bases != total_bases) throw Exception(_inputFilename + ": the DNA block table does not add up");
+    std::vector<uint64_t> thdr, tqual;
+    std::vector<uint8_t> first_header;
+    if (has_header) {
+        thdr = in.getU64(DS_HEADER_TABLE);
+        first_header = in.getBytes(DS_FIRST_HEADER);
+        if (thdr.size() != 2 * n_blocks) throw Exception(_inputFilename + ": the header block table does not match the read count");
+        for (uint64_t b = 0; b < n_blocks; b++) if (thdr[2 * b + 1] != tdna[3 * b + 1]) throw Exception(_inputFilename + ": header and DNA blocks disagree");
+    }
+    if (has_qual) {
+        tqual = in.getU64(DS_QUAL_TABLE);
+        if (tqual.size() != 3 * n_blocks) throw Exception(_inputFilename + ": the quality block table does not match the read count");
+        for (uint64_t b = 0; b < n_blocks; b++)
+            if (tqual[3 * b + 1] != tdna[3 * b + 1] || tqual[3 * b + 2] != tdna[3 * b + 2]) throw Exception(_inputFilename + ": quality and DNA blocks disagree");
+    }
+
+    CtxPtr ctx = make_ctx((uint32_t)k, tai, device_for(0), (uint32_t)n_hash, (uint32_t)nbits, (uint32_t)rpb);
+    {
+        const std::vector<uint8_t> bloom = in.getBytes(DS_BLOOM_BITS);
+        check(ctx.get(), leon_dna_bloom_upload(ctx.get(), bloom.data(), bloom.size()), "leon_dna_bloom_upload");
+    }
+    std::vector<uint64_t> anchors(std::max<uint64_t>(n_anchors * W, 1));
+    {
+        std::vector<uint8_t> dict = in.getBytes(DS_ANCHOR_DICT);
+        const uint64_t dsz = dict.size();
+        dict.push_back(0);
+        if (leon_host_anchor_dict_decode(dict.data(), dsz, n_anchors, (uint32_t)k, anchors.data()) != LEON_OK)
+            throw Exception(std::string("leon_host_anchor_dict_decode: ") + leon_last_error(nullptr));
+    }
+
+    // X.fastq.leon -> X.fastq.d (/root/reference/scripts/simple_test.sh:54,62)
+    std::string stem = _inputFilename;
+    if (ends_with(stem, ".leon")) stem.resize(stem.size() - 5);
     _outputFilename = stem + ".d";
     std::ofstream o(_outputFilename, std::ios::binary);
     if (!o) throw Exception("cannot write " + _outputFilename);
-    uint64_t at = 0;
-    for (uint32_t len : lengths) {
-        o.write(reinterpret_cast<const char*>(bases.data() + at), len);
-        o.put('\n');
-        at += len;
+    const bool fastq_out = !fasta_in && has_qual;               // "-noqual ... will decompress to fasta"
+    const char lead = fastq_out ? '@' : '>';
+
+    const uint64_t group = 256;                                  // blocks decoded per round: bounds the host memory of -d
+    std::string text;
+    uint64_t read_index = 0, bases_out = 0;
+    for (uint64_t g0 = 0; g0 < n_blocks; g0 += group) {
+        const uint64_t g1 = std::min(n_blocks, g0 + group), nb = g1 - g0;
+        auto gather = [&](const char* grp, const std::vector<uint64_t>& tab, uint32_t stride, std::vector<uint8_t>& pay, std::vector<uint64_t>& off) {
+            off.assign(nb + 1, 0);
+            for (uint64_t b = 0; b < nb; b++) off[b + 1] = off[b] + tab[stride * (g0 + b)];
+            pay.resize(off[nb] + 1);
+            for (uint64_t b = 0; b < nb; b++) {
+                const std::vector<uint8_t> blk = in.getBytes(Container::blockPath(grp, g0 + b));
+                if (blk.size() != tab[stride * (g0 + b)]) throw Exception(_inputFilename + ": block " + std::to_string(g0 + b) + " of " + grp + " has not the size its table says");
+                if (!blk.empty()) memcpy(pay.data() + off[b], blk.data(), blk.size());
+            }
+        };
+        std::vector<uint8_t> pay; std::vector<uint64_t> off;
+        std::vector<uint32_t> blk_reads(nb); std::vector<uint64_t> blk_bases(nb);
+        uint64_t g_reads = 0, g_bases = 0;
+        for (uint64_t b = 0; b < nb; b++) { blk_reads[b] = (uint32_t)tdna[3 * (g0 + b) + 1]; blk_bases[b] = tdna[3 * (g0 + b) + 2]; g_reads += blk_reads[b]; g_bases += blk_bases[b]; }
+        // DNA
+        gather(GROUP_DNA, tdna, 3, pay, off);
+        std::vector<uint8_t> bases(g_bases + 1); std::vector<uint32_t> lens(g_reads + 1);
+        check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, bases.data(), g_bases,
+                                                lens.data()), "leon_dna_decode_blocks");
+        // headers
+        std::vector<uint8_t> hdr; std::vector<uint64_t> hdr_off(g_reads + 1, 0);
+        if (has_header) {
+            gather(GROUP_HEADER, thdr, 2, pay, off);
+            uint64_t need = 0;
+            hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
+            int rc = leon_host_header_decode_blocks(pay.data(), off.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), hdr.data(), hdr.size(), hdr_off.data(),
+                                                    &need, (uint32_t)_nbCores);
+            if (rc == LEON_E_OVERFLOW) {
+                hdr.resize(need + 1);
+                rc = leon_host_header_decode_blocks(pay.data(), off.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), hdr.data(), hdr.size(), hdr_off.data(),
+                                                    &need, (uint32_t)_nbCores);
+            }
+            if (rc != LEON_OK) throw Exception(std::string("leon_host_header_decode_blocks: ") + leon_last_error(nullptr));
+        }
+        // qualities
+        std::vector<uint8_t> qual; std::vector<uint64_t> qual_off(g_reads + 1, 0);
+        if (fastq_out) {
+            gather(GROUP_QUAL, tqual, 3, pay, off);
+            qual.resize(g_bases + 1);
+            if (leon_host_qual_decode_blocks(pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, qual.data(), g_bases, qual_off.data(), (uint32_t)_nbCores) != LEON_OK)
+                throw Exception(std::string("leon_host_qual_decode_blocks: ") + leon_last_error(nullptr));
+        }
+        // records
+        text.clear();
+        uint64_t at = 0;
+        for (uint64_t r = 0; r < g_reads; r++) {
+            text.push_back(lead);
+            if (has_header) text.append(reinterpret_cast<const char*>(hdr.data()) + hdr_off[r], hdr_off[r + 1] - hdr_off[r]);
+            else text += std::to_string(read_index + r);
+            text.push_back('\n');
+            text.append(reinterpret_cast<const char*>(bases.data()) + at, lens[r]);
+            text.push_back('\n');
+            if (fastq_out) {
+                if (qual_off[r + 1] - qual_off[r] != lens[r]) throw Exception(_inputFilename + ": a read's quality and sequence lengths differ");
+                text += "+\n";
+                text.append(reinterpret_cast<const char*>(qual.data()) + qual_off[r], lens[r]);
+                text.push_back('\n');
+            }
+            at += lens[r];
+        }
+        o.write(text.data(), (std::streamsize)text.size());
+        if (!o) throw Exception("cannot write " + _outputFilename);
+        read_index += g_reads; bases_out += g_bases;
     }
-    std::cout << "DNA stream: " << n_reads << " reads, " << at << " bases decoded from " << n_blocks << " blocks, written to "
-              << _outputFilename << std::endl;
+    o.close();
+    if (read_index != n_reads) throw Exception("the block tables do not add up to the header's read count");
+    std::cout << n_reads << " reads, " << bases_out << " bases decoded from " << n_blocks << " blocks, written to " << _outputFilename << std::endl;
+    if (_verbose) std::cout << "time: " << seconds_since(t_start) << " s" << std::endl;
+    if (_testFile) testDecompressedFile();
+}
+
+// -test-file: "check decompressed file against original" (/root/reference/INSTALL:22): X.fastq.d against X.fastq (or X.fastq.gz) beside it
+void Leon::testDecompressedFile() {
+    std::string orig = _outputFilename.substr(0, _outputFilename.size() - 2);
+    gzFile a = gzopen(orig.c_str(), "rb");
+    if (!a) { orig += ".gz"; a = gzopen(orig.c_str(), "rb"); }
+    if (!a) throw Exception("-test-file: the original file is not beside " + _outputFilename);
+    gzFile b = gzopen(_outputFilename.c_str(), "rb");
+    if (!b) { gzclose(a); throw Exception("-test-file: cannot reopen " + _outputFilename); }
+    std::vector<char> ba(1 << 20), bb(1 << 20);
+    uint64_t at = 0;
+    bool same = true;
+    for (;;) {
+        const int na = gzread(a, ba.data(), (unsigned)ba.size()), nb = gzread(b, bb.data(), (unsigned)bb.size());
+        if (na != nb || na < 0 || (na > 0 && memcmp(ba.data(), bb.data(), (size_t)na) != 0)) {
+            same = false;
+            for (int i = 0; i < std::min(na, nb) && ba[i] == bb[i]; i++) at++;
+            break;
+        }
+        if (na == 0) break;
+        at += (uint64_t)na;
+    }
+    gzclose(a); gzclose(b);
+    if (!same) throw Exception("-test-file: " + _outputFilename + " differs from " + orig + " at byte " + std::to_string(at));
+    std::cout << "test-file: " << _outputFilename << " is identical to " << orig << std::endl;
+}
+
+// ------------------------------------------------------------------------------------------------ self tests (no GPU)
+int selftest_container(const std::string& path) {
+    std::vector<uint8_t> a(100000), empty;
+    for (size_t i = 0; i < a.size(); i++) a[i] = (uint8_t)(i * 2654435761u >> 13);
+    std::vector<uint64_t> t = { 1, 2, 3, ~0ull, 0 };
+    {
+        Container c(path, Container::CREATE);
+        c.putBytes(Container::blockPath(GROUP_DNA, 0), a.data(), a.size());
+        c.putBytes(Container::blockPath(GROUP_DNA, 1), empty.data(), 0);
+        c.putBytes(Container::blockPath(GROUP_HEADER, 0), a.data(), 17);
+        c.putBytes(DS_INFOBYTE, a.data(), 1);
+        c.putU64(DS_DNA_TABLE, t.data(), t.size());
+        c.putU64(DS_PARAMS, t.data(), 0);
+        c.close();
+    }
+    Container c(path, Container::READ);
+    bool ok = c.getBytes(Container::blockPath(GROUP_DNA, 0)) == a && c.getBytes(Container::blockPath(GROUP_DNA, 1)).empty() &&
+              c.getBytes(Container::blockPath(GROUP_HEADER, 0)) == std::vector<uint8_t>(a.begin(), a.begin() + 17) && c.getU64(DS_DNA_TABLE) == t &&
+              c.getU64(DS_PARAMS).empty() && c.exists(DS_INFOBYTE) && !c.exists(Container::blockPath(GROUP_QUAL, 0)) && !c.exists("nothing/here");
+    bool threw = false;
+    try { (void)c.getBytes("leon/dna/block_7"); } catch (const Exception&) { threw = true; }
+    bool threw2 = false;
+    try { (void)c.getBytes(DS_DNA_TABLE); } catch (const Exception&) { threw2 = true; }      // a u64 array is not a byte array
+    ok = ok && threw && threw2;
+    std::cout << (ok ? "container selftest OK" : "container selftest FAILED") << std::endl;
+    return ok ? 0 : 1;
+}
+
+int selftest_bank(const std::string& path) {
+    Bank bank(path);
+    ReadBatch b;
+    uint64_t n = 0, nb = 0, nh = 0, nq = 0, fnv_b = 1469598103934665603ull, fnv_h = fnv_b, fnv_q = fnv_b;
+    auto mix = [](uint64_t& h, const std::string& s) { for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; } };
+    const bool fq = bank.isFastq();
+    for (;;) {
+        b.clear();
+        const uint64_t got = bank.next(b, 1000);
+        if (!got) break;
+        n += got; nb += b.bases.size(); nh += b.headers.size(); nq += b.quals.size();
+        mix(fnv_b, b.bases); mix(fnv_h, b.headers); mix(fnv_q, b.quals);
+    }
+    std::cout << "{\"fastq\": " << (fq ? "true" : "false") << ", \"reads\": " << n << ", \"bases\": " << nb << ", \"header_bytes\": " << nh << ", \"qual_bytes\": " << nq
+              << ", \"fnv_bases\": " << fnv_b << ", \"fnv_headers\": " << fnv_h << ", \"fnv_quals\": " << fnv_q << "}" << std::endl;
+    return 0;
 }
 
 }  // namespace leon_host

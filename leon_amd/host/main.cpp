@@ -31,6 +31,9 @@ int main(int argc, char* argv[]) {
     }
     leon_host::Leon tool;
     try {
+        // host logic that needs no GPU, for the CPU test-suite: the .leon container layer and the FASTA / FASTQ reader
+        if (argc == 3 && std::string(argv[1]) == "-selftest-container") return leon_host::selftest_container(argv[2]);
+        if (argc == 3 && std::string(argv[1]) == "-selftest-bank") return leon_host::selftest_bank(argv[2]);
         tool.run(argc, argv);
     } catch (const leon_host::Exception& failure) {
         return report(failure);

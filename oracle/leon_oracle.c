@@ -1068,3 +1068,26 @@ int64_t lo_header_decode_block(const uint8_t* payload, uint64_t size, uint64_t n
     free(M);
     return rc ? rc : (int64_t)w;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Quality stream, lossy form: DnaEncoder::storeSolidCoverageInfo + smoothQuals [RECALLED med]   */
+/* cover[i] = number of the read's k-mers (N read as 'A', canonical) that are in the bloom and   */
+/* span position i; qual[i] becomes '@' where cover[i] >= 2 or qual[i] > '@'; reads shorter      */
+/* than k are left alone.  qual is rewritten in place.                                           */
+/* ------------------------------------------------------------------------------------------ */
+void lo_qual_smooth(const lo_bloom* bloom, uint32_t k, const char* seq, uint32_t len, uint8_t* qual) {
+    if (len < k) return;
+    uint32_t* cover = (uint32_t*)calloc(len, sizeof(uint32_t));
+    kmer_t km = 0;
+    const kmer_t mask = kmask(k);
+    for (uint32_t i = 0; i < len; i++) {
+        int c = nt2bin(seq[i]);
+        if (c > 3) c = 0;
+        km = ((km << 2) | (kmer_t)c) & mask;
+        if (i + 1 >= k && bloom_contains_k(bloom, canonical_k(km, k)))
+            for (uint32_t j = i + 1 - k; j <= i; j++) cover[j]++;
+    }
+    for (uint32_t i = 0; i < len; i++)
+        if (cover[i] >= 2 || qual[i] > (uint8_t)'@') qual[i] = (uint8_t)'@';
+    free(cover);
+}

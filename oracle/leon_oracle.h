@@ -95,6 +95,8 @@ int     lo_header_encode_block(const char* headers, const uint64_t* off, uint64_
 int64_t lo_header_decode_block(const uint8_t* payload, uint64_t size, uint64_t n, const char* first, uint64_t first_len,
                                char* out, uint64_t out_cap, uint64_t* out_off);
 void    lo_free(void* p);
+/* ---- quality stream, lossy form (DnaEncoder::smoothQuals): qual rewritten in place ---- */
+void    lo_qual_smooth(const lo_bloom* bloom, uint32_t k, const char* seq, uint32_t len, uint8_t* qual);
 
 /* ---- exact k-mer counting helper for tests (stands in for DSK) ---- */
 /* returns the number of distinct canonical k-mers with count >= min_abundance; fills out (may be NULL) */

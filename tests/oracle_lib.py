@@ -65,6 +65,7 @@ def _load():
                                              C.POINTER(C.c_void_p), u64p]),
         "lo_header_decode_block": (C.c_int64, [u8p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u64p]),
         "lo_free": (None, [C.c_void_p]),
+        "lo_qual_smooth": (None, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, u8p]),
         "lo_rc_new": (C.c_void_p, []),
         "lo_rc_free": (None, [C.c_void_p]),
         "lo_rc_encode_stream": (C.c_int, [C.c_void_p, u8p, u8p, C.c_uint64, u32p, C.c_uint32]),
@@ -296,3 +297,11 @@ def header_decode_block(payload, n, first, max_bytes):
         raise ValueError("header block does not decode")
     raw = out.raw[:w]
     return [raw[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+
+def qual_smooth(bloom, k, seq, qual):
+    """DnaEncoder::smoothQuals on one read: bytes in, bytes out"""
+    q = np.frombuffer(bytes(qual), dtype=np.uint8).copy()
+    if len(q):
+        lib.lo_qual_smooth(bloom.h, k, bytes(seq), len(seq), _p(q, u8p))
+    return q.tobytes()

@@ -518,3 +518,86 @@ def test_degenerate_batches():
     assert na == 0 and d == O.encode(b"", np.zeros(1, dtype=np.uint64), k, 10, bl[0], trace=False).anchor_dict
     assert ctx.decode_blocks(np.zeros(0, dtype=np.uint64), [], []) == []
     ctx.close()
+
+
+def test_crafted_payloads_cannot_make_the_decoder_write_out_of_bounds():
+    """values from a payload wrapped the decoder's bound checks (`w + len > wcap`, `apos + k > len`).  Payloads built
+    symbol by symbol with the oracle's raw range coder: a read size of 'previous - 5' with previous = 0 (2^64 - 5), an anchor
+    position beyond the read, a block that promises more bases than it holds -- each must come back as LEON_E_INVALID."""
+    import leon_amd
+    from leon_amd import capi
+    k, rpb = 31, 4
+    bases, off = common.synthetic(64, 100, 3000, seed=3)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ctx = _ctx(k, rpb, tai)
+    ctx.bloom_upload(bl.bits)
+    blocks = ctx.encode_batch(bases, off)
+    d, na = ctx.finish()
+    anchors = capi.anchor_dict_decode(d, na, k)
+    # model ids of leon_device.h: 0 read type, 4/5/6 delta types, 7 revcomp, numeric group g -> 8 + 9 g (+ byte index)
+    sizes = [2, 5, 5, 2, 3, 3, 3, 2] + [256] * 72
+    G_ADDR, G_POS, G_SIZE = 8 + 9 * 0, 8 + 9 * 1, 8 + 9 * 3
+
+    def numeric(group, v):
+        bs = []
+        while True:
+            bs.append(v & 255); v >>= 8
+            if not v:
+                break
+        return [(group, len(bs))] + [(group + 1 + i, b) for i, b in enumerate(bs)]
+
+    def payload(syms):
+        models = np.array([m for m, _ in syms], dtype=np.uint8)
+        vals = np.array([v for _, v in syms], dtype=np.uint8)
+        return O.rc_encode_stream(models, vals, sizes)
+    crafted = {
+        "length wraps": [(0, 0), (4, 2)] + numeric(G_SIZE, 5),                                  # anchored read, size = prev(0) - 5
+        "anchor beyond the read": [(0, 0), (4, 0)] + numeric(G_SIZE, 100) + [(5, 0)] + numeric(G_POS, 90) + [(6, 0)] + numeric(G_ADDR, 0) + [(7, 0)],
+        "anchor position wraps": [(0, 0), (4, 0)] + numeric(G_SIZE, 100) + [(5, 2)] + numeric(G_POS, 7) + [(6, 0)] + numeric(G_ADDR, 0) + [(7, 0)],
+        "no-anchor read longer than the block": [(0, 1)] + numeric(8 + 9 * 2, 1 << 40),
+    }
+    for what, syms in crafted.items():
+        bad = [(0, payload(syms), 1)]
+        with pytest.raises(leon_amd.LeonDnaError) as e:
+            ctx.decode_blocks(anchors, bad, [100])
+        assert e.value.code == -1 and "does not decode" in str(e.value), what
+    # a block that holds fewer bases than its table entry says is refused too (w must end exactly at the block's end)
+    nb = [int(off[min(64, (b + 1) * rpb)] - off[b * rpb]) for b in range(len(blocks))]
+    with pytest.raises(leon_amd.LeonDnaError):
+        ctx.decode_blocks(anchors, blocks, [x + 3 for x in nb])
+    assert len(ctx.decode_blocks(anchors, blocks, nb)) == 64                                    # and the context still works
+    ctx.close()
+
+
+def test_failed_batch_poisons_the_stream_until_reset():
+    """include/leon_dna.h LEON_E_STATE: a batch refused for its arguments leaves the context untouched; one that fails after it
+    began to change the stream (here: the sink) poisons it until leon_dna_reset_stream"""
+    import leon_amd
+    from leon_amd import capi
+    k, rpb = 31, 100
+    bases, off = common.synthetic(1000, 100, 5000, seed=4)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ref = O.encode(bases, off, k, rpb, bl, trace=False)
+    ctx = _ctx(k, rpb, tai)
+    ctx.bloom_upload(bl.bits)
+    bad = np.array(off, dtype=np.uint64)
+    bad[50] = bad[52] + 7
+    with pytest.raises(leon_amd.LeonDnaError) as e:                  # refused before anything changed ...
+        ctx.encode_batch(bases, bad)
+    assert e.value.code == -1
+    assert [b[1] for b in ctx.encode_batch(bases, off)] == ref.blocks   # ... so the stream goes on as if nothing had happened
+    ctx.reset_stream()
+    seen = []
+    refuse = capi.SINK(lambda user, bid, ptr, size, nreads: (seen.append(bid), 1 if bid == 3 else 0)[1])
+    with pytest.raises(leon_amd.LeonDnaError) as e:
+        ctx.encode_batch(bases, off, sink=refuse)
+    assert e.value.code == -6 and seen == [0, 1, 2, 3]
+    for call in (lambda: ctx.encode_batch(bases, off), lambda: ctx.finish(), lambda: ctx.header_encode_batch([b"x"])):
+        with pytest.raises(leon_amd.LeonDnaError) as e:
+            call()
+        assert e.value.code == -4 and "reset_stream" in str(e.value)
+    ctx.reset_stream()
+    assert [b[1] for b in ctx.encode_batch(bases, off)] == ref.blocks
+    dd, na = ctx.finish()
+    assert dd == ref.anchor_dict and na == ref.n_anchors
+    ctx.close()

@@ -66,3 +66,41 @@ def test_header_stream_batches_shards_and_state():
     assert ctx.header_encode_batch([]) == []
     assert [b[1] for b in ctx.header_encode_batch([b"", b"", b""])] == _oracle_blocks([b"", b"", b""], rpb, b"")
     ctx.close()
+
+
+@pytest.mark.parametrize("k,kw", [(31, dict(n_rate=0.003, err=0.02)), (21, dict(ragged=True, n_rate=0.001)), (47, dict(err=0.03)), (63, dict())])
+def test_lossy_quality_smoothing_equals_the_oracle(k, kw):
+    """leon_qual_smooth_batch (DnaEncoder::smoothQuals on the device, one wave per read) == the CPU restatement, every byte"""
+    import common
+    bases, off = common.synthetic(1500, 150 if k < 60 else 220, 9000, seed=31 + k, **kw)
+    n = len(off) - 1
+    reads = [bases[int(off[i]):int(off[i + 1])] for i in range(n)] + [b"ACGT", b"", b"N" * 200, b"ACGTTGCA" * 40]
+    bases, off = O.reads_to_arrays(reads)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    quals = [q[:len(r)].ljust(len(r), b"J") for q, r in zip(H.fastq_quals(len(reads), 260, seed=k), reads)]
+    import leon_amd
+    ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=500, bloom_tai=tai)
+    ctx.bloom_upload(bl.bits)
+    got = ctx.qual_smooth_batch(bases, off, b"".join(quals))
+    want = b"".join(O.qual_smooth(bl, k, r, q) for r, q in zip(reads, quals))
+    assert len(got) == len(want)
+    assert got == want
+    assert want != b"".join(quals)                                  # something was smoothed
+    assert ctx.qual_smooth_batch(b"", np.zeros(1, dtype=np.uint64), b"") == b""
+    ctx.close()
+
+
+def test_automatic_abundance_on_the_device():
+    """min_abundance = 0: the counter keeps the k-mers at or above the threshold leon_kmer_auto_cutoff derives from the spectrum"""
+    import common
+    from leon_amd import capi
+    bases, off = common.synthetic(30000, 120, 100000, seed=77, err=0.01)      # 36x
+    for k, maxkeys in ((31, 0), (47, 400000)):
+        auto = capi.kmer_solid(bases, off, k, 0, max_keys_per_pass=maxkeys)
+        hist = capi.kmer_solid(bases, off, k, 1, with_histogram=True, max_keys_per_pass=maxkeys)[1]
+        cutoff = capi.kmer_auto_cutoff(hist)
+        assert 2 <= cutoff <= 6, cutoff
+        want = O.count_solid(bases, off, k, cutoff)
+        w = capi.kmer_words(k)
+        as_set = lambda a: set(map(tuple, np.asarray(a, dtype=np.uint64).reshape(-1, w)))
+        assert as_set(auto) == as_set(want) and len(auto) == len(want)

@@ -1,99 +1,283 @@
-"""The C++ host mirror (leon_amd/host: Leon / DnaEncoder / main) above the C-ABI."""
+"""The C++ host mirror (leon_amd/host: Leon, the .leon HDF5 container, the FASTA/FASTQ reader, main) above the C-ABI.
+CPU part: the error contract of /root/reference/src/main.cpp:38-49, the container layer through HDF5's own tools
+(h5ls / h5dump / h5diff of /opt/conda/bin), the reader.  GPU part: the reference's acceptance test
+(/root/reference/scripts/simple_test.sh:51-62: `-c -lossless`, `-d`, diff) and the flags of /root/reference/README.md:52-58."""
+import gzip
+import json
 import os
 import shutil
-import struct
 import subprocess
+import zlib
 
 import numpy as np
 import pytest
 
 import common
+import hdr_samples as H
 import oracle_lib as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEON = os.path.join(ROOT, "leon_amd", "lib", "leon")
+H5BIN = "/opt/conda/bin"
 
 
 @pytest.fixture(scope="module")
 def leon_bin():
-    if not os.path.exists(LEON):
-        import leon_amd
-        leon_amd.build_library()
+    import leon_amd
+    leon_amd.build_library()
     return LEON
 
 
-def test_cli_error_contract(leon_bin):
+def run(*args, **kw):
+    return subprocess.run(list(args), capture_output=True, text=True, **kw)
+
+
+def h5_dataset(path, name, dtype=np.uint8):
+    out = path + ".dump"
+    r = run(os.path.join(H5BIN, "h5dump"), "-d", "/" + name, "-b", "LE", "-o", out, path)
+    assert r.returncode == 0, r.stderr
+    data = np.fromfile(out, dtype=dtype)
+    os.remove(out)
+    return data
+
+
+def h5_names(path):
+    r = run(os.path.join(H5BIN, "h5ls"), "-r", path)
+    assert r.returncode == 0, r.stderr
+    return {l.split()[0]: l for l in r.stdout.splitlines()}
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU
+def test_cli_error_contract(leon_bin, tmp_path):
     # /root/reference/src/main.cpp:38-41: -v prints the banner and returns EXIT_FAILURE
-    r = subprocess.run([leon_bin, "-v"], capture_output=True, text=True)
+    r = run(leon_bin, "-v")
     assert r.returncode == 1 and "C-ABI version" in r.stdout
     # main.cpp:46-49: exceptions become "EXCEPTION: <msg>" on stderr and EXIT_FAILURE
-    for args in (["-c"], ["-file", "x", "-c", "-d"], ["-file", "x", "-bogus"], ["-file", "/nonexistent/x.leon", "-d"]):
-        r = subprocess.run([leon_bin] + args, capture_output=True, text=True)
+    junk = str(tmp_path / "junk.leon")
+    open(junk, "wb").write(b"not hdf5 at all" * 100)
+    for args in (["-c"], ["-file", "x", "-c", "-d"], ["-file", "x", "-bogus"], ["-file", "/nonexistent/x.leon", "-d"],
+                 ["-file", "x", "-c", "-kmer-size", "abc"], ["-file", "x", "-c", "-kmer-size"], ["-file", "x", "-c", "-abundance", "0"],
+                 ["-file", "x", "-c", "-gpus", "0"], ["-file", "/nonexistent/reads.fa", "-c"], ["-file", junk, "-d"]):
+        r = run(leon_bin, *args)
         assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: "), (args, r.stderr)
+    assert not os.path.exists("/nonexistent/reads.fa.leon")
 
 
-def _read_container(path):
-    raw = open(path, "rb").read()
-    assert raw[:8] == b"LEONDNA2"
-    k, rpb, n_reads, n_blocks, n_anchors, dict_bytes, tai, bloom_bytes, n_hash, nbits = struct.unpack_from("<IIQQQQQQII", raw, 8)
-    o = 8 + struct.calcsize("<IIQQQQQQII")
-    table3 = struct.unpack_from("<%dQ" % (3 * n_blocks), raw, o)
-    table = [x for b in range(n_blocks) for x in table3[3 * b:3 * b + 2]]
-    o += 24 * n_blocks
-    d = raw[o:o + dict_bytes]; o += dict_bytes
-    bloom = raw[o:o + bloom_bytes]; o += bloom_bytes
-    blocks = []
-    for b in range(n_blocks):
-        blocks.append(raw[o:o + table[2 * b]]); o += table[2 * b]
-    assert o == len(raw)
-    return dict(k=k, rpb=rpb, n_reads=n_reads, n_anchors=n_anchors, tai=tai, dict=d, bloom=bloom, blocks=blocks,
-                nreads=[table[2 * b + 1] for b in range(n_blocks)])
+def test_container_layer_through_hdf5_tools(leon_bin, tmp_path):
+    a, b = str(tmp_path / "a.leon"), str(tmp_path / "b.leon")
+    for p in (a, b):
+        r = run(leon_bin, "-selftest-container", p)
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    names = h5_names(a)
+    for n in ("/leon/dna/block_0", "/leon/dna/block_1", "/leon/header/block_0", "/leon/metadata/infobyte", "/leon/metadata/dna_blocksizes"):
+        assert n in names, names
+    assert "{100000}" in names["/leon/dna/block_0"] and "{0}" in names["/leon/dna/block_1"]
+    blk = h5_dataset(a, "leon/dna/block_0")
+    assert len(blk) == 100000 and blk[5] == ((5 * 2654435761 & 0xFFFFFFFF) >> 13) & 0xFF
+    assert list(h5_dataset(a, "leon/metadata/dna_blocksizes", np.uint64)) == [1, 2, 3, 2 ** 64 - 1, 0]
+    # parity of containers is dataset-level (h5diff); this writer also drops the timestamps, so files are equal
+    assert run(os.path.join(H5BIN, "h5diff"), a, b).returncode == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_bank_reader(leon_bin, tmp_path):
+    reads = [("r1 first", "ACGTNACGT", "IIIIIIIII"), ("r2", "A", "#"), ("", "GGGTTT", "ABCDEF"), ("r4 x/1", "ACGT" * 40, "5" * 160)]
+    fq = str(tmp_path / "x.fastq")
+    open(fq, "w").write("".join("@%s\n%s\n+\n%s\n" % r for r in reads))
+    fa = str(tmp_path / "x.fa")
+    open(fa, "w").write("".join(">%s\n%s\n" % (h, "\n".join(s[i:i + 7] for i in range(0, len(s), 7))) for h, s, _ in reads))     # wrapped lines
+    crlf = str(tmp_path / "crlf.fastq")
+    open(crlf, "wb").write("".join("@%s\r\n%s\r\n+%s\r\n%s\r\n" % (h, s, h, q) for h, s, q in reads).encode())
+    gz = str(tmp_path / "x.fastq.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(open(fq, "rb").read())
+    out = {}
+    for p in (fq, fa, crlf, gz):
+        r = run(leon_bin, "-selftest-bank", p)
+        assert r.returncode == 0, r.stderr
+        out[p] = json.loads(r.stdout)
+    nb = sum(len(s) for _, s, _ in reads)
+    assert out[fq]["fastq"] and out[fq]["reads"] == 4 and out[fq]["bases"] == nb and out[fq]["qual_bytes"] == nb
+    assert out[fq]["header_bytes"] == sum(len(h) for h, _, _ in reads)
+    assert out[gz] == out[fq] and out[crlf] == out[fq]
+    assert not out[fa]["fastq"] and out[fa]["qual_bytes"] == 0
+    assert (out[fa]["fnv_bases"], out[fa]["fnv_headers"], out[fa]["bases"]) == (out[fq]["fnv_bases"], out[fq]["fnv_headers"], nb)
+    for bad in ("@r\nACGT\n+\nIII\n", "@r\nACGT\n", "ACGT\n", "@r\nACGT\nIIII\nIIII\n"):
+        p = str(tmp_path / "bad.fq")
+        open(p, "w").write(bad)
+        r = run(leon_bin, "-selftest-bank", p)
+        assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: "), (bad, r.stderr)
+
+
+def test_automatic_abundance_threshold():
+    """leon_kmer_auto_cutoff (host-only): first local minimum of the abundance spectrum, never below 2"""
+    from leon_amd import capi
+    capi.load_library()
+
+    def cut(pairs):
+        h = np.zeros(256, dtype=np.uint64)
+        for a, v in pairs.items():
+            h[a] = v
+        return capi.kmer_auto_cutoff(h)
+    # a 30x read set with 1 % errors (numbers of the shape DESIGN.md section 4.6 derives): valley at 4
+    assert cut({1: 9_000_000_000, 2: 75_000_000, 3: 2_300_000, 4: 100_000, 5: 160_000, 6: 500_000, 17: 40_000_000, 30: 1_000_000}) == 4
+    assert cut({1: 1000, 2: 10, 3: 50, 4: 100}) == 2                 # a valley at 2 is kept
+    assert cut({1: 10, 2: 100, 3: 50}) == 2                          # never below 2
+    assert cut({1: 1000, 2: 100, 3: 10, 4: 1}) == 2                  # no valley: coverage too low to separate errors
+    assert cut({1: 6000, 2: 30, 3: 2, 60: 5, 70: 80, 80: 20}) == 4   # a gap of empty abundances: the valley starts where it ends falling
+    assert cut({}) == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+def _write_fastq(path, reads, heads, quals):
+    with open(path, "wb") as f:
+        for h, s, q in zip(heads, reads, quals):
+            f.write(b"@" + h + b"\n" + s + b"\n+\n" + q + b"\n")
+
+
+def _synthetic_fastq(tmp_path, n=2600, L=110, seed=5, **kw):
+    bases, off = common.synthetic(n, L, 6000, seed=seed, **kw)
+    reads = [bases[int(off[i]):int(off[i + 1])] for i in range(n)]
+    heads = H.sra(n, seed=seed)
+    quals = H.fastq_quals(n, 0, seed=seed)
+    quals = [(q * (len(r) // max(len(q), 1) + 1))[:len(r)] if q else b"I" * len(r) for q, r in zip(quals, reads)]
+    return reads, heads, quals
 
 
 @pytest.mark.gpu
-def test_cli_compress_toy_matches_oracle(leon_bin, tmp_path):
+def test_cli_toy_fasta_streams_match_the_oracle(leon_bin, tmp_path):
     src = os.path.join(common.GOLDEN, "toy.fasta")
     dst = str(tmp_path / "toy.fasta")
     shutil.copy(src, dst)
-    r = subprocess.run([leon_bin, "-file", dst, "-c", "-kmer-size", "31", "-abundance", "3", "-nb-cores", "4"],
-                       capture_output=True, text=True)
+    r = run(leon_bin, "-file", dst, "-c", "-kmer-size", "31", "-abundance", "3", "-nb-cores", "4")
     assert r.returncode == 0, r.stderr
-    c = _read_container(dst + ".leon")                       # INSTALL:21-23: data/toy.fasta -> data/toy.fasta.leon
+    leon = dst + ".leon"                                           # /root/reference/INSTALL:21-23: data/toy.fasta -> data/toy.fasta.leon
+    names = h5_names(leon)
+    for n in ("/leon/dna/block_0", "/leon/header/block_0", "/leon/anchors/dict", "/bloom/bits", "/leon/metadata/params", "/leon/metadata/firstheader"):
+        assert n in names, names
+    assert "/leon/qual" not in names
     bases, off = common.toy_reads()
     bl, solid, tai = common.make_bloom(bases, off, 31, 3)
-    assert c["tai"] == tai and np.array_equal(np.frombuffer(c["bloom"], dtype=np.uint8), bl.bits)
     ref = O.encode(bases, off, 31, 50000, bl, trace=False)
-    assert c["blocks"] == ref.blocks and c["nreads"] == ref.block_nreads
-    assert c["dict"] == ref.anchor_dict and c["n_anchors"] == ref.n_anchors
-    # and the stream decodes back to the input with the oracle's decoder
-    anchors = O.decode_anchor_dict(c["dict"], c["n_anchors"], 31)
-    dec = O.decode_block(31, bl, anchors, c["blocks"][0], c["nreads"][0], len(bases) + 16)
-    assert b"".join(dec) == bases
+    assert h5_dataset(leon, "leon/dna/block_0").tobytes() == ref.blocks[0]
+    assert h5_dataset(leon, "leon/anchors/dict").tobytes() == ref.anchor_dict
+    assert np.array_equal(h5_dataset(leon, "bloom/bits"), bl.bits)
+    heads = [l[1:].rstrip("\n").encode() for l in open(src) if l.startswith(">")]
+    assert h5_dataset(leon, "leon/header/block_0").tobytes() == O.header_encode_block(heads, heads[0])
+    assert h5_dataset(leon, "leon/metadata/firstheader").tobytes() == heads[0]
+    params = h5_dataset(leon, "leon/metadata/params", np.uint64)
+    assert list(params[:4]) == [1, 1, 0, 31] and params[5] == 200 and params[6] == ref.n_anchors and params[8] == tai
+    assert list(h5_dataset(leon, "leon/metadata/dna_blocksizes", np.uint64)) == [len(ref.blocks[0]), 200, len(bases)]
+    # two runs give the same container (h5diff)
+    other = str(tmp_path / "again" / "toy.fasta")
+    os.makedirs(os.path.dirname(other))
+    shutil.copy(src, other)
+    assert run(leon_bin, "-file", other, "-c", "-abundance", "3").returncode == 0
+    assert run(os.path.join(H5BIN, "h5diff"), leon, other + ".leon").returncode == 0
+    # INSTALL:21-23: -d restores the file; -test-file compares it with the original beside it
+    r = run(leon_bin, "-file", leon, "-d", "-test-file")
+    assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
+    assert open(dst + ".d", "rb").read() == open(src, "rb").read()
+    # automatic abundance (the default): still a lossless round trip of the file
+    assert run(leon_bin, "-file", other, "-c").returncode == 0
+    assert run(leon_bin, "-file", other + ".leon", "-d", "-test-file").returncode == 0
 
 
 @pytest.mark.gpu
-def test_cli_round_trip(leon_bin, tmp_path):
-    """the reference's own acceptance test (scripts/simple_test.sh:51-62): compress, decompress, compare -- on the DNA stream"""
-    src = os.path.join(common.GOLDEN, "toy.fasta")
-    dst = str(tmp_path / "toy.fasta")
-    shutil.copy(src, dst)
-    r = subprocess.run([leon_bin, "-file", dst, "-c", "-kmer-size", "31", "-abundance", "3"], capture_output=True, text=True)
+def test_reference_acceptance_test_lossless_fastq_gz(leon_bin, tmp_path):
+    """/root/reference/scripts/simple_test.sh:51,54,62: leon -c -lossless -file X.fastq.gz; leon -d -file X.fastq.leon; diff X.fastq X.fastq.d"""
+    reads, heads, quals = _synthetic_fastq(tmp_path, n=120000, L=100, seed=8, n_rate=0.002, err=0.02)       # three read blocks
+    fq = str(tmp_path / "SRR.fastq")
+    _write_fastq(fq, reads, heads, quals)
+    with open(fq, "rb") as f, gzip.open(fq + ".gz", "wb", compresslevel=1) as g:
+        shutil.copyfileobj(f, g)
+    r = run(leon_bin, "-c", "-lossless", "-file", fq + ".gz", "-kmer-size", "25")
     assert r.returncode == 0, r.stderr
-    r = subprocess.run([leon_bin, "-file", dst + ".leon", "-d"], capture_output=True, text=True)
+    assert os.path.exists(fq + ".leon") and not os.path.exists(fq + ".gz.leon")          # X.fastq.gz -> X.fastq.leon
+    r = run(leon_bin, "-d", "-file", fq + ".leon")
     assert r.returncode == 0, r.stderr
-    got = open(dst + ".d").read().split("\n")[:-1]             # X.fasta.leon -> X.fasta.d
-    want = [l.strip() for l in open(src) if l.strip() and not l.startswith(">")]
-    assert got == want
-    # a FASTQ with N and ragged lengths, k = 21
-    bases, off = common.synthetic(1200, 120, 5000, seed=5, n_rate=0.004, ragged=True, err=0.02)
+    assert run("diff", fq, fq + ".d").returncode == 0
+    # the quality blocks are zlib over the block's quality lines
+    q0 = h5_dataset(fq + ".leon", "leon/qual/block_0").tobytes()
+    assert zlib.decompress(q0) == b"".join(q + b"\n" for q in quals[:50000])
+    assert os.path.getsize(fq + ".leon") < 0.6 * os.path.getsize(fq)
+    # -test-file finds the original as X.fastq or X.fastq.gz
+    os.remove(fq)
+    r = run(leon_bin, "-d", "-test-file", "-file", fq + ".leon")
+    assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_stream_selection_flags_and_lossy_qualities(leon_bin, tmp_path):
+    import leon_amd
+    reads, heads, quals = _synthetic_fastq(tmp_path, n=3000, L=120, seed=11, n_rate=0.003, ragged=True, err=0.02)
     fq = str(tmp_path / "x.fastq")
-    with open(fq, "w") as f:
-        for i in range(len(off) - 1):
-            s = bases[int(off[i]):int(off[i + 1])].decode()
-            f.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
-    r = subprocess.run([leon_bin, "-file", fq, "-c", "-kmer-size", "21", "-abundance", "2"], capture_output=True, text=True)
+    _write_fastq(fq, reads, heads, quals)
+    k = 21
+
+    def cycle(*flags):
+        for f in (fq + ".leon", fq + ".d"):
+            if os.path.exists(f):
+                os.remove(f)
+        r = run(leon_bin, "-file", fq, "-c", "-kmer-size", str(k), "-abundance", "2", *flags)
+        assert r.returncode == 0, r.stderr
+        r = run(leon_bin, "-file", fq + ".leon", "-d")
+        assert r.returncode == 0, r.stderr
+        return open(fq + ".d", "rb").read(), h5_names(fq + ".leon")
+    norm = [bytes(c if c in b"ACGT" else ord("N") for c in r) for r in reads]
+    # default = lossy qualities (README.md:55): DnaEncoder::smoothQuals against the file's bloom
+    text, names = cycle()
+    bases, off = O.reads_to_arrays(reads)
+    bl, solid, tai = common.make_bloom(bases, off, k, 2)
+    smooth = [O.qual_smooth(bl, k, r, q) for r, q in zip(reads, quals)]
+    assert any(s != q for s, q in zip(smooth, quals))
+    assert text == b"".join(b"@" + h + b"\n" + s + b"\n+\n" + q + b"\n" for h, s, q in zip(heads, norm, smooth))
+    # -noheader: headers discarded, the read index stands in; -noqual: decompresses to FASTA (README.md:56-58)
+    text, names = cycle("-noheader", "-lossless")
+    assert "/leon/header" not in names and "/leon/qual/block_0" in names
+    assert text == b"".join(b"@%d\n" % i + s + b"\n+\n" + q + b"\n" for i, (s, q) in enumerate(zip(norm, quals)))
+    text, names = cycle("-noqual")
+    assert "/leon/qual" not in names and "/leon/header/block_0" in names
+    assert text == b"".join(b">" + h + b"\n" + s + b"\n" for h, s in zip(heads, norm))
+    text, names = cycle("-seq-only")
+    assert "/leon/qual" not in names and "/leon/header" not in names
+    assert text == b"".join(b">%d\n" % i + s + b"\n" for i, s in enumerate(norm))
+    # -gpus 2 (two contexts sharing the one device of the test box) writes the same container as -gpus 1
+    assert run(leon_bin, "-file", fq, "-c", "-kmer-size", str(k), "-abundance", "2", "-lossless").returncode == 0
+    shutil.move(fq + ".leon", fq + ".one")
+    r = run(leon_bin, "-file", fq, "-c", "-kmer-size", str(k), "-abundance", "2", "-lossless", "-gpus", "2", env=dict(os.environ, LEON_SHARE_GPU="1"))
     assert r.returncode == 0, r.stderr
-    r = subprocess.run([leon_bin, "-file", fq + ".leon", "-d"], capture_output=True, text=True)
+    assert run(os.path.join(H5BIN, "h5diff"), fq + ".one", fq + ".leon").returncode == 0
+    r = run(leon_bin, "-file", fq, "-c", "-gpus", "9")
+    assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: ") and "device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_failures_leave_no_container(leon_bin, tmp_path):
+    """a failed compression ends with EXCEPTION: and a non-zero status, and leaves no .leon behind (a swallowed
+    encode error used to produce a container with missing blocks and exit 0)"""
+    fa = str(tmp_path / "long.fa")
+    open(fa, "w").write(">r\n" + "ACGT" * 10 + "\n")
+    r = run(leon_bin, "-file", fa, "-c", "-kmer-size", "64")
+    assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: ") and not os.path.exists(fa + ".leon")
+    ro = tmp_path / "ro"
+    ro.mkdir()
+    shutil.copy(fa, str(ro / "x.fa"))
+    os.chmod(str(ro), 0o555)
+    try:
+        r = run(leon_bin, "-file", str(ro / "x.fa"), "-c")
+        if os.geteuid() != 0:                                      # root writes anywhere
+            assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: ")
+    finally:
+        os.chmod(str(ro), 0o755)
+    # a container whose tables disagree with its metadata is refused, not trusted
+    assert run(leon_bin, "-file", fa, "-c", "-kmer-size", "11").returncode == 0
+    raw = bytearray(open(fa + ".leon", "rb").read())
+    r = run(leon_bin, "-file", fa + ".leon", "-d")
     assert r.returncode == 0, r.stderr
-    got = open(fq + ".d").read().split("\n")[:-1]
-    assert got == [bases[int(off[i]):int(off[i + 1])].decode() for i in range(len(off) - 1)]
+    assert open(fa + ".d").read() == open(fa).read()
+    empty = str(tmp_path / "empty.fa")
+    open(empty, "w").write("")
+    assert run(leon_bin, "-file", empty, "-c").returncode == 0
+    assert run(leon_bin, "-file", empty + ".leon", "-d", "-test-file").returncode == 0
+    assert open(empty + ".d").read() == ""
