@@ -98,12 +98,13 @@ struct leon_dna_ctx {
     uint64_t hdr_next_read = 0, hdr_next_block = 0;   // the header stream's own counters (leon_header_encode_batch)
     bool hdr_partial_seen = false;
     DevBuf hdr_first;
+    uint32_t fbits_log2 = FBITS_LOG2;
     bool poisoned = false;                       // a batch failed after it had started to change the stream: LEON_E_STATE until reset_stream
     // batch buffers
     DevBuf in_bases, in_off, slot_off, packed, nmask, rlen, ncount;
     DevBuf status, hit_pos, hit_slot, cand_pos, cand_slot, anchor_pos, anchor_addr, flags, sort_key, ins_flag, rank;
     DevBuf ulist0, ulist1, counters, cub_tmp, sort_key2, perm, perm2, events, prev, sym_off, syms;
-    DevBuf blk_begin, out_off, out_size, rc_out, rc_scratch, dst_off, payload, errflag, nerr, wbits;
+    DevBuf blk_begin, out_off, out_size, rc_out, rc_scratch, dst_off, payload, errflag, nerr, wbits, fbits, pbits;
     void* h_payload = nullptr; size_t h_payload_cap = 0;
     uint64_t last_n = 0, last_bases = 0;
     leon_dna_stats stats{};
@@ -144,6 +145,9 @@ int dict_alloc(leon_dna_ctx* c, DictDev& D, uint64_t cap) {
     D.mask = cap - 1;
     D.n_keys = c->d_nkeys;
     D.wbits = c->wbits.as<uint32_t>();
+    D.fbits = c->fbits.as<uint32_t>();
+    D.pbits = c->pbits.as<uint32_t>();
+    D.fshift = 64 - c->fbits_log2;
     D.err = c->errflag.as<int>() + 2;
     launch_dict_init(c->stream, D, cap, W);
     return LEON_OK;
@@ -255,6 +259,13 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     CREATE_CHK(c->errflag.ensure(16));
     CREATE_CHK(hipMemsetAsync(c->errflag.p, 0, 16, c->stream));
     CREATE_CHK(c->wbits.ensure((1ull << WBITS_LOG2) / 8));
+    CREATE_CHK(c->pbits.ensure((1ull << WBITS_LOG2) / 8));
+    if (const char* e = getenv("LEON_FBITS_LOG2")) {          // measurement override: size of the final-key filter
+        const int v = atoi(e);
+        if (v >= 16 && v <= (int)FBITS_LOG2_MAX) c->fbits_log2 = (uint32_t)v;
+    }
+    CREATE_CHK(c->fbits.ensure((1ull << c->fbits_log2) / 8));
+    CREATE_CHK(hipMemsetAsync(c->fbits.p, 0, (1ull << c->fbits_log2) / 8, c->stream));
     CREATE_CHK(hipStreamSynchronize(c->stream));
 #undef CREATE_CHK
     c->anchor_worker = new AnchorDictWorker(cfg->kmer_size);
@@ -272,7 +283,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
                        &c->status, &c->hit_pos, &c->hit_slot, &c->cand_pos, &c->cand_slot, &c->anchor_pos, &c->anchor_addr,
                        &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
                        &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
-                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->hdr_first };
+                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->fbits, &c->pbits, &c->hdr_first };
     for (DevBuf* b : bufs) b->release();
     if (c->d_bloom) (void)hipFree(c->d_bloom);
     if (c->d_rv16) (void)hipFree(c->d_rv16);
@@ -503,6 +514,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         if (int rc = dict_reserve(c, c->n_keys + (w1 - w0))) return rc;
         HIPCHK(c, hipMemsetAsync(counters, 0, 8, s));
         HIPCHK(c, hipMemsetAsync(c->wbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
+        HIPCHK(c, hipMemsetAsync(c->pbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
         launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters);
         uint32_t cnt = 0;
         int dict_err = 0;
@@ -975,6 +987,7 @@ int leon_dna_reset_stream(leon_dna_ctx* c) {
     c->anchor_worker->reset();
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemsetAsync(c->fbits.p, 0, (1ull << c->fbits_log2) / 8, c->stream));
     if (c->dict_cap) {
         HIPCHK(c, hipMemsetAsync(c->d_nkeys, 0, 8, c->stream));
         launch_dict_init(c->stream, c->D, c->dict_cap, kmer_words(c->cfg.kmer_size));

@@ -175,6 +175,7 @@ __device__ inline uint32_t dict_find(const DictDev& D, u128 key, uint64_t& fin) 
     }
 }
 template <typename K> __device__ inline uint32_t window_bit(K key) { return (uint32_t)(key_hash(key) >> (64 - WBITS_LOG2)); }
+template <typename K> __device__ inline uint32_t final_bit(const DictDev& D, K key) { return (uint32_t)(key_hash(key) >> D.fshift); }
 // (`created` is set when the key was not there: the caller counts new keys, one atomic per wave where it matters)
 // ---- find or insert.  SPIN = true: called by ONE lane per wave (a lane may wait for another wave's insert to
 // complete); SPIN = false: the keys being inserted are all distinct (rehash), a locked slot is someone else's.
@@ -305,7 +306,12 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
             const K cn = canon_from_words16<K>(words, gbase, base, valid ? p : (run ? limit - 1 : 0), k);   // all 64 lanes
             bool hit = false; uint32_t slot = 0xFFFFFFFFu;
             if (valid) {
-                if (phase == PH_LOOKUP) { uint64_t fin = IDX_INF; slot = dict_find(D, cn, fin); hit = slot != 0xFFFFFFFFu && fin < g; }
+                if (phase == PH_LOOKUP) {
+                    // ~95 % of the look-ups miss (one k-mer in ~35 is an anchor): a 2 MiB bit filter of the final keys, resident
+                    // in L2, answers most of them without a random sector from HBM
+                    const uint32_t fb = final_bit(D, cn);
+                    if ((D.fbits[fb >> 5] >> (fb & 31)) & 1u) { uint64_t fin = IDX_INF; slot = dict_find(D, cn, fin); hit = slot != 0xFFFFFFFFu && fin < g; }
+                }
                 else hit = bloom_contains<K>(B, rv16, cn);
             }
             const unsigned long long bal = __ballot(hit);
@@ -326,8 +332,11 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
             uint32_t sl = 0;
             for (uint32_t q = 0; q < 4; q++) {
                 if (want_insert && grp == q) {
-                    sl = dict_find_or_insert<true>(D, canon_at<K>(pk, cpos, k), created);
+                    const K ck = canon_at<K>(pk, cpos, k);
+                    sl = dict_find_or_insert<true>(D, ck, created);
                     atomicMin((unsigned long long*)tent_ptr(D, sl), (unsigned long long)g);
+                    const uint32_t pb = window_bit(ck);                     // k_check only looks up keys that are final or proposed
+                    atomicOr(&D.pbits[pb >> 5], 1u << (pb & 31));
                     V.status[i] = ST_UNRESOLVED; V.cand_pos[i] = cpos; V.cand_slot[i] = sl;
                 }
             }
@@ -374,11 +383,16 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
             bool f = false, t = false;
             const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
             if (p < nk) {
-                uint64_t fin = IDX_INF;
-                uint32_t slot = dict_find(D, cn, fin);
-                if (slot != 0xFFFFFFFFu) {
-                    f = fin < g;
-                    t = *tent_ptr(D, slot) < g;
+                // a k-mer matters only if its key is final (fbits) or proposed in this window (pbits): both filters sit in
+                // L2, and all but a few of an inserting read's ~120 k-mers are in neither
+                const uint32_t fb = final_bit(D, cn), pb = window_bit(cn);
+                if ((((D.fbits[fb >> 5] >> (fb & 31)) | (D.pbits[pb >> 5] >> (pb & 31))) & 1u) != 0) {
+                    uint64_t fin = IDX_INF;
+                    uint32_t slot = dict_find(D, cn, fin);
+                    if (slot != 0xFFFFFFFFu) {
+                        f = fin < g;
+                        t = *tent_ptr(D, slot) < g;
+                    }
                 }
             }
             anyfin = __ballot(f) != 0;
@@ -391,8 +405,11 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
                 V.status[i] = ST_INSERTER;
                 const uint32_t slot = V.cand_slot[i];
                 __hip_atomic_store(fin_ptr<K>(D, slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t wb = window_bit(dict_key<K>(D, slot));       // k_final_pos only looks up keys whose bit is set
+                const K key = dict_key<K>(D, slot);
+                const uint32_t wb = window_bit(key);                        // k_final_pos only looks up keys whose bit is set
                 atomicOr(&D.wbits[wb >> 5], 1u << (wb & 31));
+                const uint32_t fb = final_bit(D, key);                         // and k_lookup_cand, from the next window on
+                atomicOr(&D.fbits[fb >> 5], 1u << (fb & 31));
             }
         }
     }

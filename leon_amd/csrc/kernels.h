@@ -32,9 +32,16 @@ struct DictDev {
     uint64_t mask;      // capacity - 1
     unsigned long long* n_keys;
     uint32_t* wbits;    // 2^WBITS_LOG2-bit filter of the keys made final in the current resolution window (k_final_pos)
+    uint32_t* fbits;    // 2^FBITS_LOG2-bit filter of ALL final keys, small enough to stay in every XCD's L2 (k_lookup_cand, k_check)
+    uint32_t* pbits;    // 2^WBITS_LOG2-bit filter of the keys PROPOSED in the current window (k_check)
+    uint32_t fshift;    // 64 - log2(bits of fbits)
     int* err;           // set by a kernel that gave up waiting for another wave's half-written two-word key
 };
-constexpr uint32_t WBITS_LOG2 = 26;
+constexpr uint32_t WBITS_LOG2 = 23;       // the two per-window filters: 1 MiB each (a window makes <= 2^20 keys final: <= 12 % full, ~2 % at steady state)
+constexpr uint32_t FBITS_LOG2_MAX = 27;
+constexpr uint32_t FBITS_LOG2 = 25;       // 4 MiB.  Random dword loads run at ~260 G/s from a table of <= 2 MiB (L2 hits), 100-250 G/s
+                                          // from 4 MiB, ~52 G/s from HBM (profiles/r2_gather_ceiling_by_table_size.txt); measured on the
+                                          // path itself (100 M reads, resolve stage): 2^22 bits 336 ms, 2^24 300, 2^25 283, 2^26 287, 2^27 285
 
 enum : uint8_t { ST_NOANCHOR = 0, ST_HIT = 1, ST_UNRESOLVED = 2, ST_INSERTER = 3, ST_HITNEW = 4 };
 

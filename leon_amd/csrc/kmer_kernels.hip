@@ -60,7 +60,12 @@ __global__ void k_positions(const uint64_t* off, uint64_t n, uint32_t k, uint64_
 }
 // sorted keys -> flag the first element of every run of at least T equal keys; optional histogram of run lengths
 template <uint32_t W>
-__global__ void k_flag_runs(const uint64_t* keys, uint64_t n, uint32_t T, uint8_t* flags, unsigned long long* hist, uint8_t* runlen) {
+__global__ void __launch_bounds__(256) k_flag_runs(const uint64_t* keys, uint64_t n, uint32_t T, uint8_t* flags, unsigned long long* hist, uint8_t* runlen) {
+    // the spectrum is counted per workgroup in LDS and flushed once: nearly every distinct k-mer of a read set has abundance
+    // 1 or 2, and hundreds of millions of atomics on the same two global words took longer than the sort (1.9 s at 5 M reads)
+    __shared__ unsigned int sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         auto eq = [&](uint64_t a, uint64_t b) { return keys[a * W] == keys[b * W] && (W == 1 || keys[a * W + 1] == keys[b * W + 1]); };
         const bool head = i == 0 || !eq(i, i - 1);
@@ -72,12 +77,14 @@ __global__ void k_flag_runs(const uint64_t* keys, uint64_t n, uint32_t T, uint8_
                 while (lo + step < n && eq(i, lo + step)) { lo += step; step <<= 1; }
                 while (step > 1) { step >>= 1; if (lo + step < n && eq(i, lo + step)) lo += step; }
                 const uint64_t run = lo - i + 1;
-                atomicAdd(&hist[run > 255 ? 255 : run], 1ull);
+                atomicAdd(&sh[run > 255 ? 255 : run], 1u);
                 if (runlen) runlen[i] = (uint8_t)(run > 255 ? 255 : run);
             }
         }
         flags[i] = f;
     }
+    __syncthreads();
+    if (hist && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
 }
 __global__ void k_flag_at_least(const uint8_t* counts, uint64_t n, uint32_t T, uint8_t* flags) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) flags[i] = counts[i] >= T ? 1 : 0;

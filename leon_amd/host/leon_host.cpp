@@ -249,6 +249,7 @@ void Leon::executeCompression() {
         if (rc != LEON_OK) throw Exception(std::string("leon_kmer_solid_device: ") + leon_last_error(nullptr));
     }
     struct SolidGuard { uint64_t* p; ~SolidGuard() { leon_device_free(p); } } solid_guard{d_solid};
+    const double t_kmers = seconds_since(t_count);
     uint32_t abundance = (uint32_t)_abundance;
     if (_abundance == 0) (void)leon_kmer_auto_cutoff(hist, &abundance);
     const uint64_t tai = std::max<uint64_t>(n_solid * 12, 1000);         // NBITS_PER_KMER = 12 [RECALLED]
@@ -364,8 +365,8 @@ void Leon::executeCompression() {
     if (keep_qual) std::cout << "quality stream (" << (_lossless ? "lossless" : "lossy") << "): " << qual_bytes << " bytes -> " << wq.bytes << " bytes\n";
     std::cout << "written to " << _outputFilename << std::endl;
     if (_verbose)
-        std::cout << "time: parse + headers" << (keep_qual && _lossless ? " + qualities " : " ") << t_parse << " s, k-mer counting + bloom " << t_bloom
-                  << " s, DNA encode " << t_encode << " s, total " << seconds_since(t_start) << " s" << std::endl;
+        std::cout << "time: parse + headers" << (keep_qual && _lossless ? " + qualities " : " ") << t_parse << " s, k-mer counting " << t_kmers << " s, contexts + bloom "
+                  << t_bloom - t_kmers << " s, DNA encode " << t_encode << " s, total " << seconds_since(t_start) << " s" << std::endl;
 }
 
 // ------------------------------------------------------------------------------------------------ -d
