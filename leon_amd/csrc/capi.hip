@@ -1066,8 +1066,8 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     HIPCHK(c, hipMemcpyAsync(err, d_err.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (err[0]) {
-        const char* what = err[0] == 1 ? "anchor address or position out of range" : err[0] == 2 ? "more bases than the block table says"
-                                                                                                : "too many N / error positions in one read";
+        const char* what = err[0] == 1 ? "anchor address or position out of range" : err[0] == 2 ? "more or fewer bases than the block table says"
+                         : err[0] == 4 ? "the payload ends before its reads do" : "too many N / error positions in one read";
         return fail(c, LEON_E_INVALID, std::string("block ") + std::to_string(err[1]) + " does not decode: " + what);
     }
     HIPCHK(c, hipMemcpy(out_bases, d_out.p, out0[n_blocks], hipMemcpyDeviceToHost));

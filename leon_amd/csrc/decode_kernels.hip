@@ -31,6 +31,7 @@ struct Dec {                                               // wave-uniform decod
     uint32_t* gmodels;                                     // overflow numeric models (global)
     uint32_t nused;
     uint32_t lane;
+    bool bad;                                              // ran far past the payload's end: not a stream the encoder wrote
 };
 
 __device__ inline void win_load(Dec& d) {                   // bytes [i & ~255, +256): the buffer is padded past n
@@ -103,6 +104,7 @@ template <bool GLB> __device__ inline uint32_t decode_on(Dec& d, uint32_t* T, bo
         d.code = (d.code << 8) | next_byte(d);
         d.range <<= 8;
         d.low <<= 8;
+        if (d.i > d.n + 16) { d.bad = true; break; }          // (a crafted payload can drive range to 0, which would spin here for ever)
     }
     // Order0Model::update: F(x) += 1 for x > c
     if (lane > l && lane <= (small ? size : 15u)) tinc<GLB>(T, RC_LW + 16 * j + lane);
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
     constexpr uint32_t W = KT<K>::W;
     for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         Dec d;
-        d.lane = lane; d.lds = models; d.slotmap = slotmap; d.nused = 0;
+        d.lane = lane; d.lds = models; d.slotmap = slotmap; d.nused = 0; d.bad = false;
         uint32_t* blk_scratch = scratch + b * (uint64_t)((RC_NNUM - DC_NSLOT) * RC_STRIDE + 2 * DC_LIST_CAP);
         d.gmodels = blk_scratch;
         uint32_t* const Nblk = blk_scratch + (RC_NNUM - DC_NSLOT) * RC_STRIDE;
@@ -191,11 +193,12 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
             return base + cnt <= pool_words ? pool + base : nullptr;
         };
         for (uint32_t r = 0; r < blk_reads[b] && !fail; r++) {
+            if (d.bad) { fail = 4; break; }
             const uint32_t type = decode_sym(d, M_READ_TYPE);
             if (type == 1) {                                  // DnaDecoder::decodeNoAnchorRead
                 const uint64_t len = decode_numeric(d, G_NOANCHOR_READSIZE);
                 if (!len_fits(len, w, wcap)) { fail = 2; break; }
-                for (uint64_t i = 0; i < len; i++) {
+                for (uint64_t i = 0; i < len && !d.bad; i++) {
                     const uint32_t c = decode_sym(d, M_NOANCHOR_READ);
                     if (lane == 0) out[w + i] = bin2nt(c);
                 }
@@ -311,6 +314,7 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
             if (lane == 0) out_len[r0 + r] = (uint32_t)len;
             w += len;
         }
+        if (!fail && d.bad) fail = 4;
         if (!fail && w != wcap) fail = 2;                    // the block table promised exactly wcap - blk_out0[b] bases
         if (fail && lane == 0) { if (atomicCAS(err, 0, fail) == 0) err[1] = (int)b; }
     }

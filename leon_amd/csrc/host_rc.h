@@ -275,6 +275,7 @@ inline bool decode_anchor_dict(const uint8_t* p, uint64_t n, uint64_t n_anchors,
                 r = (uint64_t)(((unsigned __int128)range * inv[off]) >> 64) >> 8;     // floor(range / tot) or one less
                 if (range - r * tot >= tot) r++;
             } else r = range / tot;
+            if (r == 0) return false;
             // the symbol is the number of cumulative counts c with c * r <= code - low; the five products also are the
             // new low and range (no second multiply, no division)
             const uint64_t d = code - low;
@@ -286,6 +287,7 @@ inline bool decode_anchor_dict(const uint8_t* p, uint64_t n, uint64_t n_anchors,
                 code = (code << 8) | (i < n ? p[i] : 0); i++;
                 range <<= 8;
                 low <<= 8;
+                if (i > n + 16) return false;                  // far past the end: not a stream this coder wrote (a range of 0 would spin here)
             }
             for (uint32_t x = 1; x <= 5; x++) cum[x] += (uint64_t)(x > c);     // Order0Model::update, branch-free
             if (c > 3) return false;                           // an N inside an anchor: not a stream this coder wrote

@@ -58,10 +58,13 @@ struct Model256 {
 struct RangeDecoder {
     uint64_t low = 0, range = ~0ull, code = 0;
     const uint8_t* p; uint64_t n, i = 0;
+    uint32_t past = 0;
+    bool bad = false;                                         // the payload is not a stream this coder wrote (checked by the caller per header)
     RangeDecoder(const uint8_t* p_, uint64_t n_) : p(p_), n(n_) { for (int k = 0; k < 8; k++) code = (code << 8) | byte(); }
     uint8_t byte() { return i < n ? p[i++] : 0; }
     uint32_t next(Model256& m) {
         range /= m.total();
+        if (range == 0 || bad) { bad = true; return 0; }
         const uint32_t c = m.find((code - low) / range);
         low += (uint64_t)m.F(c) * range;
         range *= (uint64_t)(m.F(c + 1) - m.F(c));
@@ -69,6 +72,7 @@ struct RangeDecoder {
             code = (code << 8) | byte();
             range <<= 8;
             low <<= 8;
+            if (i >= n && ++past > 16) { bad = true; return 0; }   // far past the end (a range of 0 would spin here)
         }
         m.update(c);
         return c;
@@ -133,6 +137,7 @@ bool decode_header_block(const uint8_t* payload, uint64_t size, uint32_t n, cons
         };
         for (;;) {
             const uint32_t t = d.next(M.type);
+            if (d.bad) return false;
             if (t == H_END_MATCH) { copy_prev_until(~0ull); break; }
             if (t == H_END) {
                 const uint64_t f = decode_count(d, M, M.field_index);
@@ -154,7 +159,7 @@ bool decode_header_block(const uint8_t* payload, uint64_t size, uint32_t n, cons
                 const uint64_t col = decode_count(d, M, M.field_column), sz = decode_count(d, M, M.mis_size);
                 if (col > p.len || sz > max_header || cur.size() + col + sz > max_header) return false;
                 cur.append(prev, p0, col);
-                for (uint64_t j = 0; j < sz; j++) cur.push_back((char)d.next(M.ascii));
+                for (uint64_t j = 0; j < sz && !d.bad; j++) cur.push_back((char)d.next(M.ascii));
             } else {
                 uint64_t v = 0, z = 0; uint8_t sep = 0; bool has_sep = false;
                 if (t == H_FIELD_DELTA || t == H_FIELD_DELTA_2) {

@@ -275,15 +275,16 @@ static void enc_flush(rcenc* e) {
     for (int i = 0; i < 8; i++) { bv_push(&e->buf, (uint8_t)(e->low >> 56)); e->low <<= 8; }
 }
 
-typedef struct { uint64_t low, range, code; const uint8_t* p; uint64_t n, i; } rcdec;
+typedef struct { uint64_t low, range, code; const uint8_t* p; uint64_t n, i; uint32_t past; } rcdec;
 
 static inline uint8_t dec_byte(rcdec* d) { return d->i < d->n ? d->p[d->i++] : 0; }
 static void dec_init(rcdec* d, const uint8_t* p, uint64_t n) {
-    d->low = 0; d->range = (uint64_t)-1; d->code = 0; d->p = p; d->n = n; d->i = 0;
+    d->low = 0; d->range = (uint64_t)-1; d->code = 0; d->p = p; d->n = n; d->i = 0; d->past = 0;
     for (int i = 0; i < 8; i++) d->code = (d->code << 8) | dec_byte(d);
 }
 static uint8_t dec_next(rcdec* d, o0model* m) {
     d->range /= m->r[m->n];
+    if (d->range == 0) { d->range = 1; d->past = 1000; }       /* not a stream the encoder wrote: callers see garbage, never a trap */
     uint64_t value = (d->code - d->low) / d->range;
     int c = (int)m->n - 1;
     while (c > 0 && m->r[c] > value) c--;
@@ -294,6 +295,7 @@ static uint8_t dec_next(rcdec* d, o0model* m) {
         d->code = (d->code << 8) | dec_byte(d);
         d->range <<= 8;
         d->low <<= 8;
+        if (d->i >= d->n && ++d->past > 64) break;             /* far past the end (a range of 0 would spin here) */
     }
     m_update(m, (uint8_t)c);
     return (uint8_t)c;
