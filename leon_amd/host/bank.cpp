@@ -4,6 +4,7 @@
 #include <sys/stat.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstring>
 
 namespace leon_host {
@@ -77,10 +78,21 @@ uint64_t Bank::next(ReadBatch& b, uint64_t max_reads) {
         } else {
             if (line[0] != '>') throw Exception("FASTA data before the first header in " + path_);
             b.headers.append(line, 1, std::string::npos);
+            uint64_t n_lines = 0, last_len = 0;
             while (getline(line)) {                                  // sequence lines up to the next header
                 if (!line.empty() && line[0] == '>') { pending_ = line; have_pending_ = true; break; }
+                // wrapped sequences: every line but a record's last must have the same width, the last one 1..width
+                if (n_lines) {
+                    if (!wrap_seen_) { wrap_seen_ = true; wrap_ = last_len; }
+                    if (last_len != wrap_ || wrap_ == 0) wrap_ok_ = false;
+                }
+                last_len = line.size(); n_lines++;
                 b.bases += line;
             }
+            if (n_lines && last_len == 0) wrap_ok_ = false;          // an empty last line would not come back
+            if (wrap_seen_ && n_lines && last_len > wrap_) wrap_ok_ = false;
+            if (n_lines == 0) single_empty_ = true;
+            if (n_lines == 1) single_max_ = std::max<uint64_t>(single_max_, last_len);
         }
         b.header_off.push_back(b.headers.size());
         b.base_off.push_back(b.bases.size());

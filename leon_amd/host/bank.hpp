@@ -27,6 +27,9 @@ public:
     // appends up to max_reads reads to batch; returns the number appended (0 at the end of the file)
     uint64_t next(ReadBatch& batch, uint64_t max_reads);
     uint64_t bytesEstimate() const { return file_bytes_; }   // size of the file on disk (compressed size for .gz)
+    // FASTA: the width every sequence line but a record's last has when the file wraps its sequences consistently, else 0
+    // (sequences on one line, or lines of differing widths); valid once the whole file has been read
+    uint64_t fastaLineWidth() const { return (wrap_seen_ && wrap_ok_ && !single_empty_ && single_max_ <= wrap_) ? wrap_ : 0; }
 private:
     bool getline(std::string& line);
     void* gz_ = nullptr;                          // gzFile: reads plain files transparently as well
@@ -35,6 +38,9 @@ private:
     std::vector<char> buf_;
     size_t buf_pos_ = 0, buf_len_ = 0;
     uint64_t file_bytes_ = 0, n_read_ = 0;
+    uint64_t wrap_ = 0;
+    bool wrap_seen_ = false, wrap_ok_ = true, single_empty_ = false;
+    uint64_t single_max_ = 0;                     // longest sequence that sat on one line: must fit the wrap width too
 };
 
 }  // namespace leon_host

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <memory>
 #include <mutex>
@@ -213,6 +214,7 @@ void Leon::executeCompression() {
     uint64_t n_reads = 0, header_bytes = 0, qual_bytes = 0;
     const uint64_t batch_reads = 64ull * rpb;
     ReadBatch batch;
+    std::future<void> qual_job;
     for (;;) {
         batch.clear();
         const uint64_t got = bank.next(batch, batch_reads);
@@ -224,17 +226,25 @@ void Leon::executeCompression() {
                        wh, "leon_header_encode_batch");
             header_bytes += batch.headers.size();
         }
-        if (keep_qual && _lossless) {
-            int rc = leon_host_qual_encode_blocks(reinterpret_cast<const uint8_t*>(batch.quals.data()), batch.qual_off.data(), got, rpb, -1, (uint32_t)_nbCores,
-                                                  StreamWriter::sink, &wq, n_reads / rpb);
-            check_sink(nullptr, rc, wq, "leon_host_qual_encode_blocks");
-        }
         qual_bytes += batch.quals.size();
+        if (keep_qual && _lossless) {                            // deflated on the host threads while the next batch is being parsed
+            if (qual_job.valid()) qual_job.get();
+            auto quals = std::make_shared<std::string>(std::move(batch.quals));
+            auto qoff = std::make_shared<std::vector<uint64_t>>(batch.qual_off);
+            const uint64_t first_block = n_reads / rpb;
+            const uint32_t cores = (uint32_t)_nbCores;
+            qual_job = std::async(std::launch::async, [quals, qoff, got, first_block, cores, &wq] {
+                int rc = leon_host_qual_encode_blocks(reinterpret_cast<const uint8_t*>(quals->data()), qoff->data(), got, READ_PER_BLOCK, -1, cores, StreamWriter::sink, &wq,
+                                                      first_block);
+                check_sink(nullptr, rc, wq, "leon_host_qual_encode_blocks");
+            });
+        }
         for (auto& st : store) st->append(batch.bases);
         for (uint64_t i = 1; i <= got; i++) offsets.push_back(offsets[n_reads] + batch.base_off[i]);
         n_reads += got;
         if (got < batch_reads) break;                            // the partial batch is the last one
     }
+    if (qual_job.valid()) qual_job.get();
     const uint64_t n_blocks = (n_reads + rpb - 1) / rpb, n_bases = offsets.back();
     for (auto& st : store) st->set_offsets(offsets);
     hdr_ctx.reset();
@@ -352,7 +362,7 @@ void Leon::executeCompression() {
     params[P_VERSION_MAJOR] = 1; params[P_VERSION_MINOR] = 1; params[P_VERSION_PATCH] = 0;       // Leon 1.1.0, /root/reference/CMakeLists.txt:9-11
     params[P_KMER_SIZE] = k; params[P_READS_PER_BLOCK] = rpb; params[P_N_READS] = n_reads; params[P_N_ANCHORS] = n_anchors;
     params[P_ABUNDANCE] = abundance; params[P_BLOOM_TAI] = tai; params[P_BLOOM_N_HASH] = 7; params[P_BLOOM_BLOCK_NBITS] = 12;
-    params[P_TOTAL_BASES] = n_bases; params[P_FASTA_LINE_WIDTH] = 0;
+    params[P_TOTAL_BASES] = n_bases; params[P_FASTA_LINE_WIDTH] = fastq ? 0 : bank.fastaLineWidth();
     out.putU64(DS_PARAMS, params, PARAM_COUNT);
     out.close();
     if (std::rename(tmp_name.c_str(), _outputFilename.c_str()) != 0) throw Exception("cannot write " + _outputFilename);
@@ -432,6 +442,7 @@ void Leon::executeDecompression() {
     std::ofstream o(_outputFilename, std::ios::binary);
     if (!o) throw Exception("cannot write " + _outputFilename);
     const bool fastq_out = !fasta_in && has_qual;               // "-noqual ... will decompress to fasta"
+    const uint64_t wrap = fasta_in ? params[P_FASTA_LINE_WIDTH] : 0;      // sequences wrapped at this width in the original (0: one line)
     const char lead = fastq_out ? '@' : '>';
 
     const uint64_t group = 256;                                  // blocks decoded per round: bounds the host memory of -d
@@ -489,8 +500,15 @@ void Leon::executeDecompression() {
             if (has_header) text.append(reinterpret_cast<const char*>(hdr.data()) + hdr_off[r], hdr_off[r + 1] - hdr_off[r]);
             else text += std::to_string(read_index + r);
             text.push_back('\n');
-            text.append(reinterpret_cast<const char*>(bases.data()) + at, lens[r]);
-            text.push_back('\n');
+            if (wrap && lens[r] > wrap) {
+                for (uint64_t o2 = 0; o2 < lens[r]; o2 += wrap) {
+                    text.append(reinterpret_cast<const char*>(bases.data()) + at + o2, std::min<uint64_t>(wrap, lens[r] - o2));
+                    text.push_back('\n');
+                }
+            } else {
+                text.append(reinterpret_cast<const char*>(bases.data()) + at, lens[r]);
+                text.push_back('\n');
+            }
             if (fastq_out) {
                 if (qual_off[r + 1] - qual_off[r] != lens[r]) throw Exception(_inputFilename + ": a read's quality and sequence lengths differ");
                 text += "+\n";
@@ -578,7 +596,7 @@ int selftest_bank(const std::string& path) {
         mix(fnv_b, b.bases); mix(fnv_h, b.headers); mix(fnv_q, b.quals);
     }
     std::cout << "{\"fastq\": " << (fq ? "true" : "false") << ", \"reads\": " << n << ", \"bases\": " << nb << ", \"header_bytes\": " << nh << ", \"qual_bytes\": " << nq
-              << ", \"fnv_bases\": " << fnv_b << ", \"fnv_headers\": " << fnv_h << ", \"fnv_quals\": " << fnv_q << "}" << std::endl;
+              << ", \"fasta_line_width\": " << bank.fastaLineWidth() << ", \"fnv_bases\": " << fnv_b << ", \"fnv_headers\": " << fnv_h << ", \"fnv_quals\": " << fnv_q << "}" << std::endl;
     return 0;
 }
 

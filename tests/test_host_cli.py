@@ -100,7 +100,11 @@ def test_bank_reader(leon_bin, tmp_path):
     assert out[fq]["fastq"] and out[fq]["reads"] == 4 and out[fq]["bases"] == nb and out[fq]["qual_bytes"] == nb
     assert out[fq]["header_bytes"] == sum(len(h) for h, _, _ in reads)
     assert out[gz] == out[fq] and out[crlf] == out[fq]
-    assert not out[fa]["fastq"] and out[fa]["qual_bytes"] == 0
+    assert not out[fa]["fastq"] and out[fa]["qual_bytes"] == 0 and out[fa]["fasta_line_width"] == 7 and out[fq]["fasta_line_width"] == 0
+    ragged = str(tmp_path / "ragged.fa")
+    open(ragged, "w").write(">a\nACGTACG\nACG\n>b\nACGTA\nACGTACG\n")          # lines of differing widths: not reproducible, so 0
+    r = run(leon_bin, "-selftest-bank", ragged)
+    assert r.returncode == 0 and json.loads(r.stdout)["fasta_line_width"] == 0
     assert (out[fa]["fnv_bases"], out[fa]["fnv_headers"], out[fa]["bases"]) == (out[fq]["fnv_bases"], out[fq]["fnv_headers"], nb)
     for bad in ("@r\nACGT\n+\nIII\n", "@r\nACGT\n", "ACGT\n", "@r\nACGT\nIIII\nIIII\n"):
         p = str(tmp_path / "bad.fq")
@@ -178,6 +182,14 @@ def test_cli_toy_fasta_streams_match_the_oracle(leon_bin, tmp_path):
     r = run(leon_bin, "-file", leon, "-d", "-test-file")
     assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
     assert open(dst + ".d", "rb").read() == open(src, "rb").read()
+    # a FASTA whose sequences are wrapped at a fixed width comes back wrapped
+    wrapped = str(tmp_path / "wrapped.fa")
+    with open(wrapped, "w") as f:
+        for l in open(src):
+            f.write(l if l.startswith(">") else "".join(l.strip()[i:i + 60] + "\n" for i in range(0, len(l.strip()), 60)))
+    assert run(leon_bin, "-file", wrapped, "-c", "-abundance", "3").returncode == 0
+    r = run(leon_bin, "-file", wrapped + ".leon", "-d", "-test-file")
+    assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
     # automatic abundance (the default): still a lossless round trip of the file
     assert run(leon_bin, "-file", other, "-c").returncode == 0
     assert run(leon_bin, "-file", other + ".leon", "-d", "-test-file").returncode == 0

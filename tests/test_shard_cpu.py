@@ -1,5 +1,6 @@
-"""CPU tests of the N>1 path: the block partition and the order in which per-rank block tables merge,
-single-process properties plus a world_size-2 gloo run."""
+"""CPU tests of the N>1 path: the block partition and the order in which per-rank block tables merge, single-process
+properties plus a world_size-2 gloo run in which every rank codes its block range with the product library (the quality
+stream's host entry point; the GPU streams' N-process run is tests/test_gpu_multiprocess.py)."""
 import os
 import socket
 
@@ -41,18 +42,40 @@ def _worker(rank, world, port, n_blocks, rpb, n_reads, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     b0, b1 = block_range(rank, world, n_blocks)
-    # each rank "encodes" its block range: here only the table a real rank would hand to its sink
-    table = [(b, 100 + b, min(rpb, n_reads - b * rpb)) for b in range(b0, b1)]
+    # each rank codes ITS block range of the quality stream through the product library's host entry point (the one stream
+    # of the format that needs no GPU: libleon_dna.so IS called here), with the global block ids a real rank's sink sees
+    import hdr_samples as H
+    import numpy as np
+    from leon_amd import capi
+    quals = H.fastq_quals(n_reads, 40, seed=12)                 # the same file on every rank
+    mine = quals[b0 * rpb:b1 * rpb]
+    off = np.zeros(len(mine) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(q) for q in mine])
+    blocks = capi.host_qual_encode_blocks(b"".join(mine), off, rpb, n_threads=2, first_block_id=b0)
+    table = [(bid, len(pay), nr) for bid, pay, nr in blocks]
+    payloads = {bid: pay for bid, pay, nr in blocks}
     # the bloom broadcast of bench.py, on a byte tensor (gloo stands in for RCCL on CPU)
     bits = torch.arange(64, dtype=torch.uint8) if rank == 0 else torch.zeros(64, dtype=torch.uint8)
     dist.broadcast(bits, src=0)
     gathered = [None] * world
     dist.all_gather_object(gathered, table)
+    all_payloads = [None] * world
+    dist.all_gather_object(all_payloads, payloads)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                # the max-over-ranks timing reduction of bench.py
     if rank == 0:
         merged = merge_block_tables(gathered)
-        q.put((merged, bits.tolist(), float(t.item())))
+        # the union of the ranks' blocks decodes to the whole file, and equals what ONE process produces
+        joined = {}
+        for p_ in all_payloads:
+            joined.update(p_)
+        union = [(bid, joined[bid], nr) for bid, _, nr in merged]
+        nbytes = [sum(len(x) for x in quals[b * rpb:(b + 1) * rpb]) for b in range(n_blocks)]
+        whole_off = np.zeros(n_reads + 1, dtype=np.uint64)
+        whole_off[1:] = np.cumsum([len(x) for x in quals])
+        single = capi.host_qual_encode_blocks(b"".join(quals), whole_off, rpb, n_threads=2)
+        ok = capi.host_qual_decode_blocks(union, nbytes) == quals and [b[1] for b in single] == [b[1] for b in union]
+        q.put((merged, bits.tolist(), float(t.item()), ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,10 +89,11 @@ def test_two_rank_gloo_partition_and_merge():
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_blocks, rpb, n_reads, q)) for r in range(world)]
     for p in procs:
         p.start()
-    merged, bits, tmax = q.get(timeout=120)
+    merged, bits, tmax, union_ok = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert [m[0] for m in merged] == list(range(n_blocks))
     assert sum(m[2] for m in merged) == n_reads
     assert bits == list(range(64)) and tmax == 2.0
+    assert union_ok, "the union of the ranks' quality blocks is not the single-process stream"
