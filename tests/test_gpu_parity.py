@@ -601,3 +601,24 @@ def test_failed_batch_poisons_the_stream_until_reset():
     dd, na = ctx.finish()
     assert dd == ref.anchor_dict and na == ref.n_anchors
     ctx.close()
+
+
+def test_offsets_are_checked_before_the_uploader_indexes_with_them():
+    """leon_dna_encode_batch's uploader thread copies the bases group by group (first 2^17 reads, then 8 windows at a
+    time) using intermediate offsets; entries that are not an offsets array -- here a group boundary pointing far outside the
+    buffer, in both directions -- must be refused (LEON_E_INVALID), never read through, and leave the stream usable"""
+    import leon_amd
+    k, rpb, n, L = 21, 5000, 300000, 40
+    rng = np.random.default_rng(5)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n * L)].tobytes()
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    ctx = _ctx(k, rpb, 100000, resolve_window=1 << 14)               # windows of 16 k reads: group boundaries at 16 k, 147 k, 278 k
+    for at, val in ((1 << 14, 1 << 60), (1 << 14, 0), ((1 << 14) + 8 * (1 << 14), (n + 5) * L), (123, 7)):
+        bad = off.copy()
+        bad[at] = val
+        with pytest.raises(leon_amd.LeonDnaError) as e:
+            ctx.encode_batch(bases, bad)
+        assert e.value.code == -1 and "monotonic" in str(e.value), (at, val, str(e.value))
+    blocks = ctx.encode_batch(bases, off)                              # refused batches changed nothing
+    assert len(blocks) == n // rpb and sum(b[2] for b in blocks) == n
+    ctx.close()

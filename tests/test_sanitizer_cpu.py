@@ -1,0 +1,32 @@
+"""-m "not gpu": AddressSanitizer + UBSan over the host-side decoders of the C-ABI (no GPU sanitizer exists on this pool, so
+the host code is what a sanitizer can see): host_streams.cpp is rebuilt with -fsanitize=address,undefined and fed valid,
+corrupted, truncated and random header / quality payloads in a child process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib(name):
+    p = subprocess.run(["gcc", "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+def test_host_decoders_under_asan_ubsan(tmp_path):
+    asan, ubsan = _lib("libasan.so"), _lib("libubsan.so")
+    if not asan or not ubsan:
+        pytest.skip("no libasan / libubsan in this toolchain")
+    flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+    stub = tmp_path / "stub.cpp"            # the two symbols host_streams.cpp takes from the rest of the library
+    stub.write_text('#include <string>\nnamespace leon { thread_local std::string g; void set_create_error(const std::string& m) { g = m; } }\n'
+                    'extern "C" const char* leon_last_error(const void*) { return leon::g.c_str(); }\n')
+    so = str(tmp_path / "libhoststreams_asan.so")
+    subprocess.check_call(["g++"] + flags + ["-shared", "-I" + os.path.join(ROOT, "include"), "-o", so,
+                                             os.path.join(ROOT, "leon_amd", "csrc", "host_streams.cpp"), str(stub), "-lz", "-lpthread"])
+    env = dict(os.environ, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_fuzz_host_streams.py"), so], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "header decoder under ASan/UBSan: ok" in r.stdout and "quality decoder under ASan/UBSan: ok" in r.stdout
