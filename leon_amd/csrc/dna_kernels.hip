@@ -214,24 +214,38 @@ template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDe
         if (hi == KEY_EMPTY) {
             hi = atomicCAS((unsigned long long*)phi, (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_LOCKED);
             if (hi == KEY_EMPTY) {                                       // ours: low word first, then publish the high word
-                __hip_atomic_store(plo, klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(phi, khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                // Both words are written with relaxed read-modify-write atomics, which execute in issue order at the one L2
+                // channel that owns the slot's cache line: whoever sees the high word sees the low word.  (A release store
+                // at agent scope instead costs a write-back of the XCD's whole L2 -- `buffer_wbl2 sc1` -- PER INSERT:
+                // a window in which every read inserts took 33 ms at k = 63 against 2.4 ms at k = 31.)
+                (void)__hip_atomic_exchange(plo, klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_exchange(phi, khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 created = true;
                 return (uint32_t)slot;
             }
         }
         if (SPIN) {
-            // the other inserter is a lane of ANOTHER wave that is two stores away from publishing: it cannot be waiting for
+            // the other inserter is a lane of ANOTHER wave that is two atomics away from publishing: it cannot be waiting for
             // us.  Should the wait ever run out (a stalled wave), the batch is failed through D.err rather than probing on
             // and inserting the same key twice.
             uint32_t spin = 0;
             for (; hi == KEY_LOCKED && spin < (1u << 22); spin++) {
                 __builtin_amdgcn_s_sleep(1);
-                hi = __hip_atomic_load(phi, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                hi = __hip_atomic_load(phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (hi == KEY_LOCKED) { atomicExch(D.err, 1); return (uint32_t)slot; }
         }
-        if (hi == khi && __hip_atomic_load(plo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == klo) return (uint32_t)slot;
+        if (hi == khi) {
+            uint64_t lo = __hip_atomic_load(plo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // belt and braces: should the low word ever be seen after the high one, it still reads as the free slot's ~0;
+            // give it a moment before taking ~0 for a real low word (a k-mer ending in 32 G) and probing on
+            if (SPIN && lo == KEY_EMPTY && klo != KEY_EMPTY)
+                for (uint32_t spin = 0; lo == KEY_EMPTY && spin < 1024; spin++) {
+                    __builtin_amdgcn_s_sleep(1);
+                    lo = __hip_atomic_load(plo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            if (lo == klo) return (uint32_t)slot;
+        }
         slot = (slot + 1) & D.mask;
     }
 }
@@ -290,18 +304,49 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     enum : uint32_t { PH_LOOKUP = 0, PH_SEG_A = 1, PH_SEG_B = 2, PH_SEG_C = 3, PH_DONE = 4 };
-    for (uint64_t i0 = w0 + 4 * wave; i0 < w1; i0 += 4 * nwaves) {
-        const uint64_t i = i0 + grp;
-        const bool have = i < w1;
-        const uint32_t len = have ? R.len[i] : 0;
-        const uint64_t g = first_global + i;
-        const uint32_t* pk = R.packed + 2 * (have ? R.slot_off[i] : 0);
-        const uint32_t nk = len >= k ? len - k + 1 : 0;
-        // Leon::findAndInsertAnchor scan order: [n/2, n/2+10), [0, n/2), [n/2+10, n)
-        const uint32_t iMin = nk / 2, iMax = nk / 2 + 10 > nk ? nk : nk / 2 + 10;
-        uint32_t phase = PH_LOOKUP, base = 0, limit = nk;
-        if (nk == 0) { phase = PH_DONE; if (have && l == 0) V.status[i] = ST_NOANCHOR; }
-        while (__any(phase != PH_DONE)) {
+    __shared__ uint32_t lists[4][64];                             // per wave: window-relative indices of its unresolved reads
+    uint32_t* my_list = lists[threadIdx.x >> 6];
+    uint32_t n_list = 0, n_created = 0;                           // wave-uniform
+    auto flush_list = [&]() {
+        if (n_list) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(ucount, n_list);
+            at = (uint32_t)__shfl((int)at, 0);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n_list) ulist[at + lane] = my_list[lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (n_created && lane == 0) atomicAdd(D.n_keys, (unsigned long long)n_created);
+        n_list = 0; n_created = 0;
+    };
+    // Every quarter-wave walks ITS OWN sequence of reads (i, i + 4 * nwaves, ...) and takes the next one as soon as it is done
+    // with the current one: the kernel is bound by the number of wave-wide memory instructions (a read that inserts an anchor
+    // needs ~40, one that finds an anchor ~10; with four reads in lockstep the wave paid for the slowest), so the other three
+    // quarters must not idle while one read goes through all of its k-mers and the bloom scan.
+    uint64_t i = w0 + 4 * wave + grp;
+    bool have = false, started = false, exhausted = false;
+    uint32_t len = 0, nk = 0, iMin = 0, iMax = 0, phase = PH_DONE, base = 0, limit = 0;
+    uint64_t g = 0;
+    const uint32_t* pk = R.packed;
+    for (;;) {
+        if (phase == PH_DONE && !exhausted) {                     // this quarter-wave's next read
+            if (started) i += 4 * nwaves;
+            started = true;
+            have = i < w1;
+            exhausted = !have;
+            if (have) {
+                len = R.len[i];
+                g = first_global + i;
+                pk = R.packed + 2 * R.slot_off[i];
+                nk = len >= k ? len - k + 1 : 0;
+                // Leon::findAndInsertAnchor scan order: [n/2, n/2+10), [0, n/2), [n/2+10, n)
+                iMin = nk / 2; iMax = nk / 2 + 10 > nk ? nk : nk / 2 + 10;
+                base = 0; limit = nk;
+                if (nk) phase = PH_LOOKUP; else if (l == 0) V.status[i] = ST_NOANCHOR;      // (stays PH_DONE: the next round takes another read)
+            }
+        }
+        if (!__any(have)) break;                                  // every quarter-wave has run out of reads
+        {
             const bool active = phase != PH_DONE;
             // a phase whose range is exhausted moves on (empty segments fall through in later iterations)
             if (active && base >= limit) {
@@ -351,20 +396,19 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
                     V.status[i] = ST_UNRESOLVED; V.cand_pos[i] = cpos; V.cand_slot[i] = sl;
                 }
             }
-            // one atomic per wave on the window's two counters (in the first windows every read inserts: a million
-            // same-address atomics per launch were most of the kernel's time)
+            // The window's two counters get one atomic per ~60 inserting reads, not one per wave and step: the unresolved reads
+            // are collected in the wave's own LDS list and handed over in batches (same-address atomics serialise in L2; one
+            // per inserting wave-step was ~10^5 per window and most of this kernel's time).
             const unsigned long long wm = __ballot(want_insert);
             if (wm) {
-                const uint32_t leader = (uint32_t)__builtin_ctzll(wm);
-                uint32_t first = 0;
-                if (lane == leader) first = atomicAdd(ucount, (uint32_t)__popcll(wm));
-                first = (uint32_t)__shfl((int)first, (int)leader);
-                if (want_insert) ulist[first + (uint32_t)__popcll(wm & ((1ull << lane) - 1))] = (uint32_t)i;
-                const unsigned long long cm = __ballot(created);
-                if (cm && lane == leader) atomicAdd(D.n_keys, (unsigned long long)__popcll(cm));
+                if (want_insert) my_list[n_list + (uint32_t)__popcll(wm & ((1ull << lane) - 1))] = (uint32_t)i;
+                n_list += (uint32_t)__popcll(wm);
+                n_created += (uint32_t)__popcll(__ballot(created));
+                if (n_list > 64 - 4) flush_list();
             }
         }
     }
+    flush_list();
 }
 void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
                         uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount) {
