@@ -429,6 +429,19 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
     uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     uint32_t count = *ucount;
+    __shared__ uint32_t lists[4][64];                             // per wave: the reads it found blocked, handed over 64 at a time
+    uint32_t* my_list = lists[threadIdx.x >> 6];
+    uint32_t n_list = 0;                                          // wave-uniform
+    auto flush_list = [&]() {
+        if (!n_list) return;
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(next_count, n_list);
+        at = (uint32_t)__shfl((int)at, 0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n_list) next_list[at + lane] = my_list[lane];
+        __builtin_amdgcn_wave_barrier();
+        n_list = 0;
+    };
     for (uint64_t e = wave; e < count; e += nwaves) {
         uint32_t i = ulist[e];
         uint64_t g = first_global + i;
@@ -440,10 +453,11 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
             bool f = false, t = false;
             const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
             if (p < nk) {
-                // a k-mer matters only if its key is final (fbits) or proposed in this window (pbits): both filters sit in
-                // L2, and all but a few of an inserting read's ~120 k-mers are in neither
-                const uint32_t fb = final_bit(D, cn), pb = window_bit(cn);
-                if ((((D.fbits[fb >> 5] >> (fb & 31)) | (D.pbits[pb >> 5] >> (pb & 31))) & 1u) != 0) {
+                // Every read on this list went through ALL of its k-mers in k_lookup_cand without meeting a key that was final
+                // before the window, so only keys PROPOSED in this window (which include the ones made final in it) can matter:
+                // the 1 MiB array of those, a few per cent full, answers for all but a handful of the read's ~120 k-mers
+                const uint32_t pb = window_bit(cn);
+                if ((D.pbits[pb >> 5] >> (pb & 31)) & 1u) {
                     uint64_t fin = IDX_INF;
                     uint32_t slot = dict_find(D, cn, fin);
                     if (slot != 0xFFFFFFFFu) {
@@ -455,9 +469,13 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
             anyfin = __ballot(f) != 0;
             anyblock = anyblock || (__ballot(t) != 0);
         }
+        if (!anyfin && anyblock) {                                // (wave-uniform)
+            if (lane == 0) my_list[n_list] = i;
+            if (++n_list == 64) flush_list();
+        }
         if (lane == 0) {
             if (anyfin) V.status[i] = ST_HITNEW;
-            else if (anyblock) next_list[atomicAdd(next_count, 1u)] = i;
+            else if (anyblock) {}
             else {
                 V.status[i] = ST_INSERTER;
                 const uint32_t slot = V.cand_slot[i];
@@ -470,6 +488,7 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
             }
         }
     }
+    flush_list();
 }
 void launch_check(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* ulist,
                   const uint32_t* ucount, uint32_t max_count, uint32_t* next_list, uint32_t* next_count) {
