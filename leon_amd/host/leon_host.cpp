@@ -15,6 +15,7 @@
 #include "bank.hpp"
 #include "leon_container.hpp"
 
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -445,9 +446,22 @@ void Leon::executeDecompression() {
     const uint64_t wrap = fasta_in ? params[P_FASTA_LINE_WIDTH] : 0;      // sequences wrapped at this width in the original (0: one line)
     const char lead = fastq_out ? '@' : '>';
 
-    const uint64_t group = 256;                                  // blocks decoded per round: bounds the host memory of -d
-    std::string text;
+    // Blocks decoded per round.  A round costs the device ONE block's serial chain whatever the number of blocks in it (up to
+    // a few thousand: one wave per block), so rounds should be as large as the host's memory allows: bases, qualities and the
+    // formatted text of a round are ~5 bytes per base; a quarter of the available RAM is given to them.
+    uint64_t group = n_blocks ? n_blocks : 1;
+    {
+        const long pages = sysconf(_SC_AVPHYS_PAGES), page = sysconf(_SC_PAGESIZE);
+        const uint64_t avail = pages > 0 && page > 0 ? (uint64_t)pages * (uint64_t)page : (8ull << 30);
+        const uint64_t bases_per_block = n_blocks ? std::max<uint64_t>(total_bases / n_blocks, 1) : 1;
+        const uint64_t fit = avail / 4 / 5 / bases_per_block;
+        group = std::min<uint64_t>(group, std::max<uint64_t>(fit, 64));
+    }
+    std::unique_ptr<char[]> text;                                // the round's records (never zero-filled)
+    uint64_t text_cap = 0;
     uint64_t read_index = 0, bases_out = 0;
+    double t_read = 0, t_dna = 0, t_hdr = 0, t_qual = 0, t_text = 0, t_write = 0;
+    auto lap = [](std::chrono::steady_clock::time_point& t, double& acc) { const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(n - t).count(); t = n; };
     for (uint64_t g0 = 0; g0 < n_blocks; g0 += group) {
         const uint64_t g1 = std::min(n_blocks, g0 + group), nb = g1 - g0;
         auto gather = [&](const char* grp, const std::vector<uint64_t>& tab, uint32_t stride, std::vector<uint8_t>& pay, std::vector<uint64_t>& off) {
@@ -465,14 +479,18 @@ void Leon::executeDecompression() {
         uint64_t g_reads = 0, g_bases = 0;
         for (uint64_t b = 0; b < nb; b++) { blk_reads[b] = (uint32_t)tdna[3 * (g0 + b) + 1]; blk_bases[b] = tdna[3 * (g0 + b) + 2]; g_reads += blk_reads[b]; g_bases += blk_bases[b]; }
         // DNA
+        auto tl = std::chrono::steady_clock::now();
         gather(GROUP_DNA, tdna, 3, pay, off);
+        lap(tl, t_read);
         std::vector<uint8_t> bases(g_bases + 1); std::vector<uint32_t> lens(g_reads + 1);
         check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, bases.data(), g_bases,
                                                 lens.data()), "leon_dna_decode_blocks");
+        lap(tl, t_dna);
         // headers
         std::vector<uint8_t> hdr; std::vector<uint64_t> hdr_off(g_reads + 1, 0);
         if (has_header) {
             gather(GROUP_HEADER, thdr, 2, pay, off);
+            lap(tl, t_read);
             uint64_t need = 0;
             hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
             int rc = leon_host_header_decode_blocks(pay.data(), off.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), hdr.data(), hdr.size(), hdr_off.data(),
@@ -484,47 +502,61 @@ void Leon::executeDecompression() {
             }
             if (rc != LEON_OK) throw Exception(std::string("leon_host_header_decode_blocks: ") + leon_last_error(nullptr));
         }
+        lap(tl, t_hdr);
         // qualities
         std::vector<uint8_t> qual; std::vector<uint64_t> qual_off(g_reads + 1, 0);
         if (fastq_out) {
             gather(GROUP_QUAL, tqual, 3, pay, off);
+            lap(tl, t_read);
             qual.resize(g_bases + 1);
             if (leon_host_qual_decode_blocks(pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, qual.data(), g_bases, qual_off.data(), (uint32_t)_nbCores) != LEON_OK)
                 throw Exception(std::string("leon_host_qual_decode_blocks: ") + leon_last_error(nullptr));
         }
-        // records
-        text.clear();
-        uint64_t at = 0;
+        lap(tl, t_qual);
+        // records: every read's place in the text is known from the lengths, so the round is formatted by all cores at once
+        std::vector<uint64_t> rec_off(g_reads + 1, 0), base_at(g_reads + 1, 0);
+        auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
         for (uint64_t r = 0; r < g_reads; r++) {
-            text.push_back(lead);
-            if (has_header) text.append(reinterpret_cast<const char*>(hdr.data()) + hdr_off[r], hdr_off[r + 1] - hdr_off[r]);
-            else text += std::to_string(read_index + r);
-            text.push_back('\n');
-            if (wrap && lens[r] > wrap) {
-                for (uint64_t o2 = 0; o2 < lens[r]; o2 += wrap) {
-                    text.append(reinterpret_cast<const char*>(bases.data()) + at + o2, std::min<uint64_t>(wrap, lens[r] - o2));
-                    text.push_back('\n');
-                }
-            } else {
-                text.append(reinterpret_cast<const char*>(bases.data()) + at, lens[r]);
-                text.push_back('\n');
-            }
-            if (fastq_out) {
-                if (qual_off[r + 1] - qual_off[r] != lens[r]) throw Exception(_inputFilename + ": a read's quality and sequence lengths differ");
-                text += "+\n";
-                text.append(reinterpret_cast<const char*>(qual.data()) + qual_off[r], lens[r]);
-                text.push_back('\n');
-            }
-            at += lens[r];
+            const uint64_t hl = has_header ? hdr_off[r + 1] - hdr_off[r] : std::to_string(read_index + r).size();
+            if (fastq_out && qual_off[r + 1] - qual_off[r] != lens[r]) throw Exception(_inputFilename + ": a read's quality and sequence lengths differ");
+            rec_off[r + 1] = rec_off[r] + 1 + hl + 1 + seq_text_len(lens[r]) + (fastq_out ? 2 + (uint64_t)lens[r] + 1 : 0);
+            base_at[r + 1] = base_at[r] + lens[r];
         }
-        o.write(text.data(), (std::streamsize)text.size());
+        if (rec_off[g_reads] > text_cap) { text.reset(); text_cap = rec_off[g_reads] + rec_off[g_reads] / 16; text.reset(new char[text_cap]); }
+        const uint32_t n_fmt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(_nbCores > 0 ? (uint64_t)_nbCores : std::thread::hardware_concurrency(), g_reads / 4096 + 1));
+        auto format_range = [&](uint64_t ra, uint64_t rb) {
+            for (uint64_t r = ra; r < rb; r++) {
+                char* w = text.get() + rec_off[r];
+                *w++ = lead;
+                if (has_header) { const uint64_t hl = hdr_off[r + 1] - hdr_off[r]; memcpy(w, hdr.data() + hdr_off[r], hl); w += hl; }
+                else { const std::string idx = std::to_string(read_index + r); memcpy(w, idx.data(), idx.size()); w += idx.size(); }
+                *w++ = '\n';
+                const char* seq = reinterpret_cast<const char*>(bases.data()) + base_at[r];
+                const uint64_t len = lens[r];
+                if (wrap && len > wrap) {
+                    for (uint64_t o2 = 0; o2 < len; o2 += wrap) { const uint64_t m = std::min<uint64_t>(wrap, len - o2); memcpy(w, seq + o2, m); w += m; *w++ = '\n'; }
+                } else { memcpy(w, seq, len); w += len; *w++ = '\n'; }
+                if (fastq_out) { *w++ = '+'; *w++ = '\n'; memcpy(w, qual.data() + qual_off[r], len); w += len; *w++ = '\n'; }
+            }
+        };
+        if (n_fmt <= 1) format_range(0, g_reads);
+        else {
+            std::vector<std::thread> th;
+            for (uint32_t t = 0; t < n_fmt; t++) th.emplace_back(format_range, g_reads * t / n_fmt, g_reads * (t + 1) / n_fmt);
+            for (auto& t : th) t.join();
+        }
+        lap(tl, t_text);
+        o.write(text.get(), (std::streamsize)rec_off[g_reads]);
         if (!o) throw Exception("cannot write " + _outputFilename);
+        lap(tl, t_write);
         read_index += g_reads; bases_out += g_bases;
     }
     o.close();
     if (read_index != n_reads) throw Exception("the block tables do not add up to the header's read count");
     std::cout << n_reads << " reads, " << bases_out << " bases decoded from " << n_blocks << " blocks, written to " << _outputFilename << std::endl;
-    if (_verbose) std::cout << "time: " << seconds_since(t_start) << " s" << std::endl;
+    if (_verbose)
+        std::cout << "time: " << seconds_since(t_start) << " s (container reads " << t_read << ", DNA blocks on the device " << t_dna << ", header blocks " << t_hdr
+                  << ", quality blocks " << t_qual << ", formatting " << t_text << ", writing " << t_write << ")" << std::endl;
     if (_testFile) testDecompressedFile();
 }
 
