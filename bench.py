@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="one more UNTIMED step whose sink hashes every block: `verify.blocks_sha256` is a checksum of block "
                          "checksums over the union of all ranks' blocks (equal for every world size), plus the dictionary stream's")
+    ap.add_argument("--streams", action="store_true",
+                    help="also time the kernels of the streams either side of the DNA stream on device-resident synthetic data: the header "
+                         "stream (records + range coder, 10 M SRA-style headers) and the lossy quality smoothing (the workload's reads); "
+                         "reported as `streams`, never as value")
     ap.add_argument("--host-input", action="store_true",
                     help="also time ONE step through leon_dna_encode_batch (reads in pageable host memory, PCIe included); "
                          "reported as pcie_inclusive, never as value")
@@ -303,6 +307,54 @@ def main():
                           "payloads in host memory, bases back in host memory"}
         del kept, out_bases, out_lens
 
+    streams = None
+    if a.streams and world == 1:
+        streams = {}
+        # lossy qualities: DnaEncoder::smoothQuals over the workload's reads against the file's bloom (qualities: a fixed ramp)
+        quals = torch.full((n_total * L,), 70, dtype=torch.uint8, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = ctx.lib.leon_qual_smooth_batch_device(ctx.h, ctypes.c_void_p(reads.data_ptr()), ctypes.c_void_p(offsets.data_ptr()), n_total,
+                                                   ctypes.c_void_p(quals.data_ptr()))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        smoothed = float((quals == 64).float().mean().item())
+        streams["qual_smooth"] = {"ms": round(dt * 1e3, 1), "MBps": round(n_total * L / 1e6 / dt, 1), "fraction_smoothed": round(smoothed, 4),
+                                  "what": "leon_qual_smooth_batch_device over the workload's reads: pack + one wave per read, L-k+1 bloom look-ups per read"}
+        del quals
+        # header stream: 10 M SRA-style headers resident in HBM -> records (one lane per header) -> k_rc_encode
+        nh = min(10_000_000, n_total)
+        rng = np.random.default_rng(7)
+        idx = np.arange(1, nh + 1)
+        heads = np.char.add(np.char.add(b"SRR387476.", idx.astype("S")),
+                            np.char.add(b" HWI-ST1234:3:1101:", np.char.add(rng.integers(1000, 20000, nh).astype("S"),
+                                        np.char.add(b":", np.char.add(rng.integers(1000, 200000, nh).astype("S"), b" length=150")))))
+        lens = np.char.str_len(heads).astype(np.int64)
+        blob = np.frombuffer(b"".join(heads.tolist()), dtype=np.uint8)
+        hoff = np.zeros(nh + 1, dtype=np.int64); hoff[1:] = np.cumsum(lens)
+        d_blob = torch.from_numpy(blob.copy()).to(device); d_hoff = torch.from_numpy(hoff).to(device)
+        first = heads[0]
+        hbytes = [0]
+        hsink = capi.SINK(lambda user, bid, ptr, size, nreads: (hbytes.__setitem__(0, hbytes[0] + size), 0)[1])
+        best = None
+        for _ in range(3):
+            ctx.reset_stream()
+            hbytes[0] = 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = ctx.lib.leon_header_encode_batch_device(ctx.h, ctypes.c_void_p(d_blob.data_ptr()), ctypes.c_void_p(d_hoff.data_ptr()), nh, 0,
+                                                         first, len(first), hsink, None)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert rc == 0
+            best = dt if best is None else min(best, dt)
+        streams["header"] = {"headers": nh, "bytes_in": int(hoff[-1]), "bytes_out": hbytes[0], "ms": round(best * 1e3, 1),
+                             "MBps": round(int(hoff[-1]) / 1e6 / best, 1),
+                             "what": "leon_header_encode_batch_device, headers resident in HBM, best of 3: k_hdr_symbols x2 + scan + k_rc_encode + D2H"}
+        del d_blob, d_hoff
+        ctx.reset_stream()
+
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         cpu = cpu_baseline(ctx, reads, min(a.cpu_sample, n_total))
@@ -331,6 +383,7 @@ def main():
             "pcie_inclusive": pcie,
             "decode": decode,
             "verify": verify,
+            "streams": streams,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
                       "symbols": stage["n_symbols"], "resolve_rounds": stage["resolve_rounds"],
