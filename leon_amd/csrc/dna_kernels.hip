@@ -689,31 +689,42 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
     const K anchor = kmer_at<K>(pk, (uint32_t)a, k);
     const K anchor_rc = revcomp(anchor, k);
 
-    // Left and right walks are independent (events are indexed by position), so their order is free: a read whose
-    // anchor is reverse-complemented walks right first.  All reads of an anchor, whatever their strand, then step
-    // through the same genome side at the same iteration and share the bloom sectors they probe.
-    const bool right_first = (flags[i] & 1u) != 0;
-    // the read's 2-bit word (16 bases) and N-mask word (32 bases) stay in registers between reloads
-    uint32_t pw = 0, pw_idx = 0xFFFFFFFFu, nw = 0, nw_idx = 0xFFFFFFFFu;
-    for (uint32_t phase = 0; phase < 2; phase++) {
-        const bool left = (phase == 0) != right_first;
-        K x = left ? anchor_rc : anchor, y = left ? anchor : anchor_rc;          // x: the strand being extended rightwards
-        const uint32_t nsteps = left ? (uint32_t)a : len - k - (uint32_t)a;
-        for (uint32_t j = 0; j < nsteps; j++) {                       // one loop for both directions
-            const uint32_t pos = left ? (uint32_t)a - 1 - j : (uint32_t)a + k + j;
-            if ((pos >> 4) != pw_idx) { pw_idx = pos >> 4; pw = pk[pw_idx]; }
-            const uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
-            if (hasN) {
-                if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
-                if ((nw >> (pos & 31)) & 1u) {                        // N: coded as 'A' on the read strand, nothing stored
-                    const uint32_t f = left ? 2u : 0u;
-                    x = ((x << 2) | (K)f) & kmask_k;
-                    y = (y >> 2) | ((K)(f ^ 2u) << (2 * (k - 1)));
-                    continue;
-                }
+    // Left and right walks are independent (events are indexed by position), so BOTH run in the same loop, one step of
+    // each per iteration: "side A" is the walk towards the genome's left of the anchor (the read's left walk, or its right
+    // walk when the anchor is reverse-complemented in the read), "side B" the other one.  Step j of side A probes the same
+    // genome k-mer in EVERY read of the anchor, whatever its strand and wherever the anchor sits in it -- so the reads of an
+    // anchor, neighbours in the anchor-sorted order, stay in lockstep on both sides for the whole walk and their probes
+    // coalesce in the wave's own memory instruction (with one walk after the other, reads left the first walk at different
+    // iterations and the second walks of an anchor's reads were out of step).  Two independent chains per lane also keep
+    // twice the probes in flight.
+    const bool rev = (flags[i] & 1u) != 0;
+    const bool leftA = !rev, leftB = rev;                          // direction, in the read, of side A / side B
+    K xA = leftA ? anchor_rc : anchor, yA = leftA ? anchor : anchor_rc;          // x: the strand being extended rightwards
+    K xB = leftB ? anchor_rc : anchor, yB = leftB ? anchor : anchor_rc;
+    const uint32_t nL = (uint32_t)a, nR = len - k - (uint32_t)a;
+    const uint32_t nA = leftA ? nL : nR, nB = leftB ? nL : nR;
+    const uint32_t nmax = nA > nB ? nA : nB;
+    // the read's 2-bit word (16 bases) and N-mask word (32 bases) of each side stay in registers between reloads
+    uint32_t pwA = 0, pwA_idx = 0xFFFFFFFFu, nwA = 0, nwA_idx = 0xFFFFFFFFu;
+    uint32_t pwB = 0, pwB_idx = 0xFFFFFFFFu, nwB = 0, nwB_idx = 0xFFFFFFFFu;
+    auto side_step = [&](bool left, uint32_t j, K& x, K& y, uint32_t& pw, uint32_t& pw_idx, uint32_t& nw, uint32_t& nw_idx) {
+        const uint32_t pos = left ? (uint32_t)a - 1 - j : (uint32_t)a + k + j;
+        if ((pos >> 4) != pw_idx) { pw_idx = pos >> 4; pw = pk[pw_idx]; }
+        const uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
+        if (hasN) {
+            if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
+            if ((nw >> (pos & 31)) & 1u) {                            // N: coded as 'A' on the read strand, nothing stored
+                const uint32_t f = left ? 2u : 0u;
+                x = ((x << 2) | (K)f) & kmask_k;
+                y = (y >> 2) | ((K)(f ^ 2u) << (2 * (k - 1)));
+                return;
             }
-            walk_step<K>(B, rv16, k, kmask_k, x, y, nt, left, ev + pos);
         }
+        walk_step<K>(B, rv16, k, kmask_k, x, y, nt, left, ev + pos);
+    };
+    for (uint32_t j = 0; j < nmax; j++) {
+        if (j < nA) side_step(leftA, j, xA, yA, pwA, pwA_idx, nwA, nwA_idx);
+        if (j < nB) side_step(leftB, j, xB, yB, pwB, pwB_idx, nwB, nwB_idx);
     }
 }
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos, const uint8_t* flags,
