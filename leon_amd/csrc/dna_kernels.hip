@@ -649,9 +649,7 @@ void launch_anchor_symbols(hipStream_t s, const uint64_t* kmers, uint64_t n_anch
 // The bloom is strand-symmetric, so contains4_left(kmer)[n] == contains4_right(revcomp(kmer))[n ^ 2]: the left-walking
 // lanes only swap the mask's bit pairs back.  One instruction stream for both directions, no duplicated arithmetic.
 template <typename K>
-__device__ inline void walk_step(const BloomDev& B, const uint16_t* rv16, uint32_t k, K kmask_k, K& x, K& y,
-                                 uint32_t nt, bool left, uint8_t* ev_pos) {
-    uint32_t res4 = bloom_contains4<K>(B, rv16, x, y, true);
+__device__ inline void walk_apply(uint32_t res4, uint32_t k, K kmask_k, K& x, K& y, uint32_t nt, bool left, uint8_t* ev_pos) {
     if (left) res4 = ((res4 >> 2) & 3u) | ((res4 & 3u) << 2);         // back to the read strand's base codes
     const uint32_t cnt = __popc(res4);
     const bool solid = (res4 >> nt) & 1u;
@@ -707,24 +705,32 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
     // the read's 2-bit word (16 bases) and N-mask word (32 bases) of each side stay in registers between reloads
     uint32_t pwA = 0, pwA_idx = 0xFFFFFFFFu, nwA = 0, nwA_idx = 0xFFFFFFFFu;
     uint32_t pwB = 0, pwB_idx = 0xFFFFFFFFu, nwB = 0, nwB_idx = 0xFFFFFFFFu;
-    auto side_step = [&](bool left, uint32_t j, K& x, K& y, uint32_t& pw, uint32_t& pw_idx, uint32_t& nw, uint32_t& nw_idx) {
-        const uint32_t pos = left ? (uint32_t)a - 1 - j : (uint32_t)a + k + j;
+    // one step of a side in two halves, so that the probes of BOTH sides are in flight before either is waited for:
+    // side_probe returns the successor mask (0x100 = nothing to probe: past the side's end, or an N position, whose
+    // 'A' is pushed into the k-mer right away), side_apply classifies it, stores the event and moves the k-mer on
+    auto side_probe = [&](bool on, bool left, uint32_t j, K& x, K& y, uint32_t& pw, uint32_t& pw_idx, uint32_t& nw, uint32_t& nw_idx,
+                          uint32_t& pos, uint32_t& nt) -> uint32_t {
+        if (!on) return 0x100u;
+        pos = left ? (uint32_t)a - 1 - j : (uint32_t)a + k + j;
         if ((pos >> 4) != pw_idx) { pw_idx = pos >> 4; pw = pk[pw_idx]; }
-        const uint32_t nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
+        nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
         if (hasN) {
             if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
             if ((nw >> (pos & 31)) & 1u) {                            // N: coded as 'A' on the read strand, nothing stored
                 const uint32_t f = left ? 2u : 0u;
                 x = ((x << 2) | (K)f) & kmask_k;
                 y = (y >> 2) | ((K)(f ^ 2u) << (2 * (k - 1)));
-                return;
+                return 0x100u;
             }
         }
-        walk_step<K>(B, rv16, k, kmask_k, x, y, nt, left, ev + pos);
+        return bloom_contains4<K>(B, rv16, x, y, true);
     };
     for (uint32_t j = 0; j < nmax; j++) {
-        if (j < nA) side_step(leftA, j, xA, yA, pwA, pwA_idx, nwA, nwA_idx);
-        if (j < nB) side_step(leftB, j, xB, yB, pwB, pwB_idx, nwB, nwB_idx);
+        uint32_t posA = 0, ntA = 0, posB = 0, ntB = 0;
+        const uint32_t rA = side_probe(j < nA, leftA, j, xA, yA, pwA, pwA_idx, nwA, nwA_idx, posA, ntA);
+        const uint32_t rB = side_probe(j < nB, leftB, j, xB, yB, pwB, pwB_idx, nwB, nwB_idx, posB, ntB);
+        if (rA != 0x100u) walk_apply<K>(rA, k, kmask_k, xA, yA, ntA, leftA, ev + posA);
+        if (rB != 0x100u) walk_apply<K>(rB, k, kmask_k, xB, yB, ntB, leftB, ev + posB);
     }
 }
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos, const uint8_t* flags,
