@@ -56,6 +56,30 @@ def known_answers():
     }
 
 
+def stream_cases():
+    """self-golden vectors of the header stream (oracle's HeaderEncoder) and of the lossy quality rule (smoothQuals)"""
+    import hdr_samples as H
+    import synth
+    out = {"header": [], "qual_smooth": []}
+    toy_heads = [l[1:].rstrip("\n").encode() for l in open(os.path.join(common.GOLDEN, "toy.fasta")) if l.startswith(">")]
+    for name, heads, rpb in (("toy.fasta headers rpb50000", toy_heads, 50000), ("toy.fasta headers rpb64", toy_heads, 64),
+                             ("sra 3000 rpb1000", H.sra(3000, seed=1), 1000), ("nasty 600 rpb100", H.nasty(600, seed=3), 100)):
+        blocks = [O.header_encode_block(heads[i:i + rpb], heads[0]) for i in range(0, len(heads), rpb)]
+        out["header"].append({"name": name, "n": len(heads), "reads_per_block": rpb, "input_sha256": sha(b"\n".join(heads)),
+                              "block_sizes": [len(b) for b in blocks], "block_sha256": [sha(b) for b in blocks],
+                              "first_block_head_hex": blocks[0][:32].hex()})
+    bases, off = common.synthetic(800, 120, 5000, seed=103, n_rate=0.003, err=0.02)
+    reads = [bases[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+    quals = [q[:len(r)].ljust(len(r), b"J") for q, r in zip(H.fastq_quals(len(reads), 130, seed=9), reads)]
+    for k in (21, 31):
+        bl, solid, tai = common.make_bloom(bases, off, k)
+        sm = b"".join(O.qual_smooth(bl, k, r, q) for r, q in zip(reads, quals))
+        out["qual_smooth"].append({"name": "synthetic 800x120 k%d" % k, "k": k, "bloom_tai": tai, "bloom_sha256": sha(bl.bits.tobytes()),
+                                   "quals_sha256": sha(b"".join(quals)), "smoothed_sha256": sha(sm),
+                                   "changed": sum(a != b for a, b in zip(sm, b"".join(quals)))})
+    return out
+
+
 def main():
     out = {"_note": "SELF-golden vectors of oracle/leon_oracle.c (parity with reference Leon is UNPINNED)", "cases": []}
     bases, off = common.toy_reads()
@@ -66,6 +90,7 @@ def main():
     bases, off = common.synthetic(2000, 100, 6000, seed=102, ragged=True)
     out["cases"].append(case("synthetic ragged 2000x<=100 k21", bases, off, 21, 700))
     out["known_answers"] = known_answers()
+    out["streams"] = stream_cases()
     with open(os.path.join(common.GOLDEN, "self_golden.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", os.path.join(common.GOLDEN, "self_golden.json"))

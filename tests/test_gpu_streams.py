@@ -104,3 +104,69 @@ def test_automatic_abundance_on_the_device():
         w = capi.kmer_words(k)
         as_set = lambda a: set(map(tuple, np.asarray(a, dtype=np.uint64).reshape(-1, w)))
         assert as_set(auto) == as_set(want) and len(auto) == len(want)
+
+
+def test_hip_streams_match_the_committed_golden_fixtures():
+    """the device header path and the device smoothing against tests/golden/self_golden.json, without the oracle in the loop"""
+    import hashlib
+    import json
+    import os
+    import common
+    import leon_amd
+    sha = lambda b: hashlib.sha256(bytes(b)).hexdigest()
+    gold = json.load(open(os.path.join(common.GOLDEN, "self_golden.json")))["streams"]
+    toy = [l[1:].rstrip("\n").encode() for l in open(os.path.join(common.GOLDEN, "toy.fasta")) if l.startswith(">")]
+    sets = {"toy.fasta headers rpb50000": toy, "toy.fasta headers rpb64": toy, "sra 3000 rpb1000": H.sra(3000, seed=1), "nasty 600 rpb100": H.nasty(600, seed=3)}
+    for c in gold["header"]:
+        ctx = _ctx(c["reads_per_block"])
+        blocks = ctx.header_encode_batch(sets[c["name"]])
+        ctx.close()
+        assert [sha(b[1]) for b in blocks] == c["block_sha256"], c["name"]
+    bases, off = common.synthetic(800, 120, 5000, seed=103, n_rate=0.003, err=0.02)
+    reads = [bases[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+    quals = b"".join(q[:len(r)].ljust(len(r), b"J") for q, r in zip(H.fastq_quals(len(reads), 130, seed=9), reads))
+    for c in gold["qual_smooth"]:
+        bl, solid, tai = common.make_bloom(bases, off, c["k"])
+        ctx = leon_amd.DnaEncodeContext(kmer_size=c["k"], reads_per_block=500, bloom_tai=tai)
+        ctx.bloom_insert(solid)
+        assert sha(ctx.bloom_download().tobytes()) == c["bloom_sha256"]
+        assert sha(ctx.qual_smooth_batch(bases, off, quals)) == c["smoothed_sha256"], c["name"]
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_header_stream_fuzz(seed):
+    """seeded random header sets -- mutated copies of the previous header (digit fields bumped, fields inserted / dropped /
+    replaced by arbitrary bytes, leading zeros, very long runs), random block sizes: device blocks == oracle, and decode back"""
+    import random
+    from leon_amd import capi
+    rnd = random.Random(1000 + seed)
+    alphabet = [b"A", b"z", b"7", b"0", b" ", b":", b"/", b"_", b"\t", b"\x00", b"\xff", b"=", b"."]
+
+    def mutate(h):
+        fields = [h[i:i + rnd.randint(1, 9)] for i in range(0, len(h), 7)] or [b""]
+        for _ in range(rnd.randint(0, 3)):
+            op, i = rnd.randrange(6), rnd.randrange(len(fields))
+            if op == 0:
+                fields[i] = b"%d " % rnd.randint(0, 10 ** rnd.randint(1, 20))
+            elif op == 1:
+                fields[i] = b"0" * rnd.randint(1, 5) + b"%d:" % rnd.randint(0, 999)
+            elif op == 2:
+                fields.insert(i, b"".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 12))))
+            elif op == 3 and len(fields) > 1:
+                del fields[i]
+            elif op == 4:
+                fields[i] = bytes(rnd.randrange(256) for _ in range(rnd.randint(0, 30)))
+            else:
+                fields[i] = b"x" * rnd.randint(200, 600)
+        return b"".join(fields)[:2000]
+    hs = [b"SRR1.1 first 0001 length=100"]
+    for _ in range(1500):
+        hs.append(mutate(hs[-1]) if rnd.random() < 0.9 else hs[rnd.randrange(len(hs))])
+    rpb = rnd.choice([1, 7, 100, 512])
+    first = hs[rnd.randrange(len(hs))] if seed else hs[0]
+    ctx = _ctx(rpb)
+    blocks = ctx.header_encode_batch(hs, first_header=first)
+    ctx.close()
+    assert [b[1] for b in blocks] == _oracle_blocks(hs, rpb, first)
+    assert capi.host_header_decode_blocks(blocks, first, n_threads=3) == hs

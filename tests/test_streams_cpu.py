@@ -75,3 +75,27 @@ def test_lossless_quality_blocks_are_zlib_of_the_joined_lines(capi, L, n, rpb, l
     bad = [(blocks[0][0], blocks[0][1][:-3] + b"abc", blocks[0][2])] + blocks[1:]
     with pytest.raises(capi.LeonDnaError):
         capi.host_qual_decode_blocks(bad, nbytes)
+
+
+def test_stream_oracles_match_the_committed_self_golden_vectors():
+    """tests/golden/self_golden.json "streams": the header coder and the lossy quality rule, frozen (self-golden, not reference output)"""
+    import hashlib
+    import json
+    import os
+    import common
+    sha = lambda b: hashlib.sha256(bytes(b)).hexdigest()
+    gold = json.load(open(os.path.join(common.GOLDEN, "self_golden.json")))["streams"]
+    toy = [l[1:].rstrip("\n").encode() for l in open(os.path.join(common.GOLDEN, "toy.fasta")) if l.startswith(">")]
+    sets = {"toy.fasta headers rpb50000": toy, "toy.fasta headers rpb64": toy, "sra 3000 rpb1000": H.sra(3000, seed=1), "nasty 600 rpb100": H.nasty(600, seed=3)}
+    for c in gold["header"]:
+        heads, rpb = sets[c["name"]], c["reads_per_block"]
+        assert sha(b"\n".join(heads)) == c["input_sha256"]
+        blocks = [O.header_encode_block(heads[i:i + rpb], heads[0]) for i in range(0, len(heads), rpb)]
+        assert [sha(b) for b in blocks] == c["block_sha256"] and blocks[0][:32].hex() == c["first_block_head_hex"], c["name"]
+    bases, off = common.synthetic(800, 120, 5000, seed=103, n_rate=0.003, err=0.02)
+    reads = [bases[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+    quals = [q[:len(r)].ljust(len(r), b"J") for q, r in zip(H.fastq_quals(len(reads), 130, seed=9), reads)]
+    for c in gold["qual_smooth"]:
+        bl, solid, tai = common.make_bloom(bases, off, c["k"])
+        assert tai == c["bloom_tai"] and sha(bl.bits.tobytes()) == c["bloom_sha256"] and sha(b"".join(quals)) == c["quals_sha256"]
+        assert sha(b"".join(O.qual_smooth(bl, c["k"], r, q) for r, q in zip(reads, quals))) == c["smoothed_sha256"], c["name"]
