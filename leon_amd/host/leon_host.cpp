@@ -427,13 +427,20 @@ void Leon::executeDecompression() {
         const std::vector<uint8_t> bloom = in.getBytes(DS_BLOOM_BITS);
         check(ctx.get(), leon_dna_bloom_upload(ctx.get(), bloom.data(), bloom.size()), "leon_dna_bloom_upload");
     }
+    // the dictionary stream is one serial chain on a host core (3.7 s at 100 M reads): it runs beside the container reads and
+    // the first round's header / quality blocks, and is waited for right before the first DNA blocks go to the device
     std::vector<uint64_t> anchors(std::max<uint64_t>(n_anchors * W, 1));
+    std::future<void> dict_job;
     {
-        std::vector<uint8_t> dict = in.getBytes(DS_ANCHOR_DICT);
-        const uint64_t dsz = dict.size();
-        dict.push_back(0);
-        if (leon_host_anchor_dict_decode(dict.data(), dsz, n_anchors, (uint32_t)k, anchors.data()) != LEON_OK)
-            throw Exception(std::string("leon_host_anchor_dict_decode: ") + leon_last_error(nullptr));
+        auto dict = std::make_shared<std::vector<uint8_t>>(in.getBytes(DS_ANCHOR_DICT));
+        const uint64_t dsz = dict->size();
+        dict->push_back(0);
+        uint64_t* out_kmers = anchors.data();
+        const uint32_t kk = (uint32_t)k;
+        dict_job = std::async(std::launch::async, [dict, dsz, n_anchors, kk, out_kmers] {
+            if (leon_host_anchor_dict_decode(dict->data(), dsz, n_anchors, kk, out_kmers) != LEON_OK)
+                throw Exception(std::string("leon_host_anchor_dict_decode: ") + leon_last_error(nullptr));
+        });
     }
 
     // X.fastq.leon -> X.fastq.d (/root/reference/scripts/simple_test.sh:54,62)
@@ -460,7 +467,7 @@ void Leon::executeDecompression() {
     std::unique_ptr<char[]> text;                                // the round's records (never zero-filled)
     uint64_t text_cap = 0;
     uint64_t read_index = 0, bases_out = 0;
-    double t_read = 0, t_dna = 0, t_hdr = 0, t_qual = 0, t_text = 0, t_write = 0;
+    double t_read = 0, t_dna = 0, t_hdr = 0, t_qual = 0, t_text = 0, t_write = 0, t_wait = 0;
     auto lap = [](std::chrono::steady_clock::time_point& t, double& acc) { const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(n - t).count(); t = n; };
     for (uint64_t g0 = 0; g0 < n_blocks; g0 += group) {
         const uint64_t g1 = std::min(n_blocks, g0 + group), nb = g1 - g0;
@@ -478,41 +485,52 @@ void Leon::executeDecompression() {
         std::vector<uint32_t> blk_reads(nb); std::vector<uint64_t> blk_bases(nb);
         uint64_t g_reads = 0, g_bases = 0;
         for (uint64_t b = 0; b < nb; b++) { blk_reads[b] = (uint32_t)tdna[3 * (g0 + b) + 1]; blk_bases[b] = tdna[3 * (g0 + b) + 2]; g_reads += blk_reads[b]; g_bases += blk_bases[b]; }
-        // DNA
+        // the three streams' payloads of the round, then: header and quality blocks on the host threads WHILE the device
+        // decodes the DNA blocks
         auto tl = std::chrono::steady_clock::now();
+        std::vector<uint8_t> pay_h, pay_q; std::vector<uint64_t> off_h, off_q;
         gather(GROUP_DNA, tdna, 3, pay, off);
+        if (has_header) gather(GROUP_HEADER, thdr, 2, pay_h, off_h);
+        if (fastq_out) gather(GROUP_QUAL, tqual, 3, pay_q, off_q);
         lap(tl, t_read);
-        std::vector<uint8_t> bases(g_bases + 1); std::vector<uint32_t> lens(g_reads + 1);
-        check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, bases.data(), g_bases,
-                                                lens.data()), "leon_dna_decode_blocks");
-        lap(tl, t_dna);
-        // headers
         std::vector<uint8_t> hdr; std::vector<uint64_t> hdr_off(g_reads + 1, 0);
-        if (has_header) {
-            gather(GROUP_HEADER, thdr, 2, pay, off);
-            lap(tl, t_read);
-            uint64_t need = 0;
-            hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
-            int rc = leon_host_header_decode_blocks(pay.data(), off.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), hdr.data(), hdr.size(), hdr_off.data(),
-                                                    &need, (uint32_t)_nbCores);
-            if (rc == LEON_E_OVERFLOW) {
-                hdr.resize(need + 1);
-                rc = leon_host_header_decode_blocks(pay.data(), off.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), hdr.data(), hdr.size(), hdr_off.data(),
-                                                    &need, (uint32_t)_nbCores);
-            }
-            if (rc != LEON_OK) throw Exception(std::string("leon_host_header_decode_blocks: ") + leon_last_error(nullptr));
-        }
-        lap(tl, t_hdr);
-        // qualities
         std::vector<uint8_t> qual; std::vector<uint64_t> qual_off(g_reads + 1, 0);
-        if (fastq_out) {
-            gather(GROUP_QUAL, tqual, 3, pay, off);
-            lap(tl, t_read);
-            qual.resize(g_bases + 1);
-            if (leon_host_qual_decode_blocks(pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, qual.data(), g_bases, qual_off.data(), (uint32_t)_nbCores) != LEON_OK)
-                throw Exception(std::string("leon_host_qual_decode_blocks: ") + leon_last_error(nullptr));
-        }
-        lap(tl, t_qual);
+        double host_hdr_s = 0, host_qual_s = 0;
+        const uint32_t cores = (uint32_t)_nbCores;
+        std::future<void> host_job = std::async(std::launch::async, [&] {
+            auto th = std::chrono::steady_clock::now();
+            if (has_header) {
+                uint64_t need = 0;
+                hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
+                int rc = leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), hdr.data(), hdr.size(),
+                                                        hdr_off.data(), &need, cores);
+                if (rc == LEON_E_OVERFLOW) {
+                    hdr.resize(need + 1);
+                    rc = leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), hdr.data(), hdr.size(),
+                                                        hdr_off.data(), &need, cores);
+                }
+                if (rc != LEON_OK) throw Exception(std::string("leon_host_header_decode_blocks: ") + leon_last_error(nullptr));
+            }
+            lap(th, host_hdr_s);
+            if (fastq_out) {
+                qual.resize(g_bases + 1);
+                if (leon_host_qual_decode_blocks(pay_q.data(), off_q.data(), blk_reads.data(), blk_bases.data(), nb, qual.data(), g_bases, qual_off.data(), cores) != LEON_OK)
+                    throw Exception(std::string("leon_host_qual_decode_blocks: ") + leon_last_error(nullptr));
+            }
+            lap(th, host_qual_s);
+        });
+        std::vector<uint8_t> bases(g_bases + 1); std::vector<uint32_t> lens(g_reads + 1);
+        std::string dna_error;
+        try {
+            if (dict_job.valid()) dict_job.get();
+            check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, bases.data(), g_bases,
+                                                    lens.data()), "leon_dna_decode_blocks");
+        } catch (const std::exception& e) { dna_error = e.what(); }
+        lap(tl, t_dna);
+        host_job.get();                                          // (joins the host task before anything it references goes away; rethrows its error)
+        if (!dna_error.empty()) throw Exception(dna_error);
+        lap(tl, t_wait);
+        t_hdr += host_hdr_s; t_qual += host_qual_s;
         // records: every read's place in the text is known from the lengths, so the round is formatted by all cores at once
         std::vector<uint64_t> rec_off(g_reads + 1, 0), base_at(g_reads + 1, 0);
         auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
@@ -555,8 +573,8 @@ void Leon::executeDecompression() {
     if (read_index != n_reads) throw Exception("the block tables do not add up to the header's read count");
     std::cout << n_reads << " reads, " << bases_out << " bases decoded from " << n_blocks << " blocks, written to " << _outputFilename << std::endl;
     if (_verbose)
-        std::cout << "time: " << seconds_since(t_start) << " s (container reads " << t_read << ", DNA blocks on the device " << t_dna << ", header blocks " << t_hdr
-                  << ", quality blocks " << t_qual << ", formatting " << t_text << ", writing " << t_write << ")" << std::endl;
+        std::cout << "time: " << seconds_since(t_start) << " s (container reads " << t_read << ", dictionary + DNA blocks on the device " << t_dna << ", beside them on the host threads: header blocks "
+                  << t_hdr << " + quality blocks " << t_qual << " (waited " << t_wait << " more), formatting " << t_text << ", writing " << t_write << ")" << std::endl;
     if (_testFile) testDecompressedFile();
 }
 
