@@ -159,6 +159,7 @@ def main():
     ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local,
                                     resolve_window=int(os.environ.get("LEON_RESOLVE_WINDOW", 0)))
     ctx.set_shard(rank, world)
+    ctx.reserve(n_total, n_total * L)          # what a host does while it parses: the first step then allocates nothing large
     nbytes = ctx.bloom_nbytes
     bcast_ms = 0.0
     if rank == 0:

@@ -106,6 +106,11 @@ int leon_dna_encode_batch(leon_dna_ctx* ctx, const uint8_t* bases, const uint64_
 int leon_dna_encode_batch_device(leon_dna_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets,
                                  uint64_t n_reads, uint64_t first_read_index, leon_block_sink sink, void* user);
 
+/* Optional: size every per-batch device buffer for batches of up to max_reads reads / max_bases bases ahead of the first
+ * batch (a host calls it while it is still parsing the input), so that the first encode of a process allocates nothing
+ * large.  Estimates only: whatever a batch needs beyond them is grown on demand. */
+int leon_dna_reserve(leon_dna_ctx* ctx, uint64_t max_reads, uint64_t max_bases);
+
 /* N contexts, one per GPU, working on ONE output file: every rank is fed the SAME batches; each resolves the
  * anchors of all reads (replicated, so the dictionary and every read's anchor are file-order exact on every rank
  * without any exchange), then walks and codes only its contiguous share of each batch's blocks, which its sink

@@ -67,6 +67,7 @@ _EXPORTS = {
     "leon_host_anchor_dict_decode": (C.c_int, [_u8p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]),
     "leon_dna_finish": (C.c_int, [C.c_void_p, C.POINTER(_u8p), _u64p, _u64p]),
     "leon_dna_reset_stream": (C.c_int, [C.c_void_p]),
+    "leon_dna_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "leon_dna_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "leon_kmer_solid_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                           C.POINTER(C.c_void_p), _u64p, _u64p]),
@@ -443,6 +444,9 @@ class DnaEncodeContext:
                                                   _ptr(nreads, _u32p), _ptr(nbases, _u64p), nb, _ptr(out, _u8p), total,
                                                   _ptr(lens, _u32p)))
         return out[:total], lens[:n_total]
+
+    def reserve(self, max_reads, max_bases):
+        self._chk(self.lib.leon_dna_reserve(self.h, int(max_reads), int(max_bases)))
 
     def set_shard(self, rank, world):
         self._chk(self.lib.leon_dna_set_shard(self.h, rank, world))

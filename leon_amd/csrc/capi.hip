@@ -741,6 +741,56 @@ int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t*
 }
 
 
+// Sizes every per-batch device buffer for a batch of up to max_reads reads / max_bases bases before the first batch arrives
+// (a host calls it while it is still parsing): the first leon_dna_encode_batch of a process then allocates nothing large, and
+// does not wait for the driver to wipe memory another stage has just returned.  Symbol counts are an
+// estimate (40 per read); whatever turns out larger is grown on demand as before.
+int leon_dna_reserve(leon_dna_ctx* c, uint64_t max_reads, uint64_t max_bases) {
+    if (!c) return LEON_E_INVALID;
+    if (max_reads == 0) return LEON_OK;
+    if (max_reads > 0xFFFFFFF0ull) return fail(c, LEON_E_INVALID, "more than 2^32 reads in one batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = max_reads, rpb = c->cfg.reads_per_block, nbl = (n + rpb - 1) / rpb;
+    const uint64_t n_slots = max_bases / 32 + n, W = std::min<uint64_t>(c->cfg.resolve_window, n), est_syms = 40 * n;
+    HIPCHK(c, c->slot_off.ensure((n + 1) * 8));
+    HIPCHK(c, c->packed.ensure((n_slots * 2 + 16) * 4)); HIPCHK(c, c->nmask.ensure((n_slots + 4) * 4));
+    HIPCHK(c, c->rlen.ensure(n * 4)); HIPCHK(c, c->ncount.ensure(n * 4));
+    HIPCHK(c, c->status.ensure(n));
+    HIPCHK(c, c->hit_pos.ensure(n * 4)); HIPCHK(c, c->hit_slot.ensure(n * 4));
+    HIPCHK(c, c->cand_pos.ensure(n * 4)); HIPCHK(c, c->cand_slot.ensure(n * 4));
+    HIPCHK(c, c->anchor_pos.ensure(n * 4)); HIPCHK(c, c->anchor_addr.ensure(n * 4));
+    HIPCHK(c, c->flags.ensure(n)); HIPCHK(c, c->sort_key.ensure(n * 8));
+    HIPCHK(c, c->ins_flag.ensure(W * 4)); HIPCHK(c, c->rank.ensure(W * 4));
+    HIPCHK(c, c->ulist0.ensure(W * 4)); HIPCHK(c, c->ulist1.ensure(W * 4));
+    HIPCHK(c, c->sort_key2.ensure(n * 8)); HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(n * 4));
+    HIPCHK(c, c->events.ensure(max_bases + 16));
+    HIPCHK(c, c->prev.ensure(n * 8)); HIPCHK(c, c->sym_off.ensure((n + 1) * 8)); HIPCHK(c, c->nerr.ensure(n * 4));
+    HIPCHK(c, c->syms.ensure(est_syms * 2 + 256));
+    HIPCHK(c, c->blk_begin.ensure((nbl + 1) * 8)); HIPCHK(c, c->out_off.ensure((nbl + 1) * 8));
+    HIPCHK(c, c->out_size.ensure(nbl * 8)); HIPCHK(c, c->dst_off.ensure((nbl + 1) * 8));
+    HIPCHK(c, c->rc_out.ensure(3 * est_syms + 72 * (nbl + 1)));
+    HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
+    HIPCHK(c, c->payload.ensure(max_bases / 12 + 4096));
+    size_t t1 = 0, t2 = 0, t3 = 0;                               // the scans' and the sort's work space
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t1, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, c->stream));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, t2, c->sort_key.as<uint64_t>(), c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>(), c->perm2.as<uint32_t>(),
+                                                 n, 0, 33, c->stream));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t3, c->ins_flag.as<uint32_t>(), c->rank.as<uint32_t>(), W, c->stream));
+    if (int rc = ensure_cub(c, std::max(t1, std::max(t2, t3)))) return rc;
+    if (max_bases / 12 + 4096 > c->h_payload_cap) {
+        if (c->h_payload) HIPCHK(c, hipHostFree(c->h_payload));
+        c->h_payload = nullptr; c->h_payload_cap = 0;
+        const size_t want = max_bases / 12 + 4096;
+        HIPCHK(c, hipHostMalloc(&c->h_payload, want, hipHostMallocDefault));
+        c->h_payload_cap = want;
+    }
+    // the dictionary: one anchor per ~6 reads of a 30x read set; it grows (rehash) if the data want more
+    if (int rc = dict_reserve(c, c->n_keys + n / 6 + 1024)) return rc;
+    if ((n / 6) * 8 * kmer_words(c->cfg.kmer_size) > c->anchor_kmers.cap && c->n_anchors == 0) HIPCHK(c, c->anchor_kmers.ensure((n / 6) * 8 * kmer_words(c->cfg.kmer_size)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LEON_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ header stream
 // Leon::startHeaderCompression: Dispatcher::iterate(bank, HeaderEncoder(this)) [RECALLED].  Records of every header
 // against the previous one in parallel (hdr_kernels.hip), then the per-block chains on k_rc_encode with the header
