@@ -622,3 +622,20 @@ def test_offsets_are_checked_before_the_uploader_indexes_with_them():
     blocks = ctx.encode_batch(bases, off)                              # refused batches changed nothing
     assert len(blocks) == n // rpb and sum(b[2] for b in blocks) == n
     ctx.close()
+
+
+def test_reserve_is_only_a_hint():
+    """leon_dna_reserve sizes the buffers ahead of the first batch; a batch larger than the reservation (or with more symbols per
+    read than it assumed) still encodes, bit-exact"""
+    k, rpb = 31, 200
+    bases, off = common.synthetic(3000, 150, 9000, seed=33, err=0.08, n_rate=0.01)      # error-dense: many symbols per read
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ref = O.encode(bases, off, k, rpb, bl, trace=False)
+    for reserve in ((3000, len(bases)), (10, 1000), (1 << 20, 1 << 27)):
+        ctx = _ctx(k, rpb, tai)
+        ctx.bloom_upload(bl.bits)
+        ctx.reserve(*reserve)
+        assert [b[1] for b in ctx.encode_batch(bases, off)] == ref.blocks
+        d, na = ctx.finish()
+        assert d == ref.anchor_dict and na == ref.n_anchors
+        ctx.close()
