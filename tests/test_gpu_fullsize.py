@@ -1,6 +1,6 @@
 """-m gpu: BASELINE.json's single-GPU configurations #2 and #3 at FULL size (10 M and 100 M x 150 bp, k = 31) and
-configuration #5's workload (250 bp reads, k = 63: two-word k-mers) at the read count one GPU holds with the path's
-current buffers -- 40 M reads = 10 G bases (the configuration itself is 500 M reads over 8 GPUs: 62.5 M per GPU) --
+configuration #5's workload (250 bp reads, k = 63: two-word k-mers) at ONE GPU's share of it -- the configuration is
+500 M reads over 8 GPUs, i.e. 62.5 M reads = 15.6 G bases per GPU --
 checked through size-independent properties: decode(encode(x)) == x on sampled blocks (oracle decoder), run-to-run
 determinism, shard-union == single stream via a checksum of block checksums, and the device decoder on every base."""
 import hashlib
@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 RPB = 50000
 # (reads, k, read length); LEON_FULLSIZE_CASES="n:k:L,..." overrides
 CASES = [tuple(int(v) for v in x.split(":")) for x in
-         os.environ.get("LEON_FULLSIZE_CASES", "10000000:31:150,100000000:31:150,40000000:63:250").split(",")]
+         os.environ.get("LEON_FULLSIZE_CASES", "10000000:31:150,100000000:31:150,62500000:63:250").split(",")]
 
 
 def _checksum(blocks):
