@@ -293,3 +293,36 @@ def test_cli_failures_leave_no_container(leon_bin, tmp_path):
     assert run(leon_bin, "-file", empty, "-c").returncode == 0
     assert run(leon_bin, "-file", empty + ".leon", "-d", "-test-file").returncode == 0
     assert open(empty + ".d").read() == ""
+
+
+@pytest.mark.gpu
+def test_cli_corrupted_containers_are_reported_not_crashed_on(leon_bin, tmp_path):
+    """`leon -d` on damaged .leon files (random byte flips and truncations anywhere in the HDF5 file: metadata, tables, payloads,
+    the bloom): every run must end by itself with status 0 (damage that happens not to matter, or that only changes the
+    output) or 1 with `EXCEPTION:` -- never by a signal, never by a hang"""
+    import random
+    reads, heads, quals = _synthetic_fastq(tmp_path, n=400, L=80, seed=21, n_rate=0.01, err=0.03)
+    fq = str(tmp_path / "f.fastq")
+    _write_fastq(fq, reads, heads, quals)
+    assert run(leon_bin, "-file", fq, "-c", "-kmer-size", "15", "-abundance", "2", "-lossless").returncode == 0
+    good = open(fq + ".leon", "rb").read()
+    rnd = random.Random(5)
+    outcomes = {0: 0, 1: 0}
+    for trial in range(40):
+        raw = bytearray(good)
+        if trial % 8 == 7:
+            raw = raw[:rnd.randrange(len(raw))]
+        else:
+            for _ in range(rnd.choice([1, 1, 4, 64])):
+                raw[rnd.randrange(len(raw))] = rnd.randrange(256)
+        bad = str(tmp_path / ("bad%d.fastq.leon" % trial))
+        open(bad, "wb").write(raw)
+        r = subprocess.run([leon_bin, "-file", bad, "-d"], capture_output=True, text=True, timeout=120)
+        assert r.returncode in (0, 1), (trial, r.returncode, r.stderr[-300:])
+        if r.returncode == 1:
+            assert r.stderr.startswith("EXCEPTION: "), (trial, r.stderr[-300:])
+        outcomes[r.returncode] += 1
+        for f in (bad, bad[:-5] + ".d"):
+            if os.path.exists(f):
+                os.remove(f)
+    assert outcomes[1] > 0
