@@ -279,7 +279,8 @@ void Leon::executeCompression() {
 
     // ---- the DNA stream: Dispatcher::iterate(bank, DnaEncoder(this)) upstream, the device path here ----
     const auto t_dna = std::chrono::steady_clock::now();
-    const uint64_t batch_blocks = n_blocks <= 2400 ? std::max<uint64_t>(n_blocks, 1) : 1000;     // whole file at once up to 120 M reads
+    uint64_t batch_blocks = n_blocks <= 2400 ? std::max<uint64_t>(n_blocks, 1) : 1000;           // whole file at once up to 120 M reads
+    if (const char* e = getenv("LEON_BATCH_BLOCKS")) { const long v = atol(e); if (v > 0) batch_blocks = (uint64_t)v; }   // (tests: several batches on a small file)
     std::vector<std::string> gpu_error(n_gpus);
     auto encode_on = [&](int g) {
         try {

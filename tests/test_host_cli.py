@@ -209,6 +209,11 @@ def test_reference_acceptance_test_lossless_fastq_gz(leon_bin, tmp_path):
     r = run(leon_bin, "-d", "-file", fq + ".leon")
     assert r.returncode == 0, r.stderr
     assert run("diff", fq, fq + ".d").returncode == 0
+    # the same file encoded in batches of one block (the path a file above 120 M reads takes) gives the same container
+    shutil.move(fq + ".leon", fq + ".whole")
+    r = run(leon_bin, "-c", "-lossless", "-file", fq + ".gz", "-kmer-size", "25", env=dict(os.environ, LEON_BATCH_BLOCKS="1"))
+    assert r.returncode == 0, r.stderr
+    assert run(os.path.join(H5BIN, "h5diff"), fq + ".whole", fq + ".leon").returncode == 0
     # the quality blocks are zlib over the block's quality lines
     q0 = h5_dataset(fq + ".leon", "leon/qual/block_0").tobytes()
     assert zlib.decompress(q0) == b"".join(q + b"\n" for q in quals[:50000])
