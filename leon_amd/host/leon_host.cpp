@@ -464,6 +464,7 @@ void Leon::executeDecompression() {
         const uint64_t bases_per_block = n_blocks ? std::max<uint64_t>(total_bases / n_blocks, 1) : 1;
         const uint64_t fit = avail / 4 / 5 / bases_per_block;
         group = std::min<uint64_t>(group, std::max<uint64_t>(fit, 64));
+        if (const char* e = getenv("LEON_DECODE_BLOCKS")) { const long v = atol(e); if (v > 0) group = (uint64_t)v; }   // (tests: several rounds on a small file)
     }
     std::unique_ptr<char[]> text;                                // the round's records (never zero-filled)
     uint64_t text_cap = 0;

@@ -214,6 +214,17 @@ def test_reference_acceptance_test_lossless_fastq_gz(leon_bin, tmp_path):
     r = run(leon_bin, "-c", "-lossless", "-file", fq + ".gz", "-kmer-size", "25", env=dict(os.environ, LEON_BATCH_BLOCKS="1"))
     assert r.returncode == 0, r.stderr
     assert run(os.path.join(H5BIN, "h5diff"), fq + ".whole", fq + ".leon").returncode == 0
+    # and decoded in rounds of one block (the path a host short of memory takes) it gives the same file
+    r = run(leon_bin, "-d", "-file", fq + ".leon", env=dict(os.environ, LEON_DECODE_BLOCKS="1"))
+    assert r.returncode == 0, r.stderr
+    assert run("diff", fq, fq + ".d").returncode == 0
+    r = run(leon_bin, "-c", "-noheader", "-noqual", "-file", fq + ".gz", "-kmer-size", "25")
+    assert r.returncode == 0, r.stderr
+    r = run(leon_bin, "-d", "-file", fq + ".leon", env=dict(os.environ, LEON_DECODE_BLOCKS="2"))
+    assert r.returncode == 0, r.stderr
+    got = open(fq + ".d", "rb").read().split(b"\n")
+    assert got[0] == b">0" and got[2 * 119999] == b">119999" and len(got) == 2 * 120000 + 1      # the read index runs on across rounds
+    shutil.copy(fq + ".whole", fq + ".leon")
     # the quality blocks are zlib over the block's quality lines
     q0 = h5_dataset(fq + ".leon", "leon/qual/block_0").tobytes()
     assert zlib.decompress(q0) == b"".join(q + b"\n" for q in quals[:50000])
