@@ -639,3 +639,28 @@ def test_reserve_is_only_a_hint():
         d, na = ctx.finish()
         assert d == ref.anchor_dict and na == ref.n_anchors
         ctx.close()
+
+
+@pytest.mark.parametrize("k", [33, 47, 63])
+def test_two_word_keys_under_insert_contention(k):
+    """thousands of reads proposing the SAME few two-word keys in one resolution window (a low-complexity read set: every wave's
+    inserting lane meets slots another wave is just writing): the lock-free two-step insert must neither duplicate a key nor
+    lose one -- the stream stays bit-exact with the oracle"""
+    rng = np.random.default_rng(k)
+    unit = b"ACGTTGCATGCAAGCTTAGCTAGGATCCAGTCAGTCGATCGATTTAGCGCGATATCGGCTA"
+    genome = (unit * 8)[:400]                                     # a 400 bp "genome": a handful of distinct k-mers
+    reads = []
+    for _ in range(60000):
+        s = int(rng.integers(0, len(genome) - 150))
+        reads.append(genome[s:s + 150])
+    bases, off = O.reads_to_arrays(reads)
+    bl, solid, tai = common.make_bloom(bases, off, k, 2)
+    ref = O.encode(bases, off, k, 5000, bl, trace=False)
+    for window in (0, 1 << 12):
+        ctx = _ctx(k, 5000, tai, resolve_window=window)
+        ctx.bloom_upload(bl.bits)
+        blocks = ctx.encode_batch(bases, off)
+        d, na = ctx.finish()
+        assert na == ref.n_anchors and d == ref.anchor_dict
+        assert [b[1] for b in blocks] == ref.blocks
+        ctx.close()
