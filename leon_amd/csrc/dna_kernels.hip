@@ -254,12 +254,16 @@ template <> __device__ inline uint64_t dict_key<uint64_t>(const DictDev& D, uint
 template <> __device__ inline u128 dict_key<u128>(const DictDev& D, uint32_t slot) { return ((u128)D.slots[4 * (uint64_t)slot + 1] << 64) | D.slots[4 * (uint64_t)slot]; }
 
 template <typename K> __global__ void k_dict_rehash(DictDev from, uint64_t from_cap, DictDev to) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < from_cap; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (from.slots[i * DS<K>::STRIDE + DS<K>::CLAIM] == KEY_EMPTY) continue;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i0 = blockIdx.x * (uint64_t)blockDim.x; i0 < from_cap; i0 += stride) {     // (whole waves stay in the loop: ballot below)
+        const uint64_t i = i0 + threadIdx.x;
         bool created = false;
-        uint32_t s = dict_find_or_insert<false>(to, dict_key<K>(from, (uint32_t)i), created);
-        if (created) atomicAdd(to.n_keys, 1ull);
-        *fin_ptr<K>(to, s) = *fin_ptr<K>(from, i); *tent_ptr(to, s) = IDX_INF; to.addr[s] = from.addr[i];
+        if (i < from_cap && from.slots[i * DS<K>::STRIDE + DS<K>::CLAIM] != KEY_EMPTY) {
+            uint32_t s = dict_find_or_insert<false>(to, dict_key<K>(from, (uint32_t)i), created);
+            *fin_ptr<K>(to, s) = *fin_ptr<K>(from, i); *tent_ptr(to, s) = IDX_INF; to.addr[s] = from.addr[i];
+        }
+        const unsigned long long cm = __ballot(created);                                     // one atomic per wave on the key counter
+        if (cm && lane_id() == (uint32_t)__builtin_ctzll(cm)) atomicAdd(to.n_keys, (unsigned long long)__popcll(cm));
     }
 }
 void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to, uint32_t k) {
