@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -23,8 +24,25 @@ namespace {
 
 int fail(int code, const std::string& msg) { leon::set_create_error(msg); return code; }
 
+// "all cores" = what this process may actually use: the container's CPU quota (cgroup v2 cpu.max, v1 cfs_quota) when it is
+// below the number of logical CPUs -- 256 threads on a 16-CPU quota only get each other throttled
+uint32_t usable_cpus() {
+    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+    long long quota = -1, period = -1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else {
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+    }
+    if (quota > 0 && period > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (quota + period - 1) / period));
+    return n;
+}
+
 template <typename F> void parallel_blocks(uint64_t n_blocks, uint32_t n_threads, F&& f) {
-    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads == 0) n_threads = usable_cpus();
     n_threads = (uint32_t)std::min<uint64_t>(n_threads, std::max<uint64_t>(n_blocks, 1));
     std::atomic<uint64_t> next{0};
     auto work = [&] { for (uint64_t b; (b = next.fetch_add(1)) < n_blocks;) f(b); };

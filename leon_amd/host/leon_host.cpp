@@ -29,6 +29,19 @@
 #include <mutex>
 #include <thread>
 
+// threads this process may keep busy: the logical CPUs, capped by the container's CPU quota (cgroup v2 cpu.max)
+static uint64_t usableCpus() {
+    uint64_t n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        long long period = 0;
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && std::string(q) != "max" && period > 0)
+            n = std::min<uint64_t>(n, (uint64_t)std::max<long long>(1, (atoll(q) + period - 1) / period));
+        fclose(f);
+    }
+    return n;
+}
+
 namespace leon_host {
 
 const char* Leon::STR_COMPRESS = "-c";
@@ -543,7 +556,7 @@ void Leon::executeDecompression() {
             base_at[r + 1] = base_at[r] + lens[r];
         }
         if (rec_off[g_reads] > text_cap) { text.reset(); text_cap = rec_off[g_reads] + rec_off[g_reads] / 16; text.reset(new char[text_cap]); }
-        const uint32_t n_fmt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(_nbCores > 0 ? (uint64_t)_nbCores : std::thread::hardware_concurrency(), g_reads / 4096 + 1));
+        const uint32_t n_fmt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(_nbCores > 0 ? (uint64_t)_nbCores : usableCpus(), g_reads / 4096 + 1));
         auto format_range = [&](uint64_t ra, uint64_t rb) {
             for (uint64_t r = ra; r < rb; r++) {
                 char* w = text.get() + rec_off[r];
