@@ -107,6 +107,11 @@ struct leon_dna_ctx {
     DevBuf blk_begin, out_off, out_size, rc_out, rc_scratch, dst_off, payload, errflag, nerr, wbits, fbits, pbits;
     void* h_payload = nullptr; size_t h_payload_cap = 0;
     uint64_t last_n = 0, last_bases = 0;
+    // decoder: the path cache (decode_kernels.hip) lives as long as the bloom it was learnt from
+    DevBuf dc_cache;
+    PathCache dc_pc{};
+    uint64_t dc_bloom_fp = 0;                    // fingerprint of the bloom bits the cache's entries were derived from
+    bool dc_filled = false;
     leon_dna_stats stats{};
     hipEvent_t ev[12]{};
     std::vector<hipEvent_t> pack_ev;             // pairs around the pack launches of a batch
@@ -283,7 +288,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
                        &c->status, &c->hit_pos, &c->hit_slot, &c->cand_pos, &c->cand_slot, &c->anchor_pos, &c->anchor_addr,
                        &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
                        &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
-                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->fbits, &c->pbits, &c->hdr_first };
+                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->fbits, &c->pbits, &c->hdr_first, &c->dc_cache };
     for (DevBuf* b : bufs) b->release();
     if (c->d_bloom) (void)hipFree(c->d_bloom);
     if (c->d_rv16) (void)hipFree(c->d_rv16);
@@ -1076,6 +1081,15 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
         return fail(c, LEON_E_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    static const bool trace = getenv("LEON_TRACE_DECODE") != nullptr;    // where a call's time goes, on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[leon decode] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     const uint32_t W = kmer_words(c->cfg.kmer_size);
     std::vector<uint64_t> read0(n_blocks + 1, 0), out0(n_blocks + 1, 0);
     for (uint64_t b = 0; b < n_blocks; b++) {
@@ -1092,10 +1106,41 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     HIPCHK(c, d_off.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_nreads.ensure(n_blocks * 4));
     HIPCHK(c, d_read0.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_out0.ensure((n_blocks + 1) * 8));
     HIPCHK(c, d_out.ensure(out0[n_blocks] + 64)); HIPCHK(c, d_len.ensure(std::max<uint64_t>(read0[n_blocks], 1) * 4));
-    HIPCHK(c, d_scr.ensure(decode_scratch_bytes(n_blocks))); HIPCHK(c, d_err.ensure(16));
+    HIPCHK(c, d_scr.ensure(decode_scratch_bytes(n_blocks))); HIPCHK(c, d_err.ensure(128));
     // position lists longer than a block's own scratch (8192 N or error positions in ONE read) come from this pool
     const uint64_t pool_words = std::min<uint64_t>(std::max<uint64_t>(out0[n_blocks] / 2, 1ull << 20), 1ull << 28);
     HIPCHK(c, d_pool.ensure(pool_words * 4 + 16));
+    lap("buffers");
+    // The path cache: a few bytes per solid k-mer, kept from call to call for as long as the bloom's bits stay what they
+    // were (their fingerprint is taken again at every call: 0.3 ms for a gigabyte).  4 slots per k-mer the bloom was sized
+    // for (two orientations, half full), at most 40 % of the free memory; LEON_DC_CACHE_MB overrides (0: no cache).
+    {
+        uint64_t want_buckets = std::max<uint64_t>(c->cfg.bloom_tai / 12 * (W == 2 ? 2 : 1), 1024);
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        uint64_t budget = (uint64_t)(free_b + c->dc_cache.cap) * 2 / 5;
+        if (const char* e = getenv("LEON_DC_CACHE_MB")) budget = (uint64_t)std::max<long long>(0, atoll(e)) << 20;
+        uint64_t buckets = 1024;
+        while (buckets < want_buckets) buckets <<= 1;
+        while (buckets > 1024 && buckets * 64 > budget) buckets >>= 1;
+        if (buckets * 64 > budget) buckets = 0;
+        uint64_t* d_fp = d_err.as<uint64_t>() + 1;
+        HIPCHK(c, hipMemsetAsync(d_fp, 0, 8, s));
+        launch_bloom_fingerprint(s, c->d_bloom, c->bloom_nchar, d_fp);
+        uint64_t fp = 0;
+        HIPCHK(c, hipMemcpyAsync(&fp, d_fp, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (!buckets) { c->dc_cache.release(); c->dc_pc = PathCache{}; c->dc_filled = false; }
+        else if (!c->dc_pc.slots || c->dc_pc.bucket_mask != buckets - 1 || !c->dc_filled || fp != c->dc_bloom_fp) {
+            if (c->dc_pc.bucket_mask != buckets - 1 || !c->dc_pc.slots) {
+                c->dc_cache.release();
+                if (c->dc_cache.ensure(buckets * 64) != hipSuccess) { (void)hipGetLastError(); c->dc_pc = PathCache{}; buckets = 0; }   // no room: decode without it
+                else { c->dc_pc.slots = c->dc_cache.as<uint64_t>(); c->dc_pc.bucket_mask = buckets - 1; }
+            }
+            if (buckets) { launch_path_cache_init(s, c->dc_pc, c->cfg.kmer_size); c->dc_bloom_fp = fp; c->dc_filled = true; }
+        }
+    }
+    lap("path cache");
     std::vector<uint64_t> rel_off(n_blocks + 1);
     for (uint64_t b = 0; b <= n_blocks; b++) rel_off[b] = payload_off[b] - payload_off[0];
     if (n_anchors) HIPCHK(c, hipMemcpyAsync(d_anchors.p, anchors, n_anchors * W * 8, hipMemcpyHostToDevice, s));
@@ -1105,16 +1150,26 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     HIPCHK(c, hipMemcpyAsync(d_nreads.p, block_n_reads, n_blocks * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_read0.p, read0.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_out0.p, out0.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(d_err.p, 0, 16, s));
+    HIPCHK(c, hipMemsetAsync(d_err.p, 0, 128, s));
     HIPCHK(c, hipMemsetAsync((uint8_t*)d_pool.p + pool_words * 4, 0, 16, s));           // the pool's cursor lives behind it
-    launch_decode_blocks(s, c->B, c->d_rv16, d_anchors.as<uint64_t>(), n_anchors, d_pay.as<uint8_t>(), d_off.as<uint64_t>(),
+    lap("payloads to the device");
+    launch_decode_blocks(s, c->B, c->dc_pc, c->d_rv16, d_anchors.as<uint64_t>(), n_anchors, d_pay.as<uint8_t>(), d_off.as<uint64_t>(),
                          d_nreads.as<uint32_t>(), d_read0.as<uint64_t>(), d_out0.as<uint64_t>(), n_blocks, d_out.as<uint8_t>(),
                          d_len.as<uint32_t>(), d_scr.as<uint32_t>(), d_pool.as<uint32_t>(),
-                         (unsigned long long*)((uint8_t*)d_pool.p + pool_words * 4), pool_words, d_err.as<int>());
+                         (unsigned long long*)((uint8_t*)d_pool.p + pool_words * 4), pool_words, d_err.as<int>(),
+                         trace ? (unsigned long long*)((uint8_t*)d_err.p + 64) : nullptr);
     HIPCHK(c, hipGetLastError());
     int err[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(err, d_err.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    lap("k_decode_blocks");
+    if (trace) {
+        unsigned long long st[8] = {0};
+        HIPCHK(c, hipMemcpy(st, (uint8_t*)d_err.p + 64, 64, hipMemcpyDeviceToHost));
+        const double nr = st[5] ? (double)st[5] : 1.0;
+        fprintf(stderr, "[leon decode] per read: %.2f table jumps (%.1f positions), %.2f table misses, %.2f probe rounds, %.2f probe rounds answered by the table\n",
+                st[0] / nr, st[4] / nr, st[1] / nr, st[2] / nr, st[3] / nr);
+    }
     if (err[0]) {
         const char* what = err[0] == 1 ? "anchor address or position out of range" : err[0] == 2 ? "more or fewer bases than the block table says"
                          : err[0] == 4 ? "the payload ends before its reads do" : "too many N / error positions in one read";
@@ -1122,6 +1177,7 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     }
     HIPCHK(c, hipMemcpy(out_bases, d_out.p, out0[n_blocks], hipMemcpyDeviceToHost));
     if (read0[n_blocks]) HIPCHK(c, hipMemcpy(out_len, d_len.p, read0[n_blocks] * 4, hipMemcpyDeviceToHost));
+    lap("bases to the host");
     return LEON_OK;
 }
 

@@ -16,6 +16,8 @@ constexpr uint32_t DC_NSLOT = 14;                          // numeric models in 
 constexpr uint32_t DC_LIST_CAP = 8192;                     // N / error positions of ONE read in the block's own scratch; longer
                                                            // lists (a 70 kb read full of errors) come from a shared bump pool
 
+constexpr uint32_t DC_LIST_LDS = 64;                       // the first entries of both lists are mirrored in LDS (a cursor step is then no memory round trip)
+
 size_t decode_scratch_bytes(uint64_t n_blocks) {
     return (size_t)n_blocks * ((RC_NNUM - DC_NSLOT) * RC_STRIDE + 2 * DC_LIST_CAP) * sizeof(uint32_t);
 }
@@ -114,8 +116,7 @@ template <bool GLB> __device__ inline uint32_t decode_on(Dec& d, uint32_t* T, bo
     return c;
 }
 
-__device__ inline uint32_t decode_sym(Dec& d, uint32_t m) {
-    if (m < N_SMALL_MODELS) return decode_on<false>(d, d.lds + m * RC_SSTRIDE, true, small_model_size(m));
+__device__ inline uint32_t decode_sym(Dec& d, uint32_t m) {   // a numeric model (m >= N_SMALL_MODELS)
     uint32_t slot = d.slotmap[m - N_SMALL_MODELS];
     if (slot == 255) {                                       // first use in this block: Order0Model::clear
         slot = d.nused++;
@@ -132,12 +133,18 @@ __device__ inline uint32_t decode_sym(Dec& d, uint32_t m) {
     if (slot < DC_NSLOT) return decode_on<false>(d, d.lds + RC_SMALL_WORDS + slot * RC_STRIDE, false, 256);
     return decode_on<true>(d, d.gmodels + (uint64_t)(slot - DC_NSLOT) * RC_STRIDE, false, 256);
 }
-// CompressionUtils::decodeNumeric
+__device__ inline uint32_t decode_small(Dec& d, uint32_t m) {   // m < N_SMALL_MODELS
+    return decode_on<false>(d, d.lds + m * RC_SSTRIDE, true, small_model_size(m));
+}
+// CompressionUtils::decodeNumeric: the byte count, then the bytes, low first (one decode site: see the kernel's note on its size)
 __device__ inline uint64_t decode_numeric(Dec& d, uint32_t group) {
-    uint32_t bc = decode_sym(d, numeric_model_id(group, 0));
-    if (bc > 8) bc = 8;
+    uint32_t bc = 0;
     uint64_t v = 0;
-    for (uint32_t i = 0; i < bc; i++) v |= (uint64_t)decode_sym(d, numeric_model_id(group, i + 1)) << (8 * i);
+#pragma unroll 1
+    for (uint32_t i = 0; i <= bc; i++) {
+        const uint32_t c = decode_sym(d, numeric_model_id(group, i));
+        if (i == 0) bc = c > 8 ? 8 : c; else v |= (uint64_t)c << (8 * (i - 1));
+    }
     return v;
 }
 __device__ inline uint64_t from_delta(uint32_t type, uint64_t prev, uint64_t delta) {
@@ -150,21 +157,106 @@ __device__ inline uint8_t bin2nt(uint32_t c) { return (uint8_t)("ACTGN"[c % 5]);
 
 }  // namespace
 
+// ---- the path cache -------------------------------------------------------------------------------------------------
+// What the walk learns from the bloom is a pure function of the k-mer: "from k-mer X, the next m steps each have exactly
+// one solid successor, and they are b1..bm".  Every genome locus is walked by every read that covers it (30x), by
+// thousands of blocks at once, so the waves share that knowledge through a hash table in HBM (this GPU has 288 GB; the
+// table is a few bytes per solid k-mer): a walker that finds its k-mer takes up to 28 positions from ONE 64-byte sector
+// instead of 7 probes per position and a memory round trip per three positions.  K-mers are stored ORIENTED -- the k-mer as
+// it is extended to the right; a left walk over the read is a right walk over the reverse complement -- so both walks of
+// both strands meet in the same entries.  A slot's key is written once (compare-and-swap from EMPTY); its payload
+// (count << 56 | path) only grows by atomic max -- two paths from the same k-mer are prefixes of one another -- so a reader
+// either sees a complete, correct entry or none: the table changes how fast a base is decoded, never which base.
+constexpr uint32_t PC_MAX = 28;                            // bases per entry (56 bits) ...
+constexpr uint32_t PC_REG = 30;                            // ... the walker remembers the last 30 (a round decides up to 3 positions)
+constexpr uint64_t PC_M60 = (1ull << 60) - 1, PC_M56 = (1ull << 56) - 1;
+constexpr uint64_t PC_EMPTY = ~0ull;
+template <typename K> struct PCL;
+template <> struct PCL<uint64_t> { static constexpr uint32_t SLOTS = 4, WORDS = 2, PAY = 1; };   // {key, payload}
+template <> struct PCL<u128> { static constexpr uint32_t SLOTS = 2, WORDS = 4, PAY = 2; };       // {lo, hi, payload, -}
+
+__device__ inline uint64_t pc_ld(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void pc_st(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint64_t pc_cas(uint64_t* p, uint64_t expect, uint64_t v) {
+    (void)__hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expect;
+}
+__device__ inline void pc_max(uint64_t* p, uint64_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint64_t readlane64(uint64_t v, uint32_t l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+}
+
+// An insertion in flight, one per lane.  Its memory operations ride on the walk's own round trips: the compare-and-swap is
+// issued next to a round's probes (pc_issue) and looked at when the probes are back (pc_retire), so publishing costs the
+// chain instructions, not latency.  Whatever goes wrong (bucket full, a racing writer) only drops the entry.
+template <typename K> struct Pend { uint32_t st = 0, tr = 0; K key = 0; uint64_t pay = 0, ret = 0, bucket = 0; };   // st: 0 idle, 1 to claim, 3 to verify
+
+template <typename K> __device__ inline uint64_t* pc_slot(const PathCache& C, uint64_t bucket, uint32_t i) {
+    return C.slots + (bucket * PCL<K>::SLOTS + i) * PCL<K>::WORDS;
+}
+template <typename K> __device__ inline uint32_t pc_issue(const PathCache& C, Pend<K>& P) {
+    const uint32_t st = P.st;
+    if (st == 1) P.ret = pc_cas(pc_slot<K>(C, P.bucket, P.tr), PC_EMPTY, (uint64_t)P.key);
+    else if (KT<K>::W == 2 && st == 3) P.ret = pc_ld(pc_slot<K>(C, P.bucket, P.tr) + 1);
+    return st;
+}
+template <typename K> __device__ inline void pc_retire(const PathCache& C, Pend<K>& P, uint32_t issued) {
+    if (issued == 0) return;
+    uint64_t* sp = pc_slot<K>(C, P.bucket, P.tr);
+    const uint64_t lo = (uint64_t)P.key, hi = KT<K>::W == 2 ? (uint64_t)(P.key >> (KT<K>::W == 2 ? 64 : 0)) : 0;
+    bool next = false;
+    if (issued == 1) {
+        if (P.ret == PC_EMPTY) { if (KT<K>::W == 2) pc_st(sp + 1, hi); pc_max(sp + PCL<K>::PAY, P.pay); P.st = 0; }     // claimed
+        else if (P.ret == lo) { if (KT<K>::W == 1) { pc_max(sp + PCL<K>::PAY, P.pay); P.st = 0; } else P.st = 3; }         // there already (two words: look at the other)
+        else next = true;
+    } else {
+        if (P.ret == hi) { pc_max(sp + PCL<K>::PAY, P.pay); P.st = 0; }
+        else if (P.ret == PC_EMPTY) P.st = 0;                                      // its writer is between its two stores: let it be
+        else next = true;
+    }
+    if (next) { P.tr++; P.st = P.tr < PCL<K>::SLOTS ? 1u : 0u; }
+}
+// Entries for the k-mers a..b steps back (a <= b <= PC_REG), taken by idle lanes.  old:p60 is the oriented sequence walked
+// so far (old = the k-mer 30 steps back, p60 = the 30 bases since); the k-mer d steps back is followed by min(d, 28) known bases.
+template <typename K> __device__ inline void pc_offer(const PathCache& C, Pend<K>& P, uint32_t lane, uint32_t a, uint32_t b, K old, uint64_t p60, K kmk) {
+    if (!C.slots || a > b) return;
+    const unsigned long long idle = __ballot(P.st == 0);
+    const uint32_t d = a + (uint32_t)__popcll(idle & ((1ull << lane) - 1));
+    if (P.st == 0 && d <= b) {
+        const uint32_t cnt = d < PC_MAX ? d : PC_MAX;
+        const K key = ((old << (2 * (PC_REG - d))) | (K)(p60 >> (2 * d))) & kmk;
+        const uint64_t path = (p60 >> (2 * (d - cnt))) & ((1ull << (2 * cnt)) - 1);
+        if ((uint64_t)key != PC_EMPTY) {
+            P.key = key; P.pay = ((uint64_t)cnt << 56) | path; P.tr = 0; P.st = 1;
+            P.bucket = key_hash(key) & C.bucket_mask;
+        }
+    }
+}
+
+__global__ void k_pc_init(uint64_t* slots, uint64_t n_words, uint32_t words_per_slot, uint32_t pay) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = (uint32_t)(i % words_per_slot);
+        slots[i] = w < pay ? PC_EMPTY : 0ull;
+    }
+}
+
 // err[0]: 0 ok; otherwise 1 + the first failing block in err[1] (code: 1 address/position out of range, 2 output
 // overflow, 3 too many N / error positions in one read)
 template <typename K, bool DEEP>
-__global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors,
+__global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors,
                                                      const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads,
                                                      const uint64_t* blk_read0, const uint64_t* blk_out0, uint64_t n_blocks,
                                                      uint8_t* out, uint32_t* out_len, uint32_t* scratch, uint32_t* pool,
-                                                     unsigned long long* pool_cursor, uint64_t pool_words, int* err) {
+                                                     unsigned long long* pool_cursor, uint64_t pool_words, int* err, unsigned long long* stats) {
     __shared__ uint16_t rv16[256];
     __shared__ uint32_t models[RC_SMALL_WORDS + DC_NSLOT * RC_STRIDE];
     __shared__ uint8_t slotmap[RC_NNUM];
+    __shared__ uint32_t lstN[DC_LIST_LDS], lstE[DC_LIST_LDS];  // the first entries of the read's N / error positions (the usual read has a few)
     load_rv16(rv16, rv16g);
     const uint32_t lane = lane_id(), k = B.k;
     const K kmk = kmask<K>(k);
     constexpr uint32_t W = KT<K>::W;
+    const bool cache_on = PCc.slots != nullptr;
     for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         Dec d;
         d.lane = lane; d.lds = models; d.slotmap = slotmap; d.nused = 0; d.bad = false;
@@ -185,6 +277,8 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
         const uint64_t wcap = blk_out0[b + 1];
         const uint64_t r0 = blk_read0[b];
         int fail = 0;
+        Pend<K> P;
+        uint32_t n_fast = 0, n_miss = 0, n_slow = 0, n_slowjump = 0, n_jumped = 0, n_offer = 0;   // rounds by kind (stats != nullptr: measurement)
         auto pool_alloc = [&](uint64_t cnt) -> uint32_t* {           // wave-uniform; never freed (rare, bounded by pool_words)
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(pool_cursor, (unsigned long long)cnt);
@@ -194,50 +288,65 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
         };
         for (uint32_t r = 0; r < blk_reads[b] && !fail; r++) {
             if (d.bad) { fail = 4; break; }
-            const uint32_t type = decode_sym(d, M_READ_TYPE);
+            const uint32_t type = decode_small(d, M_READ_TYPE);
             if (type == 1) {                                  // DnaDecoder::decodeNoAnchorRead
                 const uint64_t len = decode_numeric(d, G_NOANCHOR_READSIZE);
                 if (!len_fits(len, w, wcap)) { fail = 2; break; }
                 for (uint64_t i = 0; i < len && !d.bad; i++) {
-                    const uint32_t c = decode_sym(d, M_NOANCHOR_READ);
+                    const uint32_t c = decode_small(d, M_NOANCHOR_READ);
                     if (lane == 0) out[w + i] = bin2nt(c);
                 }
                 if (lane == 0) out_len[r0 + r] = (uint32_t)len;
                 w += len;
                 continue;
             }
-            uint32_t dt; uint64_t dv;
-            dt = decode_sym(d, M_READSIZE_DT); dv = decode_numeric(d, G_READSIZE);
-            const uint64_t len = from_delta(dt, prevLen, dv); prevLen = len;
-            dt = decode_sym(d, M_ANCHORPOS_DT); dv = decode_numeric(d, G_ANCHOR_POS);
-            const uint64_t apos = from_delta(dt, prevPos, dv); prevPos = apos;
-            dt = decode_sym(d, M_ANCHORADDR_DT); dv = decode_numeric(d, G_ANCHOR_ADDRESS);
-            const uint64_t addr = from_delta(dt, prevAddr, dv); prevAddr = addr;
-            const uint32_t rev = decode_sym(d, M_ANCHOR_REVCOMP);
+            // read size, anchor position, anchor address: a delta type and a numeric each (one copy of the code: the
+            // kernel's instruction footprint is what a lone wave per SIMD pays for)
+            uint64_t len = 0, apos = 0, addr = 0;
+#pragma unroll 1
+            for (uint32_t f = 0; f < 3; f++) {
+                const uint32_t dt = decode_small(d, M_READSIZE_DT + f);
+                const uint64_t dv = decode_numeric(d, f == 0 ? G_READSIZE : (f == 1 ? G_ANCHOR_POS : G_ANCHOR_ADDRESS));
+                if (f == 0) { len = from_delta(dt, prevLen, dv); prevLen = len; }
+                else if (f == 1) { apos = from_delta(dt, prevPos, dv); prevPos = apos; }
+                else { addr = from_delta(dt, prevAddr, dv); prevAddr = addr; }
+            }
+            const uint32_t rev = decode_small(d, M_ANCHOR_REVCOMP);
             // values from the payload: compared without sums that could wrap (a crafted delta of type 2 makes them ~2^64)
             if (!len_fits(len, w, wcap)) { fail = 2; break; }
             if (addr >= n_anchors || !anchor_fits(apos, len, k)) { fail = 1; break; }
-            const uint64_t nN = decode_numeric(d, G_NUMERIC);
-            if (nN > len) { fail = 3; break; }
-            uint32_t* Npos = nN > DC_LIST_CAP ? pool_alloc(nN) : Nblk;
-            if (!Npos) { fail = 3; break; }
-            uint64_t pv = 0;
-            for (uint64_t i = 0; i < nN; i++) { pv += decode_numeric(d, G_NPOS); if (lane == 0) Npos[i] = (uint32_t)pv; }
-            const uint64_t nErr = decode_numeric(d, G_LEFT_ERROR);
-            if (nErr > len) { fail = 3; break; }
-            uint32_t* Epos = nErr > DC_LIST_CAP ? pool_alloc(nErr) : Eblk;
-            if (!Epos) { fail = 3; break; }
-            pv = 0;
-            for (uint64_t i = 0; i < nErr; i++) { pv += decode_numeric(d, G_ERRPOS); if (lane == 0) Epos[i] = (uint32_t)pv; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // N positions, then the positions of the recorded sequencing errors
+            uint64_t nN = 0, nErr = 0;
+            uint32_t *Npos = Nblk, *Epos = Eblk;
+#pragma unroll 1
+            for (uint32_t l = 0; l < 2 && !fail; l++) {
+                const uint64_t cntv = decode_numeric(d, l == 0 ? G_NUMERIC : G_LEFT_ERROR);
+                if (cntv > len) { fail = 3; break; }
+                uint32_t* gl = cntv > DC_LIST_CAP ? pool_alloc(cntv) : (l == 0 ? Nblk : Eblk);
+                if (!gl) { fail = 3; break; }
+                volatile uint32_t* ll = l == 0 ? lstN : lstE;
+                uint64_t pv = 0;
+                for (uint64_t i = 0; i < cntv; i++) {
+                    pv += decode_numeric(d, l == 0 ? G_NPOS : G_ERRPOS);
+                    if (lane == 0) { gl[i] = (uint32_t)pv; if (i < DC_LIST_LDS) ll[i] = (uint32_t)pv; }
+                }
+                if (l == 0) { nN = cntv; Npos = gl; } else { nErr = cntv; Epos = gl; }
+            }
+            if (fail) break;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 
             K anchor = load_kmer<K>(anchors + addr * W);
             if (rev) anchor = revcomp(anchor, k);
             uint8_t* s = out + w;
             if (lane < k) s[apos + lane] = bin2nt((uint32_t)(uint64_t)(anchor >> (2 * (k - 1 - lane))) & 3u);
+            // entry idx of a position list: LDS for the first DC_LIST_LDS, the block's scratch (or the pool) beyond
+            auto lget = [&](const uint32_t* gl, const volatile uint32_t* ll, int64_t idx) -> uint32_t {
+                return idx < (int64_t)DC_LIST_LDS ? ll[idx] : __hip_atomic_load(gl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
             // DnaDecoder::extendAnchor, left then right.  The position lists are ascending: the left walk consumes them
             // from their ends, the right walk from the first entry beyond the anchor.
+#pragma unroll 1
             for (int dir = 0; dir < 2; dir++) {
                 K kmer = anchor;
                 int64_t pos = dir == 0 ? (int64_t)apos - 1 : (int64_t)(apos + k);
@@ -245,70 +354,142 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
                 // cursors: index of the next list entry this walk can meet
                 int64_t ni, ei;
                 if (dir == 0) {
-                    ni = (int64_t)nN - 1; while (ni >= 0 && __hip_atomic_load(Npos + ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint64_t)(pos < 0 ? 0 : pos) ) ni--;
+                    ni = (int64_t)nN - 1; while (ni >= 0 && lget(Npos, lstN, ni) > (uint64_t)(pos < 0 ? 0 : pos)) ni--;
                     if (pos < 0) ni = -1;
-                    ei = (int64_t)nErr - 1; while (ei >= 0 && __hip_atomic_load(Epos + ei, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint64_t)(pos < 0 ? 0 : pos)) ei--;
+                    ei = (int64_t)nErr - 1; while (ei >= 0 && lget(Epos, lstE, ei) > (uint64_t)(pos < 0 ? 0 : pos)) ei--;
                     if (pos < 0) ei = -1;
                 } else {
-                    ni = 0; while (ni < (int64_t)nN && __hip_atomic_load(Npos + ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint64_t)pos) ni++;
-                    ei = 0; while (ei < (int64_t)nErr && __hip_atomic_load(Epos + ei, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint64_t)pos) ei++;
+                    ni = 0; while (ni < (int64_t)nN && lget(Npos, lstN, ni) < (uint64_t)pos) ni++;
+                    ei = 0; while (ei < (int64_t)nErr && lget(Epos, lstE, ei) < (uint64_t)pos) ei++;
                 }
-                auto cur = [&](const uint32_t* list, int64_t idx, int64_t cnt) -> int64_t {
-                    return (idx >= 0 && idx < cnt) ? (int64_t)__hip_atomic_load(list + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+                auto cur = [&](const uint32_t* gl, const volatile uint32_t* ll, int64_t idx, int64_t cnt) -> int64_t {
+                    return (idx >= 0 && idx < cnt) ? (int64_t)lget(gl, ll, idx) : -1;
                 };
-                int64_t nextN = cur(Npos, ni, (int64_t)nN), nextE = cur(Epos, ei, (int64_t)nErr);
+                int64_t nextN = cur(Npos, lstN, ni, (int64_t)nN), nextE = cur(Epos, lstE, ei, (int64_t)nErr);
+                // the walked sequence in the walk's own orientation, for the path cache: oldk = the k-mer PC_REG steps
+                // back, p60 = the bases since; `run` = how many of the last steps had exactly one solid successor in a
+                // row, `fresh` = how many of those this wave probed itself (what it knows and the table may not)
+                const K y0 = dir == 1 ? anchor : revcomp(anchor, k);
+                K oldk = (K)(y0 >> 60);
+                uint64_t p60 = (uint64_t)y0 & PC_M60;
+                uint32_t run = 0, fresh = 0;
+                bool slow = !cache_on;                        // slow: probe the bloom; else: ask the table only
                 // One position: the decoded base goes out, the k-mer moves on by the base the GRAPH follows.
-                auto advance = [&](uint32_t res4) {
+                auto advance = [&](uint32_t res4) -> uint32_t {
                     uint32_t nt_out, nt_seed;
+                    bool clean = false;
                     if (pos == nextN) {                       // an N: 'A' in the k-mer, no probe, no symbol
-                        ni += step; nextN = cur(Npos, ni, (int64_t)nN);
-                        if (pos == nextE) { ei += step; nextE = cur(Epos, ei, (int64_t)nErr); }   // (never both, kept in step)
+                        ni += step; nextN = cur(Npos, lstN, ni, (int64_t)nN);
+                        if (pos == nextE) { ei += step; nextE = cur(Epos, lstE, ei, (int64_t)nErr); }   // (never both, kept in step)
                         nt_out = 4; nt_seed = 0;
                     } else {
                         const uint32_t cnt = (uint32_t)__popc(res4);
                         const uint32_t first = res4 ? (uint32_t)__builtin_ctz(res4) : 0u;
-                        if (pos == nextE) {                   // a recorded sequencing error: the true base, the graph's successor
-                            ei += step; nextE = cur(Epos, ei, (int64_t)nErr);
-                            const uint32_t nt = decode_sym(d, M_BIFURCATION);
-                            nt_out = nt; nt_seed = res4 ? first : (nt & 3u);
-                        } else if (cnt == 1) { nt_out = first; nt_seed = first; }
-                        else if (cnt == 2) {
-                            const uint32_t second = (uint32_t)__builtin_ctz(res4 & (res4 - 1));
-                            const uint32_t nt = decode_sym(d, M_BIFURCATION_BINARY) == 0 ? first : second;
-                            nt_out = nt; nt_seed = nt;
-                        } else {
-                            const uint32_t nt = decode_sym(d, M_BIFURCATION);
-                            nt_out = nt; nt_seed = nt & 3u;
+                        const bool is_err = pos == nextE;     // a recorded sequencing error: the true base, the graph's successor
+                        clean = cnt == 1;
+                        nt_out = first; nt_seed = first;
+                        if (is_err || cnt != 1) {
+                            const uint32_t m = (!is_err && cnt == 2) ? M_BIFURCATION_BINARY : M_BIFURCATION;
+                            const uint32_t c = decode_small(d, m);
+                            if (is_err) { ei += step; nextE = cur(Epos, lstE, ei, (int64_t)nErr); nt_out = c; nt_seed = res4 ? first : (c & 3u); }
+                            else if (cnt == 2) { nt_out = c == 0 ? first : (uint32_t)__builtin_ctz(res4 & (res4 - 1)); nt_seed = nt_out; }
+                            else { nt_out = c; nt_seed = c & 3u; }
                         }
                     }
                     if (lane == 0) s[pos] = bin2nt(nt_out);
                     kmer = dir == 1 ? (((kmer << 2) | (K)nt_seed) & kmk) : ((kmer >> 2) | ((K)nt_seed << (2 * (k - 1))));
                     pos += step;
+                    // the same step in the walk's orientation (a base prepended on the left is its complement appended on the right)
+                    if (!clean) { if (fresh) pc_offer<K>(PCc, P, lane, 1, run < PC_MAX - 1 ? run : PC_MAX - 1, oldk, p60, kmk); run = 0; fresh = 0; }
+                    const uint32_t e = dir == 1 ? nt_seed : (nt_seed ^ 2u);
+                    oldk = ((oldk << 2) | (K)((p60 >> 58) & 3u)) & kmk;
+                    p60 = ((p60 << 2) | e) & PC_M60;
+                    if (clean) { run++; fresh++; }
                     return nt_seed;
                 };
-                // Two (DEEP: three) positions per memory round trip: lane 0 probes the current k-mer, lanes 1..4 its four
-                // possible successors, DEEP lanes 5..20 the sixteen k-mers two steps ahead (the other lanes repeat lane
-                // 0's addresses, which costs no traffic), so when a position is decided the probe of the k-mer it leads
-                // to is already there.  DEEP asks for 21 probe sets per round; with 2 000 waves in flight that is ~45 G sectors/s,
-                // still under the chip's random-sector rate.
                 auto succ = [&](K x, uint32_t nt) -> K {
                     return dir == 1 ? (((x << 2) | (K)nt) & kmk) : ((x >> 2) | ((K)nt << (2 * (k - 1))));
                 };
-                while (pos >= 0 && pos < (int64_t)len) {
-                    K km = kmer;
-                    if (lane >= 1 && lane <= 4) km = succ(kmer, (lane - 1) & 3u);
-                    if (DEEP && lane >= 5 && lane <= 20) km = succ(succ(kmer, ((lane - 5) >> 2) & 3u), (lane - 5) & 3u);
-                    const uint32_t res = bloom_contains4<K>(B, rv16, km, revcomp(km, k), dir == 1);
-                    const uint32_t seed0 = advance((uint32_t)__builtin_amdgcn_readlane((int)res, 0));
-                    if (pos >= 0 && pos < (int64_t)len) {
-                        const uint32_t seed1 = advance((uint32_t)__builtin_amdgcn_readlane((int)res, (int)(1 + seed0)));
-                        if (DEEP && pos >= 0 && pos < (int64_t)len)
-                            (void)advance((uint32_t)__builtin_amdgcn_readlane((int)res, (int)(5 + 4 * seed0 + seed1)));
+                while (pos >= 0 && pos < (int64_t)len && !d.bad) {
+                    if (pos == nextN) { (void)advance(0); continue; }                  // nothing to ask the graph
+                    // this round's memory operations, all in flight together: the table's bucket for the current k-mer, an
+                    // insertion's compare-and-swap, and (slow) the bloom probes of 1 + 4 (+ 16) k-mers -- lane 0 the current
+                    // k-mer, lanes 1..4 its four possible successors, DEEP lanes 5..20 the sixteen k-mers two steps ahead
+                    // (the other lanes repeat lane 0's addresses, which costs no traffic) -- so that when a position is
+                    // decided, the probe of the k-mer it leads to is already there.
+                    uint64_t pl = 0;
+                    K y = 0;
+                    if (cache_on) {
+                        y = dir == 1 ? kmer : revcomp(kmer, k);
+                        if (lane < PCL<K>::SLOTS) {
+                            const uint64_t* sp = pc_slot<K>(PCc, key_hash(y) & PCc.bucket_mask, lane);
+                            const uint64_t k0 = pc_ld(sp), k1 = W == 2 ? pc_ld(sp + 1) : 0, v = pc_ld(sp + PCL<K>::PAY);
+                            if (k0 == (uint64_t)y && (W == 1 || k1 == (uint64_t)(y >> (W == 2 ? 64 : 0)))) pl = v;
+                        }
                     }
+                    const uint32_t issued = cache_on ? pc_issue<K>(PCc, P) : 0u;
+                    uint32_t res = 0;
+                    if (slow) {
+                        K km = kmer;
+                        if (lane >= 1 && lane <= 4) km = succ(kmer, (lane - 1) & 3u);
+                        if (DEEP && lane >= 5 && lane <= 20) km = succ(succ(kmer, ((lane - 5) >> 2) & 3u), (lane - 5) & 3u);
+                        res = bloom_contains4<K>(B, rv16, km, revcomp(km, k), dir == 1);
+                    }
+                    const uint64_t remaining = dir == 1 ? (uint64_t)((int64_t)len - pos) : (uint64_t)(pos + 1);
+                    uint32_t cnt = 0;
+                    uint64_t path = 0;
+                    if (cache_on) {
+                        const unsigned long long hit = __ballot(pl != 0);
+                        if (hit) { pl = readlane64(pl, (uint32_t)__builtin_ctzll(hit)); cnt = (uint32_t)(pl >> 56); path = pl & PC_M56; }
+                        pc_retire<K>(PCc, P, issued);
+                        if (cnt > PC_MAX) cnt = 0;
+                    }
+                    if (cnt != 0 && (!slow || cnt >= 3 || cnt >= remaining)) {
+                        if (slow) n_slowjump++; else n_fast++;
+                        // the table knows the next cnt steps: take as many as the read has, up to its next N
+                        if (fresh) pc_offer<K>(PCc, P, lane, 1, run < PC_MAX - 1 ? run : PC_MAX - 1, oldk, p60, kmk);
+                        fresh = 0;
+                        uint64_t jj = cnt < remaining ? cnt : remaining;
+                        if (nextN >= 0) { const uint64_t dN = (uint64_t)(dir == 1 ? nextN - pos : pos - nextN); if (dN < jj) jj = dN; }
+                        const uint32_t j = (uint32_t)jj;      // >= 1: pos is not an N position here
+                        const uint64_t pj = path >> (2 * (cnt - j));
+                        uint32_t ovr = 0xFFu;                 // a recorded error inside the jump: its base comes from the stream, in walk order
+                        while (nextE >= 0 && !d.bad) {
+                            const uint64_t tE = (uint64_t)(dir == 1 ? nextE - pos : pos - nextE);
+                            if (tE >= j) break;
+                            const uint32_t c = decode_small(d, M_BIFURCATION);
+                            if (lane == tE) ovr = c;
+                            ei += step; nextE = cur(Epos, lstE, ei, (int64_t)nErr);
+                        }
+                        if (lane < j) {
+                            const uint32_t c = (uint32_t)(pj >> (2 * (j - 1 - lane))) & 3u;
+                            s[pos + step * (int64_t)lane] = bin2nt(ovr != 0xFFu ? ovr : (dir == 1 ? c : (c ^ 2u)));
+                        }
+                        const K yn = ((y << (2 * j)) | (K)pj) & kmk;
+                        kmer = dir == 1 ? yn : revcomp(yn, k);
+                        oldk = ((oldk << (2 * j)) | (K)(p60 >> (60 - 2 * j))) & kmk;
+                        p60 = ((p60 << (2 * j)) | pj) & PC_M60;
+                        run += j; pos += step * (int64_t)j; n_jumped += j;
+                        slow = j == cnt && cnt < PC_MAX;      // the entry ended where the graph stops being a path: probe there
+                        continue;
+                    }
+                    if (!slow) { slow = true; n_miss++; continue; }     // not in the table: the next round probes
+                    n_slow++;
+                    uint32_t seed0 = 0, seed1 = 0, done = 0;
+#pragma unroll 1
+                    for (uint32_t st = 0; st < (DEEP ? 3u : 2u) && pos >= 0 && pos < (int64_t)len; st++) {
+                        const uint32_t src = st == 0 ? 0u : (st == 1 ? 1u + seed0 : 5u + 4u * seed0 + seed1);
+                        const uint32_t sd = advance((uint32_t)__builtin_amdgcn_readlane((int)res, (int)src));
+                        if (st == 0) seed0 = sd; else seed1 = sd;
+                        done++;
+                    }
+                    // k-mers whose 28 following bases became known in this round (none if a step broke the run: run < 3 then)
+                    if (run >= PC_MAX) pc_offer<K>(PCc, P, lane, PC_MAX, run < PC_MAX - 1 + done ? run : PC_MAX - 1 + done, oldk, p60, kmk);
                 }
+                if (fresh) pc_offer<K>(PCc, P, lane, 1, run < PC_MAX - 1 ? run : PC_MAX - 1, oldk, p60, kmk);   // the walk's last steps
             }
             if (lane == 0) for (uint64_t i = 0; i < nN; i++) {                                       // also inside the anchor
-                const uint32_t q = __hip_atomic_load(Npos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t q = i < DC_LIST_LDS ? ((volatile uint32_t*)lstN)[i] : __hip_atomic_load(Npos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (q < len) s[q] = 'N';
             }
             if (lane == 0) out_len[r0 + r] = (uint32_t)len;
@@ -317,19 +498,45 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, const uint16_t
         if (!fail && d.bad) fail = 4;
         if (!fail && w != wcap) fail = 2;                    // the block table promised exactly wcap - blk_out0[b] bases
         if (fail && lane == 0) { if (atomicCAS(err, 0, fail) == 0) err[1] = (int)b; }
+        if (stats && lane == 0) {
+            atomicAdd(stats + 0, n_fast); atomicAdd(stats + 1, n_miss); atomicAdd(stats + 2, n_slow); atomicAdd(stats + 3, n_slowjump);
+            atomicAdd(stats + 4, n_jumped); atomicAdd(stats + 5, (unsigned long long)blk_reads[b]);
+        }
+        (void)n_offer;
     }
 }
 
-void launch_decode_blocks(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors,
+size_t path_cache_slot_bytes(uint32_t k) { return k >= 32 ? 32 : 16; }
+// position-dependent 64-bit sum of the bloom's words (the array is padded past n_bytes, bytes beyond it are never set)
+__global__ void k_bloom_fingerprint(const uint8_t* bits, uint64_t n_words, uint64_t* sum) {
+    uint64_t acc = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t w; __builtin_memcpy(&w, bits + 8 * i, 8);
+        acc += mix64(w + 0x9E3779B97F4A7C15ULL * (i + 1));
+    }
+    for (int o = 32; o; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd((unsigned long long*)sum, (unsigned long long)acc);
+}
+void launch_bloom_fingerprint(hipStream_t s, const uint8_t* bits, uint64_t n_bytes, uint64_t* d_sum) {
+    hipLaunchKernelGGL(k_bloom_fingerprint, dim3(256 * 8), dim3(256), 0, s, bits, (n_bytes + 7) / 8, d_sum);
+}
+void launch_path_cache_init(hipStream_t s, PathCache C, uint32_t k) {
+    if (!C.slots) return;
+    const uint32_t wps = k >= 32 ? 4 : 2, pay = k >= 32 ? 2 : 1;
+    const uint64_t n_words = (C.bucket_mask + 1) * 8;       // a bucket is one 64-byte sector
+    hipLaunchKernelGGL(k_pc_init, dim3(256 * 32), dim3(256), 0, s, C.slots, n_words, wps, pay);
+}
+
+void launch_decode_blocks(hipStream_t s, BloomDev B, PathCache C, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors,
                           const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads, const uint64_t* blk_read0,
                           const uint64_t* blk_out0, uint64_t n_blocks, uint8_t* out, uint32_t* out_len, uint32_t* scratch,
-                          uint32_t* pool, unsigned long long* pool_cursor, uint64_t pool_words, int* err) {
+                          uint32_t* pool, unsigned long long* pool_cursor, uint64_t pool_words, int* err, unsigned long long* stats) {
     if (!n_blocks) return;
-    const uint32_t g = (uint32_t)(n_blocks > 256 * 9 ? 256 * 9 : n_blocks);
+    const uint32_t g = (uint32_t)(n_blocks > 256 * 8 ? 256 * 8 : n_blocks);   // 8 waves per CU: the kernel's registers allow two per SIMD
     static const char* force = getenv("LEON_DC_DEEP");       // measurement override
     const bool deep = force ? force[0] == '1' : true;        // 21 probe sets per round and wave: measured better at 200 and at 2 000 blocks
-#define DC_LAUNCH(KT, D) hipLaunchKernelGGL((k_decode_blocks<KT, D>), dim3(g), dim3(64), 0, s, B, rv16, anchors, n_anchors, payloads, pay_off, \
-                                            blk_reads, blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err)
+#define DC_LAUNCH(KT, D) hipLaunchKernelGGL((k_decode_blocks<KT, D>), dim3(g), dim3(64), 0, s, B, C, rv16, anchors, n_anchors, payloads, pay_off, \
+                                            blk_reads, blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err, stats)
     if (B.k >= 32) { if (deep) DC_LAUNCH(u128, true); else DC_LAUNCH(u128, false); }
     else { if (deep) DC_LAUNCH(uint64_t, true); else DC_LAUNCH(uint64_t, false); }
 #undef DC_LAUNCH

@@ -105,10 +105,16 @@ void launch_gather_payload(hipStream_t s, const uint8_t* out, const uint64_t* ou
 // ---- quality stream, lossy form: DnaEncoder::smoothQuals over packed reads, quals in place (indexed like the bases) ----
 void launch_qual_smooth(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, uint8_t* quals);
 // ---- decoder (DnaDecoder) ----
+// what the decoding waves have learnt from the bloom, shared in HBM (decode_kernels.hip): 64-byte buckets of write-once slots
+struct PathCache { uint64_t* slots; uint64_t bucket_mask; };          // slots == nullptr: off
+size_t path_cache_slot_bytes(uint32_t k);
+void launch_path_cache_init(hipStream_t s, PathCache C, uint32_t k);
+void launch_bloom_fingerprint(hipStream_t s, const uint8_t* bits, uint64_t n_bytes, uint64_t* d_sum /* zeroed by the caller */);
 size_t decode_scratch_bytes(uint64_t n_blocks);
-void launch_decode_blocks(hipStream_t s, BloomDev B, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors,
+void launch_decode_blocks(hipStream_t s, BloomDev B, PathCache C, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors,
                           const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads, const uint64_t* blk_read0,
                           const uint64_t* blk_out0, uint64_t n_blocks, uint8_t* out, uint32_t* out_len, uint32_t* scratch,
-                          uint32_t* pool, unsigned long long* pool_cursor, uint64_t pool_words, int* err);
+                          uint32_t* pool, unsigned long long* pool_cursor, uint64_t pool_words, int* err,
+                          unsigned long long* stats /* nullptr, or 8 counters of rounds by kind (LEON_TRACE_DECODE) */);
 
 }  // namespace leon

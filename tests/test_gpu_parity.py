@@ -462,6 +462,50 @@ def test_device_decoder_round_trip(k, kw):
     ctx.close()
 
 
+@pytest.mark.parametrize("k", [31, 63])
+def test_device_decoder_path_cache_changes_nothing_but_the_time(k, monkeypatch):
+    """the decoder's path cache (what the waves learnt from the bloom, shared in HBM) is an accelerator, never a source of
+    bases: off, at its default size, and so small that most insertions are dropped (1 MiB: buckets overflow), the decoded reads
+    are the same, call after call on the same context; and a context whose bloom changes between two calls forgets the
+    entries it learnt from the old one"""
+    from leon_amd import capi
+    rpb = 250
+    bases, off = common.synthetic(6000, 150 if k < 32 else 230, 7000, seed=300 + k, err=0.02, n_rate=0.002)     # ~130x coverage: most walks meet known paths
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    n = len(off) - 1
+    reads = [bases[int(off[i]):int(off[i + 1])] for i in range(n)]
+    norm = lambda r: bytes(c if c in b"ACGT" else ord("N") for c in r)
+    want = [norm(r) for r in reads]
+    ctx = _ctx(k, rpb, tai)
+    ctx.bloom_upload(bl.bits)
+    blocks = ctx.encode_batch(bases, off)
+    d, na = ctx.finish()
+    anchors = capi.anchor_dict_decode(d, na, k)
+    nbases = [sum(len(r) for r in reads[b * rpb:(b + 1) * rpb]) for b in range(len(blocks))]
+    for mb in ("0", None, None, "1", "1", "0"):
+        if mb is None:
+            monkeypatch.delenv("LEON_DC_CACHE_MB", raising=False)
+        else:
+            monkeypatch.setenv("LEON_DC_CACHE_MB", mb)
+        assert ctx.decode_blocks(anchors, blocks, nbases) == want, "cache setting %r" % mb
+    monkeypatch.delenv("LEON_DC_CACHE_MB", raising=False)
+    # one block alone, then all of them: entries learnt by an earlier call serve the later one
+    assert ctx.decode_blocks(anchors, blocks[:1], nbases[:1]) == want[:blocks[0][2]]
+    assert ctx.decode_blocks(anchors, blocks, nbases) == want
+    # another read set through the same context: new bloom bits, the old entries must not be used
+    bases2, off2 = common.synthetic(3000, 150 if k < 32 else 230, 7000, seed=900 + k, err=0.02)
+    bl2 = O.Bloom(tai, k)
+    bl2.insert(O.count_solid(bases2, off2, k, 2))
+    ctx.reset_stream()
+    ctx.bloom_upload(bl2.bits)
+    blocks2 = ctx.encode_batch(bases2, off2)
+    d2, na2 = ctx.finish()
+    reads2 = [bases2[int(off2[i]):int(off2[i + 1])] for i in range(len(off2) - 1)]
+    nb2 = [sum(len(r) for r in reads2[b * rpb:(b + 1) * rpb]) for b in range(len(blocks2))]
+    assert ctx.decode_blocks(capi.anchor_dict_decode(d2, na2, k), blocks2, nb2) == [norm(r) for r in reads2]
+    ctx.close()
+
+
 def _decode_round_trip(reads, k, rpb, bloom=None):
     from leon_amd import capi
     bases, off = O.reads_to_arrays(reads)
