@@ -1106,7 +1106,7 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     HIPCHK(c, d_off.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_nreads.ensure(n_blocks * 4));
     HIPCHK(c, d_read0.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_out0.ensure((n_blocks + 1) * 8));
     HIPCHK(c, d_out.ensure(out0[n_blocks] + 64)); HIPCHK(c, d_len.ensure(std::max<uint64_t>(read0[n_blocks], 1) * 4));
-    HIPCHK(c, d_scr.ensure(decode_scratch_bytes(n_blocks))); HIPCHK(c, d_err.ensure(128));
+    HIPCHK(c, d_scr.ensure(decode_scratch_bytes(n_blocks))); HIPCHK(c, d_err.ensure(256));
     // position lists longer than a block's own scratch (8192 N or error positions in ONE read) come from this pool
     const uint64_t pool_words = std::min<uint64_t>(std::max<uint64_t>(out0[n_blocks] / 2, 1ull << 20), 1ull << 28);
     HIPCHK(c, d_pool.ensure(pool_words * 4 + 16));
@@ -1150,7 +1150,7 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     HIPCHK(c, hipMemcpyAsync(d_nreads.p, block_n_reads, n_blocks * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_read0.p, read0.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_out0.p, out0.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(d_err.p, 0, 128, s));
+    HIPCHK(c, hipMemsetAsync(d_err.p, 0, 256, s));
     HIPCHK(c, hipMemsetAsync((uint8_t*)d_pool.p + pool_words * 4, 0, 16, s));           // the pool's cursor lives behind it
     lap("payloads to the device");
     launch_decode_blocks(s, c->B, c->dc_pc, c->d_rv16, d_anchors.as<uint64_t>(), n_anchors, d_pay.as<uint8_t>(), d_off.as<uint64_t>(),
@@ -1164,11 +1164,12 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     HIPCHK(c, hipStreamSynchronize(s));
     lap("k_decode_blocks");
     if (trace) {
-        unsigned long long st[8] = {0};
-        HIPCHK(c, hipMemcpy(st, (uint8_t*)d_err.p + 64, 64, hipMemcpyDeviceToHost));
+        unsigned long long st[16] = {0};
+        HIPCHK(c, hipMemcpy(st, (uint8_t*)d_err.p + 64, 128, hipMemcpyDeviceToHost));
         const double nr = st[5] ? (double)st[5] : 1.0;
-        fprintf(stderr, "[leon decode] per read: %.2f table jumps (%.1f positions), %.2f table misses, %.2f probe rounds, %.2f probe rounds answered by the table\n",
-                st[0] / nr, st[4] / nr, st[1] / nr, st[2] / nr, st[3] / nr);
+        fprintf(stderr, "[leon decode] per read: %.2f table jumps (%.1f positions), %.2f table misses, %.2f one-k-mer probe rounds, %.2f deep probe rounds, %.2f more answered by the table\n",
+                st[0] / nr, st[4] / nr, st[1] / nr, st[6] / nr, st[2] / nr, st[3] / nr);
+        fprintf(stderr, "[leon decode] per read: %.2f us in its fields, %.2f us in its walks (100 MHz clock, the wave's own time)\n", st[7] / nr / 100.0, st[8] / nr / 100.0);
     }
     if (err[0]) {
         const char* what = err[0] == 1 ? "anchor address or position out of range" : err[0] == 2 ? "more or fewer bases than the block table says"

@@ -24,11 +24,13 @@ size_t decode_scratch_bytes(uint64_t n_blocks) {
 
 namespace {
 
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
 struct Dec {                                               // wave-uniform decoder state
     uint64_t low, range, code;
     const uint8_t* p; uint64_t n, i;                       // payload, its size, next byte
     uint32_t win;                                          // this lane's 4 bytes of the current 256-byte window
-    uint32_t* lds;                                         // small models + DC_NSLOT numeric slots
+    lds_u32* lds;                                          // small models + DC_NSLOT numeric slots (typed as LDS: ds_read, not flat loads)
     uint8_t* slotmap;
     uint32_t* gmodels;                                     // overflow numeric models (global)
     uint32_t nused;
@@ -53,31 +55,29 @@ __device__ inline uint32_t next_byte(Dec& d) {
 }
 
 // table access: LDS (plain, in order within the wave) or the global overflow area (through L2: other lanes' updates must be seen)
-template <bool GLB> __device__ inline uint32_t tld(const uint32_t* t, uint32_t idx) {
-    if (GLB) return __hip_atomic_load(t + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return ((const volatile uint32_t*)t)[idx];
-}
-template <bool GLB> __device__ inline void tinc(uint32_t* t, uint32_t idx) {
-    if (GLB) (void)__hip_atomic_fetch_add(t + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else ((volatile uint32_t*)t)[idx] = ((volatile uint32_t*)t)[idx] + 1;
-}
+__device__ inline uint32_t tld(const uint32_t* t, uint32_t idx) { return __hip_atomic_load(t + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint32_t tld(const lds_u32* t, uint32_t idx) { return ((const volatile lds_u32*)t)[idx]; }
+__device__ inline void tinc(uint32_t* t, uint32_t idx) { (void)__hip_atomic_fetch_add(t + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void tinc(lds_u32* t, uint32_t idx) { ((volatile lds_u32*)t)[idx] = ((volatile lds_u32*)t)[idx] + 1; }
 
 // floor(x / d) for d < 2^31: two rounds of a double-precision estimate (the generic 64-bit division is ~150 instructions
-// on this chain), then an exact fix-up
+// on this chain), then an exact fix-up.  The reciprocal is the correctly rounded one (v_rcp_f64 alone is good to ~2^-26
+// only: an estimate ABOVE the quotient would wrap the remainder); the fix-up loop is bounded whatever the estimates were.
 __device__ inline uint64_t div_u64_u32(uint64_t x, uint32_t dv) {
     const double inv = 1.0 / (double)dv;
     uint64_t q = (uint64_t)((double)x * inv * 0.99999999999);          // never above the quotient (x < 2^64: q fits)
     uint64_t rem = x - q * dv;                                          // < ~2^13 * dv + ...: a second, now exact-ish, round
     const uint64_t q2 = (uint64_t)((double)rem * inv * 0.99999999999);
     q += q2; rem -= q2 * dv;
-    while (rem >= dv) { q++; rem -= dv; }                               // at most a step or two
+    for (int i = 0; i < 4 && rem >= dv; i++) { q++; rem -= dv; }        // a step or two
+    if (rem >= dv) q = x / dv;                                          // (never taken; keeps the chain finite by construction)
     return q;
 }
 
 // RangeDecoder::nextByte on one model: the symbol, with the model updated (Order0Model::update)
-template <bool GLB> __device__ inline uint32_t decode_on(Dec& d, uint32_t* T, bool small, uint32_t size) {
+template <bool GLB, typename PT> __device__ inline uint32_t decode_on(Dec& d, PT T, bool small, uint32_t size) {
     const uint32_t lane = d.lane;
-    const uint32_t tot = small ? tld<GLB>(T, RC_LW + size) : tld<GLB>(T, 16);
+    const uint32_t tot = small ? tld(T, RC_LW + size) : tld(T, 16);
     const uint64_t r = div_u64_u32(d.range, tot);
     // RangeDecoder: value = (code - low) / r, symbol = the last c with F(c) <= value.  Equivalently the last c with
     // F(c) * r <= code - low: every lane multiplies its own cumulative count, no second division (F(c) * r <= range).
@@ -85,21 +85,21 @@ template <bool GLB> __device__ inline uint32_t decode_on(Dec& d, uint32_t* T, bo
     // level 1: the 16-block, F(16 j) = H[j]
     uint32_t j = 0, base = 0;
     if (!small) {
-        const uint32_t h = lane < 16 ? tld<GLB>(T, lane) : 0xFFFFFFFFu;
+        const uint32_t h = lane < 16 ? tld(T, lane) : 0xFFFFFFFFu;
         const unsigned long long m1 = __ballot(lane < 16 && (uint64_t)h * r <= dist);
         j = m1 ? (uint32_t)__popcll(m1) - 1 : 0;             // H[0] = 0 passes
         base = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)j);
     }
     // level 2: inside the block, F(16 j + l) = H[j] + Lw[16 j + l]; a small model's Lw[size] is its total
     const uint32_t lim = small ? size : 16u;
-    const uint32_t f = lane <= lim && (small || lane < 16) ? base + tld<GLB>(T, RC_LW + 16 * j + lane) : 0xFFFFFFFFu;
+    const uint32_t f = lane <= lim && (small || lane < 16) ? base + tld(T, RC_LW + 16 * j + lane) : 0xFFFFFFFFu;
     const unsigned long long m2 = __ballot(lane < lim && (uint64_t)f * r <= dist);
     const uint32_t l = m2 ? (uint32_t)__popcll(m2) - 1 : 0;
     const uint32_t c = 16 * j + l;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)l);
     uint32_t hi;
     if (small || l < 15) hi = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)(l + 1));
-    else hi = tld<GLB>(T, j + 1);                            // next block's start (H[16] = the total)
+    else hi = tld(T, j + 1);                            // next block's start (H[16] = the total)
     d.low += (uint64_t)lo * r;
     d.range = r * (uint64_t)(hi - lo);
     while ((d.low ^ (d.low + d.range)) < (1ull << 56) || (d.range < RC_BOTTOM && ((d.range = (0 - d.low) & (RC_BOTTOM - 1)), true))) {
@@ -109,8 +109,8 @@ template <bool GLB> __device__ inline uint32_t decode_on(Dec& d, uint32_t* T, bo
         if (d.i > d.n + 16) { d.bad = true; break; }          // (a crafted payload can drive range to 0, which would spin here for ever)
     }
     // Order0Model::update: F(x) += 1 for x > c
-    if (lane > l && lane <= (small ? size : 15u)) tinc<GLB>(T, RC_LW + 16 * j + lane);
-    if (!small && lane >= 16 && lane <= 32 && lane - 16 > j) tinc<GLB>(T, lane - 16);
+    if (lane > l && lane <= (small ? size : 15u)) tinc(T, RC_LW + 16 * j + lane);
+    if (!small && lane >= 16 && lane <= 32 && lane - 16 > j) tinc(T, lane - 16);
     if (GLB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     return c;
@@ -243,7 +243,7 @@ __global__ void k_pc_init(uint64_t* slots, uint64_t n_words, uint32_t words_per_
 // err[0]: 0 ok; otherwise 1 + the first failing block in err[1] (code: 1 address/position out of range, 2 output
 // overflow, 3 too many N / error positions in one read)
 template <typename K, bool DEEP>
-__global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_decode_blocks(BloomDev B, PathCache PCc, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors,
                                                      const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads,
                                                      const uint64_t* blk_read0, const uint64_t* blk_out0, uint64_t n_blocks,
                                                      uint8_t* out, uint32_t* out_len, uint32_t* scratch, uint32_t* pool,
@@ -251,15 +251,17 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc,
     __shared__ uint16_t rv16[256];
     __shared__ uint32_t models[RC_SMALL_WORDS + DC_NSLOT * RC_STRIDE];
     __shared__ uint8_t slotmap[RC_NNUM];
-    __shared__ uint32_t lstN[DC_LIST_LDS], lstE[DC_LIST_LDS];  // the first entries of the read's N / error positions (the usual read has a few)
+    __shared__ uint32_t lstN_[DC_LIST_LDS], lstE_[DC_LIST_LDS];  // the first entries of the read's N / error positions (the usual read has a few)
     load_rv16(rv16, rv16g);
+    volatile lds_u32* const lstN = (volatile lds_u32*)lstN_;
+    volatile lds_u32* const lstE = (volatile lds_u32*)lstE_;
     const uint32_t lane = lane_id(), k = B.k;
     const K kmk = kmask<K>(k);
     constexpr uint32_t W = KT<K>::W;
     const bool cache_on = PCc.slots != nullptr;
     for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         Dec d;
-        d.lane = lane; d.lds = models; d.slotmap = slotmap; d.nused = 0; d.bad = false;
+        d.lane = lane; d.lds = (lds_u32*)models; d.slotmap = slotmap; d.nused = 0; d.bad = false;
         uint32_t* blk_scratch = scratch + b * (uint64_t)((RC_NNUM - DC_NSLOT) * RC_STRIDE + 2 * DC_LIST_CAP);
         d.gmodels = blk_scratch;
         uint32_t* const Nblk = blk_scratch + (RC_NNUM - DC_NSLOT) * RC_STRIDE;
@@ -278,7 +280,8 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc,
         const uint64_t r0 = blk_read0[b];
         int fail = 0;
         Pend<K> P;
-        uint32_t n_fast = 0, n_miss = 0, n_slow = 0, n_slowjump = 0, n_jumped = 0, n_offer = 0;   // rounds by kind (stats != nullptr: measurement)
+        uint32_t n_fast = 0, n_miss = 0, n_slow = 0, n_slowjump = 0, n_jumped = 0, n_hybrid = 0;
+        unsigned long long t_head = 0, t_walk = 0, t_mark = stats ? wall_clock64() : 0;   // rounds by kind (stats != nullptr: measurement)
         auto pool_alloc = [&](uint64_t cnt) -> uint32_t* {           // wave-uniform; never freed (rare, bounded by pool_words)
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(pool_cursor, (unsigned long long)cnt);
@@ -324,7 +327,7 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc,
                 if (cntv > len) { fail = 3; break; }
                 uint32_t* gl = cntv > DC_LIST_CAP ? pool_alloc(cntv) : (l == 0 ? Nblk : Eblk);
                 if (!gl) { fail = 3; break; }
-                volatile uint32_t* ll = l == 0 ? lstN : lstE;
+                volatile lds_u32* ll = l == 0 ? lstN : lstE;
                 uint64_t pv = 0;
                 for (uint64_t i = 0; i < cntv; i++) {
                     pv += decode_numeric(d, l == 0 ? G_NPOS : G_ERRPOS);
@@ -338,10 +341,11 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc,
 
             K anchor = load_kmer<K>(anchors + addr * W);
             if (rev) anchor = revcomp(anchor, k);
+            if (stats) { const unsigned long long t = wall_clock64(); t_head += t - t_mark; t_mark = t; }
             uint8_t* s = out + w;
             if (lane < k) s[apos + lane] = bin2nt((uint32_t)(uint64_t)(anchor >> (2 * (k - 1 - lane))) & 3u);
             // entry idx of a position list: LDS for the first DC_LIST_LDS, the block's scratch (or the pool) beyond
-            auto lget = [&](const uint32_t* gl, const volatile uint32_t* ll, int64_t idx) -> uint32_t {
+            auto lget = [&](const uint32_t* gl, const volatile lds_u32* ll, int64_t idx) -> uint32_t {
                 return idx < (int64_t)DC_LIST_LDS ? ll[idx] : __hip_atomic_load(gl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
             // DnaDecoder::extendAnchor, left then right.  The position lists are ascending: the left walk consumes them
@@ -362,7 +366,7 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc,
                     ni = 0; while (ni < (int64_t)nN && lget(Npos, lstN, ni) < (uint64_t)pos) ni++;
                     ei = 0; while (ei < (int64_t)nErr && lget(Epos, lstE, ei) < (uint64_t)pos) ei++;
                 }
-                auto cur = [&](const uint32_t* gl, const volatile uint32_t* ll, int64_t idx, int64_t cnt) -> int64_t {
+                auto cur = [&](const uint32_t* gl, const volatile lds_u32* ll, int64_t idx, int64_t cnt) -> int64_t {
                     return (idx >= 0 && idx < cnt) ? (int64_t)lget(gl, ll, idx) : -1;
                 };
                 int64_t nextN = cur(Npos, lstN, ni, (int64_t)nN), nextE = cur(Epos, lstE, ei, (int64_t)nErr);
@@ -373,7 +377,6 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc,
                 K oldk = (K)(y0 >> 60);
                 uint64_t p60 = (uint64_t)y0 & PC_M60;
                 uint32_t run = 0, fresh = 0;
-                bool slow = !cache_on;                        // slow: probe the bloom; else: ask the table only
                 // One position: the decoded base goes out, the k-mer moves on by the base the GRAPH follows.
                 auto advance = [&](uint32_t res4) -> uint32_t {
                     uint32_t nt_out, nt_seed;
@@ -410,42 +413,74 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc,
                 auto succ = [&](K x, uint32_t nt) -> K {
                     return dir == 1 ? (((x << 2) | (K)nt) & kmk) : ((x >> 2) | ((K)nt << (2 * (k - 1))));
                 };
+                // Rounds.  FAST: the table's bucket for the current k-mer (one sector).  HYBRID, where the graph is expected
+                // to branch (an entry ended there, or the table had nothing): the bloom probes of the current k-mer alone,
+                // beside the buckets of its four possible successors -- the position is decided and the walk jumps on from
+                // the successor in the same round.  SLOW, where the table knows nothing yet: the probes of 1 + 4 (+ 16)
+                // k-mers -- lane 0 the current k-mer, lanes 1..4 its four possible successors, DEEP lanes 5..20 the sixteen
+                // k-mers two steps ahead (the other lanes repeat lane 0's addresses, which costs no traffic) -- so that
+                // when a position is decided, the probe of the k-mer it leads to is already there; what it learns is
+                // published.  All memory operations of a round, an insertion's compare-and-swap included, are in flight together.
+                enum : uint32_t { FAST = 0, HYBRID = 1, SLOW = 2 };
+                uint32_t mode = cache_on ? FAST : SLOW;
+                constexpr uint64_t PRE_NONE = ~0ull;
+                uint64_t pre = PRE_NONE;                      // the table's answer for the current k-mer, fetched a round early (0: not there)
                 while (pos >= 0 && pos < (int64_t)len && !d.bad) {
-                    if (pos == nextN) { (void)advance(0); continue; }                  // nothing to ask the graph
-                    // this round's memory operations, all in flight together: the table's bucket for the current k-mer, an
-                    // insertion's compare-and-swap, and (slow) the bloom probes of 1 + 4 (+ 16) k-mers -- lane 0 the current
-                    // k-mer, lanes 1..4 its four possible successors, DEEP lanes 5..20 the sixteen k-mers two steps ahead
-                    // (the other lanes repeat lane 0's addresses, which costs no traffic) -- so that when a position is
-                    // decided, the probe of the k-mer it leads to is already there.
+                    if (pos == nextN) { (void)advance(0); pre = PRE_NONE; continue; }  // nothing to ask the graph
+                    const K y = cache_on ? (dir == 1 ? kmer : revcomp(kmer, k)) : (K)0;
+                    const bool had_pre = pre != PRE_NONE;
                     uint64_t pl = 0;
-                    K y = 0;
-                    if (cache_on) {
-                        y = dir == 1 ? kmer : revcomp(kmer, k);
-                        if (lane < PCL<K>::SLOTS) {
-                            const uint64_t* sp = pc_slot<K>(PCc, key_hash(y) & PCc.bucket_mask, lane);
-                            const uint64_t k0 = pc_ld(sp), k1 = W == 2 ? pc_ld(sp + 1) : 0, v = pc_ld(sp + PCL<K>::PAY);
-                            if (k0 == (uint64_t)y && (W == 1 || k1 == (uint64_t)(y >> (W == 2 ? 64 : 0)))) pl = v;
+                    uint32_t res = 0;
+                    if (had_pre) { pl = pre; pre = PRE_NONE; }
+                    else {
+                        uint64_t plc = 0;                     // per lane: the payload of the slot it looked at, if the key is there
+                        uint32_t child = 4;
+                        if (cache_on) {
+                            K yq = y;
+                            uint32_t slot = lane;
+                            bool ask = lane < PCL<K>::SLOTS;
+                            if (mode == HYBRID) {             // lanes 4..: successor e = 0..3 of the oriented k-mer, slot by slot
+                                child = (lane - 4) / PCL<K>::SLOTS; slot = (lane - 4) % PCL<K>::SLOTS;
+                                ask = lane >= 4 && child < 4;
+                                yq = ((y << 2) | (K)(child & 3u)) & kmk;
+                            }
+                            if (ask) {
+                                const uint64_t* sp = pc_slot<K>(PCc, key_hash(yq) & PCc.bucket_mask, slot);
+                                const uint64_t k0 = pc_ld(sp), k1 = W == 2 ? pc_ld(sp + 1) : 0, v = pc_ld(sp + PCL<K>::PAY);
+                                if (k0 == (uint64_t)yq && (W == 1 || k1 == (uint64_t)(yq >> (W == 2 ? 64 : 0)))) plc = v;
+                            }
+                        }
+                        const uint32_t issued = cache_on ? pc_issue<K>(PCc, P) : 0u;
+                        if (mode != FAST) {
+                            K km = kmer;
+                            if (mode == SLOW) {
+                                if (lane >= 1 && lane <= 4) km = succ(kmer, (lane - 1) & 3u);
+                                if (DEEP && lane >= 5 && lane <= 20) km = succ(succ(kmer, ((lane - 5) >> 2) & 3u), (lane - 5) & 3u);
+                            }
+                            res = bloom_contains4<K>(B, rv16, km, revcomp(km, k), dir == 1);
+                        }
+                        if (cache_on) {
+                            if (mode == HYBRID) {
+                                n_hybrid++;
+                                const uint32_t sd = advance((uint32_t)__builtin_amdgcn_readlane((int)res, 0));
+                                const uint32_t e = dir == 1 ? sd : (sd ^ 2u);
+                                const unsigned long long hit = __ballot(plc != 0 && child == e);
+                                pre = hit ? readlane64(plc, (uint32_t)__builtin_ctzll(hit)) : 0ull;
+                                pc_retire<K>(PCc, P, issued);
+                                if (run >= PC_MAX && fresh) pc_offer<K>(PCc, P, lane, PC_MAX, PC_MAX, oldk, p60, kmk);
+                                continue;
+                            }
+                            const unsigned long long hit = __ballot(plc != 0);
+                            if (hit) pl = readlane64(plc, (uint32_t)__builtin_ctzll(hit));
+                            pc_retire<K>(PCc, P, issued);
                         }
                     }
-                    const uint32_t issued = cache_on ? pc_issue<K>(PCc, P) : 0u;
-                    uint32_t res = 0;
-                    if (slow) {
-                        K km = kmer;
-                        if (lane >= 1 && lane <= 4) km = succ(kmer, (lane - 1) & 3u);
-                        if (DEEP && lane >= 5 && lane <= 20) km = succ(succ(kmer, ((lane - 5) >> 2) & 3u), (lane - 5) & 3u);
-                        res = bloom_contains4<K>(B, rv16, km, revcomp(km, k), dir == 1);
-                    }
                     const uint64_t remaining = dir == 1 ? (uint64_t)((int64_t)len - pos) : (uint64_t)(pos + 1);
-                    uint32_t cnt = 0;
-                    uint64_t path = 0;
-                    if (cache_on) {
-                        const unsigned long long hit = __ballot(pl != 0);
-                        if (hit) { pl = readlane64(pl, (uint32_t)__builtin_ctzll(hit)); cnt = (uint32_t)(pl >> 56); path = pl & PC_M56; }
-                        pc_retire<K>(PCc, P, issued);
-                        if (cnt > PC_MAX) cnt = 0;
-                    }
-                    if (cnt != 0 && (!slow || cnt >= 3 || cnt >= remaining)) {
-                        if (slow) n_slowjump++; else n_fast++;
+                    uint32_t cnt = (uint32_t)(pl >> 56);
+                    const uint64_t path = pl & PC_M56;
+                    if (cnt > PC_MAX) cnt = 0;
+                    if (cnt != 0 && (mode != SLOW || had_pre || cnt >= 3 || cnt >= remaining)) {
+                        if (mode == SLOW && !had_pre) n_slowjump++; else n_fast++;
                         // the table knows the next cnt steps: take as many as the read has, up to its next N
                         if (fresh) pc_offer<K>(PCc, P, lane, 1, run < PC_MAX - 1 ? run : PC_MAX - 1, oldk, p60, kmk);
                         fresh = 0;
@@ -470,10 +505,11 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc,
                         oldk = ((oldk << (2 * j)) | (K)(p60 >> (60 - 2 * j))) & kmk;
                         p60 = ((p60 << (2 * j)) | pj) & PC_M60;
                         run += j; pos += step * (int64_t)j; n_jumped += j;
-                        slow = j == cnt && cnt < PC_MAX;      // the entry ended where the graph stops being a path: probe there
+                        mode = (j == cnt && cnt < PC_MAX) ? HYBRID : FAST;       // the entry ended where the graph stops being a path
                         continue;
                     }
-                    if (!slow) { slow = true; n_miss++; continue; }     // not in the table: the next round probes
+                    if (had_pre) { mode = SLOW; continue; }   // the successor is not in the table either: unknown ground, probe deep
+                    if (mode == FAST) { mode = HYBRID; n_miss++; continue; }
                     n_slow++;
                     uint32_t seed0 = 0, seed1 = 0, done = 0;
 #pragma unroll 1
@@ -489,20 +525,21 @@ __global__ void __launch_bounds__(64) k_decode_blocks(BloomDev B, PathCache PCc,
                 if (fresh) pc_offer<K>(PCc, P, lane, 1, run < PC_MAX - 1 ? run : PC_MAX - 1, oldk, p60, kmk);   // the walk's last steps
             }
             if (lane == 0) for (uint64_t i = 0; i < nN; i++) {                                       // also inside the anchor
-                const uint32_t q = i < DC_LIST_LDS ? ((volatile uint32_t*)lstN)[i] : __hip_atomic_load(Npos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t q = i < DC_LIST_LDS ? lstN[i] : __hip_atomic_load(Npos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (q < len) s[q] = 'N';
             }
             if (lane == 0) out_len[r0 + r] = (uint32_t)len;
             w += len;
+            if (stats) { const unsigned long long t = wall_clock64(); t_walk += t - t_mark; t_mark = t; }
         }
         if (!fail && d.bad) fail = 4;
         if (!fail && w != wcap) fail = 2;                    // the block table promised exactly wcap - blk_out0[b] bases
         if (fail && lane == 0) { if (atomicCAS(err, 0, fail) == 0) err[1] = (int)b; }
         if (stats && lane == 0) {
             atomicAdd(stats + 0, n_fast); atomicAdd(stats + 1, n_miss); atomicAdd(stats + 2, n_slow); atomicAdd(stats + 3, n_slowjump);
-            atomicAdd(stats + 4, n_jumped); atomicAdd(stats + 5, (unsigned long long)blk_reads[b]);
+            atomicAdd(stats + 4, n_jumped); atomicAdd(stats + 5, (unsigned long long)blk_reads[b]); atomicAdd(stats + 6, n_hybrid);
+            atomicAdd(stats + 7, t_head); atomicAdd(stats + 8, t_walk);
         }
-        (void)n_offer;
     }
 }
 

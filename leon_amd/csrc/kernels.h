@@ -115,6 +115,6 @@ void launch_decode_blocks(hipStream_t s, BloomDev B, PathCache C, const uint16_t
                           const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads, const uint64_t* blk_read0,
                           const uint64_t* blk_out0, uint64_t n_blocks, uint8_t* out, uint32_t* out_len, uint32_t* scratch,
                           uint32_t* pool, unsigned long long* pool_cursor, uint64_t pool_words, int* err,
-                          unsigned long long* stats /* nullptr, or 8 counters of rounds by kind (LEON_TRACE_DECODE) */);
+                          unsigned long long* stats /* nullptr, or 16 counters: rounds by kind, time by part (LEON_TRACE_DECODE) */);
 
 }  // namespace leon
