@@ -301,12 +301,20 @@ def main():
         t1 = time.perf_counter()
         out_bases, out_lens = ctx.decode_blocks_raw(anchors, kept, [b[2] * L for b in kept])
         t2 = time.perf_counter()
-        same = bool(np.array_equal(out_bases, reads.cpu().numpy().reshape(-1))) and bool(np.all(out_lens == L))
+        ref = reads.cpu().numpy().reshape(-1)
+        same = bool(np.array_equal(out_bases, ref)) and bool(np.all(out_lens == L))
+        del out_bases, out_lens
+        # a second call on the same context: the decoder's path cache already holds what the first call learnt from the bloom
+        t2b = time.perf_counter()
+        out_bases, out_lens = ctx.decode_blocks_raw(anchors, kept, [b[2] * L for b in kept])
+        t3 = time.perf_counter()
+        same = same and bool(np.array_equal(out_bases, ref)) and bool(np.all(out_lens == L))
         decode = {"value": round(n_total * L / 1e6 / (t2 - t0), 1), "unit": "MB/s", "dictionary_s": round(t1 - t0, 2),
-                  "blocks_s": round(t2 - t1, 2), "blocks_MBps": round(n_total * L / 1e6 / (t2 - t1), 1), "equals_input": same,
-                  "what": "leon_host_anchor_dict_decode (one host core) then leon_dna_decode_blocks (one wave per block), "
-                          "payloads in host memory, bases back in host memory"}
-        del kept, out_bases, out_lens
+                  "blocks_s": round(t2 - t1, 2), "blocks_MBps": round(n_total * L / 1e6 / (t2 - t1), 1),
+                  "blocks_s_second_call": round(t3 - t2b, 2), "equals_input": same,
+                  "what": "leon_host_anchor_dict_decode (one host core) then leon_dna_decode_blocks (one wave per block, path cache "
+                          "in HBM), payloads in host memory, bases back in host memory"}
+        del kept, out_bases, out_lens, ref
 
     streams = None
     if a.streams and world == 1:

@@ -1111,6 +1111,7 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     const uint64_t pool_words = std::min<uint64_t>(std::max<uint64_t>(out0[n_blocks] / 2, 1ull << 20), 1ull << 28);
     HIPCHK(c, d_pool.ensure(pool_words * 4 + 16));
     lap("buffers");
+    bool cache_is_new = false;
     // The path cache: a few bytes per solid k-mer, kept from call to call for as long as the bloom's bits stay what they
     // were (their fingerprint is taken again at every call: 0.3 ms for a gigabyte).  4 slots per k-mer the bloom was sized
     // for (two orientations, half full), at most 40 % of the free memory; LEON_DC_CACHE_MB overrides (0: no cache).
@@ -1137,7 +1138,7 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
                 if (c->dc_cache.ensure(buckets * 64) != hipSuccess) { (void)hipGetLastError(); c->dc_pc = PathCache{}; buckets = 0; }   // no room: decode without it
                 else { c->dc_pc.slots = c->dc_cache.as<uint64_t>(); c->dc_pc.bucket_mask = buckets - 1; }
             }
-            if (buckets) { launch_path_cache_init(s, c->dc_pc, c->cfg.kmer_size); c->dc_bloom_fp = fp; c->dc_filled = true; }
+            if (buckets) { launch_path_cache_init(s, c->dc_pc, c->cfg.kmer_size); c->dc_bloom_fp = fp; c->dc_filled = true; cache_is_new = true; }
         }
     }
     lap("path cache");
@@ -1153,6 +1154,12 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     HIPCHK(c, hipMemsetAsync(d_err.p, 0, 256, s));
     HIPCHK(c, hipMemsetAsync((uint8_t*)d_pool.p + pool_words * 4, 0, 16, s));           // the pool's cursor lives behind it
     lap("payloads to the device");
+    if (cache_is_new) {                                       // what the bloom says around every anchor, before the blocks ask (decode_kernels.hip)
+        static const char* pw = getenv("LEON_DC_PREWALK");    // measurement override: steps per anchor and orientation, 0 = none
+        const uint32_t steps = pw ? (uint32_t)std::max(0, atoi(pw)) : 64u;
+        if (steps) launch_path_cache_prewalk(s, c->B, c->dc_pc, c->d_rv16, d_anchors.as<uint64_t>(), n_anchors, steps);
+        lap("path cache: walks from the anchors");
+    }
     launch_decode_blocks(s, c->B, c->dc_pc, c->d_rv16, d_anchors.as<uint64_t>(), n_anchors, d_pay.as<uint8_t>(), d_off.as<uint64_t>(),
                          d_nreads.as<uint32_t>(), d_read0.as<uint64_t>(), d_out0.as<uint64_t>(), n_blocks, d_out.as<uint8_t>(),
                          d_len.as<uint32_t>(), d_scr.as<uint32_t>(), d_pool.as<uint32_t>(),

@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // values from the payload: compared without sums that could wrap (a crafted delta of type 2 makes them ~2^64)
             if (!len_fits(len, w, wcap)) { fail = 2; break; }
             if (addr >= n_anchors || !anchor_fits(apos, len, k)) { fail = 1; break; }
+            K anchor = load_kmer<K>(anchors + addr * W);      // (asked for here: it arrives while the position lists are decoded)
             // N positions, then the positions of the recorded sequencing errors
             uint64_t nN = 0, nErr = 0;
             uint32_t *Npos = Nblk, *Epos = Eblk;
@@ -339,7 +340,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 
-            K anchor = load_kmer<K>(anchors + addr * W);
             if (rev) anchor = revcomp(anchor, k);
             if (stats) { const unsigned long long t = wall_clock64(); t_head += t - t_mark; t_mark = t; }
             uint8_t* s = out + w;
@@ -541,6 +541,63 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             atomicAdd(stats + 7, t_head); atomicAdd(stats + 8, t_walk);
         }
     }
+}
+
+// Before the blocks: what the bloom says around every anchor.  One lane per (anchor, orientation) follows the graph to the
+// right for as long as there is exactly one solid successor (at most max_steps) and publishes what a decoding wave would
+// have learnt there -- the k-mer 28 steps back with its 28 bases at every step, the last k-mers with the shorter paths that
+// lead up to the stop at the end.  Anchors sit every few dozen bases of the genome in both orientations, so the decoding
+// waves find most of their ground already known and the probe rounds they are left with are those beyond a branch.
+// Massively parallel (25 M lanes at 100 M reads), so its own insertions simply wait for their answers.
+template <typename K> __device__ inline void pc_insert_now(const PathCache& C, K key, uint64_t pay) {
+    const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> (KT<K>::W == 2 ? 64 : 0));
+    if (lo == PC_EMPTY) return;
+    const uint64_t bucket = key_hash(key) & C.bucket_mask;
+    for (uint32_t tr = 0; tr < PCL<K>::SLOTS; tr++) {
+        uint64_t* sp = pc_slot<K>(C, bucket, tr);
+        const uint64_t old = pc_cas(sp, PC_EMPTY, lo);
+        if (old == PC_EMPTY) { if (KT<K>::W == 2) pc_st(sp + 1, hi); pc_max(sp + PCL<K>::PAY, pay); return; }
+        if (old == lo) {
+            if (KT<K>::W == 1) { pc_max(sp + PCL<K>::PAY, pay); return; }
+            const uint64_t h = pc_ld(sp + 1);
+            if (h == hi) { pc_max(sp + PCL<K>::PAY, pay); return; }
+            if (h == PC_EMPTY) return;                       // its writer is between its two stores
+        }
+    }
+}
+template <typename K>
+__global__ void __launch_bounds__(256) k_pc_prewalk(BloomDev B, PathCache C, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors, uint32_t max_steps) {
+    __shared__ uint16_t rv16[256];
+    load_rv16(rv16, rv16g);
+    const uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (idx >= 2 * n_anchors) return;
+    const uint32_t k = B.k;
+    const K kmk = kmask<K>(k);
+    K y = load_kmer<K>(anchors + (idx >> 1) * KT<K>::W) & kmk;
+    K rc = revcomp(y, k);
+    if (idx & 1) { const K t = y; y = rc; rc = t; }
+    K oldk = (K)(y >> 60);
+    uint64_t p60 = (uint64_t)y & PC_M60;
+    uint32_t run = 0;
+    for (uint32_t s = 0; s < max_steps; s++) {
+        const uint32_t res4 = bloom_contains4<K>(B, rv16, y, rc, true);
+        if (__popc(res4) != 1) break;
+        const uint32_t e = (uint32_t)__builtin_ctz(res4);
+        y = ((y << 2) | (K)e) & kmk;
+        rc = (rc >> 2) | ((K)(e ^ 2u) << (2 * (k - 1)));
+        oldk = ((oldk << 2) | (K)((p60 >> 58) & 3u)) & kmk;
+        p60 = ((p60 << 2) | e) & PC_M60;
+        run++;
+        if (run >= PC_MAX) pc_insert_now<K>(C, ((oldk << 4) | (K)(p60 >> 56)) & kmk, ((uint64_t)PC_MAX << 56) | (p60 & PC_M56));
+    }
+    for (uint32_t d = run < PC_MAX - 1 ? run : PC_MAX - 1; d >= 1; d--)
+        pc_insert_now<K>(C, ((oldk << (2 * (PC_REG - d))) | (K)(p60 >> (2 * d))) & kmk, ((uint64_t)d << 56) | (p60 & ((1ull << (2 * d)) - 1)));
+}
+void launch_path_cache_prewalk(hipStream_t s, BloomDev B, PathCache C, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors, uint32_t max_steps) {
+    if (!C.slots || !n_anchors) return;
+    const uint64_t nb = (2 * n_anchors + 255) / 256;
+    if (B.k >= 32) hipLaunchKernelGGL(k_pc_prewalk<u128>, dim3((uint32_t)nb), dim3(256), 0, s, B, C, rv16, anchors, n_anchors, max_steps);
+    else hipLaunchKernelGGL(k_pc_prewalk<uint64_t>, dim3((uint32_t)nb), dim3(256), 0, s, B, C, rv16, anchors, n_anchors, max_steps);
 }
 
 size_t path_cache_slot_bytes(uint32_t k) { return k >= 32 ? 32 : 16; }

@@ -109,6 +109,7 @@ void launch_qual_smooth(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* r
 struct PathCache { uint64_t* slots; uint64_t bucket_mask; };          // slots == nullptr: off
 size_t path_cache_slot_bytes(uint32_t k);
 void launch_path_cache_init(hipStream_t s, PathCache C, uint32_t k);
+void launch_path_cache_prewalk(hipStream_t s, BloomDev B, PathCache C, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors, uint32_t max_steps);
 void launch_bloom_fingerprint(hipStream_t s, const uint8_t* bits, uint64_t n_bytes, uint64_t* d_sum /* zeroed by the caller */);
 size_t decode_scratch_bytes(uint64_t n_blocks);
 void launch_decode_blocks(hipStream_t s, BloomDev B, PathCache C, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors,
