@@ -58,7 +58,7 @@ __device__ inline uint32_t next_byte(Dec& d) {
 __device__ inline uint32_t tld(const uint32_t* t, uint32_t idx) { return __hip_atomic_load(t + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline uint32_t tld(const lds_u32* t, uint32_t idx) { return ((const volatile lds_u32*)t)[idx]; }
 __device__ inline void tinc(uint32_t* t, uint32_t idx) { (void)__hip_atomic_fetch_add(t + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline void tinc(lds_u32* t, uint32_t idx) { ((volatile lds_u32*)t)[idx] = ((volatile lds_u32*)t)[idx] + 1; }
+__device__ inline void tinc(lds_u32* t, uint32_t idx) { (void)__hip_atomic_fetch_add(t + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_add_u32
 
 // floor(x / d) for d < 2^31: two rounds of a double-precision estimate (the generic 64-bit division is ~150 instructions
 // on this chain), then an exact fix-up.  The reciprocal is the correctly rounded one (v_rcp_f64 alone is good to ~2^-26
@@ -233,6 +233,21 @@ template <typename K> __device__ inline void pc_offer(const PathCache& C, Pend<K
     }
 }
 
+// a bucket look-up, split in two so that the answer can be asked for early and read late: every asking lane looks at one slot
+template <typename K> __device__ inline uint64_t pc_ask(const PathCache& C, K yq, uint32_t slot, bool ask) {
+    uint64_t v = 0;
+    if (ask) {
+        const uint64_t* sp = pc_slot<K>(C, key_hash(yq) & C.bucket_mask, slot);
+        const uint64_t k0 = pc_ld(sp), k1 = KT<K>::W == 2 ? pc_ld(sp + 1) : 0, pv = pc_ld(sp + PCL<K>::PAY);
+        if (k0 == (uint64_t)yq && (KT<K>::W == 1 || k1 == (uint64_t)(yq >> (KT<K>::W == 2 ? 64 : 0)))) v = pv;
+    }
+    return v;
+}
+__device__ inline uint64_t pc_pick(uint64_t plc, bool mine) {         // the payload some lane found (wave-uniform), 0 if none did
+    const unsigned long long hit = __ballot(plc != 0 && mine);
+    return hit ? readlane64(plc, (uint32_t)__builtin_ctzll(hit)) : 0ull;
+}
+
 __global__ void k_pc_init(uint64_t* slots, uint64_t n_words, uint32_t words_per_slot, uint32_t pay) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t w = (uint32_t)(i % words_per_slot);
@@ -314,11 +329,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 else if (f == 1) { apos = from_delta(dt, prevPos, dv); prevPos = apos; }
                 else { addr = from_delta(dt, prevAddr, dv); prevAddr = addr; }
             }
-            const uint32_t rev = decode_small(d, M_ANCHOR_REVCOMP);
             // values from the payload: compared without sums that could wrap (a crafted delta of type 2 makes them ~2^64)
             if (!len_fits(len, w, wcap)) { fail = 2; break; }
             if (addr >= n_anchors || !anchor_fits(apos, len, k)) { fail = 1; break; }
-            K anchor = load_kmer<K>(anchors + addr * W);      // (asked for here: it arrives while the position lists are decoded)
+            K anchor = load_kmer<K>(anchors + addr * W);      // (asked for here: it arrives under the next symbol)
+            const uint32_t rev = decode_small(d, M_ANCHOR_REVCOMP);
+            if (rev) anchor = revcomp(anchor, k);
+            // both walks start at the anchor: their first buckets are asked for now and read when the walks begin, after the lists
+            uint64_t plc_walk[2] = {0, 0};
+            if (cache_on) {
+                plc_walk[0] = pc_ask<K>(PCc, revcomp(anchor, k), lane, lane < PCL<K>::SLOTS && apos > 0);
+                plc_walk[1] = pc_ask<K>(PCc, anchor, lane, lane < PCL<K>::SLOTS && apos + k < len);
+            }
             // N positions, then the positions of the recorded sequencing errors
             uint64_t nN = 0, nErr = 0;
             uint32_t *Npos = Nblk, *Epos = Eblk;
@@ -340,7 +362,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 
-            if (rev) anchor = revcomp(anchor, k);
             if (stats) { const unsigned long long t = wall_clock64(); t_head += t - t_mark; t_mark = t; }
             uint8_t* s = out + w;
             if (lane < k) s[apos + lane] = bin2nt((uint32_t)(uint64_t)(anchor >> (2 * (k - 1 - lane))) & 3u);
@@ -424,7 +445,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 enum : uint32_t { FAST = 0, HYBRID = 1, SLOW = 2 };
                 uint32_t mode = cache_on ? FAST : SLOW;
                 constexpr uint64_t PRE_NONE = ~0ull;
-                uint64_t pre = PRE_NONE;                      // the table's answer for the current k-mer, fetched a round early (0: not there)
+                // the table's answer for the current k-mer when it was asked for ahead of time (0: not there)
+                uint64_t pre = cache_on && pos >= 0 && pos < (int64_t)len ? pc_pick(dir == 0 ? plc_walk[0] : plc_walk[1], true) : PRE_NONE;
                 while (pos >= 0 && pos < (int64_t)len && !d.bad) {
                     if (pos == nextN) { (void)advance(0); pre = PRE_NONE; continue; }  // nothing to ask the graph
                     const K y = cache_on ? (dir == 1 ? kmer : revcomp(kmer, k)) : (K)0;
@@ -436,19 +458,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         uint64_t plc = 0;                     // per lane: the payload of the slot it looked at, if the key is there
                         uint32_t child = 4;
                         if (cache_on) {
-                            K yq = y;
-                            uint32_t slot = lane;
-                            bool ask = lane < PCL<K>::SLOTS;
                             if (mode == HYBRID) {             // lanes 4..: successor e = 0..3 of the oriented k-mer, slot by slot
-                                child = (lane - 4) / PCL<K>::SLOTS; slot = (lane - 4) % PCL<K>::SLOTS;
-                                ask = lane >= 4 && child < 4;
-                                yq = ((y << 2) | (K)(child & 3u)) & kmk;
-                            }
-                            if (ask) {
-                                const uint64_t* sp = pc_slot<K>(PCc, key_hash(yq) & PCc.bucket_mask, slot);
-                                const uint64_t k0 = pc_ld(sp), k1 = W == 2 ? pc_ld(sp + 1) : 0, v = pc_ld(sp + PCL<K>::PAY);
-                                if (k0 == (uint64_t)yq && (W == 1 || k1 == (uint64_t)(yq >> (W == 2 ? 64 : 0)))) plc = v;
-                            }
+                                child = (lane - 4) / PCL<K>::SLOTS;
+                                plc = pc_ask<K>(PCc, ((y << 2) | (K)(child & 3u)) & kmk, (lane - 4) % PCL<K>::SLOTS, lane >= 4 && child < 4);
+                            } else plc = pc_ask<K>(PCc, y, lane, lane < PCL<K>::SLOTS);
                         }
                         const uint32_t issued = cache_on ? pc_issue<K>(PCc, P) : 0u;
                         if (mode != FAST) {
@@ -464,14 +477,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                 n_hybrid++;
                                 const uint32_t sd = advance((uint32_t)__builtin_amdgcn_readlane((int)res, 0));
                                 const uint32_t e = dir == 1 ? sd : (sd ^ 2u);
-                                const unsigned long long hit = __ballot(plc != 0 && child == e);
-                                pre = hit ? readlane64(plc, (uint32_t)__builtin_ctzll(hit)) : 0ull;
+                                pre = pc_pick(plc, child == e);
                                 pc_retire<K>(PCc, P, issued);
                                 if (run >= PC_MAX && fresh) pc_offer<K>(PCc, P, lane, PC_MAX, PC_MAX, oldk, p60, kmk);
                                 continue;
                             }
-                            const unsigned long long hit = __ballot(plc != 0);
-                            if (hit) pl = readlane64(plc, (uint32_t)__builtin_ctzll(hit));
+                            pl = pc_pick(plc, true);
                             pc_retire<K>(PCc, P, issued);
                         }
                     }
@@ -488,6 +499,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         if (nextN >= 0) { const uint64_t dN = (uint64_t)(dir == 1 ? nextN - pos : pos - nextN); if (dN < jj) jj = dN; }
                         const uint32_t j = (uint32_t)jj;      // >= 1: pos is not an N position here
                         const uint64_t pj = path >> (2 * (cnt - j));
+                        const K yn = ((y << (2 * j)) | (K)pj) & kmk;
+                        // a whole entry taken and the read goes on: the next bucket is asked for now and read after this jump's bookkeeping
+                        const bool ahead = j == PC_MAX && j < remaining;
+                        const uint64_t plc_next = ahead ? pc_ask<K>(PCc, yn, lane, lane < PCL<K>::SLOTS) : 0ull;
                         uint32_t ovr = 0xFFu;                 // a recorded error inside the jump: its base comes from the stream, in walk order
                         while (nextE >= 0 && !d.bad) {
                             const uint64_t tE = (uint64_t)(dir == 1 ? nextE - pos : pos - nextE);
@@ -500,15 +515,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             const uint32_t c = (uint32_t)(pj >> (2 * (j - 1 - lane))) & 3u;
                             s[pos + step * (int64_t)lane] = bin2nt(ovr != 0xFFu ? ovr : (dir == 1 ? c : (c ^ 2u)));
                         }
-                        const K yn = ((y << (2 * j)) | (K)pj) & kmk;
                         kmer = dir == 1 ? yn : revcomp(yn, k);
                         oldk = ((oldk << (2 * j)) | (K)(p60 >> (60 - 2 * j))) & kmk;
                         p60 = ((p60 << (2 * j)) | pj) & PC_M60;
                         run += j; pos += step * (int64_t)j; n_jumped += j;
                         mode = (j == cnt && cnt < PC_MAX) ? HYBRID : FAST;       // the entry ended where the graph stops being a path
+                        if (ahead) pre = pc_pick(plc_next, true);
                         continue;
                     }
-                    if (had_pre) { mode = SLOW; continue; }   // the successor is not in the table either: unknown ground, probe deep
+                    if (had_pre) { mode = mode == HYBRID ? SLOW : HYBRID; continue; }   // (after a one-k-mer round: the successor is not in the table either -- unknown ground, probe deep)
                     if (mode == FAST) { mode = HYBRID; n_miss++; continue; }
                     n_slow++;
                     uint32_t seed0 = 0, seed1 = 0, done = 0;
