@@ -15,6 +15,7 @@
 #include "bank.hpp"
 #include "leon_container.hpp"
 
+#include <fcntl.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -461,29 +462,98 @@ void Leon::executeDecompression() {
     std::string stem = _inputFilename;
     if (ends_with(stem, ".leon")) stem.resize(stem.size() - 5);
     _outputFilename = stem + ".d";
-    std::ofstream o(_outputFilename, std::ios::binary);
-    if (!o) throw Exception("cannot write " + _outputFilename);
+    struct Fd {
+        int fd = -1; std::string path; bool keep = false;
+        ~Fd() { if (fd >= 0) ::close(fd); if (!keep && !path.empty()) std::remove(path.c_str()); }     // a failed run leaves no partial output behind
+    } ofd;
+    ofd.fd = ::open(_outputFilename.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (ofd.fd < 0) throw Exception("cannot write " + _outputFilename);
+    ofd.path = _outputFilename;
     const bool fastq_out = !fasta_in && has_qual;               // "-noqual ... will decompress to fasta"
     const uint64_t wrap = fasta_in ? params[P_FASTA_LINE_WIDTH] : 0;      // sequences wrapped at this width in the original (0: one line)
     const char lead = fastq_out ? '@' : '>';
 
     // Blocks decoded per round.  A round costs the device ONE block's serial chain whatever the number of blocks in it (up to
-    // a few thousand: one wave per block), so rounds should be as large as the host's memory allows: bases, qualities and the
-    // formatted text of a round are ~5 bytes per base; a quarter of the available RAM is given to them.
+    // a few thousand: one wave per block), so rounds should be large; two are alive at a time (one being decoded, the one
+    // before it being formatted and written), each ~5 bytes per base in bases, qualities and text: an eighth of the available
+    // RAM each.  Files of more than a few hundred blocks are cut into at least four rounds, so that the host's share of the
+    // work (header and quality blocks, formatting, writing) of one round runs beside the decoding of the next.
     uint64_t group = n_blocks ? n_blocks : 1;
     {
         const long pages = sysconf(_SC_AVPHYS_PAGES), page = sysconf(_SC_PAGESIZE);
         const uint64_t avail = pages > 0 && page > 0 ? (uint64_t)pages * (uint64_t)page : (8ull << 30);
         const uint64_t bases_per_block = n_blocks ? std::max<uint64_t>(total_bases / n_blocks, 1) : 1;
-        const uint64_t fit = avail / 4 / 5 / bases_per_block;
+        const uint64_t fit = avail / 8 / 5 / bases_per_block;
         group = std::min<uint64_t>(group, std::max<uint64_t>(fit, 64));
+        if (n_blocks >= 800) group = std::min<uint64_t>(group, (n_blocks + 3) / 4);
         if (const char* e = getenv("LEON_DECODE_BLOCKS")) { const long v = atol(e); if (v > 0) group = (uint64_t)v; }   // (tests: several rounds on a small file)
     }
-    std::unique_ptr<char[]> text;                                // the round's records (never zero-filled)
+    const uint32_t cores = (uint32_t)_nbCores;
+    const uint32_t n_cpu = (uint32_t)(_nbCores > 0 ? (uint64_t)_nbCores : usableCpus());
+    // what one round hands from the decoding stage to the writing stage
+    struct Round {
+        uint64_t read_index = 0, file_off = 0, g_reads = 0, g_bases = 0, n_text = 0;
+        std::vector<uint8_t> bases, hdr, qual;
+        std::vector<uint32_t> lens;
+        std::vector<uint64_t> hdr_off, qual_off;
+    };
+    std::unique_ptr<char[]> text;                                // the writing stage's records (never zero-filled)
     uint64_t text_cap = 0;
-    uint64_t read_index = 0, bases_out = 0;
-    double t_read = 0, t_dna = 0, t_hdr = 0, t_qual = 0, t_text = 0, t_write = 0, t_wait = 0;
+    double t_read = 0, t_dna = 0, t_hdr = 0, t_qual = 0, t_text = 0, t_write = 0, t_wait = 0, t_writer_wait = 0;
     auto lap = [](std::chrono::steady_clock::time_point& t, double& acc) { const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(n - t).count(); t = n; };
+    // the writing stage: every read's place in the text is known from the lengths, so a round is formatted by all cores at
+    // once and written by several (pwrite at disjoint offsets)
+    auto write_round = [&](std::shared_ptr<Round> R) {
+        auto tl = std::chrono::steady_clock::now();
+        const uint64_t g_reads = R->g_reads;
+        std::vector<uint64_t> rec_off(g_reads + 1, 0), base_at(g_reads + 1, 0);
+        auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
+        for (uint64_t r = 0; r < g_reads; r++) {
+            const uint64_t hl = has_header ? R->hdr_off[r + 1] - R->hdr_off[r] : std::to_string(R->read_index + r).size();
+            if (fastq_out && R->qual_off[r + 1] - R->qual_off[r] != R->lens[r]) throw Exception(_inputFilename + ": a read's quality and sequence lengths differ");
+            rec_off[r + 1] = rec_off[r] + 1 + hl + 1 + seq_text_len(R->lens[r]) + (fastq_out ? 2 + (uint64_t)R->lens[r] + 1 : 0);
+            base_at[r + 1] = base_at[r] + R->lens[r];
+        }
+        const uint64_t n_text = rec_off[g_reads];
+        if (n_text != R->n_text) throw Exception(_inputFilename + ": the decoded reads do not add up to their blocks' sizes");
+        if (n_text > text_cap) { text.reset(); text_cap = n_text + n_text / 16; text.reset(new char[text_cap]); }
+        const uint32_t n_fmt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_cpu, g_reads / 4096 + 1));
+        std::mutex err_mu;
+        std::string werr;
+        auto format_range = [&](uint64_t ra, uint64_t rb) {
+            for (uint64_t r = ra; r < rb; r++) {
+                char* w = text.get() + rec_off[r];
+                *w++ = lead;
+                if (has_header) { const uint64_t hl = R->hdr_off[r + 1] - R->hdr_off[r]; memcpy(w, R->hdr.data() + R->hdr_off[r], hl); w += hl; }
+                else { const std::string idx = std::to_string(R->read_index + r); memcpy(w, idx.data(), idx.size()); w += idx.size(); }
+                *w++ = '\n';
+                const char* seq = reinterpret_cast<const char*>(R->bases.data()) + base_at[r];
+                const uint64_t len = R->lens[r];
+                if (wrap && len > wrap) {
+                    for (uint64_t o2 = 0; o2 < len; o2 += wrap) { const uint64_t m = std::min<uint64_t>(wrap, len - o2); memcpy(w, seq + o2, m); w += m; *w++ = '\n'; }
+                } else { memcpy(w, seq, len); w += len; *w++ = '\n'; }
+                if (fastq_out) { *w++ = '+'; *w++ = '\n'; memcpy(w, R->qual.data() + R->qual_off[r], len); w += len; *w++ = '\n'; }
+            }
+            // this thread's share of the text goes out as soon as it is formatted
+            uint64_t at = rec_off[ra];
+            const uint64_t end = rec_off[rb];
+            while (at < end) {
+                const ssize_t got = ::pwrite(ofd.fd, text.get() + at, (size_t)std::min<uint64_t>(end - at, 1ull << 30), (off_t)(R->file_off + at));
+                if (got <= 0) { std::lock_guard<std::mutex> g(err_mu); werr = "cannot write " + _outputFilename; return; }
+                at += (uint64_t)got;
+            }
+        };
+        if (n_fmt <= 1) format_range(0, g_reads);
+        else {
+            std::vector<std::thread> th;
+            for (uint32_t t = 0; t < n_fmt; t++) th.emplace_back(format_range, g_reads * t / n_fmt, g_reads * (t + 1) / n_fmt);
+            for (auto& t : th) t.join();
+        }
+        if (!werr.empty()) throw Exception(werr);
+        lap(tl, t_text);
+    };
+    std::future<void> writer;
+    uint64_t read_index = 0, bases_out = 0, file_off = 0;
     for (uint64_t g0 = 0; g0 < n_blocks; g0 += group) {
         const uint64_t g1 = std::min(n_blocks, g0 + group), nb = g1 - g0;
         auto gather = [&](const char* grp, const std::vector<uint64_t>& tab, uint32_t stride, std::vector<uint8_t>& pay, std::vector<uint64_t>& off) {
@@ -496,100 +566,88 @@ void Leon::executeDecompression() {
                 if (!blk.empty()) memcpy(pay.data() + off[b], blk.data(), blk.size());
             }
         };
+        auto R = std::make_shared<Round>();
         std::vector<uint8_t> pay; std::vector<uint64_t> off;
         std::vector<uint32_t> blk_reads(nb); std::vector<uint64_t> blk_bases(nb);
         uint64_t g_reads = 0, g_bases = 0;
         for (uint64_t b = 0; b < nb; b++) { blk_reads[b] = (uint32_t)tdna[3 * (g0 + b) + 1]; blk_bases[b] = tdna[3 * (g0 + b) + 2]; g_reads += blk_reads[b]; g_bases += blk_bases[b]; }
+        R->read_index = read_index; R->file_off = file_off; R->g_reads = g_reads; R->g_bases = g_bases;
         // the three streams' payloads of the round, then: header and quality blocks on the host threads WHILE the device
-        // decodes the DNA blocks
+        // decodes the DNA blocks (and while the round before is being formatted and written)
         auto tl = std::chrono::steady_clock::now();
         std::vector<uint8_t> pay_h, pay_q; std::vector<uint64_t> off_h, off_q;
         gather(GROUP_DNA, tdna, 3, pay, off);
         if (has_header) gather(GROUP_HEADER, thdr, 2, pay_h, off_h);
         if (fastq_out) gather(GROUP_QUAL, tqual, 3, pay_q, off_q);
         lap(tl, t_read);
-        std::vector<uint8_t> hdr; std::vector<uint64_t> hdr_off(g_reads + 1, 0);
-        std::vector<uint8_t> qual; std::vector<uint64_t> qual_off(g_reads + 1, 0);
+        R->hdr_off.assign(g_reads + 1, 0); R->qual_off.assign(g_reads + 1, 0);
         double host_hdr_s = 0, host_qual_s = 0;
-        const uint32_t cores = (uint32_t)_nbCores;
         std::future<void> host_job = std::async(std::launch::async, [&] {
             auto th = std::chrono::steady_clock::now();
             if (has_header) {
                 uint64_t need = 0;
-                hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
-                int rc = leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), hdr.data(), hdr.size(),
-                                                        hdr_off.data(), &need, cores);
+                R->hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
+                int rc = leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(), R->hdr.size(),
+                                                        R->hdr_off.data(), &need, cores);
                 if (rc == LEON_E_OVERFLOW) {
-                    hdr.resize(need + 1);
-                    rc = leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), hdr.data(), hdr.size(),
-                                                        hdr_off.data(), &need, cores);
+                    R->hdr.resize(need + 1);
+                    rc = leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(), R->hdr.size(),
+                                                        R->hdr_off.data(), &need, cores);
                 }
                 if (rc != LEON_OK) throw Exception(std::string("leon_host_header_decode_blocks: ") + leon_last_error(nullptr));
             }
             lap(th, host_hdr_s);
             if (fastq_out) {
-                qual.resize(g_bases + 1);
-                if (leon_host_qual_decode_blocks(pay_q.data(), off_q.data(), blk_reads.data(), blk_bases.data(), nb, qual.data(), g_bases, qual_off.data(), cores) != LEON_OK)
+                R->qual.resize(g_bases + 1);
+                if (leon_host_qual_decode_blocks(pay_q.data(), off_q.data(), blk_reads.data(), blk_bases.data(), nb, R->qual.data(), g_bases, R->qual_off.data(), cores) != LEON_OK)
                     throw Exception(std::string("leon_host_qual_decode_blocks: ") + leon_last_error(nullptr));
             }
             lap(th, host_qual_s);
         });
-        std::vector<uint8_t> bases(g_bases + 1); std::vector<uint32_t> lens(g_reads + 1);
+        R->bases.resize(g_bases + 1); R->lens.resize(g_reads + 1);
         std::string dna_error;
         try {
             if (dict_job.valid()) dict_job.get();
-            check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, bases.data(), g_bases,
-                                                    lens.data()), "leon_dna_decode_blocks");
+            check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, R->bases.data(), g_bases,
+                                                    R->lens.data()), "leon_dna_decode_blocks");
         } catch (const std::exception& e) { dna_error = e.what(); }
         lap(tl, t_dna);
-        host_job.get();                                          // (joins the host task before anything it references goes away; rethrows its error)
-        if (!dna_error.empty()) throw Exception(dna_error);
+        try { host_job.get(); }                                  // (joins the host task before anything it references goes away)
+        catch (const std::exception& e) { if (writer.valid()) { try { writer.get(); } catch (...) {} } throw Exception(e.what()); }
+        if (!dna_error.empty()) { if (writer.valid()) { try { writer.get(); } catch (...) {} } throw Exception(dna_error); }
         lap(tl, t_wait);
         t_hdr += host_hdr_s; t_qual += host_qual_s;
-        // records: every read's place in the text is known from the lengths, so the round is formatted by all cores at once
-        std::vector<uint64_t> rec_off(g_reads + 1, 0), base_at(g_reads + 1, 0);
-        auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
-        for (uint64_t r = 0; r < g_reads; r++) {
-            const uint64_t hl = has_header ? hdr_off[r + 1] - hdr_off[r] : std::to_string(read_index + r).size();
-            if (fastq_out && qual_off[r + 1] - qual_off[r] != lens[r]) throw Exception(_inputFilename + ": a read's quality and sequence lengths differ");
-            rec_off[r + 1] = rec_off[r] + 1 + hl + 1 + seq_text_len(lens[r]) + (fastq_out ? 2 + (uint64_t)lens[r] + 1 : 0);
-            base_at[r + 1] = base_at[r] + lens[r];
-        }
-        if (rec_off[g_reads] > text_cap) { text.reset(); text_cap = rec_off[g_reads] + rec_off[g_reads] / 16; text.reset(new char[text_cap]); }
-        const uint32_t n_fmt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(_nbCores > 0 ? (uint64_t)_nbCores : usableCpus(), g_reads / 4096 + 1));
-        auto format_range = [&](uint64_t ra, uint64_t rb) {
-            for (uint64_t r = ra; r < rb; r++) {
-                char* w = text.get() + rec_off[r];
-                *w++ = lead;
-                if (has_header) { const uint64_t hl = hdr_off[r + 1] - hdr_off[r]; memcpy(w, hdr.data() + hdr_off[r], hl); w += hl; }
-                else { const std::string idx = std::to_string(read_index + r); memcpy(w, idx.data(), idx.size()); w += idx.size(); }
-                *w++ = '\n';
-                const char* seq = reinterpret_cast<const char*>(bases.data()) + base_at[r];
-                const uint64_t len = lens[r];
-                if (wrap && len > wrap) {
-                    for (uint64_t o2 = 0; o2 < len; o2 += wrap) { const uint64_t m = std::min<uint64_t>(wrap, len - o2); memcpy(w, seq + o2, m); w += m; *w++ = '\n'; }
-                } else { memcpy(w, seq, len); w += len; *w++ = '\n'; }
-                if (fastq_out) { *w++ = '+'; *w++ = '\n'; memcpy(w, qual.data() + qual_off[r], len); w += len; *w++ = '\n'; }
-            }
-        };
-        if (n_fmt <= 1) format_range(0, g_reads);
+        // the size of this round's text, so that the next round knows where its own begins
+        uint64_t n_text = 0;
+        if (has_header && !wrap)                                 // (the decoder has checked that the lengths add up to the block table's bases)
+            n_text = 2 * g_reads + R->hdr_off[g_reads] + g_bases + g_reads + (fastq_out ? 3 * g_reads + g_bases : 0);
         else {
-            std::vector<std::thread> th;
-            for (uint32_t t = 0; t < n_fmt; t++) th.emplace_back(format_range, g_reads * t / n_fmt, g_reads * (t + 1) / n_fmt);
-            for (auto& t : th) t.join();
+            auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
+            for (uint64_t r = 0; r < g_reads; r++) {
+                const uint64_t hl = has_header ? R->hdr_off[r + 1] - R->hdr_off[r] : std::to_string(read_index + r).size();
+                n_text += 1 + hl + 1 + seq_text_len(R->lens[r]) + (fastq_out ? 2 + (uint64_t)R->lens[r] + 1 : 0);
+            }
         }
-        lap(tl, t_text);
-        o.write(text.get(), (std::streamsize)rec_off[g_reads]);
-        if (!o) throw Exception("cannot write " + _outputFilename);
-        lap(tl, t_write);
-        read_index += g_reads; bases_out += g_bases;
+        R->n_text = n_text;
+        if (writer.valid()) writer.get();                        // the round before is on disk (its errors surface here)
+        lap(tl, t_writer_wait);
+        writer = std::async(std::launch::async, write_round, R);
+        read_index += g_reads; bases_out += g_bases; file_off += n_text;
     }
-    o.close();
+    {
+        auto tl = std::chrono::steady_clock::now();
+        if (writer.valid()) writer.get();
+        lap(tl, t_write);
+    }
+    if (::close(ofd.fd) != 0) { ofd.fd = -1; throw Exception("cannot write " + _outputFilename); }
+    ofd.fd = -1;
     if (read_index != n_reads) throw Exception("the block tables do not add up to the header's read count");
+    ofd.keep = true;
     std::cout << n_reads << " reads, " << bases_out << " bases decoded from " << n_blocks << " blocks, written to " << _outputFilename << std::endl;
     if (_verbose)
-        std::cout << "time: " << seconds_since(t_start) << " s (container reads " << t_read << ", dictionary + DNA blocks on the device " << t_dna << ", beside them on the host threads: header blocks "
-                  << t_hdr << " + quality blocks " << t_qual << " (waited " << t_wait << " more), formatting " << t_text << ", writing " << t_write << ")" << std::endl;
+        std::cout << "time: " << seconds_since(t_start) << " s (" << (n_blocks + group - 1) / group << " round(s); container reads " << t_read << ", dictionary + DNA blocks on the device " << t_dna
+                  << ", beside them on the host threads: header blocks " << t_hdr << " + quality blocks " << t_qual << " (waited " << t_wait << " more); formatting + writing "
+                  << t_text << " beside the next round's decoding, waited for " << t_writer_wait + t_write << ")" << std::endl;
     if (_testFile) testDecompressedFile();
 }
 
