@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // values from the payload: compared without sums that could wrap (a crafted delta of type 2 makes them ~2^64)
             if (!len_fits(len, w, wcap)) { fail = 2; break; }
             if (addr >= n_anchors || !anchor_fits(apos, len, k)) { fail = 1; break; }
-            K anchor = load_kmer<K>(anchors + addr * W);      // (asked for here: it arrives under the next symbol)
+            K anchor = load_kmer<K>(anchors + addr * W) & kmk;   // (asked for here: it arrives under the next symbol)
             const uint32_t rev = decode_small(d, M_ANCHOR_REVCOMP);
             if (rev) anchor = revcomp(anchor, k);
             // both walks start at the anchor: their first buckets are asked for now and read when the walks begin, after the lists
