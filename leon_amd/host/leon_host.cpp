@@ -230,6 +230,13 @@ void Leon::executeCompression() {
     const uint64_t batch_reads = 64ull * rpb;
     ReadBatch batch;
     std::future<void> qual_job;
+    // Lossy qualities need the bloom, which needs the whole file: they stay resident on device 0 (one byte per base, indexed
+    // like the bases) until then, unless the file is too large for that (LEON_QUAL_RESIDENT_MB, default 64 GB): then a
+    // second pass over the file feeds them through.
+    std::unique_ptr<DeviceReads> qstore;
+    uint64_t qual_resident_max = 64ull << 30;
+    if (const char* e = getenv("LEON_QUAL_RESIDENT_MB")) qual_resident_max = (uint64_t)std::max<long long>(0, atoll(e)) << 20;
+    if (fastq && !_noQual && !_lossless && qual_resident_max) { qstore.reset(new DeviceReads()); qstore->device = store[0]->device; }
     for (;;) {
         batch.clear();
         const uint64_t got = bank.next(batch, batch_reads);
@@ -255,6 +262,11 @@ void Leon::executeCompression() {
             });
         }
         for (auto& st : store) st->append(batch.bases);
+        if (qstore) {                                            // lossy mode: the qualities wait in HBM, beside the bases, for the bloom
+            try { qstore->append(batch.quals); }
+            catch (const Exception&) { qstore.reset(); }         // no room: they are read again from the file afterwards
+            if (qstore && qstore->n_bases > qual_resident_max) qstore.reset();
+        }
         for (uint64_t i = 1; i <= got; i++) offsets.push_back(offsets[n_reads] + batch.base_off[i]);
         n_reads += got;
         if (got < batch_reads) break;                            // the partial batch is the last one
@@ -318,7 +330,32 @@ void Leon::executeCompression() {
     const double t_encode = seconds_since(t_dna);
 
     // ---- lossy qualities (the default): smoothed against the bloom on the device, then the same zlib blocks ----
-    if (keep_qual && !_lossless) {
+    if (keep_qual && !_lossless && qstore && qstore->n_bases == n_bases) {
+        // smoothed where they lie, then back to the host chunk by chunk: chunk i is deflated by the host threads while
+        // chunk i + 1 is smoothed and copied
+        for (uint64_t r = 0; r < n_reads;) {
+            const uint64_t got = std::min<uint64_t>(batch_reads, n_reads - r);
+            const uint64_t nb = offsets[r + got] - offsets[r];
+            check(ctx[0].get(), leon_qual_smooth_batch_device(ctx[0].get(), store[0]->d_bases, store[0]->d_off + r, got, qstore->d_bases + offsets[r]),
+                  "leon_qual_smooth_batch_device");
+            auto quals = std::make_shared<std::string>();
+            quals->resize(nb);
+            if (nb) check(nullptr, leon_device_download(store[0]->device, &(*quals)[0], qstore->d_bases + offsets[r], nb), "leon_device_download");
+            auto qoff = std::make_shared<std::vector<uint64_t>>(got + 1);
+            for (uint64_t i = 0; i <= got; i++) (*qoff)[i] = offsets[r + i] - offsets[r];
+            if (qual_job.valid()) qual_job.get();
+            const uint64_t first_block = r / rpb;
+            const uint32_t cores = (uint32_t)_nbCores;
+            qual_job = std::async(std::launch::async, [quals, qoff, got, first_block, cores, &wq] {
+                int rc = leon_host_qual_encode_blocks(reinterpret_cast<const uint8_t*>(quals->data()), qoff->data(), got, READ_PER_BLOCK, -1, cores, StreamWriter::sink, &wq,
+                                                      first_block);
+                check_sink(nullptr, rc, wq, "leon_host_qual_encode_blocks");
+            });
+            r += got;
+        }
+        if (qual_job.valid()) qual_job.get();
+        qstore.reset();
+    } else if (keep_qual && !_lossless) {
         Bank again(_inputFilename);
         uint64_t r = 0;
         void* d_q = nullptr; uint64_t d_q_cap = 0;
