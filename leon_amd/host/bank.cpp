@@ -56,38 +56,56 @@ bool Bank::isFastq() {
     return fastq_;
 }
 
+// the next line without its terminator, not copied when it ends inside the read buffer (the usual case: a megabyte of
+// buffer, lines of a few hundred bytes); valid until the next call
+bool Bank::view(const char*& p, size_t& n) {
+    if (have_pending_) { have_pending_ = false; p = pending_.data(); n = pending_.size(); return true; }
+    if (buf_pos_ < buf_len_) {
+        const char* s = buf_.data() + buf_pos_;
+        const char* nl = (const char*)memchr(s, '\n', buf_len_ - buf_pos_);
+        if (nl) {
+            p = s; n = (size_t)(nl - s);
+            buf_pos_ += n + 1;
+            if (n && p[n - 1] == '\r') n--;
+            return true;
+        }
+    }
+    if (!getline(spill_)) return false;                         // crosses a refill (or the file ends without a newline)
+    p = spill_.data(); n = spill_.size();
+    return true;
+}
+
 uint64_t Bank::next(ReadBatch& b, uint64_t max_reads) {
     isFastq();
     uint64_t n = 0;
-    std::string line;
-    auto take = [&](std::string& l) -> bool {
-        if (have_pending_) { l.swap(pending_); have_pending_ = false; return true; }
-        return getline(l);
-    };
+    const char* p; size_t len;
     while (n < max_reads) {
-        if (!take(line)) break;
-        if (line.empty()) continue;
+        if (!view(p, len)) break;
+        if (len == 0) continue;
         if (fastq_) {
-            if (line[0] != '@') throw Exception("malformed FASTQ record " + std::to_string(n_read_ + 1) + " in " + path_);
-            b.headers.append(line, 1, std::string::npos);
-            std::string seq, plus, qual;
-            if (!getline(seq) || !getline(plus) || !getline(qual)) throw Exception("truncated FASTQ record in " + path_);
-            if (plus.empty() || plus[0] != '+') throw Exception("malformed FASTQ record " + std::to_string(n_read_ + 1) + " in " + path_);
-            if (qual.size() != seq.size()) throw Exception("FASTQ record " + std::to_string(n_read_ + 1) + " of " + path_ + ": quality and sequence lengths differ");
-            b.bases += seq; b.quals += qual;
+            if (p[0] != '@') throw Exception("malformed FASTQ record " + std::to_string(n_read_ + 1) + " in " + path_);
+            b.headers.append(p + 1, len - 1);
+            if (!view(p, len)) throw Exception("truncated FASTQ record in " + path_);
+            const size_t seq_len = len;
+            b.bases.append(p, len);
+            if (!view(p, len)) throw Exception("truncated FASTQ record in " + path_);
+            if (len == 0 || p[0] != '+') throw Exception("malformed FASTQ record " + std::to_string(n_read_ + 1) + " in " + path_);
+            if (!view(p, len)) throw Exception("truncated FASTQ record in " + path_);
+            if (len != seq_len) throw Exception("FASTQ record " + std::to_string(n_read_ + 1) + " of " + path_ + ": quality and sequence lengths differ");
+            b.quals.append(p, len);
         } else {
-            if (line[0] != '>') throw Exception("FASTA data before the first header in " + path_);
-            b.headers.append(line, 1, std::string::npos);
+            if (p[0] != '>') throw Exception("FASTA data before the first header in " + path_);
+            b.headers.append(p + 1, len - 1);
             uint64_t n_lines = 0, last_len = 0;
-            while (getline(line)) {                                  // sequence lines up to the next header
-                if (!line.empty() && line[0] == '>') { pending_ = line; have_pending_ = true; break; }
+            while (view(p, len)) {                                   // sequence lines up to the next header
+                if (len && p[0] == '>') { pending_.assign(p, len); have_pending_ = true; break; }
                 // wrapped sequences: every line but a record's last must have the same width, the last one 1..width
                 if (n_lines) {
                     if (!wrap_seen_) { wrap_seen_ = true; wrap_ = last_len; }
                     if (last_len != wrap_ || wrap_ == 0) wrap_ok_ = false;
                 }
-                last_len = line.size(); n_lines++;
-                b.bases += line;
+                last_len = len; n_lines++;
+                b.bases.append(p, len);
             }
             if (n_lines && last_len == 0) wrap_ok_ = false;          // an empty last line would not come back
             if (wrap_seen_ && n_lines && last_len > wrap_) wrap_ok_ = false;

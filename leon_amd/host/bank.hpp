@@ -32,8 +32,9 @@ public:
     uint64_t fastaLineWidth() const { return (wrap_seen_ && wrap_ok_ && !single_empty_ && single_max_ <= wrap_) ? wrap_ : 0; }
 private:
     bool getline(std::string& line);
+    bool view(const char*& p, size_t& n);         // the next line where it lies (in the read buffer when it ends there), else assembled in spill_
     void* gz_ = nullptr;                          // gzFile: reads plain files transparently as well
-    std::string path_, pending_;
+    std::string path_, pending_, spill_;
     bool have_pending_ = false, decided_ = false, fastq_ = false;
     std::vector<char> buf_;
     size_t buf_pos_ = 0, buf_len_ = 0;
