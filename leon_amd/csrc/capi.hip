@@ -1176,6 +1176,7 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
         const double nr = st[5] ? (double)st[5] : 1.0;
         fprintf(stderr, "[leon decode] per read: %.2f table jumps (%.1f positions), %.2f table misses, %.2f one-k-mer probe rounds, %.2f deep probe rounds, %.2f more answered by the table\n",
                 st[0] / nr, st[4] / nr, st[1] / nr, st[6] / nr, st[2] / nr, st[3] / nr);
+        fprintf(stderr, "[leon decode] per read: %.2f entries taken to their end before the last base, one-k-mer rounds: %.2f on a branching k-mer, %.2f found the successor in the table\n", st[10] / nr, st[11] / nr, st[9] / nr);
         fprintf(stderr, "[leon decode] per read: %.2f us in its fields, %.2f us in its walks (100 MHz clock, the wave's own time)\n", st[7] / nr / 100.0, st[8] / nr / 100.0);
     }
     if (err[0]) {

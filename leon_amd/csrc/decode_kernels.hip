@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const uint64_t r0 = blk_read0[b];
         int fail = 0;
         Pend<K> P;
-        uint32_t n_fast = 0, n_miss = 0, n_slow = 0, n_slowjump = 0, n_jumped = 0, n_hybrid = 0;
+        uint32_t n_fast = 0, n_miss = 0, n_slow = 0, n_slowjump = 0, n_jumped = 0, n_hybrid = 0, n_childhit = 0, n_short = 0, n_unclean = 0;
         unsigned long long t_head = 0, t_walk = 0, t_mark = stats ? wall_clock64() : 0;   // rounds by kind (stats != nullptr: measurement)
         auto pool_alloc = [&](uint64_t cnt) -> uint32_t* {           // wave-uniform; never freed (rare, bounded by pool_words)
             unsigned long long base = 0;
@@ -478,6 +478,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                 const uint32_t sd = advance((uint32_t)__builtin_amdgcn_readlane((int)res, 0));
                                 const uint32_t e = dir == 1 ? sd : (sd ^ 2u);
                                 pre = pc_pick(plc, child == e);
+                                if (pre) n_childhit++;
+                                if (run == 0) n_unclean++;
                                 pc_retire<K>(PCc, P, issued);
                                 if (run >= PC_MAX && fresh) pc_offer<K>(PCc, P, lane, PC_MAX, PC_MAX, oldk, p60, kmk);
                                 continue;
@@ -520,6 +522,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         p60 = ((p60 << (2 * j)) | pj) & PC_M60;
                         run += j; pos += step * (int64_t)j; n_jumped += j;
                         mode = (j == cnt && cnt < PC_MAX) ? HYBRID : FAST;       // the entry ended where the graph stops being a path
+                        if (mode == HYBRID) n_short++;
                         if (ahead) pre = pc_pick(plc_next, true);
                         continue;
                     }
@@ -554,6 +557,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             atomicAdd(stats + 0, n_fast); atomicAdd(stats + 1, n_miss); atomicAdd(stats + 2, n_slow); atomicAdd(stats + 3, n_slowjump);
             atomicAdd(stats + 4, n_jumped); atomicAdd(stats + 5, (unsigned long long)blk_reads[b]); atomicAdd(stats + 6, n_hybrid);
             atomicAdd(stats + 7, t_head); atomicAdd(stats + 8, t_walk);
+            atomicAdd(stats + 9, n_childhit); atomicAdd(stats + 10, n_short); atomicAdd(stats + 11, n_unclean);
         }
     }
 }
@@ -583,30 +587,43 @@ template <typename K> __device__ inline void pc_insert_now(const PathCache& C, K
 template <typename K>
 __global__ void __launch_bounds__(256) k_pc_prewalk(BloomDev B, PathCache C, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors, uint32_t max_steps) {
     __shared__ uint16_t rv16[256];
+    __shared__ K todo[3][256];                                // k-mers beyond a branch, still to be walked from (per lane)
     load_rv16(rv16, rv16g);
     const uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (idx >= 2 * n_anchors) return;
-    const uint32_t k = B.k;
+    const uint32_t k = B.k, t = threadIdx.x;
     const K kmk = kmask<K>(k);
     K y = load_kmer<K>(anchors + (idx >> 1) * KT<K>::W) & kmk;
-    K rc = revcomp(y, k);
-    if (idx & 1) { const K t = y; y = rc; rc = t; }
-    K oldk = (K)(y >> 60);
-    uint64_t p60 = (uint64_t)y & PC_M60;
-    uint32_t run = 0;
-    for (uint32_t s = 0; s < max_steps; s++) {
-        const uint32_t res4 = bloom_contains4<K>(B, rv16, y, rc, true);
-        if (__popc(res4) != 1) break;
-        const uint32_t e = (uint32_t)__builtin_ctz(res4);
-        y = ((y << 2) | (K)e) & kmk;
-        rc = (rc >> 2) | ((K)(e ^ 2u) << (2 * (k - 1)));
-        oldk = ((oldk << 2) | (K)((p60 >> 58) & 3u)) & kmk;
-        p60 = ((p60 << 2) | e) & PC_M60;
-        run++;
-        if (run >= PC_MAX) pc_insert_now<K>(C, ((oldk << 4) | (K)(p60 >> 56)) & kmk, ((uint64_t)PC_MAX << 56) | (p60 & PC_M56));
+    if (idx & 1) y = revcomp(y, k);
+    uint32_t n_todo = 0, budget = max_steps;
+    for (;;) {                                                // one stretch of one-successor steps per turn
+        K rc = revcomp(y, k);
+        K oldk = (K)(y >> 60);
+        uint64_t p60 = (uint64_t)y & PC_M60;
+        uint32_t run = 0, res4 = 0;
+        while (budget) {
+            budget--;
+            res4 = bloom_contains4<K>(B, rv16, y, rc, true);
+            if (__popc(res4) != 1) break;
+            const uint32_t e = (uint32_t)__builtin_ctz(res4);
+            y = ((y << 2) | (K)e) & kmk;
+            rc = (rc >> 2) | ((K)(e ^ 2u) << (2 * (k - 1)));
+            oldk = ((oldk << 2) | (K)((p60 >> 58) & 3u)) & kmk;
+            p60 = ((p60 << 2) | e) & PC_M60;
+            run++;
+            res4 = 0;
+            if (run >= PC_MAX) pc_insert_now<K>(C, ((oldk << 4) | (K)(p60 >> 56)) & kmk, ((uint64_t)PC_MAX << 56) | (p60 & PC_M56));
+        }
+        for (uint32_t d = run < PC_MAX - 1 ? run : PC_MAX - 1; d >= 1; d--)
+            pc_insert_now<K>(C, ((oldk << (2 * (PC_REG - d))) | (K)(p60 >> (2 * d))) & kmk, ((uint64_t)d << 56) | (p60 & ((1ull << (2 * d)) - 1)));
+        // a branch: the decoder will take ONE of the solid successors, whichever its stream says -- all of them are walked
+        // from (a false positive of the bloom ends after a step or two), within the lane's budget of probes
+        if (__popc(res4) >= 2 && budget)
+            for (uint32_t e = 0; e < 4; e++)
+                if (((res4 >> e) & 1u) && n_todo < 3) todo[n_todo++][t] = ((y << 2) | (K)e) & kmk;
+        if (!n_todo || !budget) break;
+        y = todo[--n_todo][t];
     }
-    for (uint32_t d = run < PC_MAX - 1 ? run : PC_MAX - 1; d >= 1; d--)
-        pc_insert_now<K>(C, ((oldk << (2 * (PC_REG - d))) | (K)(p60 >> (2 * d))) & kmk, ((uint64_t)d << 56) | (p60 & ((1ull << (2 * d)) - 1)));
 }
 void launch_path_cache_prewalk(hipStream_t s, BloomDev B, PathCache C, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors, uint32_t max_steps) {
     if (!C.slots || !n_anchors) return;
