@@ -1156,7 +1156,10 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     lap("payloads to the device");
     if (cache_is_new) {                                       // what the bloom says around every anchor, before the blocks ask (decode_kernels.hip)
         static const char* pw = getenv("LEON_DC_PREWALK");    // measurement override: steps per anchor and orientation, 0 = none
-        const uint32_t steps = pw ? (uint32_t)std::max(0, atoi(pw)) : (c->cfg.kmer_size >= 32 ? 128u : 64u);   // measured: 64 -> 128 gives 1 % at k = 31, 5 % at k = 63
+        // probes per anchor and orientation.  The walks are throughput (0.25 s for 25 M lanes x 64), the blocks' chains latency:
+        // 128 pays for files of a few hundred blocks (10 M reads: 26 + 1 697 ms -> 52 + 1 593) and for two-word k-mers, 64 at
+        // 2 000 blocks (249 + 2 215 ms against 534 + 2 065)
+        const uint32_t steps = pw ? (uint32_t)std::max(0, atoi(pw)) : ((c->cfg.kmer_size >= 32 || n_anchors < (4u << 20)) ? 128u : 64u);
         if (steps) launch_path_cache_prewalk(s, c->B, c->dc_pc, c->d_rv16, d_anchors.as<uint64_t>(), n_anchors, steps);
         lap("path cache: walks from the anchors");
     }
