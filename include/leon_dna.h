@@ -157,7 +157,8 @@ int leon_host_anchor_dict_encode(const uint64_t* kmers, uint64_t n_anchors, uint
  * LEON_E_INVALID with a message when a payload does not decode against this bloom / dictionary.
  * Memory: the context keeps a table of what the decoding waves have learnt from the bloom (16 or 32 bytes x 4 per solid
  * k-mer the bloom was sized for, at most 40 % of the device's free memory; LEON_DC_CACHE_MB in the environment overrides,
- * 0 = none) from call to call, for as long as the bloom's bits do not change; it makes the call faster, never different.
+ * 0 = none) from call to call, for as long as the bloom's bits do not change and the context does not encode (an encode
+ * call returns the table's memory first); it makes the call faster, never different.
  * n_threads of the host functions below: 0 = the CPUs this process may use (its cgroup's quota). */
 int leon_dna_decode_blocks(leon_dna_ctx* ctx, const uint64_t* anchors, uint64_t n_anchors, const uint8_t* payloads,
                            const uint64_t* payload_off, const uint32_t* block_n_reads, const uint64_t* block_n_bases,

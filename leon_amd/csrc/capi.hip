@@ -401,6 +401,10 @@ static int encode_batch_guarded(leon_dna_ctx* c, const uint8_t* d_bases, const u
                                 uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up) {
     if (!c) return LEON_E_INVALID;
     if (c->poisoned) return fail(c, LEON_E_STATE, "an earlier batch failed part-way: the stream is unusable until leon_dna_reset_stream");
+    if (c->dc_pc.slots) {                                     // a context that goes back to encoding gives the decoder's table (up to 40 % of the HBM) back first
+        (void)hipStreamSynchronize(c->stream);
+        c->dc_cache.release(); c->dc_pc = PathCache{}; c->dc_filled = false;
+    }
     const int rc = encode_batch_impl(c, d_bases, d_off, n, first_read_index, sink, user, up);
     if (rc != LEON_OK && c->poisoned) c->err += " (stream poisoned: leon_dna_reset_stream to go on)";
     return rc;
