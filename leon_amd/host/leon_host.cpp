@@ -237,10 +237,17 @@ void Leon::executeCompression() {
     uint64_t qual_resident_max = 64ull << 30;
     if (const char* e = getenv("LEON_QUAL_RESIDENT_MB")) qual_resident_max = (uint64_t)std::max<long long>(0, atoll(e)) << 20;
     if (fastq && !_noQual && !_lossless && qual_resident_max) { qstore.reset(new DeviceReads()); qstore->device = store[0]->device; }
-    for (;;) {
-        batch.clear();
-        const uint64_t got = bank.next(batch, batch_reads);
+    // the reader runs one batch ahead on its own thread: batch i + 1 is parsed while batch i's headers are coded on the device
+    // and its bases (and qualities) cross to it
+    ReadBatch buffers[2];
+    auto parse_next = [&bank, batch_reads](ReadBatch* b) -> uint64_t { b->clear(); return bank.next(*b, batch_reads); };
+    std::future<uint64_t> parsing = std::async(std::launch::async, parse_next, &buffers[0]);
+    struct ParseJoin { std::future<uint64_t>& f; ~ParseJoin() { if (f.valid()) { try { f.get(); } catch (...) {} } } } parse_join{parsing};   // (never left running over dead buffers)
+    for (uint32_t cur = 0;; cur ^= 1) {
+        const uint64_t got = parsing.get();                      // (the reader's exceptions surface here)
         if (!got) break;
+        ReadBatch& batch = buffers[cur];
+        if (got == batch_reads) parsing = std::async(std::launch::async, parse_next, &buffers[cur ^ 1]);
         if (n_reads == 0) first_header.assign(batch.headers, 0, batch.header_off[1]);
         if (keep_header) {
             check_sink(hdr_ctx.get(), leon_header_encode_batch(hdr_ctx.get(), reinterpret_cast<const uint8_t*>(batch.headers.data()), batch.header_off.data(), got, n_reads,
