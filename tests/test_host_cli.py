@@ -260,6 +260,11 @@ def test_cli_stream_selection_flags_and_lossy_qualities(leon_bin, tmp_path):
     smooth = [O.qual_smooth(bl, k, r, q) for r, q in zip(reads, quals)]
     assert any(s != q for s, q in zip(smooth, quals))
     assert text == b"".join(b"@" + h + b"\n" + s + b"\n+\n" + q + b"\n" for h, s, q in zip(heads, norm, smooth))
+    # -test-file on a lossy round trip reports the first byte that differs (both files plain: compared in slices by all cores)
+    r = run(leon_bin, "-file", fq + ".leon", "-d", "-test-file")
+    orig_text = open(fq, "rb").read()
+    first = next(i for i in range(min(len(text), len(orig_text))) if text[i] != orig_text[i])
+    assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: ") and ("differs from %s at byte %d" % (fq, first)) in r.stderr, r.stderr
     # the lossy qualities wait for the bloom in HBM; a file too large for that goes through the file a second time
     # (LEON_QUAL_RESIDENT_MB=0 forces it): the same container either way
     shutil.move(fq + ".leon", fq + ".resident")
