@@ -535,10 +535,17 @@ void Leon::executeDecompression() {
     }
     const uint32_t cores = (uint32_t)_nbCores;
     const uint32_t n_cpu = (uint32_t)(_nbCores > 0 ? (uint64_t)_nbCores : usableCpus());
+    // bytes that are about to be overwritten anyway: std::vector would clear all of them first, on the critical path
+    struct RawBytes {
+        std::unique_ptr<uint8_t[]> p; uint64_t n = 0;
+        void resize(uint64_t want) { if (want > n) { p.reset(); p.reset(new uint8_t[want]); n = want; } }
+        uint8_t* data() { return p.get(); }
+        uint64_t size() const { return n; }
+    };
     // what one round hands from the decoding stage to the writing stage
     struct Round {
         uint64_t read_index = 0, file_off = 0, g_reads = 0, g_bases = 0, n_text = 0;
-        std::vector<uint8_t> bases, hdr, qual;
+        RawBytes bases, hdr, qual;                               // (gigabytes each: never zero-filled)
         std::vector<uint32_t> lens;
         std::vector<uint64_t> hdr_off, qual_off;
     };
@@ -601,7 +608,7 @@ void Leon::executeDecompression() {
     uint64_t read_index = 0, bases_out = 0, file_off = 0;
     for (uint64_t g0 = 0; g0 < n_blocks; g0 += group) {
         const uint64_t g1 = std::min(n_blocks, g0 + group), nb = g1 - g0;
-        auto gather = [&](const char* grp, const std::vector<uint64_t>& tab, uint32_t stride, std::vector<uint8_t>& pay, std::vector<uint64_t>& off) {
+        auto gather = [&](const char* grp, const std::vector<uint64_t>& tab, uint32_t stride, RawBytes& pay, std::vector<uint64_t>& off) {
             off.assign(nb + 1, 0);
             for (uint64_t b = 0; b < nb; b++) off[b + 1] = off[b] + tab[stride * (g0 + b)];
             pay.resize(off[nb] + 1);
@@ -612,7 +619,7 @@ void Leon::executeDecompression() {
             }
         };
         auto R = std::make_shared<Round>();
-        std::vector<uint8_t> pay; std::vector<uint64_t> off;
+        RawBytes pay; std::vector<uint64_t> off;
         std::vector<uint32_t> blk_reads(nb); std::vector<uint64_t> blk_bases(nb);
         uint64_t g_reads = 0, g_bases = 0;
         for (uint64_t b = 0; b < nb; b++) { blk_reads[b] = (uint32_t)tdna[3 * (g0 + b) + 1]; blk_bases[b] = tdna[3 * (g0 + b) + 2]; g_reads += blk_reads[b]; g_bases += blk_bases[b]; }
@@ -620,7 +627,7 @@ void Leon::executeDecompression() {
         // the three streams' payloads of the round, then: header and quality blocks on the host threads WHILE the device
         // decodes the DNA blocks (and while the round before is being formatted and written)
         auto tl = std::chrono::steady_clock::now();
-        std::vector<uint8_t> pay_h, pay_q; std::vector<uint64_t> off_h, off_q;
+        RawBytes pay_h, pay_q; std::vector<uint64_t> off_h, off_q;
         gather(GROUP_DNA, tdna, 3, pay, off);
         if (has_header) gather(GROUP_HEADER, thdr, 2, pay_h, off_h);
         if (fastq_out) gather(GROUP_QUAL, tqual, 3, pay_q, off_q);
