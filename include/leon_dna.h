@@ -186,6 +186,12 @@ int leon_header_encode_batch_device(leon_dna_ctx* ctx, const uint8_t* d_headers,
 int leon_host_header_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
                                    uint64_t n_blocks, const uint8_t* first_header, uint64_t first_header_len, uint8_t* out,
                                    uint64_t out_cap, uint64_t* out_off, uint64_t* out_size, uint32_t n_threads);
+/* The same with the arithmetic decoding on the device (one wave per block, every block at once; the header TEXT is rebuilt from
+ * the decoded symbols on n_threads host threads): same arguments, same results and errors as leon_host_header_decode_blocks.
+ * A block with more symbols than the device buffer gives it (free text in every header) sends the call to the host decoder. */
+int leon_header_decode_blocks(leon_dna_ctx* ctx, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
+                              uint64_t n_blocks, const uint8_t* first_header, uint64_t first_header_len, uint8_t* out,
+                              uint64_t out_cap, uint64_t* out_off, uint64_t* out_size, uint32_t n_threads);
 /* Quality stream, lossy form (Leon's default, /root/reference/README.md:55): DnaEncoder::storeSolidCoverageInfo + smoothQuals
  * [RECALLED]: a quality becomes '@' where at least two of the read's solid k-mers (in the bloom of ctx) span the position, or
  * where it is above '@'; reads shorter than k are left alone.  quals: one byte per base, same offsets as the bases, rewritten

@@ -86,6 +86,8 @@ _EXPORTS = {
                                                    SINK, C.c_void_p]),
     "leon_host_header_decode_blocks": (C.c_int, [_u8p, _u64p, _u32p, C.c_uint64, C.c_char_p, C.c_uint64, _u8p, C.c_uint64, _u64p,
                                                   _u64p, C.c_uint32]),
+    "leon_header_decode_blocks": (C.c_int, [C.c_void_p, _u8p, _u64p, _u32p, C.c_uint64, C.c_char_p, C.c_uint64, _u8p, C.c_uint64, _u64p,
+                                             _u64p, C.c_uint32]),
     "leon_qual_smooth_batch": (C.c_int, [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _u8p]),
     "leon_qual_smooth_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "leon_kmer_auto_cutoff": (C.c_int, [_u64p, _u32p]),
@@ -402,6 +404,27 @@ class DnaEncodeContext:
                                                     len(first_header), cb, None))
         self._hdr_next += len(headers)
         return blocks
+
+    def header_decode_blocks(self, blocks, first_header, n_threads=0):
+        """HeaderDecoder with the symbols decoded on the device and the text rebuilt on host threads:
+        blocks = [(id, payload, n_reads)] -> list of header bytes (same results as host_header_decode_blocks)"""
+        if not blocks:
+            return []
+        pay, off, nr = _join_blocks(blocks)
+        total = int(nr[:len(blocks)].sum())
+        out_off = np.zeros(total + 1, dtype=np.uint64)
+        need = C.c_uint64()
+        cap = max(64, 64 * total)
+        for _ in range(2):
+            out = np.zeros(cap, dtype=np.uint8)
+            rc = self.lib.leon_header_decode_blocks(self.h, _ptr(pay, _u8p), _ptr(off, _u64p), _ptr(nr, _u32p), len(blocks), first_header,
+                                                    len(first_header), _ptr(out, _u8p), cap, _ptr(out_off, _u64p), C.byref(need), n_threads)
+            if rc != -5:
+                break
+            cap = need.value
+        self._chk(rc)
+        raw = out.tobytes()
+        return [raw[int(out_off[i]):int(out_off[i + 1])] for i in range(total)]
 
     def qual_smooth_batch(self, bases, offsets, quals):
         """DnaEncoder::smoothQuals (lossy qualities) over a batch: returns the smoothed quality bytes (same offsets)"""

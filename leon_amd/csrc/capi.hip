@@ -1197,6 +1197,69 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     return LEON_OK;
 }
 
+// Header blocks: the symbols on the device (one wave per block, all blocks at once), the text on host threads
+extern "C++" { namespace leon {                                // (host_streams.cpp)
+int header_blocks_from_symbols(const uint8_t* syms, const uint64_t* sym_begin, const uint64_t* sym_count, const uint32_t* block_n_reads, uint64_t n_blocks,
+                               const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
+                               uint64_t* out_size, uint32_t n_threads);
+} }
+int leon_header_decode_blocks(leon_dna_ctx* c, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads, uint64_t n_blocks,
+                              const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
+                              uint64_t* out_size, uint32_t n_threads) {
+    if (!c) return LEON_E_INVALID;
+    if (!out_size || (n_blocks && (!payloads || !payload_off || !block_n_reads || !out_off)) || (!first_header && first_header_len))
+        return fail(c, LEON_E_INVALID, "null argument");
+    *out_size = 0;
+    if (!n_blocks) return LEON_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    // a block's share of the symbol buffer: generous for the headers sequencers write (a dozen symbols each); a block that
+    // needs more (free text in every header) sends the whole call to the host decoder -- same result, its speed
+    std::vector<uint64_t> rel_off(n_blocks + 1), sym_begin(n_blocks + 1, 0);
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        if (payload_off[b + 1] < payload_off[b]) return fail(c, LEON_E_INVALID, "payload offsets are not monotonic");
+        sym_begin[b + 1] = sym_begin[b] + 64ull * block_n_reads[b] + 4 * (payload_off[b + 1] - payload_off[b]) + 256;
+    }
+    for (uint64_t b = 0; b <= n_blocks; b++) rel_off[b] = payload_off[b] - payload_off[0];
+    const uint64_t pay_bytes = rel_off[n_blocks], sym_cap = sym_begin[n_blocks];
+    TmpBuf d_pay, d_off, d_nreads, d_begin, d_count, d_syms, d_err;
+    HIPCHK(c, d_pay.ensure(pay_bytes + 1024));                  // (the payload window reads up to 256 + 3 bytes past a block's end)
+    HIPCHK(c, d_off.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_nreads.ensure(n_blocks * 4));
+    HIPCHK(c, d_begin.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_count.ensure(n_blocks * 8));
+    HIPCHK(c, d_syms.ensure(sym_cap + 64)); HIPCHK(c, d_err.ensure(16));
+    HIPCHK(c, hipMemcpyAsync(d_pay.p, payloads + payload_off[0], pay_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync((uint8_t*)d_pay.p + pay_bytes, 0, 1024, s));
+    HIPCHK(c, hipMemcpyAsync(d_off.p, rel_off.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_nreads.p, block_n_reads, n_blocks * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_begin.p, sym_begin.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(d_err.p, 0, 16, s));
+    launch_hdr_decode_symbols(s, d_pay.as<uint8_t>(), d_off.as<uint64_t>(), d_nreads.as<uint32_t>(), n_blocks, d_syms.as<uint8_t>(),
+                              d_begin.as<uint64_t>(), (unsigned long long*)d_count.p, d_err.as<int>());
+    HIPCHK(c, hipGetLastError());
+    int err[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(err, d_err.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (err[0] == 2) return fail(c, LEON_E_INVALID, "header block " + std::to_string(err[1]) + " does not decode");
+    if (err[0] == 1) {                                           // more symbols than a block's share: the host decodes the payloads itself
+        int rc = leon_host_header_decode_blocks(payloads, payload_off, block_n_reads, n_blocks, first_header, first_header_len, out, out_cap, out_off, out_size, n_threads);
+        if (rc != LEON_OK) c->err = leon_last_error(nullptr);
+        return rc;
+    }
+    std::vector<uint64_t> sym_count(n_blocks);
+    HIPCHK(c, hipMemcpy(sym_count.data(), d_count.p, n_blocks * 8, hipMemcpyDeviceToHost));
+    // only the symbols that were written come back (a block's share is mostly empty)
+    std::vector<uint64_t> host_begin(n_blocks + 1, 0);
+    for (uint64_t b = 0; b < n_blocks; b++) host_begin[b + 1] = host_begin[b] + sym_count[b];
+    std::unique_ptr<uint8_t[]> syms(new uint8_t[host_begin[n_blocks] + 1]);
+    for (uint64_t b = 0; b < n_blocks; b++)
+        if (sym_count[b]) HIPCHK(c, hipMemcpyAsync(syms.get() + host_begin[b], d_syms.as<uint8_t>() + sym_begin[b], sym_count[b], hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int rc = leon::header_blocks_from_symbols(syms.get(), host_begin.data(), sym_count.data(), block_n_reads, n_blocks, first_header, first_header_len, out, out_cap,
+                                              out_off, out_size, n_threads);
+    if (rc != LEON_OK) c->err = leon_last_error(nullptr);
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------------ traces
 int leon_dna_trace_anchors(leon_dna_ctx* c, int32_t* pos, uint32_t* addr, uint8_t* flags, uint64_t n) {
     if (!c) return LEON_E_INVALID;

@@ -632,6 +632,85 @@ void launch_path_cache_prewalk(hipStream_t s, BloomDev B, PathCache C, const uin
     else hipLaunchKernelGGL(k_pc_prewalk<uint64_t>, dim3((uint32_t)nb), dim3(256), 0, s, B, C, rv16, anchors, n_anchors, max_steps);
 }
 
+// ---- header blocks: the symbols of the stream, decoded on the device ----------------------------------------------------
+// A header block is one serial chain too (HeaderDecoder): which model the next symbol is read with depends on
+// the record so far, never on the header TEXT.  So the arithmetic decoding -- the expensive part -- runs here, one wave per
+// block, all blocks at once, and hands the symbols on as plain bytes in stream order; the host threads rebuild the text from
+// them (host_streams.cpp, the same code that decodes a payload itself, reading bytes instead).
+__device__ inline uint32_t hdr_sym(Dec& d, uint32_t m, uint8_t* syms, uint64_t& w, uint64_t cap, bool& over) {
+    const uint32_t c = m == HM_TYPE ? decode_on<false>(d, d.lds, true, H_TYPE_COUNT) : decode_sym(d, m);
+    if (w < cap) { if (d.lane == 0) syms[w] = (uint8_t)c; } else over = true;
+    w++;
+    return c;
+}
+__device__ inline uint64_t hdr_numeric(Dec& d, uint8_t* syms, uint64_t& w, uint64_t cap, bool& over) {
+    uint32_t bc = hdr_sym(d, HM_NUMERIC0, syms, w, cap, over);
+    if (bc > 8) bc = 8;
+    uint64_t v = 0;
+#pragma unroll 1
+    for (uint32_t i = 0; i < bc; i++) v |= (uint64_t)hdr_sym(d, HM_NUMERIC0 + 1 + i, syms, w, cap, over) << (8 * i);
+    return v;
+}
+__device__ inline uint64_t hdr_count(Dec& d, uint32_t m, uint8_t* syms, uint64_t& w, uint64_t cap, bool& over) {
+    const uint64_t x = hdr_sym(d, m, syms, w, cap, over);
+    return x < 255 ? x : 255 + hdr_numeric(d, syms, w, cap, over);
+}
+// err[0]: 0 ok, 1 a block's symbols do not fit its share of `syms` (the caller decodes on the host instead), 2 a payload that
+// is not a header stream; err[1]: the block
+__global__ void __launch_bounds__(64) k_hdr_decode_symbols(const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads, uint64_t n_blocks,
+                                                          uint8_t* syms, const uint64_t* sym_begin, unsigned long long* sym_count, int* err) {
+    __shared__ uint32_t models[RC_SMALL_WORDS + DC_NSLOT * RC_STRIDE];
+    __shared__ uint8_t slotmap[RC_NNUM];
+    const uint32_t lane = lane_id();
+    for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        Dec d;
+        d.lane = lane; d.lds = (lds_u32*)models; d.slotmap = slotmap; d.nused = 0; d.bad = false; d.gmodels = nullptr;   // 14 models: all in LDS
+        d.p = payloads + pay_off[b]; d.n = pay_off[b + 1] - pay_off[b]; d.i = 0;
+        d.low = 0; d.range = ~0ull; d.code = 0;
+        __syncthreads();
+        model_init(&models[0], lane, true);                   // the record type (9 symbols)
+        for (uint32_t i = lane; i < RC_NNUM; i += 64) slotmap[i] = 255;
+        __syncthreads();
+        win_load(d);
+        for (int i = 0; i < 8; i++) d.code = (d.code << 8) | next_byte(d);
+        uint64_t w = sym_begin[b];
+        const uint64_t cap = sym_begin[b + 1];
+        bool over = false;
+        int fail = 0;
+        for (uint32_t r = 0; r < blk_reads[b] && !fail; r++) {
+            for (;;) {                                        // one record per turn, at least one symbol each: bounded by the block's share
+                if (d.bad) { fail = 2; break; }
+                if (over) { fail = 1; break; }
+                const uint32_t t = hdr_sym(d, HM_TYPE, syms, w, cap, over);
+                if (t == H_END_MATCH) break;
+                if (t == H_END) { (void)hdr_count(d, HM_FIELD_INDEX, syms, w, cap, over); break; }
+                if (t < H_FIELD_ASCII || t >= H_TYPE_COUNT) { fail = 2; break; }
+                (void)hdr_count(d, HM_FIELD_INDEX, syms, w, cap, over);
+                if (t == H_FIELD_ASCII) {
+                    (void)hdr_count(d, HM_FIELD_COLUMN, syms, w, cap, over);
+                    const uint64_t sz = hdr_count(d, HM_MIS_SIZE, syms, w, cap, over);
+                    for (uint64_t j = 0; j < sz && !d.bad && !over; j++) (void)hdr_sym(d, HM_ASCII, syms, w, cap, over);
+                } else if (t == H_FIELD_DELTA || t == H_FIELD_DELTA_2) (void)hdr_numeric(d, syms, w, cap, over);
+                else {
+                    if (t != H_FIELD_NUMERIC) (void)hdr_count(d, HM_ZERO, syms, w, cap, over);
+                    if (t != H_FIELD_ZERO_ONLY) (void)hdr_numeric(d, syms, w, cap, over);
+                    (void)hdr_sym(d, HM_ASCII, syms, w, cap, over);
+                }
+            }
+        }
+        if (!fail && d.bad) fail = 2;
+        if (!fail && over) fail = 1;
+        if (lane == 0) sym_count[b] = fail ? 0ull : (unsigned long long)(w - sym_begin[b]);
+        if (fail && lane == 0) { if (atomicCAS(err, 0, fail) == 0) err[1] = (int)b; }
+    }
+}
+void launch_hdr_decode_symbols(hipStream_t s, const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads, uint64_t n_blocks,
+                               uint8_t* syms, const uint64_t* sym_begin, unsigned long long* sym_count, int* err) {
+    if (!n_blocks) return;
+    const uint32_t g = (uint32_t)(n_blocks > 256 * 8 ? 256 * 8 : n_blocks);
+    hipLaunchKernelGGL(k_hdr_decode_symbols, dim3(g), dim3(64), 0, s, payloads, pay_off, blk_reads, n_blocks, syms, sym_begin, sym_count, err);
+}
+
 size_t path_cache_slot_bytes(uint32_t k) { return k >= 32 ? 32 : 16; }
 // position-dependent 64-bit sum of the bloom's words (the array is padded past n_bytes, bytes beyond it are never set)
 __global__ void k_bloom_fingerprint(const uint8_t* bits, uint64_t n_words, uint64_t* sum) {

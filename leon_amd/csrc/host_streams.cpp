@@ -106,16 +106,40 @@ struct HeaderModels {
         for (auto& m : numeric) m.init(256);
     }
 };
-uint64_t decode_numeric(RangeDecoder& d, HeaderModels& M) {
-    uint32_t bc = d.next(M.numeric[0]);
+// Where the header decoder's symbols come from: the block's range-coded payload (decoded here, on a host thread), or the
+// block's symbols already decoded on the device (leon_header_decode_blocks: the arithmetic decoding is the expensive part
+// of a header block and a serial chain per block -- the device runs all the chains at once --, the text is not).
+enum ModelId { MI_TYPE, MI_FIELD_INDEX, MI_FIELD_COLUMN, MI_MIS_SIZE, MI_ASCII, MI_ZERO, MI_NUMERIC0 };   // MI_NUMERIC0 + i: byte-count model, then one per byte
+struct RangeSource {
+    RangeDecoder d;
+    HeaderModels* M;
+    RangeSource(const uint8_t* p, uint64_t n) : d(p, n), M(new HeaderModels()) {}
+    ~RangeSource() { delete M; }
+    RangeSource(const RangeSource&) = delete;
+    bool bad() const { return d.bad; }
+    uint32_t next(uint32_t id) {
+        Model256& m = id == MI_TYPE ? M->type : id == MI_FIELD_INDEX ? M->field_index : id == MI_FIELD_COLUMN ? M->field_column
+                    : id == MI_MIS_SIZE ? M->mis_size : id == MI_ASCII ? M->ascii : id == MI_ZERO ? M->zero : M->numeric[id - MI_NUMERIC0];
+        return d.next(m);
+    }
+};
+struct SymbolSource {
+    const uint8_t* p; uint64_t n, i = 0;
+    bool over = false;
+    SymbolSource(const uint8_t* p_, uint64_t n_) : p(p_), n(n_) {}
+    bool bad() const { return over; }
+    uint32_t next(uint32_t) { if (i < n) return p[i++]; over = true; return 0; }
+};
+template <typename S> uint64_t decode_numeric(S& d) {
+    uint32_t bc = d.next(MI_NUMERIC0);
     if (bc > 8) bc = 8;
     uint64_t v = 0;
-    for (uint32_t i = 0; i < bc; i++) v |= (uint64_t)d.next(M.numeric[i + 1]) << (8 * i);
+    for (uint32_t i = 0; i < bc; i++) v |= (uint64_t)d.next(MI_NUMERIC0 + 1 + i) << (8 * i);
     return v;
 }
-uint64_t decode_count(RangeDecoder& d, HeaderModels& M, Model256& m) {
-    const uint64_t x = d.next(m);
-    return x < 255 ? x : 255 + decode_numeric(d, M);
+template <typename S> uint64_t decode_count(S& d, uint32_t id) {
+    const uint64_t x = d.next(id);
+    return x < 255 ? x : 255 + decode_numeric(d);
 }
 inline bool is_alnum(uint8_t c) { return (uint8_t)(c - '0') < 10 || (uint8_t)((c | 32) - 'a') < 26; }
 struct Field { uint64_t len = 0; bool numeric = false, has_sep = false; uint8_t sep = 0; uint64_t value = 0; };
@@ -136,12 +160,8 @@ Field field_at(const uint8_t* h, uint64_t len, uint64_t pos) {
 }
 
 // one block; out receives the headers back to back, off[n + 1] (relative to out); false when the payload does not decode
-bool decode_header_block(const uint8_t* payload, uint64_t size, uint32_t n, const uint8_t* first, uint64_t first_len,
-                         std::string& out, std::vector<uint64_t>& off) {
-    RangeDecoder d(payload, size);
-    HeaderModels* Mp = new HeaderModels();
-    HeaderModels& M = *Mp;
-    struct Free { HeaderModels* p; ~Free() { delete p; } } fr{Mp};
+template <typename S>
+bool decode_header_block(S& d, uint32_t n, const uint8_t* first, uint64_t first_len, std::string& out, std::vector<uint64_t>& off) {
     out.clear(); off.assign(1, 0);
     std::string prev(reinterpret_cast<const char*>(first), first_len), cur;
     const uint64_t max_header = 1ull << 31;
@@ -154,18 +174,18 @@ bool decode_header_block(const uint8_t* payload, uint64_t size, uint32_t n, cons
             while (nf < limit && pp < lp) { const Field p = field_at(ph, lp, pp); cur.append(prev, pp, p.len); pp += p.len; nf++; }
         };
         for (;;) {
-            const uint32_t t = d.next(M.type);
-            if (d.bad) return false;
+            const uint32_t t = d.next(MI_TYPE);
+            if (d.bad()) return false;
             if (t == H_END_MATCH) { copy_prev_until(~0ull); break; }
             if (t == H_END) {
-                const uint64_t f = decode_count(d, M, M.field_index);
+                const uint64_t f = decode_count(d, MI_FIELD_INDEX);
                 if (f < nf) return false;
                 copy_prev_until(f);
                 if (nf != f) return false;
                 break;
             }
             if (t < H_FIELD_ASCII || t >= H_TYPE_COUNT) return false;
-            const uint64_t idx = decode_count(d, M, M.field_index);
+            const uint64_t idx = decode_count(d, MI_FIELD_INDEX);
             if (idx < nf) return false;
             copy_prev_until(idx);
             if (nf != idx) return false;
@@ -174,21 +194,21 @@ bool decode_header_block(const uint8_t* payload, uint64_t size, uint32_t n, cons
             const uint64_t p0 = pp;
             if (have_p) { p = field_at(ph, lp, pp); pp += p.len; }
             if (t == H_FIELD_ASCII) {
-                const uint64_t col = decode_count(d, M, M.field_column), sz = decode_count(d, M, M.mis_size);
+                const uint64_t col = decode_count(d, MI_FIELD_COLUMN), sz = decode_count(d, MI_MIS_SIZE);
                 if (col > p.len || sz > max_header || cur.size() + col + sz > max_header) return false;
                 cur.append(prev, p0, col);
-                for (uint64_t j = 0; j < sz && !d.bad; j++) cur.push_back((char)d.next(M.ascii));
+                for (uint64_t j = 0; j < sz && !d.bad(); j++) cur.push_back((char)d.next(MI_ASCII));
             } else {
                 uint64_t v = 0, z = 0; uint8_t sep = 0; bool has_sep = false;
                 if (t == H_FIELD_DELTA || t == H_FIELD_DELTA_2) {
-                    const uint64_t dv = decode_numeric(d, M);
+                    const uint64_t dv = decode_numeric(d);
                     if (!have_p || !p.numeric) return false;
                     v = t == H_FIELD_DELTA ? p.value + dv : p.value - dv;
                     sep = p.sep; has_sep = p.has_sep;
                 } else {
-                    if (t != H_FIELD_NUMERIC) z = decode_count(d, M, M.zero);
-                    if (t != H_FIELD_ZERO_ONLY) v = decode_numeric(d, M);
-                    sep = (uint8_t)d.next(M.ascii); has_sep = sep != 0;
+                    if (t != H_FIELD_NUMERIC) z = decode_count(d, MI_ZERO);
+                    if (t != H_FIELD_ZERO_ONLY) v = decode_numeric(d);
+                    sep = (uint8_t)d.next(MI_ASCII); has_sep = sep != 0;
                 }
                 if (z > max_header || cur.size() + z > max_header) return false;
                 cur.append(z, '0');
@@ -204,25 +224,14 @@ bool decode_header_block(const uint8_t* payload, uint64_t size, uint32_t n, cons
     return true;
 }
 
-}  // namespace
-
-extern "C" {
-
-int leon_host_header_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads, uint64_t n_blocks,
-                                   const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap,
-                                   uint64_t* out_off, uint64_t* out_size, uint32_t n_threads) {
-    if (!out_size || (n_blocks && (!payloads || !payload_off || !block_n_reads || !out_off)) || (!first_header && first_header_len))
-        return fail(LEON_E_INVALID, "null argument");
-    *out_size = 0;
-    if (!n_blocks) return LEON_OK;
-    for (uint64_t b = 0; b < n_blocks; b++)
-        if (payload_off[b + 1] < payload_off[b]) return fail(LEON_E_INVALID, "payload offsets are not monotonic");
+// blocks in parallel on host threads, then the texts back to back with the offsets of every header
+template <typename F>
+int header_blocks_common(uint64_t n_blocks, uint8_t* out, uint64_t out_cap, uint64_t* out_off, uint64_t* out_size, uint32_t n_threads, F&& decode_one) {
     std::vector<std::string> texts(n_blocks);
     std::vector<std::vector<uint64_t>> offs(n_blocks);
     std::atomic<int64_t> bad{-1};
     parallel_blocks(n_blocks, n_threads, [&](uint64_t b) {
-        if (!decode_header_block(payloads + payload_off[b], payload_off[b + 1] - payload_off[b], block_n_reads[b], first_header,
-                                 first_header_len, texts[b], offs[b])) {
+        if (!decode_one(b, texts[b], offs[b])) {
             int64_t expect = -1;
             bad.compare_exchange_strong(expect, (int64_t)b);
         }
@@ -240,6 +249,38 @@ int leon_host_header_decode_blocks(const uint8_t* payloads, const uint64_t* payl
         w += texts[b].size();
     }
     return LEON_OK;
+}
+
+}  // namespace
+
+namespace leon {
+// the text of header blocks whose symbols the device has decoded (capi.hip, leon_header_decode_blocks): block b's symbols are
+// syms[sym_begin[b] .. + sym_count[b]), one byte each, in the order the HeaderDecoder asks for them
+int header_blocks_from_symbols(const uint8_t* syms, const uint64_t* sym_begin, const uint64_t* sym_count, const uint32_t* block_n_reads, uint64_t n_blocks,
+                               const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
+                               uint64_t* out_size, uint32_t n_threads) {
+    return header_blocks_common(n_blocks, out, out_cap, out_off, out_size, n_threads, [&](uint64_t b, std::string& text, std::vector<uint64_t>& off) {
+        SymbolSource src(syms + sym_begin[b], sym_count[b]);
+        return decode_header_block(src, block_n_reads[b], first_header, first_header_len, text, off) && !src.over && src.i == src.n;
+    });
+}
+}  // namespace leon
+
+extern "C" {
+
+int leon_host_header_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads, uint64_t n_blocks,
+                                   const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap,
+                                   uint64_t* out_off, uint64_t* out_size, uint32_t n_threads) {
+    if (!out_size || (n_blocks && (!payloads || !payload_off || !block_n_reads || !out_off)) || (!first_header && first_header_len))
+        return fail(LEON_E_INVALID, "null argument");
+    *out_size = 0;
+    if (!n_blocks) return LEON_OK;
+    for (uint64_t b = 0; b < n_blocks; b++)
+        if (payload_off[b + 1] < payload_off[b]) return fail(LEON_E_INVALID, "payload offsets are not monotonic");
+    return header_blocks_common(n_blocks, out, out_cap, out_off, out_size, n_threads, [&](uint64_t b, std::string& text, std::vector<uint64_t>& off) {
+        RangeSource src(payloads + payload_off[b], payload_off[b + 1] - payload_off[b]);
+        return decode_header_block(src, block_n_reads[b], first_header, first_header_len, text, off);
+    });
 }
 
 // ---- quality stream, lossless: one zlib stream per read block over the block's quality lines, each followed by '\n' ----

@@ -112,6 +112,9 @@ void launch_path_cache_init(hipStream_t s, PathCache C, uint32_t k);
 void launch_path_cache_prewalk(hipStream_t s, BloomDev B, PathCache C, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors, uint32_t max_steps);
 void launch_bloom_fingerprint(hipStream_t s, const uint8_t* bits, uint64_t n_bytes, uint64_t* d_sum /* zeroed by the caller */);
 size_t decode_scratch_bytes(uint64_t n_blocks);
+// header blocks: the stream's symbols as bytes, block b's in syms[sym_begin[b] .. sym_begin[b + 1]) (its share), sym_count[b] of them
+void launch_hdr_decode_symbols(hipStream_t s, const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads, uint64_t n_blocks,
+                               uint8_t* syms, const uint64_t* sym_begin, unsigned long long* sym_count, int* err);
 void launch_decode_blocks(hipStream_t s, BloomDev B, PathCache C, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors,
                           const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads, const uint64_t* blk_read0,
                           const uint64_t* blk_out0, uint64_t n_blocks, uint8_t* out, uint32_t* out_len, uint32_t* scratch,

@@ -483,6 +483,8 @@ void Leon::executeDecompression() {
     }
 
     CtxPtr ctx = make_ctx((uint32_t)k, tai, device_for(0), (uint32_t)n_hash, (uint32_t)nbits, (uint32_t)rpb);
+    CtxPtr hdr_ctx;                                              // header blocks decode on the device too, on a stream of their own
+    if (has_header) hdr_ctx = make_ctx((uint32_t)k, 1000, device_for(0));
     {
         const std::vector<uint8_t> bloom = in.getBytes(DS_BLOOM_BITS);
         check(ctx.get(), leon_dna_bloom_upload(ctx.get(), bloom.data(), bloom.size()), "leon_dna_bloom_upload");
@@ -639,14 +641,15 @@ void Leon::executeDecompression() {
             if (has_header) {
                 uint64_t need = 0;
                 R->hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
-                int rc = leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(), R->hdr.size(),
-                                                        R->hdr_off.data(), &need, cores);
+                // the stream's symbols on the device (its own context and stream, beside the DNA blocks), the text on the host threads
+                int rc = leon_header_decode_blocks(hdr_ctx.get(), pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
+                                                   R->hdr.size(), R->hdr_off.data(), &need, cores);
                 if (rc == LEON_E_OVERFLOW) {
                     R->hdr.resize(need + 1);
-                    rc = leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(), R->hdr.size(),
-                                                        R->hdr_off.data(), &need, cores);
+                    rc = leon_header_decode_blocks(hdr_ctx.get(), pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
+                                                   R->hdr.size(), R->hdr_off.data(), &need, cores);
                 }
-                if (rc != LEON_OK) throw Exception(std::string("leon_host_header_decode_blocks: ") + leon_last_error(nullptr));
+                if (rc != LEON_OK) throw Exception(std::string("leon_header_decode_blocks: ") + leon_last_error(hdr_ctx.get()));
             }
             lap(th, host_hdr_s);
             if (fastq_out) {

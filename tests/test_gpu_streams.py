@@ -32,6 +32,19 @@ def test_header_blocks_bit_exact(name, make, n, rpb):
     for i, (b, r) in enumerate(zip(blocks, ref)):
         assert b[1] == r, "header block %d differs from the oracle" % i
     assert capi.host_header_decode_blocks(blocks, hs[0]) == hs
+    # the decoder with the arithmetic decoding on the device (symbols there, text on the host threads): the same headers;
+    # "nasty" has headers with hundreds of symbols, more than a block's share of the device buffer: the host decodes instead
+    assert ctx.header_decode_blocks(blocks, hs[0]) == hs
+    assert ctx.header_decode_blocks(blocks, hs[0], n_threads=3) == hs
+    assert ctx.header_decode_blocks([], b"") == []
+    if len(blocks) > 1:                                            # a payload that is not a header stream is reported, by both decoders
+        bad = list(blocks)
+        bad[1] = (bad[1][0], bytes(255 - x for x in bad[1][1]), bad[1][2])
+        for dec in (lambda: ctx.header_decode_blocks(bad, hs[0]), lambda: capi.host_header_decode_blocks(bad, hs[0])):
+            try:
+                assert dec()[rpb:2 * rpb] != hs[rpb:2 * rpb]
+            except capi.LeonDnaError as e:
+                assert "does not decode" in str(e)
     ctx.close()
 
 
@@ -167,6 +180,7 @@ def test_header_stream_fuzz(seed):
     first = hs[rnd.randrange(len(hs))] if seed else hs[0]
     ctx = _ctx(rpb)
     blocks = ctx.header_encode_batch(hs, first_header=first)
-    ctx.close()
     assert [b[1] for b in blocks] == _oracle_blocks(hs, rpb, first)
     assert capi.host_header_decode_blocks(blocks, first, n_threads=3) == hs
+    assert ctx.header_decode_blocks(blocks, first, n_threads=3) == hs
+    ctx.close()
