@@ -361,7 +361,31 @@ def main():
         streams["header"] = {"headers": nh, "bytes_in": int(hoff[-1]), "bytes_out": hbytes[0], "ms": round(best * 1e3, 1),
                              "MBps": round(int(hoff[-1]) / 1e6 / best, 1),
                              "what": "leon_header_encode_batch_device, headers resident in HBM, best of 3: k_hdr_symbols x2 + scan + k_rc_encode + D2H"}
-        del d_blob, d_hoff
+        # ... and back: the blocks of the last run through both decoders (C calls only: payloads in, text + offsets out)
+        hblocks = []
+        keep_h = capi.SINK(lambda user, bid, ptr, size, nreads: (hblocks.append((int(bid), ctypes.string_at(ptr, size), int(nreads))), 0)[1])
+        ctx.reset_stream()
+        rc = ctx.lib.leon_header_encode_batch_device(ctx.h, ctypes.c_void_p(d_blob.data_ptr()), ctypes.c_void_p(d_hoff.data_ptr()), nh, 0, first, len(first), keep_h, None)
+        assert rc == 0
+        pay, poff, pnr = capi._join_blocks(hblocks)
+        out_off = np.zeros(nh + 1, dtype=np.uint64); need = ctypes.c_uint64(); cap = int(hoff[-1]) + 64
+        texts = {}
+        for name, call in (("host_threads", lambda o: ctx.lib.leon_host_header_decode_blocks(capi._ptr(pay, capi._u8p), capi._ptr(poff, capi._u64p), capi._ptr(pnr, capi._u32p),
+                                len(hblocks), first, len(first), capi._ptr(o, capi._u8p), cap, capi._ptr(out_off, capi._u64p), ctypes.byref(need), 0)),
+                           ("device_symbols", lambda o: ctx.lib.leon_header_decode_blocks(ctx.h, capi._ptr(pay, capi._u8p), capi._ptr(poff, capi._u64p), capi._ptr(pnr, capi._u32p),
+                                len(hblocks), first, len(first), capi._ptr(o, capi._u8p), cap, capi._ptr(out_off, capi._u64p), ctypes.byref(need), 0))):
+            best = None
+            for _ in range(2):
+                o = np.empty(cap, dtype=np.uint8)
+                t0 = time.perf_counter(); rc = call(o); dt = time.perf_counter() - t0
+                assert rc == 0, rc
+                best = dt if best is None else min(best, dt)
+            texts[name] = (round(best * 1e3, 1), bool(np.array_equal(o[:int(hoff[-1])], blob)))
+        streams["header_decode"] = {"headers": nh, "blocks": len(hblocks), "host_threads_ms": texts["host_threads"][0], "device_symbols_ms": texts["device_symbols"][0],
+                                    "equal_input": texts["host_threads"][1] and texts["device_symbols"][1],
+                                    "what": "leon_host_header_decode_blocks (all the CPUs of the quota) against leon_header_decode_blocks (symbols on the device, one wave per "
+                                            "block; text on the host threads), payloads in and text out in host memory, best of 2"}
+        del d_blob, d_hoff, hblocks, pay
         ctx.reset_stream()
 
     cpu = None

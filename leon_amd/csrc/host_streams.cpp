@@ -241,13 +241,16 @@ int header_blocks_common(uint64_t n_blocks, uint8_t* out, uint64_t out_cap, uint
     for (uint64_t b = 0; b < n_blocks; b++) w += texts[b].size();
     *out_size = w;
     if (w > out_cap || !out) return fail(LEON_E_OVERFLOW, "header output needs " + std::to_string(w) + " bytes");
-    w = 0;
+    // every block's text and offsets to their final places, again by all threads (gigabytes: not a job for one core)
+    std::vector<uint64_t> w0(n_blocks + 1, 0), r0(n_blocks + 1, 0);
+    for (uint64_t b = 0; b < n_blocks; b++) { w0[b + 1] = w0[b] + texts[b].size(); r0[b + 1] = r0[b] + (offs[b].empty() ? 0 : offs[b].size() - 1); }
     out_off[0] = 0;
-    for (uint64_t b = 0; b < n_blocks; b++) {
-        if (!texts[b].empty()) memcpy(out + w, texts[b].data(), texts[b].size());
-        for (size_t i = 1; i < offs[b].size(); i++) out_off[++r] = w + offs[b][i];
-        w += texts[b].size();
-    }
+    parallel_blocks(n_blocks, n_threads, [&](uint64_t b) {
+        if (!texts[b].empty()) memcpy(out + w0[b], texts[b].data(), texts[b].size());
+        for (size_t i = 1; i < offs[b].size(); i++) out_off[r0[b] + i] = w0[b] + offs[b][i];
+        std::string().swap(texts[b]);
+    });
+    (void)r;
     return LEON_OK;
 }
 

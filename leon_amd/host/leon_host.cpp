@@ -485,6 +485,8 @@ void Leon::executeDecompression() {
     CtxPtr ctx = make_ctx((uint32_t)k, tai, device_for(0), (uint32_t)n_hash, (uint32_t)nbits, (uint32_t)rpb);
     CtxPtr hdr_ctx;                                              // header blocks decode on the device too, on a stream of their own
     if (has_header) hdr_ctx = make_ctx((uint32_t)k, 1000, device_for(0));
+    uint64_t header_blocks_on_device = 384;                      // rounds of at least this many blocks (LEON_HEADER_DEVICE_BLOCKS; tests: 0 = always, a huge number = never)
+    if (const char* e = getenv("LEON_HEADER_DEVICE_BLOCKS")) header_blocks_on_device = (uint64_t)std::max<long long>(0, atoll(e));
     {
         const std::vector<uint8_t> bloom = in.getBytes(DS_BLOOM_BITS);
         check(ctx.get(), leon_dna_bloom_upload(ctx.get(), bloom.data(), bloom.size()), "leon_dna_bloom_upload");
@@ -641,15 +643,19 @@ void Leon::executeDecompression() {
             if (has_header) {
                 uint64_t need = 0;
                 R->hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
-                // the stream's symbols on the device (its own context and stream, beside the DNA blocks), the text on the host threads
-                int rc = leon_header_decode_blocks(hdr_ctx.get(), pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
-                                                   R->hdr.size(), R->hdr_off.data(), &need, cores);
-                if (rc == LEON_E_OVERFLOW) {
-                    R->hdr.resize(need + 1);
-                    rc = leon_header_decode_blocks(hdr_ctx.get(), pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
-                                                   R->hdr.size(), R->hdr_off.data(), &need, cores);
-                }
-                if (rc != LEON_OK) throw Exception(std::string("leon_header_decode_blocks: ") + leon_last_error(hdr_ctx.get()));
+                // A round of many blocks: the stream's symbols on the device (its own context and stream, beside the DNA blocks: a
+                // block is a serial chain there too, ~1.3 s for 50 000 headers, but all of them at once) and the text on the host
+                // threads.  A few hundred blocks: the host threads alone are quicker (10 M headers in 200 blocks: 0.62 s against 1.27 s).
+                auto decode = [&]() -> int {
+                    if (nb >= header_blocks_on_device)
+                        return leon_header_decode_blocks(hdr_ctx.get(), pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
+                                                         R->hdr.size(), R->hdr_off.data(), &need, cores);
+                    return leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
+                                                          R->hdr.size(), R->hdr_off.data(), &need, cores);
+                };
+                int rc = decode();
+                if (rc == LEON_E_OVERFLOW) { R->hdr.resize(need + 1); rc = decode(); }
+                if (rc != LEON_OK) throw Exception(std::string("header blocks: ") + leon_last_error(nb >= header_blocks_on_device ? hdr_ctx.get() : nullptr));
             }
             lap(th, host_hdr_s);
             if (fastq_out) {
