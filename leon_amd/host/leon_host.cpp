@@ -523,16 +523,15 @@ void Leon::executeDecompression() {
     const char lead = fastq_out ? '@' : '>';
 
     // Blocks decoded per round.  A round costs the device ONE block's serial chain whatever the number of blocks in it (up to
-    // a few thousand: one wave per block), so rounds should be large; two are alive at a time (one being decoded, the one
-    // before it being formatted and written), each ~5 bytes per base in bases, qualities and text: an eighth of the available
-    // RAM each.  Files of more than a few hundred blocks are cut into at least four rounds, so that the host's share of the
+    // a few thousand: one wave per block), so rounds should be large; three are alive at a time (see the stages below), each
+    // ~5 bytes per base in bases, qualities and text: a twelfth of the available RAM each.  Files of more than a few hundred blocks are cut into at least four rounds, so that the host's share of the
     // work (header and quality blocks, formatting, writing) of one round runs beside the decoding of the next.
     uint64_t group = n_blocks ? n_blocks : 1;
     {
         const long pages = sysconf(_SC_AVPHYS_PAGES), page = sysconf(_SC_PAGESIZE);
         const uint64_t avail = pages > 0 && page > 0 ? (uint64_t)pages * (uint64_t)page : (8ull << 30);
         const uint64_t bases_per_block = n_blocks ? std::max<uint64_t>(total_bases / n_blocks, 1) : 1;
-        const uint64_t fit = avail / 8 / 5 / bases_per_block;
+        const uint64_t fit = avail / 12 / 5 / bases_per_block;
         group = std::min<uint64_t>(group, std::max<uint64_t>(fit, 64));
         if (n_blocks >= 800) group = std::min<uint64_t>(group, (n_blocks + 3) / 4);
         if (const char* e = getenv("LEON_DECODE_BLOCKS")) { const long v = atol(e); if (v > 0) group = (uint64_t)v; }   // (tests: several rounds on a small file)
@@ -548,14 +547,16 @@ void Leon::executeDecompression() {
     };
     // what one round hands from the decoding stage to the writing stage
     struct Round {
-        uint64_t read_index = 0, file_off = 0, g_reads = 0, g_bases = 0, n_text = 0;
-        RawBytes bases, hdr, qual;                               // (gigabytes each: never zero-filled)
+        uint64_t read_index = 0, file_off = 0, g_reads = 0, g_bases = 0, n_text = 0, nb = 0;
+        RawBytes bases, hdr, qual, pay_h, pay_q;                 // (gigabytes each: never zero-filled)
+        std::vector<uint64_t> off_h, off_q, blk_bases;
+        std::vector<uint32_t> blk_reads;
         std::vector<uint32_t> lens;
         std::vector<uint64_t> hdr_off, qual_off;
     };
     std::unique_ptr<char[]> text;                                // the writing stage's records (never zero-filled)
     uint64_t text_cap = 0;
-    double t_read = 0, t_dna = 0, t_hdr = 0, t_qual = 0, t_text = 0, t_write = 0, t_wait = 0, t_writer_wait = 0;
+    double t_read = 0, t_dna = 0, t_hdr = 0, t_qual = 0, t_text = 0, t_write = 0, t_writer_wait = 0;
     auto lap = [](std::chrono::steady_clock::time_point& t, double& acc) { const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(n - t).count(); t = n; };
     // the writing stage: every read's place in the text is known from the lengths, so a round is formatted by all cores at
     // once and written by several (pwrite at disjoint offsets)
@@ -608,10 +609,23 @@ void Leon::executeDecompression() {
         if (!werr.empty()) throw Exception(werr);
         lap(tl, t_text);
     };
-    std::future<void> writer;
-    uint64_t read_index = 0, bases_out = 0, file_off = 0;
+    // Three stages, each round through them in turn, the stages of different rounds side by side:
+    //   A (this thread)   the round's payloads out of the container, its DNA blocks on the device;
+    //   B (a task)        its header and quality blocks (one round at a time: they share the header context and the host threads);
+    //   C (a task)        formatting and writing, in file order, once A and B of the round are done.
+    // A round costs the device one block's serial chain whatever is going on beside it, so A never waits for B or C of the same
+    // round -- only for C of the round before last (three rounds alive at most).
+    struct Drain {                                               // (no task outlives what it refers to, whatever way this function is left)
+        std::vector<std::shared_future<void>> all;
+        ~Drain() { for (auto& f : all) if (f.valid()) f.wait(); }
+    } drain;
+    std::shared_future<void> host_before, writer_before, writer_before2;
+    uint64_t read_index = 0, bases_out = 0, next_file_off = 0;  // next_file_off: owned by stage C (one round at a time)
     for (uint64_t g0 = 0; g0 < n_blocks; g0 += group) {
         const uint64_t g1 = std::min(n_blocks, g0 + group), nb = g1 - g0;
+        auto tl = std::chrono::steady_clock::now();
+        if (writer_before2.valid()) writer_before2.get();        // (its errors, and those of its stage B, surface here)
+        lap(tl, t_writer_wait);
         auto gather = [&](const char* grp, const std::vector<uint64_t>& tab, uint32_t stride, RawBytes& pay, std::vector<uint64_t>& off) {
             off.assign(nb + 1, 0);
             for (uint64_t b = 0; b < nb; b++) off[b + 1] = off[b] + tab[stride * (g0 + b)];
@@ -624,22 +638,20 @@ void Leon::executeDecompression() {
         };
         auto R = std::make_shared<Round>();
         RawBytes pay; std::vector<uint64_t> off;
-        std::vector<uint32_t> blk_reads(nb); std::vector<uint64_t> blk_bases(nb);
+        R->nb = nb; R->blk_reads.resize(nb); R->blk_bases.resize(nb);
         uint64_t g_reads = 0, g_bases = 0;
-        for (uint64_t b = 0; b < nb; b++) { blk_reads[b] = (uint32_t)tdna[3 * (g0 + b) + 1]; blk_bases[b] = tdna[3 * (g0 + b) + 2]; g_reads += blk_reads[b]; g_bases += blk_bases[b]; }
-        R->read_index = read_index; R->file_off = file_off; R->g_reads = g_reads; R->g_bases = g_bases;
-        // the three streams' payloads of the round, then: header and quality blocks on the host threads WHILE the device
-        // decodes the DNA blocks (and while the round before is being formatted and written)
-        auto tl = std::chrono::steady_clock::now();
-        RawBytes pay_h, pay_q; std::vector<uint64_t> off_h, off_q;
+        for (uint64_t b = 0; b < nb; b++) { R->blk_reads[b] = (uint32_t)tdna[3 * (g0 + b) + 1]; R->blk_bases[b] = tdna[3 * (g0 + b) + 2]; g_reads += R->blk_reads[b]; g_bases += R->blk_bases[b]; }
+        R->read_index = read_index; R->g_reads = g_reads; R->g_bases = g_bases;
         gather(GROUP_DNA, tdna, 3, pay, off);
-        if (has_header) gather(GROUP_HEADER, thdr, 2, pay_h, off_h);
-        if (fastq_out) gather(GROUP_QUAL, tqual, 3, pay_q, off_q);
+        if (has_header) gather(GROUP_HEADER, thdr, 2, R->pay_h, R->off_h);
+        if (fastq_out) gather(GROUP_QUAL, tqual, 3, R->pay_q, R->off_q);
         lap(tl, t_read);
         R->hdr_off.assign(g_reads + 1, 0); R->qual_off.assign(g_reads + 1, 0);
-        double host_hdr_s = 0, host_qual_s = 0;
-        std::future<void> host_job = std::async(std::launch::async, [&] {
+        // stage B
+        std::shared_future<void> host_job = std::async(std::launch::async, [&, R, host_before] {
+            if (host_before.valid()) host_before.wait();
             auto th = std::chrono::steady_clock::now();
+            const uint64_t nb = R->nb, g_reads = R->g_reads, g_bases = R->g_bases;
             if (has_header) {
                 uint64_t need = 0;
                 R->hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
@@ -648,56 +660,59 @@ void Leon::executeDecompression() {
                 // threads.  A few hundred blocks: the host threads alone are quicker (10 M headers in 200 blocks: 0.62 s against 1.27 s).
                 auto decode = [&]() -> int {
                     if (nb >= header_blocks_on_device)
-                        return leon_header_decode_blocks(hdr_ctx.get(), pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
-                                                         R->hdr.size(), R->hdr_off.data(), &need, cores);
-                    return leon_host_header_decode_blocks(pay_h.data(), off_h.data(), blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
+                        return leon_header_decode_blocks(hdr_ctx.get(), R->pay_h.data(), R->off_h.data(), R->blk_reads.data(), nb, first_header.data(), first_header.size(),
+                                                         R->hdr.data(), R->hdr.size(), R->hdr_off.data(), &need, cores);
+                    return leon_host_header_decode_blocks(R->pay_h.data(), R->off_h.data(), R->blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
                                                           R->hdr.size(), R->hdr_off.data(), &need, cores);
                 };
                 int rc = decode();
                 if (rc == LEON_E_OVERFLOW) { R->hdr.resize(need + 1); rc = decode(); }
                 if (rc != LEON_OK) throw Exception(std::string("header blocks: ") + leon_last_error(nb >= header_blocks_on_device ? hdr_ctx.get() : nullptr));
             }
-            lap(th, host_hdr_s);
+            lap(th, t_hdr);
             if (fastq_out) {
                 R->qual.resize(g_bases + 1);
-                if (leon_host_qual_decode_blocks(pay_q.data(), off_q.data(), blk_reads.data(), blk_bases.data(), nb, R->qual.data(), g_bases, R->qual_off.data(), cores) != LEON_OK)
+                if (leon_host_qual_decode_blocks(R->pay_q.data(), R->off_q.data(), R->blk_reads.data(), R->blk_bases.data(), nb, R->qual.data(), g_bases, R->qual_off.data(), cores) != LEON_OK)
                     throw Exception(std::string("leon_host_qual_decode_blocks: ") + leon_last_error(nullptr));
             }
-            lap(th, host_qual_s);
-        });
+            lap(th, t_qual);
+            R->pay_h = RawBytes(); R->pay_q = RawBytes();         // (the payloads are not needed any more)
+        }).share();
+        drain.all.push_back(host_job);
+        // stage A, the device part
         R->bases.resize(g_bases + 1); R->lens.resize(g_reads + 1);
-        std::string dna_error;
-        try {
-            if (dict_job.valid()) dict_job.get();
-            check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), blk_reads.data(), blk_bases.data(), nb, R->bases.data(), g_bases,
-                                                    R->lens.data()), "leon_dna_decode_blocks");
-        } catch (const std::exception& e) { dna_error = e.what(); }
+        if (dict_job.valid()) dict_job.get();
+        check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), R->blk_reads.data(), R->blk_bases.data(), nb, R->bases.data(), g_bases,
+                                                R->lens.data()), "leon_dna_decode_blocks");
         lap(tl, t_dna);
-        try { host_job.get(); }                                  // (joins the host task before anything it references goes away)
-        catch (const std::exception& e) { if (writer.valid()) { try { writer.get(); } catch (...) {} } throw Exception(e.what()); }
-        if (!dna_error.empty()) { if (writer.valid()) { try { writer.get(); } catch (...) {} } throw Exception(dna_error); }
-        lap(tl, t_wait);
-        t_hdr += host_hdr_s; t_qual += host_qual_s;
-        // the size of this round's text, so that the next round knows where its own begins
-        uint64_t n_text = 0;
-        if (has_header && !wrap)                                 // (the decoder has checked that the lengths add up to the block table's bases)
-            n_text = 2 * g_reads + R->hdr_off[g_reads] + g_bases + g_reads + (fastq_out ? 3 * g_reads + g_bases : 0);
-        else {
-            auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
-            for (uint64_t r = 0; r < g_reads; r++) {
-                const uint64_t hl = has_header ? R->hdr_off[r + 1] - R->hdr_off[r] : std::to_string(read_index + r).size();
-                n_text += 1 + hl + 1 + seq_text_len(R->lens[r]) + (fastq_out ? 2 + (uint64_t)R->lens[r] + 1 : 0);
+        // stage C
+        std::shared_future<void> writer = std::async(std::launch::async, [&, R, host_job, writer_before] {
+            host_job.get();                                      // (a failed stage B fails this round's stage C with its message)
+            if (writer_before.valid()) writer_before.get();      // file order; a failure before this round stops the rounds after it
+            const uint64_t g_reads = R->g_reads, g_bases = R->g_bases;
+            // the size of this round's text: where the next round's begins
+            uint64_t n_text = 0;
+            if (has_header && !wrap)                             // (the decoder has checked that the lengths add up to the block table's bases)
+                n_text = 2 * g_reads + R->hdr_off[g_reads] + g_bases + g_reads + (fastq_out ? 3 * g_reads + g_bases : 0);
+            else {
+                auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
+                for (uint64_t r = 0; r < g_reads; r++) {
+                    const uint64_t hl = has_header ? R->hdr_off[r + 1] - R->hdr_off[r] : std::to_string(R->read_index + r).size();
+                    n_text += 1 + hl + 1 + seq_text_len(R->lens[r]) + (fastq_out ? 2 + (uint64_t)R->lens[r] + 1 : 0);
+                }
             }
-        }
-        R->n_text = n_text;
-        if (writer.valid()) writer.get();                        // the round before is on disk (its errors surface here)
-        lap(tl, t_writer_wait);
-        writer = std::async(std::launch::async, write_round, R);
-        read_index += g_reads; bases_out += g_bases; file_off += n_text;
+            R->n_text = n_text; R->file_off = next_file_off;
+            next_file_off += n_text;
+            write_round(R);
+        }).share();
+        drain.all.push_back(writer);
+        writer_before2 = writer_before; writer_before = writer; host_before = host_job;
+        read_index += g_reads; bases_out += g_bases;
     }
     {
         auto tl = std::chrono::steady_clock::now();
-        if (writer.valid()) writer.get();
+        if (writer_before2.valid()) writer_before2.get();
+        if (writer_before.valid()) writer_before.get();
         lap(tl, t_write);
     }
     if (::close(ofd.fd) != 0) { ofd.fd = -1; throw Exception("cannot write " + _outputFilename); }
@@ -707,8 +722,8 @@ void Leon::executeDecompression() {
     std::cout << n_reads << " reads, " << bases_out << " bases decoded from " << n_blocks << " blocks, written to " << _outputFilename << std::endl;
     if (_verbose)
         std::cout << "time: " << seconds_since(t_start) << " s (" << (n_blocks + group - 1) / group << " round(s); container reads " << t_read << ", dictionary + DNA blocks on the device " << t_dna
-                  << ", beside them on the host threads: header blocks " << t_hdr << " + quality blocks " << t_qual << " (waited " << t_wait << " more); formatting + writing "
-                  << t_text << " beside the next round's decoding, waited for " << t_writer_wait + t_write << ")" << std::endl;
+                  << "; beside them, a round behind: header blocks " << t_hdr << " + quality blocks " << t_qual << "; another round behind: formatting + writing "
+                  << t_text << "; waited for them " << t_writer_wait + t_write << ")" << std::endl;
     if (_testFile) testDecompressedFile();
 }
 
