@@ -237,7 +237,7 @@ int header_blocks_common(uint64_t n_blocks, uint8_t* out, uint64_t out_cap, uint
         }
     });
     if (bad.load() >= 0) return fail(LEON_E_INVALID, "header block " + std::to_string(bad.load()) + " does not decode");
-    uint64_t w = 0, r = 0;
+    uint64_t w = 0;
     for (uint64_t b = 0; b < n_blocks; b++) w += texts[b].size();
     *out_size = w;
     if (w > out_cap || !out) return fail(LEON_E_OVERFLOW, "header output needs " + std::to_string(w) + " bytes");
@@ -250,7 +250,6 @@ int header_blocks_common(uint64_t n_blocks, uint8_t* out, uint64_t out_cap, uint
         for (size_t i = 1; i < offs[b].size(); i++) out_off[r0[b] + i] = w0[b] + offs[b][i];
         std::string().swap(texts[b]);
     });
-    (void)r;
     return LEON_OK;
 }
 
