@@ -277,19 +277,37 @@ inline bool decode_anchor_dict(const uint8_t* p, uint64_t n, uint64_t n_anchors,
             } else r = range / tot;
             if (r == 0) return false;
             // the symbol is the number of cumulative counts c with c * r <= code - low; the five products also are the
-            // new low and range (no second multiply, no division)
+            // new low and range (no second multiply, no division).  Selected with conditional moves: the symbol is as good
+            // as random, a branch on it would be mispredicted three times out of four
             const uint64_t d = code - low;
-            uint64_t pp[6] = {0, r * cum[1], r * cum[2], r * cum[3], r * cum[4], r * tot};
-            const uint32_t c = (uint32_t)(d >= pp[1]) + (uint32_t)(d >= pp[2]) + (uint32_t)(d >= pp[3]) + (uint32_t)(d >= pp[4]);
-            low += pp[c];
-            range = pp[c + 1] - pp[c];
-            while ((low ^ (low + range)) < kTop || (range < kBottom && ((range = (0 - low) & (kBottom - 1)), true))) {
-                code = (code << 8) | (i < n ? p[i] : 0); i++;
-                range <<= 8;
-                low <<= 8;
-                if (i > n + 16) return false;                  // far past the end: not a stream this coder wrote (a range of 0 would spin here)
+            const uint64_t p1 = r * cum[1], p2 = r * cum[2], p3 = r * cum[3], p4 = r * cum[4], p5 = r * tot;
+            const uint64_t g1 = d >= p1, g2 = d >= p2, g3 = d >= p3, g4 = d >= p4;
+            const uint32_t c = (uint32_t)(g1 + g2 + g3 + g4);
+            uint64_t lo = g1 ? p1 : 0, hi = g1 ? p2 : p1;
+            lo = g2 ? p2 : lo; hi = g2 ? p3 : hi;
+            lo = g3 ? p3 : lo; hi = g3 ? p4 : hi;
+            lo = g4 ? p4 : lo; hi = g4 ? p5 : hi;
+            low += lo;
+            range = hi - lo;
+            // renormalisation: nothing or one byte in the usual case, both formed and selected without a branch (a byte leaves
+            // after every fourth symbol or so: as a branch that is a misprediction per byte); the rare cases take the loop
+            {
+                const uint64_t x = low ^ (low + range);
+                const bool one = x < kTop;                       // the top byte is settled
+                const uint64_t low1 = low << 8, range1 = range << 8, code1 = (code << 8) | (i < n ? p[i] : 0);
+                const uint64_t x1 = low1 ^ (low1 + range1);
+                if (__builtin_expect((one && (x1 < kTop || range1 < kBottom)) || (!one && range < kBottom), 0)) {
+                    while ((low ^ (low + range)) < kTop || (range < kBottom && ((range = (0 - low) & (kBottom - 1)), true))) {
+                        code = (code << 8) | (i < n ? p[i] : 0); i++;
+                        range <<= 8;
+                        low <<= 8;
+                        if (i > n + 16) return false;              // far past the end: not a stream this coder wrote (a range of 0 would spin here)
+                    }
+                } else {
+                    low = one ? low1 : low; range = one ? range1 : range; code = one ? code1 : code; i += one;
+                }
             }
-            for (uint32_t x = 1; x <= 5; x++) cum[x] += (uint64_t)(x > c);     // Order0Model::update, branch-free
+            cum[1] += (uint64_t)(c < 1); cum[2] += (uint64_t)(c < 2); cum[3] += (uint64_t)(c < 3); cum[4] += (uint64_t)(c < 4);   // Order0Model::update, branch-free
             if (c > 3) return false;                           // an N inside an anchor: not a stream this coder wrote
             km = (km << 2) | c;
         }

@@ -128,3 +128,37 @@ def test_host_anchor_dict_decode_inverts_encode(lib, k, n):
     got = capi.anchor_dict_decode(stream, n, k)
     assert np.array_equal(got, kmers)
     assert O.kmers_to_ints(O.decode_anchor_dict(stream, n, k), k) == ints
+
+
+@pytest.mark.parametrize("kind", ["uniform", "poly_a", "skewed", "two_letter", "long"])
+def test_host_anchor_dict_decode_on_skewed_streams(lib, kind):
+    """the decoder's renormalisation is branch-free for "no byte" / "one byte" and a loop for the rest: streams that spend most
+    of their time in the rest (poly-A: many symbols per byte, then several bytes at once) and a long one (past the reciprocal
+    stream's first chunks) decode back to what was coded, and to what the oracle's decoder gives"""
+    import numpy as np
+    import oracle_lib as O
+    from leon_amd import capi
+    rng = np.random.default_rng(11)
+    k, n = 31, 300000 if kind == "long" else 20000
+    if kind == "poly_a":
+        syms = np.zeros(n * k, dtype=np.uint8)
+        syms[rng.integers(0, n * k, 200)] = rng.integers(1, 4, 200)
+    elif kind == "skewed":
+        syms = rng.choice(4, size=n * k, p=[0.97, 0.01, 0.01, 0.01]).astype(np.uint8)
+    elif kind == "two_letter":
+        syms = (rng.integers(0, 2, n * k) * 2).astype(np.uint8)
+    else:
+        syms = rng.integers(0, 4, n * k).astype(np.uint8)
+    s2 = syms.reshape(n, k).astype(np.uint64)
+    kmers = np.zeros(n, dtype=np.uint64)
+    for i in range(k):
+        kmers = (kmers << np.uint64(2)) | s2[:, i]
+    stream = capi.host_anchor_dict_encode(kmers, k)
+    assert np.array_equal(capi.anchor_dict_decode(stream, n, k), kmers)
+    if kind != "long":
+        assert np.array_equal(np.asarray(O.decode_anchor_dict(stream, n, k), dtype=np.uint64).reshape(-1)[:n], kmers)
+    for cut in (len(stream) // 2, 3):                              # a truncated stream decodes to something or is refused: never a crash, never a hang
+        try:
+            capi.anchor_dict_decode(stream[:cut], n, k)
+        except capi.LeonDnaError:
+            pass
