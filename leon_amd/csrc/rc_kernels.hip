@@ -33,7 +33,10 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                                                             uint32_t* scratch, int* err, uint32_t small_sizes) {
     constexpr uint32_t MW = RC_SMALL_WORDS + RC_NSLOT * RC_STRIDE;
     __shared__ uint32_t models_all[G * MW];
-    __shared__ uint32_t ring_all[G][2][5][RC_RING];          // one spare entry per row: the coder prefetches record j + 1
+    // a step's record: {cumLow, freq, total, cumLow + freq} and the total's 64-bit reciprocal -- two LDS reads for the coder (its
+    // step is paid in issue slots); one spare entry per row: the coder prefetches record j + 1
+    __shared__ uint4 ring_a[G][2][RC_RING];
+    __shared__ uint2 ring_b[G][2][RC_RING];
     __shared__ uint8_t slotmap_all[G][RC_NNUM];
     __shared__ uint32_t ntiles_s[G];
     const uint32_t lane = threadIdx.x & 63;
@@ -210,25 +213,26 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                     }
                     __builtin_amdgcn_wave_barrier();
                     const uint64_t inv = ~0ull / (uint64_t)tot;        // per lane, off the serial chains
-                    uint32_t(*rg)[RC_RING] = ring_all[mi][t & 1];
-                    rg[0][lane] = lo; rg[1][lane] = hi - lo; rg[2][lane] = tot;
-                    rg[3][lane] = (uint32_t)inv; rg[4][lane] = (uint32_t)(inv >> 32);
+                    ring_a[mi][t & 1][lane] = make_uint4(lo, hi - lo, tot, hi);
+                    ring_b[mi][t & 1][lane] = make_uint2((uint32_t)inv, (uint32_t)(inv >> 32));
                 } else if (t < T) {
                     // the group's longer blocks go on: records that leave a chain as it is (cumLow 0, freq = total = 1)
-                    uint32_t(*rg)[RC_RING] = ring_all[mi][t & 1];
-                    rg[0][lane] = 0; rg[1][lane] = 1; rg[2][lane] = 1; rg[3][lane] = ~0u; rg[4][lane] = ~0u;
+                    ring_a[mi][t & 1][lane] = make_uint4(0u, 1u, 1u, 1u);
+                    ring_b[mi][t & 1][lane] = make_uint2(~0u, ~0u);
                 }
             } else if (t > 0) {
                 // =================== coder: tile t-1 of every block of the group, lane = block ===================
                 // (symbols past a block's end are "leave as it is" records, so the 64 steps are uniform)
                 if (valid) {
-                    const uint32_t* rg = &ring_all[lane][(t - 1) & 1][0][0];
-                    uint32_t p_lo = rg[0], p_fr = rg[RC_RING], p_tot = rg[2 * RC_RING], p_b0 = rg[3 * RC_RING], p_b1 = rg[4 * RC_RING];
+                    const uint4* ra = &ring_a[lane][(t - 1) & 1][0];
+                    const uint2* rb = &ring_b[lane][(t - 1) & 1][0];
+                    uint4 pa = ra[0];
+                    uint2 pb = rb[0];
 #pragma unroll 4
                     for (uint32_t j = 0; j < 64; j++) {
-                        const uint32_t s_lo = p_lo, s_fr = p_fr, s_tot = p_tot, b0 = p_b0, b1 = p_b1;
+                        const uint32_t s_lo = pa.x, s_fr = pa.y, s_tot = pa.z, s_hc = pa.w, b0 = pb.x, b1 = pb.y;
                         const uint32_t jn = j + 1;                                 // next step's record, fetched under this step
-                        p_lo = rg[jn]; p_fr = rg[RC_RING + jn]; p_tot = rg[2 * RC_RING + jn]; p_b0 = rg[3 * RC_RING + jn]; p_b1 = rg[4 * RC_RING + jn];
+                        pa = ra[jn]; pb = rb[jn];
                         // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
                         // total < 2^30), fixed up on the low word
                         const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
@@ -240,7 +244,6 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                         asm volatile("" : "+v"(e));                                 // (one 64-bit add, not three)
                         q += e;
                         const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
-                        const uint32_t s_hc = s_lo + s_fr;
                         // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq)
                         uint64_t top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
                         low = (uint64_t)q0 * s_lo + low;            low += (uint64_t)(q1 * s_lo) << 32;
