@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -523,15 +524,15 @@ void Leon::executeDecompression() {
     const char lead = fastq_out ? '@' : '>';
 
     // Blocks decoded per round.  A round costs the device ONE block's serial chain whatever the number of blocks in it (up to
-    // a few thousand: one wave per block), so rounds should be large; three are alive at a time (see the stages below), each
-    // ~5 bytes per base in bases, qualities and text: a twelfth of the available RAM each.  Files of more than a few hundred blocks are cut into at least four rounds, so that the host's share of the
+    // a few thousand: one wave per block), so rounds should be large; up to five are alive at a time (see the stages below), each
+    // ~5 bytes per base in bases, qualities and text: a twentieth of the available RAM each.  Files of more than a few hundred blocks are cut into at least four rounds, so that the host's share of the
     // work (header and quality blocks, formatting, writing) of one round runs beside the decoding of the next.
     uint64_t group = n_blocks ? n_blocks : 1;
     {
         const long pages = sysconf(_SC_AVPHYS_PAGES), page = sysconf(_SC_PAGESIZE);
         const uint64_t avail = pages > 0 && page > 0 ? (uint64_t)pages * (uint64_t)page : (8ull << 30);
         const uint64_t bases_per_block = n_blocks ? std::max<uint64_t>(total_bases / n_blocks, 1) : 1;
-        const uint64_t fit = avail / 12 / 5 / bases_per_block;
+        const uint64_t fit = avail / 20 / 5 / bases_per_block;
         group = std::min<uint64_t>(group, std::max<uint64_t>(fit, 64));
         if (n_blocks >= 800) group = std::min<uint64_t>(group, (n_blocks + 3) / 4);
         if (const char* e = getenv("LEON_DECODE_BLOCKS")) { const long v = atol(e); if (v > 0) group = (uint64_t)v; }   // (tests: several rounds on a small file)
@@ -546,12 +547,15 @@ void Leon::executeDecompression() {
         uint64_t size() const { return n; }
     };
     // what one round hands from the decoding stage to the writing stage
+    struct DnaGroup { RawBytes bases; std::unique_ptr<uint32_t[]> lens; };   // the DNA blocks of one device call: the bases and lengths of its rounds
     struct Round {
         uint64_t read_index = 0, file_off = 0, g_reads = 0, g_bases = 0, n_text = 0, nb = 0;
-        RawBytes bases, hdr, qual, pay_h, pay_q;                 // (gigabytes each: never zero-filled)
+        std::shared_ptr<DnaGroup> dna; uint64_t base0 = 0, read0 = 0;   // this round's share of them
+        const uint8_t* bases() const { return dna->bases.p.get() + base0; }
+        const uint32_t* lens() const { return dna->lens.get() + read0; }
+        RawBytes hdr, qual, pay_h, pay_q;                        // (gigabytes each: never zero-filled)
         std::vector<uint64_t> off_h, off_q, blk_bases;
         std::vector<uint32_t> blk_reads;
-        std::vector<uint32_t> lens;
         std::vector<uint64_t> hdr_off, qual_off;
     };
     std::unique_ptr<char[]> text;                                // the writing stage's records (never zero-filled)
@@ -567,9 +571,9 @@ void Leon::executeDecompression() {
         auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
         for (uint64_t r = 0; r < g_reads; r++) {
             const uint64_t hl = has_header ? R->hdr_off[r + 1] - R->hdr_off[r] : std::to_string(R->read_index + r).size();
-            if (fastq_out && R->qual_off[r + 1] - R->qual_off[r] != R->lens[r]) throw Exception(_inputFilename + ": a read's quality and sequence lengths differ");
-            rec_off[r + 1] = rec_off[r] + 1 + hl + 1 + seq_text_len(R->lens[r]) + (fastq_out ? 2 + (uint64_t)R->lens[r] + 1 : 0);
-            base_at[r + 1] = base_at[r] + R->lens[r];
+            if (fastq_out && R->qual_off[r + 1] - R->qual_off[r] != R->lens()[r]) throw Exception(_inputFilename + ": a read's quality and sequence lengths differ");
+            rec_off[r + 1] = rec_off[r] + 1 + hl + 1 + seq_text_len(R->lens()[r]) + (fastq_out ? 2 + (uint64_t)R->lens()[r] + 1 : 0);
+            base_at[r + 1] = base_at[r] + R->lens()[r];
         }
         const uint64_t n_text = rec_off[g_reads];
         if (n_text != R->n_text) throw Exception(_inputFilename + ": the decoded reads do not add up to their blocks' sizes");
@@ -584,8 +588,8 @@ void Leon::executeDecompression() {
                 if (has_header) { const uint64_t hl = R->hdr_off[r + 1] - R->hdr_off[r]; memcpy(w, R->hdr.data() + R->hdr_off[r], hl); w += hl; }
                 else { const std::string idx = std::to_string(R->read_index + r); memcpy(w, idx.data(), idx.size()); w += idx.size(); }
                 *w++ = '\n';
-                const char* seq = reinterpret_cast<const char*>(R->bases.data()) + base_at[r];
-                const uint64_t len = R->lens[r];
+                const char* seq = reinterpret_cast<const char*>(R->bases()) + base_at[r];
+                const uint64_t len = R->lens()[r];
                 if (wrap && len > wrap) {
                     for (uint64_t o2 = 0; o2 < len; o2 += wrap) { const uint64_t m = std::min<uint64_t>(wrap, len - o2); memcpy(w, seq + o2, m); w += m; *w++ = '\n'; }
                 } else { memcpy(w, seq, len); w += len; *w++ = '\n'; }
@@ -610,23 +614,27 @@ void Leon::executeDecompression() {
         lap(tl, t_text);
     };
     // Three stages, each round through them in turn, the stages of different rounds side by side:
-    //   A (this thread)   the round's payloads out of the container, its DNA blocks on the device;
-    //   B (a task)        its header and quality blocks (one round at a time: they share the header context and the host threads);
+    //   A (this thread)   the payloads out of the container, the DNA blocks on the device -- of `dna_rounds` rounds per device call:
+    //                     a call costs one block's serial chain whatever the number of blocks, so a large file makes two calls;
+    //   B (a task)        a round's header blocks (their symbols on the device for rounds of many blocks: the host threads are idle
+    //                     meanwhile) and, beside them, its quality blocks; one round at a time;
     //   C (a task)        formatting and writing, in file order, once A and B of the round are done.
-    // A round costs the device one block's serial chain whatever is going on beside it, so A never waits for B or C of the same
-    // round -- only for C of the round before last (three rounds alive at most).
+    // A never waits for B or C of its own rounds -- only for C of rounds further back (memory).
+    uint64_t dna_rounds = n_blocks >= 800 ? 2 : 1;
+    if (const char* e = getenv("LEON_DECODE_DNA_ROUNDS")) { const long v = atol(e); if (v > 0) dna_rounds = (uint64_t)v; }   // (tests)
     struct Drain {                                               // (no task outlives what it refers to, whatever way this function is left)
         std::vector<std::shared_future<void>> all;
         ~Drain() { for (auto& f : all) if (f.valid()) f.wait(); }
     } drain;
-    std::shared_future<void> host_before, writer_before, writer_before2;
+    std::shared_future<void> host_before, writer_before;
+    std::deque<std::shared_future<void>> pending;               // stage C of the rounds in flight, oldest first
     uint64_t read_index = 0, bases_out = 0, next_file_off = 0;  // next_file_off: owned by stage C (one round at a time)
-    for (uint64_t g0 = 0; g0 < n_blocks; g0 += group) {
-        const uint64_t g1 = std::min(n_blocks, g0 + group), nb = g1 - g0;
+    for (uint64_t a0 = 0; a0 < n_blocks; a0 += group * dna_rounds) {
+        const uint64_t a1 = std::min(n_blocks, a0 + group * dna_rounds), na = a1 - a0;
         auto tl = std::chrono::steady_clock::now();
-        if (writer_before2.valid()) writer_before2.get();        // (its errors, and those of its stage B, surface here)
+        while (pending.size() > dna_rounds) { pending.front().get(); pending.pop_front(); }   // (their errors, and those of their stage B, surface here)
         lap(tl, t_writer_wait);
-        auto gather = [&](const char* grp, const std::vector<uint64_t>& tab, uint32_t stride, RawBytes& pay, std::vector<uint64_t>& off) {
+        auto gather = [&](const char* grp, const std::vector<uint64_t>& tab, uint32_t stride, uint64_t g0, uint64_t nb, RawBytes& pay, std::vector<uint64_t>& off) {
             off.assign(nb + 1, 0);
             for (uint64_t b = 0; b < nb; b++) off[b + 1] = off[b] + tab[stride * (g0 + b)];
             pay.resize(off[nb] + 1);
@@ -636,83 +644,110 @@ void Leon::executeDecompression() {
                 if (!blk.empty()) memcpy(pay.data() + off[b], blk.data(), blk.size());
             }
         };
-        auto R = std::make_shared<Round>();
+        // stage A, its host part: the DNA payloads of the call, and every round's header and quality payloads
+        auto G = std::make_shared<DnaGroup>();
         RawBytes pay; std::vector<uint64_t> off;
-        R->nb = nb; R->blk_reads.resize(nb); R->blk_bases.resize(nb);
-        uint64_t g_reads = 0, g_bases = 0;
-        for (uint64_t b = 0; b < nb; b++) { R->blk_reads[b] = (uint32_t)tdna[3 * (g0 + b) + 1]; R->blk_bases[b] = tdna[3 * (g0 + b) + 2]; g_reads += R->blk_reads[b]; g_bases += R->blk_bases[b]; }
-        R->read_index = read_index; R->g_reads = g_reads; R->g_bases = g_bases;
-        gather(GROUP_DNA, tdna, 3, pay, off);
-        if (has_header) gather(GROUP_HEADER, thdr, 2, R->pay_h, R->off_h);
-        if (fastq_out) gather(GROUP_QUAL, tqual, 3, R->pay_q, R->off_q);
-        lap(tl, t_read);
-        R->hdr_off.assign(g_reads + 1, 0); R->qual_off.assign(g_reads + 1, 0);
-        // stage B
-        std::shared_future<void> host_job = std::async(std::launch::async, [&, R, host_before] {
-            if (host_before.valid()) host_before.wait();
-            auto th = std::chrono::steady_clock::now();
-            const uint64_t nb = R->nb, g_reads = R->g_reads, g_bases = R->g_bases;
-            if (has_header) {
-                uint64_t need = 0;
-                R->hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
-                // A round of many blocks: the stream's symbols on the device (its own context and stream, beside the DNA blocks: a
-                // block is a serial chain there too, ~1.3 s for 50 000 headers, but all of them at once) and the text on the host
-                // threads.  A few hundred blocks: the host threads alone are quicker (10 M headers in 200 blocks: 0.62 s against 1.27 s).
-                auto decode = [&]() -> int {
-                    if (nb >= header_blocks_on_device)
-                        return leon_header_decode_blocks(hdr_ctx.get(), R->pay_h.data(), R->off_h.data(), R->blk_reads.data(), nb, first_header.data(), first_header.size(),
-                                                         R->hdr.data(), R->hdr.size(), R->hdr_off.data(), &need, cores);
-                    return leon_host_header_decode_blocks(R->pay_h.data(), R->off_h.data(), R->blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
-                                                          R->hdr.size(), R->hdr_off.data(), &need, cores);
+        std::vector<uint32_t> a_reads(na); std::vector<uint64_t> a_bases(na);
+        uint64_t ga_reads = 0, ga_bases = 0;
+        for (uint64_t b = 0; b < na; b++) { a_reads[b] = (uint32_t)tdna[3 * (a0 + b) + 1]; a_bases[b] = tdna[3 * (a0 + b) + 2]; ga_reads += a_reads[b]; ga_bases += a_bases[b]; }
+        gather(GROUP_DNA, tdna, 3, a0, na, pay, off);
+        G->bases.resize(ga_bases + 1); G->lens.reset(new uint32_t[ga_reads + 1]);
+        std::vector<std::pair<std::shared_ptr<Round>, std::shared_future<void>>> rounds;
+        uint64_t base0 = 0, read0 = 0;
+        for (uint64_t g0 = a0; g0 < a1; g0 += group) {
+            const uint64_t g1 = std::min(a1, g0 + group), nb = g1 - g0;
+            auto R = std::make_shared<Round>();
+            R->nb = nb; R->blk_reads.assign(a_reads.begin() + (g0 - a0), a_reads.begin() + (g1 - a0)); R->blk_bases.assign(a_bases.begin() + (g0 - a0), a_bases.begin() + (g1 - a0));
+            uint64_t g_reads = 0, g_bases = 0;
+            for (uint64_t b = 0; b < nb; b++) { g_reads += R->blk_reads[b]; g_bases += R->blk_bases[b]; }
+            R->read_index = read_index; R->g_reads = g_reads; R->g_bases = g_bases;
+            R->dna = G; R->base0 = base0; R->read0 = read0;
+            if (has_header) gather(GROUP_HEADER, thdr, 2, g0, nb, R->pay_h, R->off_h);
+            if (fastq_out) gather(GROUP_QUAL, tqual, 3, g0, nb, R->pay_q, R->off_q);
+            R->hdr_off.assign(g_reads + 1, 0); R->qual_off.assign(g_reads + 1, 0);
+            // stage B
+            std::shared_future<void> host_job = std::async(std::launch::async, [&, R, host_before] {
+                if (host_before.valid()) host_before.wait();
+                auto th = std::chrono::steady_clock::now();
+                const uint64_t nb = R->nb, g_reads = R->g_reads, g_bases = R->g_bases;
+                const bool on_device = has_header && nb >= header_blocks_on_device;
+                auto decode_quals = [&] {
+                    R->qual.resize(g_bases + 1);
+                    if (leon_host_qual_decode_blocks(R->pay_q.data(), R->off_q.data(), R->blk_reads.data(), R->blk_bases.data(), nb, R->qual.data(), g_bases, R->qual_off.data(), cores) != LEON_OK)
+                        throw Exception(std::string("leon_host_qual_decode_blocks: ") + leon_last_error(nullptr));
                 };
-                int rc = decode();
-                if (rc == LEON_E_OVERFLOW) { R->hdr.resize(need + 1); rc = decode(); }
-                if (rc != LEON_OK) throw Exception(std::string("header blocks: ") + leon_last_error(nb >= header_blocks_on_device ? hdr_ctx.get() : nullptr));
-            }
-            lap(th, t_hdr);
-            if (fastq_out) {
-                R->qual.resize(g_bases + 1);
-                if (leon_host_qual_decode_blocks(R->pay_q.data(), R->off_q.data(), R->blk_reads.data(), R->blk_bases.data(), nb, R->qual.data(), g_bases, R->qual_off.data(), cores) != LEON_OK)
-                    throw Exception(std::string("leon_host_qual_decode_blocks: ") + leon_last_error(nullptr));
-            }
-            lap(th, t_qual);
-            R->pay_h = RawBytes(); R->pay_q = RawBytes();         // (the payloads are not needed any more)
-        }).share();
-        drain.all.push_back(host_job);
+                // while the device decodes the header symbols the host threads have nothing to do: the quality blocks go then
+                std::future<void> quals_beside;
+                if (fastq_out && on_device) quals_beside = std::async(std::launch::async, decode_quals);
+                if (has_header) {
+                    uint64_t need = 0;
+                    R->hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
+                    // A round of many blocks: the stream's symbols on the device (its own context and stream, beside the DNA blocks: a
+                    // block is a serial chain there too, ~1.3 s for 50 000 headers, but all of them at once) and the text on the host
+                    // threads.  A few hundred blocks: the host threads alone are quicker (10 M headers in 200 blocks: 0.62 s against 1.27 s).
+                    auto decode = [&]() -> int {
+                        if (on_device)
+                            return leon_header_decode_blocks(hdr_ctx.get(), R->pay_h.data(), R->off_h.data(), R->blk_reads.data(), nb, first_header.data(), first_header.size(),
+                                                             R->hdr.data(), R->hdr.size(), R->hdr_off.data(), &need, cores);
+                        return leon_host_header_decode_blocks(R->pay_h.data(), R->off_h.data(), R->blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
+                                                              R->hdr.size(), R->hdr_off.data(), &need, cores);
+                    };
+                    int rc = decode();
+                    if (rc == LEON_E_OVERFLOW) { R->hdr.resize(need + 1); rc = decode(); }
+                    if (rc != LEON_OK) {
+                        const std::string msg = std::string("header blocks: ") + leon_last_error(on_device ? hdr_ctx.get() : nullptr);
+                        if (quals_beside.valid()) { try { quals_beside.get(); } catch (...) {} }
+                        throw Exception(msg);
+                    }
+                }
+                lap(th, t_hdr);
+                if (quals_beside.valid()) quals_beside.get();
+                else if (fastq_out) decode_quals();
+                lap(th, t_qual);
+                R->pay_h = RawBytes(); R->pay_q = RawBytes();     // (the payloads are not needed any more)
+            }).share();
+            drain.all.push_back(host_job);
+            host_before = host_job;
+            rounds.emplace_back(R, host_job);
+            base0 += g_bases; read0 += g_reads; read_index += g_reads; bases_out += g_bases;
+        }
+        lap(tl, t_read);
         // stage A, the device part
-        R->bases.resize(g_bases + 1); R->lens.resize(g_reads + 1);
         if (dict_job.valid()) dict_job.get();
-        check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), R->blk_reads.data(), R->blk_bases.data(), nb, R->bases.data(), g_bases,
-                                                R->lens.data()), "leon_dna_decode_blocks");
+        check(ctx.get(), leon_dna_decode_blocks(ctx.get(), anchors.data(), n_anchors, pay.data(), off.data(), a_reads.data(), a_bases.data(), na, G->bases.data(), ga_bases,
+                                                G->lens.get()), "leon_dna_decode_blocks");
         lap(tl, t_dna);
         // stage C
-        std::shared_future<void> writer = std::async(std::launch::async, [&, R, host_job, writer_before] {
-            host_job.get();                                      // (a failed stage B fails this round's stage C with its message)
-            if (writer_before.valid()) writer_before.get();      // file order; a failure before this round stops the rounds after it
-            const uint64_t g_reads = R->g_reads, g_bases = R->g_bases;
-            // the size of this round's text: where the next round's begins
-            uint64_t n_text = 0;
-            if (has_header && !wrap)                             // (the decoder has checked that the lengths add up to the block table's bases)
-                n_text = 2 * g_reads + R->hdr_off[g_reads] + g_bases + g_reads + (fastq_out ? 3 * g_reads + g_bases : 0);
-            else {
-                auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
-                for (uint64_t r = 0; r < g_reads; r++) {
-                    const uint64_t hl = has_header ? R->hdr_off[r + 1] - R->hdr_off[r] : std::to_string(R->read_index + r).size();
-                    n_text += 1 + hl + 1 + seq_text_len(R->lens[r]) + (fastq_out ? 2 + (uint64_t)R->lens[r] + 1 : 0);
+        for (auto& rh : rounds) {
+            std::shared_ptr<Round> R = rh.first;
+            std::shared_future<void> host_job = rh.second;
+            std::shared_future<void> writer = std::async(std::launch::async, [&, R, host_job, writer_before] {
+                host_job.get();                                  // (a failed stage B fails this round's stage C with its message)
+                if (writer_before.valid()) writer_before.get();  // file order; a failure before this round stops the rounds after it
+                const uint64_t g_reads = R->g_reads, g_bases = R->g_bases;
+                // the size of this round's text: where the next round's begins
+                uint64_t n_text = 0;
+                if (has_header && !wrap)                         // (the decoder has checked that the lengths add up to the block table's bases)
+                    n_text = 2 * g_reads + R->hdr_off[g_reads] + g_bases + g_reads + (fastq_out ? 3 * g_reads + g_bases : 0);
+                else {
+                    auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
+                    for (uint64_t r = 0; r < g_reads; r++) {
+                        const uint64_t hl = has_header ? R->hdr_off[r + 1] - R->hdr_off[r] : std::to_string(R->read_index + r).size();
+                        n_text += 1 + hl + 1 + seq_text_len(R->lens()[r]) + (fastq_out ? 2 + (uint64_t)R->lens()[r] + 1 : 0);
+                    }
                 }
-            }
-            R->n_text = n_text; R->file_off = next_file_off;
-            next_file_off += n_text;
-            write_round(R);
-        }).share();
-        drain.all.push_back(writer);
-        writer_before2 = writer_before; writer_before = writer; host_before = host_job;
-        read_index += g_reads; bases_out += g_bases;
+                R->n_text = n_text; R->file_off = next_file_off;
+                next_file_off += n_text;
+                write_round(R);
+            }).share();
+            drain.all.push_back(writer);
+            pending.push_back(writer);
+            writer_before = writer;
+        }
     }
     {
         auto tl = std::chrono::steady_clock::now();
-        if (writer_before2.valid()) writer_before2.get();
-        if (writer_before.valid()) writer_before.get();
+        while (!pending.empty()) { pending.front().get(); pending.pop_front(); }
         lap(tl, t_write);
     }
     if (::close(ofd.fd) != 0) { ofd.fd = -1; throw Exception("cannot write " + _outputFilename); }

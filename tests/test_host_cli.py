@@ -218,6 +218,10 @@ def test_reference_acceptance_test_lossless_fastq_gz(leon_bin, tmp_path):
     r = run(leon_bin, "-d", "-file", fq + ".leon", env=dict(os.environ, LEON_DECODE_BLOCKS="1"))
     assert r.returncode == 0, r.stderr
     assert run("diff", fq, fq + ".d").returncode == 0
+    # ... and with the DNA blocks of two rounds decoded by one device call (what files of 800 blocks or more do)
+    r = run(leon_bin, "-d", "-file", fq + ".leon", env=dict(os.environ, LEON_DECODE_BLOCKS="1", LEON_DECODE_DNA_ROUNDS="2", LEON_HEADER_DEVICE_BLOCKS="0"))
+    assert r.returncode == 0, r.stderr
+    assert run("diff", fq, fq + ".d").returncode == 0
     # header blocks through the device (what rounds of hundreds of blocks do) and through the host threads alone: the same file
     for where in ("0", "1000000"):
         r = run(leon_bin, "-d", "-file", fq + ".leon", env=dict(os.environ, LEON_HEADER_DEVICE_BLOCKS=where))
