@@ -2,11 +2,21 @@
 """bench.py -- compressed-input MB/s of the DNA encode path on synthetic 150 bp reads (BASELINE.json metric).
 
 One "step" = one pass of the hot path (pack -> anchor resolution -> walk -> symbols -> range coder -> blocks
-handed to the sink, plus leon_dna_finish) over the whole synthetic read set, inputs resident in HBM.
+handed to the sink, plus leon_dna_finish) over the whole synthetic read set, inputs resident in HBM, fed to the
+library as ONE ordered stream in batches of at most --batch-reads reads (whole read blocks; 100 M by default, so
+BASELINE's 100 M x 150 bp job is one batch and the 500 M x 250 bp job of configuration #5 is five).
 N > 1: one process per GPU (torch.distributed / RCCL); rank 0 builds the bloom and broadcasts it over xGMI; every
 rank holds the read set, resolves the anchors of all reads (replicated: file-order dictionary semantics without any
-exchange, leon_dna_set_shard) and walks / codes its contiguous range of read blocks; rank 0 writes the dictionary
-stream.  The job is one file of fixed size: strong scaling.  Prints ONE JSON line on rank 0.
+exchange, leon_dna_set_shard) and walks / codes its contiguous range of every batch's read blocks; rank 0 writes the
+dictionary stream.  The job is one file of fixed size: strong scaling.  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` without a launcher starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+itself, as a child process, before anything touches the GPU, and relays rank 0's line.
+
+`value` is the HBM-resident figure (the bench contract: inputs resident when the timed region starts).  SURVEY 8(d)
+also wants the figure with the H2D copy inside: `pcie_inclusive` (one step through leon_dna_encode_batch, reads in
+pageable host memory) is measured in every default N = 1 run, beside `verify` (checksum of block checksums), `decode`
+(the whole file back through the device decoder, compared with the input) and `end_to_end` (`leon -c -lossless` and
+`leon -d -test-file` on a FASTQ in /dev/shm) -- none of them is ever `value`; --quick skips them.
 """
 import argparse
 import ctypes
@@ -38,24 +48,28 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("LEON_BENCH_READS", 100_000_000)),
                     help="total reads of the job (BASELINE.json metric: 100M x 150 bp)")
-    ap.add_argument("--genome", type=int, default=0, help="genome length; default reads*150/30 (30x coverage)")
+    ap.add_argument("--batch-reads", type=int, default=int(os.environ.get("LEON_BENCH_BATCH_READS", 100_000_000)),
+                    help="reads handed to the library per leon_dna_encode_batch_device call (rounded down to whole read blocks)")
+    ap.add_argument("--genome", type=int, default=0, help="genome length; default reads*L/30 (30x coverage)")
+    ap.add_argument("--bloom-from", choices=("auto", "count", "genome"), default="auto",
+                    help="where the bloom's solid k-mers come from, outside the timed region: `count` = the device k-mer counter over the "
+                         "reads (abundance >= 3), `genome` = the genome's own k-mers (the counter's partitions would take minutes on "
+                         "configuration #5's 94 G k-mers); auto = count up to 200 M reads")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("LEON_BENCH_CPU_SAMPLE", 4_000_000)),
                     help="reads timed through the CPU restatement on rank 0 at N=1 (0 = skip)")
     ap.add_argument("--err", type=float, default=0.01)
     ap.add_argument("--kmer-max-keys", type=int, default=0, help="k-mers sorted per pass by the solid k-mer counter (0 = sized by the library)")
-    ap.add_argument("--decode", action="store_true",
-                    help="also decode the whole file on the device (DnaDecoder, SURVEY 8f-1) and compare it with the input; "
-                         "reported as `decode`, never as value")
-    ap.add_argument("--verify", action="store_true",
-                    help="one more UNTIMED step whose sink hashes every block: `verify.blocks_sha256` is a checksum of block "
-                         "checksums over the union of all ranks' blocks (equal for every world size), plus the dictionary stream's")
+    ap.add_argument("--quick", action="store_true",
+                    help="only the timed steps, roofline and cpu_baseline: skip pcie_inclusive / verify / decode / end_to_end")
+    ap.add_argument("--decode", action="store_true", help="(always on at N = 1 unless --quick) decode the whole file on the device and compare it with the input")
+    ap.add_argument("--verify", action="store_true", help="(always on unless --quick) one more UNTIMED step whose sink hashes every block")
+    ap.add_argument("--host-input", action="store_true", help="(always on at N = 1 unless --quick) one step through leon_dna_encode_batch, PCIe included")
+    ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("LEON_BENCH_E2E_READS", 10_000_000)),
+                    help="reads of the FASTQ that `end_to_end` takes through the leon CLI (0 = skip)")
     ap.add_argument("--streams", action="store_true",
                     help="also time the kernels of the streams either side of the DNA stream on device-resident synthetic data: the header "
                          "stream (records + range coder, 10 M SRA-style headers) and the lossy quality smoothing (the workload's reads); "
                          "reported as `streams`, never as value")
-    ap.add_argument("--host-input", action="store_true",
-                    help="also time ONE step through leon_dna_encode_batch (reads in pageable host memory, PCIe included); "
-                         "reported as pcie_inclusive, never as value")
     return ap.parse_args()
 
 
@@ -84,6 +98,34 @@ def gen_reads_chunk(genome, chunk_id, n, err, device, L=None):
     return lut[codes.long()]
 
 
+def genome_kmers_chunk(genome, lo, hi, k):
+    """canonical k-mers starting at genome positions [lo, hi) as the C-ABI wants them (one uint64 below k = 32, else
+    (low word, high word) pairs), computed with torch on the device: the `--bloom-from genome` source of solid k-mers"""
+    dev = genome.device
+    n = hi - lo
+    seg = genome[lo:hi + k - 1].to(torch.int64)
+    W = 2 if k >= 32 else 1
+    fw = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(W)]      # [low, high]
+    rc = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(W)]
+    for j in range(k):
+        b = seg[j:j + n]                                  # base j of every k-mer: goes to bit 2*(k-1-j) of the forward k-mer
+        sh = 2 * (k - 1 - j)
+        fw[sh // 64] |= b << (sh % 64)
+        sh = 2 * j                                        # and, complemented (code ^ 2), to bit 2*j of the reverse complement
+        rc[sh // 64] |= (b ^ 2) << (sh % 64)
+    if W == 1:
+        return torch.minimum(fw[0], rc[0]).contiguous()   # k <= 31: both fit 62 bits, signed compare == unsigned compare
+    sgn = torch.tensor(-2 ** 63, dtype=torch.int64, device=dev)
+    hi_lt = fw[1] < rc[1]                                 # high words hold 2k - 64 <= 62 bits: non-negative
+    hi_eq = fw[1] == rc[1]
+    lo_lt = (fw[0] ^ sgn) < (rc[0] ^ sgn)                 # unsigned compare of the low words
+    take_f = hi_lt | (hi_eq & lo_lt)
+    out = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    out[:, 0] = torch.where(take_f, fw[0], rc[0])
+    out[:, 1] = torch.where(take_f, fw[1], rc[1])
+    return out.contiguous()
+
+
 def walk_bytes_per_read(k):
     """algorithmic bytes of ONE read in the dominant kernel k_walk, SURVEY.md section 8(d)'s per-unit terms for it:
     the 2-bit read in, ONE 64-byte bloom line per extension step (L-k steps), the per-position event bytes out.
@@ -92,14 +134,49 @@ def walk_bytes_per_read(k):
     return (L + 3) // 4 + (L - k) * 64 + (L + 3) // 4
 
 
+def walk_source_id():
+    """identity of the k_walk the library was built from: profiles/walk_traffic.json names the one its PMC figure was
+    measured on, and `roofline.traffic` is null for any other"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("dna_kernels.hip", "leon_device.h"):
+        h.update(open(os.path.join(ROOT, "leon_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of a torch.distributed.run child
+    (this process has not touched the GPU and never will) and relay rank 0's JSON line"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    for l in p.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    raise SystemExit(p.returncode if p.returncode else (0 if lines else 1))
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (WORLD_SIZE=%d expected)" % a.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     import torch.distributed as dist
     n_dev = torch.cuda.device_count()
     if local >= n_dev:                       # rehearsal of the N>1 path on a one-GPU box (LEON_BENCH_BACKEND=gloo)
@@ -121,8 +198,11 @@ def main():
     n_total = (a.reads // RPB) * RPB or RPB
     G = a.genome or max(n_total * L // 30, 10 * L)
     n_blocks = n_total // RPB
-    b0, b1 = block_range(rank, world, n_blocks)
-    n_local = (b1 - b0) * RPB                # reads this rank walks and codes (it resolves all n_total)
+    B = max(RPB, min(a.batch_reads, n_total) // RPB * RPB)
+    batches = [(lo, min(n_total, lo + B)) for lo in range(0, n_total, B)]
+    # this rank's blocks: its contiguous share of EVERY batch's blocks (leon_dna_set_shard)
+    n_local = sum((lambda r: r[1] - r[0])(block_range(rank, world, (hi - lo) // RPB)) for lo, hi in batches) * RPB
+    bloom_from = a.bloom_from if a.bloom_from != "auto" else ("count" if n_total <= 200_000_000 else "genome")
 
     genome = gen_genome(G, device)
     # the whole read set on every rank (same seeds everywhere), generated chunk by chunk
@@ -133,7 +213,6 @@ def main():
         reads[lo:hi] = chunk[:hi - lo]
         del chunk
     offsets = (torch.arange(n_total + 1, dtype=torch.int64, device=device) * L).contiguous()
-    del genome
     torch.cuda.synchronize()
     if world > 1:                            # the replicated anchor resolution needs the SAME reads on every rank
         chk = torch.stack([reads[::97].sum(dtype=torch.int64), reads[-1].sum(dtype=torch.int64)])
@@ -143,14 +222,18 @@ def main():
             raise SystemExit("rank %d: the synthetic read set differs between ranks" % rank)
 
     # bloom = the reads' solid k-mers (abundance >= 3, Leon's `-abundance 3`), counted on the device by rank 0
-    # (leon_kmer_solid_device, the DSK stand-in: outside the timed region, it is the step before the path)
+    # (leon_kmer_solid_device, the DSK stand-in: outside the timed region, it is the step before the path); for read sets
+    # beyond the counter's comfortable size (--bloom-from genome) the genome's own k-mers, inserted slice by slice
     t_b = time.time()
     n_solid_t = torch.zeros(1, dtype=torch.int64, device=device)
     d_solid = 0
-    if rank == 0:
-        d_solid, n_solid = capi.kmer_solid_device(reads.data_ptr(), offsets.data_ptr(), n_total, K, ABUNDANCE, device_id=local,
-                                                  max_keys_per_pass=a.kmer_max_keys)
-        n_solid_t[0] = n_solid
+    if bloom_from == "count":
+        if rank == 0:
+            d_solid, n_solid = capi.kmer_solid_device(reads.data_ptr(), offsets.data_ptr(), n_total, K, ABUNDANCE, device_id=local,
+                                                      max_keys_per_pass=a.kmer_max_keys)
+            n_solid_t[0] = n_solid
+    else:
+        n_solid_t[0] = G - K + 1
     count_s = time.time() - t_b
     if world > 1:
         dist.broadcast(n_solid_t, src=0)
@@ -159,12 +242,21 @@ def main():
     ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local,
                                     resolve_window=int(os.environ.get("LEON_RESOLVE_WINDOW", 0)))
     ctx.set_shard(rank, world)
-    ctx.reserve(n_total, n_total * L)          # what a host does while it parses: the first step then allocates nothing large
+    ctx.reserve(B, B * L)                      # what a host does while it parses: the first step then allocates nothing large
     nbytes = ctx.bloom_nbytes
     bcast_ms = 0.0
     if rank == 0:
-        ctx.bloom_insert_device(d_solid, n_solid)
-        capi.device_free(d_solid)
+        if bloom_from == "count":
+            ctx.bloom_insert_device(d_solid, n_solid)
+            capi.device_free(d_solid)
+        else:
+            SL = 1 << 26
+            for lo in range(0, G - K + 1, SL):
+                km = genome_kmers_chunk(genome, lo, min(G - K + 1, lo + SL), K)
+                torch.cuda.synchronize()
+                ctx.bloom_insert_device(km.data_ptr(), km.shape[0])
+                del km
+    del genome
     if world > 1:                           # RCCL broadcast of the bloom over xGMI, device to device
         bits = torch.empty(nbytes, dtype=torch.uint8, device=device)
         if rank == 0:
@@ -186,13 +278,27 @@ def main():
         payload[1] += 1
         return 0
     cb = capi.SINK(sink)
+    STAGES = ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder", "ms_d2h", "ms_total")
+    COUNTS = ("n_symbols", "resolve_rounds", "resolve_windows", "walk_launches")
+
+    def encode_stream(the_sink):
+        """one file: every batch in order through leon_dna_encode_batch_device; returns the stage times summed over the batches"""
+        ctx.reset_stream()
+        acc = {k: 0.0 for k in STAGES + COUNTS}
+        for lo, hi in batches:
+            ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr() + 8 * lo, hi - lo, sink=the_sink)
+            st = ctx.stats()
+            for k in STAGES + COUNTS:
+                acc[k] += st[k]
+        return acc
 
     def step():
-        ctx.reset_stream()
         payload[0] = payload[1] = 0
-        ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_total, sink=cb)
+        acc = encode_stream(cb)
         d_size, na = ctx.finish(copy=False)                  # the stream stays in the context, as for a C caller
-        return d_size, na
+        st = ctx.stats()
+        acc["ms_anchor_wait"], acc["ms_chain_busy"] = st["ms_anchor_wait"], st["ms_chain_busy"]
+        return d_size, na, acc
 
     def sync():
         torch.cuda.synchronize()
@@ -201,7 +307,7 @@ def main():
             torch.cuda.synchronize()
 
     # the very first pass through the path in this process (whether it is a warm-up or a timed step): what `leon -c`,
-    # which encodes a file exactly once, sees -- allocations, code-object loads and all
+    # which encodes a file exactly once, sees -- code-object loads and whatever leon_dna_reserve did not size
     cold_ms = [None]
 
     def timed_step():
@@ -216,14 +322,13 @@ def main():
 
     for _ in range(a.warmup):
         timed_step()
-    times, walk_ms, dev_ms, stage = [], [], [], None
+    times, walk_ms, walk_n, dev_ms, stage = [], [], [], [], None
     for _ in range(a.steps):
-        (dict_bytes, n_anchors), dt = timed_step()
+        (dict_bytes, n_anchors, acc), dt = timed_step()
         times.append(dt)
-        st = ctx.stats()
-        walk_ms.append(st["ms_walk"])
-        dev_ms.append(st["ms_total"])
-        stage = st
+        walk_ms.append(acc["ms_walk"]); walk_n.append(max(acc["walk_launches"], 1))
+        dev_ms.append(acc["ms_total"])
+        stage = acc
     # max over ranks: whole step, device stages alone (HIP events on each rank's stream), cold first step
     red = torch.tensor([sum(times), float(np.mean(dev_ms)), cold_ms[0]], dtype=torch.float64, device=device)
     if world > 1:
@@ -232,8 +337,9 @@ def main():
     ms_per_step = total_s / a.steps * 1e3
     value = n_total * L / 1e6 / (total_s / a.steps)
 
+    extras = not a.quick
     verify = None
-    if a.verify:
+    if a.verify or extras:
         import hashlib
         mine = []
 
@@ -241,8 +347,7 @@ def main():
             mine.append((int(block_id), hashlib.sha256(ctypes.string_at(p, size)).hexdigest(), int(n_reads)))
             return 0
         hcb = capi.SINK(hsink)
-        ctx.reset_stream()
-        ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_total, sink=hcb)
+        encode_stream(hcb)
         dstream, na_v = ctx.finish()
         tables = [mine]
         if world > 1:
@@ -255,46 +360,54 @@ def main():
                 h.update(bytes.fromhex(digest) + bid.to_bytes(8, "little") + nr.to_bytes(4, "little"))
             verify = {"blocks_sha256": h.hexdigest(), "n_blocks": sum(len(t) for t in tables),
                       "dict_sha256": hashlib.sha256(dstream).hexdigest(), "n_anchors": int(na_v),
-                      "blocks_per_rank": [len(t) for t in tables]}
+                      "blocks_per_rank": [len(t) for t in tables],
+                      "what": "checksum of block checksums over the union of all ranks' blocks (gap-free table checked) + the dictionary "
+                              "stream's: equal for every world size and batch size"}
+        del dstream
 
     # dominant kernel: k_walk, HIP events recorded on the library's launch stream around each launch
-    walk_avg_ms = float(np.mean(walk_ms))
-    alg_bytes = n_local * walk_bytes_per_read(K)
+    n_launch = float(np.mean(walk_n))
+    walk_avg_ms = float(np.mean(walk_ms)) / n_launch
+    alg_bytes = n_local * walk_bytes_per_read(K) / n_launch
     achieved = alg_bytes / (walk_avg_ms * 1e-3) / 1e9
-    traffic = None                                            # PMC-measured HBM bytes per launch (profiles/README.md)
-    try:
+    traffic, traffic_note = None, "no PMC figure for this workload in profiles/walk_traffic.json"
+    try:                                                      # PMC-measured HBM bytes per launch (profiles/README.md)
         tj = json.load(open(os.path.join(ROOT, "profiles", "walk_traffic.json")))
         wl = tj["workload"]
-        if (wl["reads"], wl["read_len"], wl["kmer_size"], wl["genome"], wl["n_gpus"]) == (n_total, L, K, G, world):
-            traffic = tj["traffic_bytes"]
+        if (wl["reads"], wl["read_len"], wl["kmer_size"], wl["genome"], wl["n_gpus"]) == (n_total, L, K, G, world) and len(batches) == 1:
+            if tj.get("k_walk_source") == walk_source_id():
+                traffic, traffic_note = tj["traffic_bytes"], "PMC FETCH_SIZE + WRITE_SIZE of this k_walk (source id %s) on this workload" % tj["k_walk_source"]
+            else:
+                traffic_note = "stale: profiles/walk_traffic.json was measured on another k_walk (%s, this build %s)" % (tj.get("k_walk_source"), walk_source_id())
     except (OSError, KeyError, ValueError):
         pass
     roofline = {"kernel": "k_walk", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(traffic) if traffic else None,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(walk_avg_ms, 3)}
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(traffic) if traffic else None, "traffic_note": traffic_note,
+                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(walk_avg_ms, 3), "launches_per_step": n_launch}
 
     pcie = None
-    if a.host_input and world == 1:
+    if (a.host_input or extras) and world == 1:
         h_reads = reads.cpu().numpy()
-        h_off = offsets.cpu().numpy()
+        h_off = offsets.cpu().numpy().astype(np.uint64)
         ctx.reset_stream()
         payload[0] = payload[1] = 0
         sync()
         t0 = time.perf_counter()
-        ctx.encode_batch(h_reads, h_off, sink=cb)
+        for lo, hi in batches:
+            ctx.encode_batch(h_reads[lo:hi].reshape(-1), h_off[lo:hi + 1] - h_off[lo], sink=cb)
         ctx.finish(copy=False)
         sync()
         dt = time.perf_counter() - t0
         pcie = {"value": round(n_total * L / 1e6 / dt, 1), "unit": "MB/s", "ms": round(dt * 1e3, 1),
-                "what": "one step through leon_dna_encode_batch: reads and offsets in pageable host memory, H2D inside the timed region"}
+                "what": "SURVEY 8(d)'s form of the metric: one step through leon_dna_encode_batch, reads and offsets in pageable host "
+                        "memory, H2D inside the timed region (an uploader thread copies group by group under the resolution stage)"}
         del h_reads, h_off
 
     decode = None
-    if a.decode and world == 1:
+    if (a.decode or extras) and world == 1:
         kept = []
         keep = capi.SINK(lambda user, bid, ptr, size, nreads: (kept.append((int(bid), ctypes.string_at(ptr, size), int(nreads))), 0)[1])
-        ctx.reset_stream()
-        ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n_total, sink=keep)
+        encode_stream(keep)
         dstream, n_anchors = ctx.finish()
         t0 = time.perf_counter()
         anchors = capi.anchor_dict_decode(dstream, n_anchors, K)
@@ -313,80 +426,17 @@ def main():
                   "blocks_s": round(t2 - t1, 2), "blocks_MBps": round(n_total * L / 1e6 / (t2 - t1), 1),
                   "blocks_s_second_call": round(t3 - t2b, 2), "equals_input": same,
                   "what": "leon_host_anchor_dict_decode (one host core) then leon_dna_decode_blocks (one wave per block, path cache "
-                          "in HBM), payloads in host memory, bases back in host memory"}
-        del kept, out_bases, out_lens, ref
+                          "in HBM), payloads in host memory, bases back in host memory; every base compared with the input"}
+        del kept, out_bases, out_lens, ref, anchors, dstream
+        ctx.reset_stream()
 
     streams = None
     if a.streams and world == 1:
-        streams = {}
-        # lossy qualities: DnaEncoder::smoothQuals over the workload's reads against the file's bloom (qualities: a fixed ramp)
-        quals = torch.full((n_total * L,), 70, dtype=torch.uint8, device=device)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        rc = ctx.lib.leon_qual_smooth_batch_device(ctx.h, ctypes.c_void_p(reads.data_ptr()), ctypes.c_void_p(offsets.data_ptr()), n_total,
-                                                   ctypes.c_void_p(quals.data_ptr()))
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        assert rc == 0
-        smoothed = float((quals == 64).float().mean().item())
-        streams["qual_smooth"] = {"ms": round(dt * 1e3, 1), "MBps": round(n_total * L / 1e6 / dt, 1), "fraction_smoothed": round(smoothed, 4),
-                                  "what": "leon_qual_smooth_batch_device over the workload's reads: pack + one wave per read, L-k+1 bloom look-ups per read"}
-        del quals
-        # header stream: 10 M SRA-style headers resident in HBM -> records (one lane per header) -> k_rc_encode
-        nh = min(10_000_000, n_total)
-        rng = np.random.default_rng(7)
-        idx = np.arange(1, nh + 1)
-        heads = np.char.add(np.char.add(b"SRR387476.", idx.astype("S")),
-                            np.char.add(b" HWI-ST1234:3:1101:", np.char.add(rng.integers(1000, 20000, nh).astype("S"),
-                                        np.char.add(b":", np.char.add(rng.integers(1000, 200000, nh).astype("S"), b" length=150")))))
-        lens = np.char.str_len(heads).astype(np.int64)
-        blob = np.frombuffer(b"".join(heads.tolist()), dtype=np.uint8)
-        hoff = np.zeros(nh + 1, dtype=np.int64); hoff[1:] = np.cumsum(lens)
-        d_blob = torch.from_numpy(blob.copy()).to(device); d_hoff = torch.from_numpy(hoff).to(device)
-        first = heads[0]
-        hbytes = [0]
-        hsink = capi.SINK(lambda user, bid, ptr, size, nreads: (hbytes.__setitem__(0, hbytes[0] + size), 0)[1])
-        best = None
-        for _ in range(3):
-            ctx.reset_stream()
-            hbytes[0] = 0
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            rc = ctx.lib.leon_header_encode_batch_device(ctx.h, ctypes.c_void_p(d_blob.data_ptr()), ctypes.c_void_p(d_hoff.data_ptr()), nh, 0,
-                                                         first, len(first), hsink, None)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            assert rc == 0
-            best = dt if best is None else min(best, dt)
-        streams["header"] = {"headers": nh, "bytes_in": int(hoff[-1]), "bytes_out": hbytes[0], "ms": round(best * 1e3, 1),
-                             "MBps": round(int(hoff[-1]) / 1e6 / best, 1),
-                             "what": "leon_header_encode_batch_device, headers resident in HBM, best of 3: k_hdr_symbols x2 + scan + k_rc_encode + D2H"}
-        # ... and back: the blocks of the last run through both decoders (C calls only: payloads in, text + offsets out)
-        hblocks = []
-        keep_h = capi.SINK(lambda user, bid, ptr, size, nreads: (hblocks.append((int(bid), ctypes.string_at(ptr, size), int(nreads))), 0)[1])
-        ctx.reset_stream()
-        rc = ctx.lib.leon_header_encode_batch_device(ctx.h, ctypes.c_void_p(d_blob.data_ptr()), ctypes.c_void_p(d_hoff.data_ptr()), nh, 0, first, len(first), keep_h, None)
-        assert rc == 0
-        pay, poff, pnr = capi._join_blocks(hblocks)
-        out_off = np.zeros(nh + 1, dtype=np.uint64); need = ctypes.c_uint64(); cap = int(hoff[-1]) + 64
-        texts = {}
-        for name, call in (("host_threads", lambda o: ctx.lib.leon_host_header_decode_blocks(capi._ptr(pay, capi._u8p), capi._ptr(poff, capi._u64p), capi._ptr(pnr, capi._u32p),
-                                len(hblocks), first, len(first), capi._ptr(o, capi._u8p), cap, capi._ptr(out_off, capi._u64p), ctypes.byref(need), 0)),
-                           ("device_symbols", lambda o: ctx.lib.leon_header_decode_blocks(ctx.h, capi._ptr(pay, capi._u8p), capi._ptr(poff, capi._u64p), capi._ptr(pnr, capi._u32p),
-                                len(hblocks), first, len(first), capi._ptr(o, capi._u8p), cap, capi._ptr(out_off, capi._u64p), ctypes.byref(need), 0))):
-            best = None
-            for _ in range(2):
-                o = np.empty(cap, dtype=np.uint8)
-                t0 = time.perf_counter(); rc = call(o); dt = time.perf_counter() - t0
-                assert rc == 0, rc
-                best = dt if best is None else min(best, dt)
-            texts[name] = (round(best * 1e3, 1), bool(np.array_equal(o[:int(hoff[-1])], blob)))
-        streams["header_decode"] = {"headers": nh, "blocks": len(hblocks), "host_threads_ms": texts["host_threads"][0], "device_symbols_ms": texts["device_symbols"][0],
-                                    "equal_input": texts["host_threads"][1] and texts["device_symbols"][1],
-                                    "what": "leon_host_header_decode_blocks (all the CPUs of the quota) against leon_header_decode_blocks (symbols on the device, one wave per "
-                                            "block; text on the host threads), payloads in and text out in host memory, best of 2"}
-        del d_blob, d_hoff, hblocks, pay
-        ctx.reset_stream()
+        streams = bench_streams(ctx, capi, reads, offsets, n_total, device)
+
+    e2e = None
+    if extras and world == 1 and rank == 0 and a.e2e_reads > 0:
+        e2e = end_to_end(min(a.e2e_reads, n_total), device)
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
@@ -396,18 +446,23 @@ def main():
         out = {
             "metric": "compressed input MB/s (DNA encode path)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
+            "value_hbm_resident": round(value, 1),
+            "value_h2d_inclusive": pcie["value"] if pcie else None,
             "cold_first_step_ms": round(cold_first_step_ms, 2),
             # the multi-GPU truth: the job also waits for the file-wide dictionary stream, one serial
             # chain on a host core of rank 0 whatever N is; the device stages are what shards
             "device_ms_max_over_ranks": round(device_ms_max, 2), "host_chain_ms": round(stage["ms_chain_busy"], 2),
             "value_device_only": round(n_total * L / 1e6 / (device_ms_max * 1e-3), 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "parity": "bit-identical to oracle/leon_oracle.c in the -m gpu tests; the oracle is a restatement: parity with reference Leon is UNPINNED (gatb-core absent)",
             "config": {"workload": "%d x %d bp synthetic reads, k=%d, genome %d bp (30x), 1%% substitutions, "
-                                   "bloom %d bits/k-mer x %d hashes over the reads' %d solid k-mers (abundance >= %d, device counter)"
-                                   % (n_total, L, K, G, BITS_PER_KMER, N_HASH, n_solid, ABUNDANCE),
+                                   "bloom %d bits/k-mer x %d hashes over %d solid k-mers (%s)"
+                                   % (n_total, L, K, G, BITS_PER_KMER, N_HASH, n_solid,
+                                      "the reads' k-mers of abundance >= %d, device counter" % ABUNDANCE if bloom_from == "count" else "the genome's k-mers"),
                        "reads": n_total, "read_len": L, "kmer_size": K, "reads_per_block": RPB,
+                       "batches": len(batches), "batch_reads": B,
                        "sharding": "bloom broadcast over RCCL; anchor resolution replicated on every rank (file-order "
-                                   "dictionary, no exchange); walk + range coder on contiguous block ranges; "
+                                   "dictionary, no exchange); walk + range coder on contiguous block ranges of every batch; "
                                    "dictionary stream on rank 0" if world > 1 else "single GPU",
                        "bloom_bytes": nbytes, "bloom_bcast_ms": round(bcast_ms, 2), "bloom_build_s": round(bloom_s, 2),
                        "kmer_count_s": round(count_s, 2), "solid_kmers": n_solid},
@@ -416,16 +471,173 @@ def main():
             "pcie_inclusive": pcie,
             "decode": decode,
             "verify": verify,
+            "end_to_end": e2e,
             "streams": streams,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
-                      "symbols": stage["n_symbols"], "resolve_rounds": stage["resolve_rounds"],
+                      "symbols": int(stage["n_symbols"]), "resolve_rounds": int(stage["resolve_rounds"]),
                       "bits_per_base": round(8.0 * (payload[0] + dict_bytes) / (max(n_local, 1) * L), 4)},
         }
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_streams(ctx, capi, reads, offsets, n_total, device):
+    """--streams: the kernels of the streams either side of the DNA stream on device-resident synthetic data"""
+    streams = {}
+    # lossy qualities: DnaEncoder::smoothQuals over the workload's reads against the file's bloom (qualities: a fixed ramp)
+    quals = torch.full((n_total * L,), 70, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc = ctx.lib.leon_qual_smooth_batch_device(ctx.h, ctypes.c_void_p(reads.data_ptr()), ctypes.c_void_p(offsets.data_ptr()), n_total,
+                                               ctypes.c_void_p(quals.data_ptr()))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    smoothed = float((quals == 64).float().mean().item())
+    streams["qual_smooth"] = {"ms": round(dt * 1e3, 1), "MBps": round(n_total * L / 1e6 / dt, 1), "fraction_smoothed": round(smoothed, 4),
+                              "what": "leon_qual_smooth_batch_device over the workload's reads: pack + one wave per read, L-k+1 bloom look-ups per read"}
+    del quals
+    # header stream: 10 M SRA-style headers resident in HBM -> records (one lane per header) -> k_rc_encode
+    nh = min(10_000_000, n_total)
+    rng = np.random.default_rng(7)
+    idx = np.arange(1, nh + 1)
+    heads = np.char.add(np.char.add(b"SRR387476.", idx.astype("S")),
+                        np.char.add(b" HWI-ST1234:3:1101:", np.char.add(rng.integers(1000, 20000, nh).astype("S"),
+                                    np.char.add(b":", np.char.add(rng.integers(1000, 200000, nh).astype("S"), b" length=150")))))
+    lens = np.char.str_len(heads).astype(np.int64)
+    blob = np.frombuffer(b"".join(heads.tolist()), dtype=np.uint8)
+    hoff = np.zeros(nh + 1, dtype=np.int64); hoff[1:] = np.cumsum(lens)
+    d_blob = torch.from_numpy(blob.copy()).to(device); d_hoff = torch.from_numpy(hoff).to(device)
+    first = heads[0]
+    hbytes = [0]
+    hsink = capi.SINK(lambda user, bid, ptr, size, nreads: (hbytes.__setitem__(0, hbytes[0] + size), 0)[1])
+    best = None
+    for _ in range(3):
+        ctx.reset_stream()
+        hbytes[0] = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = ctx.lib.leon_header_encode_batch_device(ctx.h, ctypes.c_void_p(d_blob.data_ptr()), ctypes.c_void_p(d_hoff.data_ptr()), nh, 0,
+                                                     first, len(first), hsink, None)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        best = dt if best is None else min(best, dt)
+    streams["header"] = {"headers": nh, "bytes_in": int(hoff[-1]), "bytes_out": hbytes[0], "ms": round(best * 1e3, 1),
+                         "MBps": round(int(hoff[-1]) / 1e6 / best, 1),
+                         "what": "leon_header_encode_batch_device, headers resident in HBM, best of 3: k_hdr_symbols x2 + scan + k_rc_encode + D2H"}
+    # ... and back: the blocks of the last run through both decoders (C calls only: payloads in, text + offsets out)
+    hblocks = []
+    keep_h = capi.SINK(lambda user, bid, ptr, size, nreads: (hblocks.append((int(bid), ctypes.string_at(ptr, size), int(nreads))), 0)[1])
+    ctx.reset_stream()
+    rc = ctx.lib.leon_header_encode_batch_device(ctx.h, ctypes.c_void_p(d_blob.data_ptr()), ctypes.c_void_p(d_hoff.data_ptr()), nh, 0, first, len(first), keep_h, None)
+    assert rc == 0
+    pay, poff, pnr = capi._join_blocks(hblocks)
+    out_off = np.zeros(nh + 1, dtype=np.uint64); need = ctypes.c_uint64(); cap = int(hoff[-1]) + 64
+    texts = {}
+    for name, call in (("host_threads", lambda o: ctx.lib.leon_host_header_decode_blocks(capi._ptr(pay, capi._u8p), capi._ptr(poff, capi._u64p), capi._ptr(pnr, capi._u32p),
+                            len(hblocks), first, len(first), capi._ptr(o, capi._u8p), cap, capi._ptr(out_off, capi._u64p), ctypes.byref(need), 0)),
+                       ("device_symbols", lambda o: ctx.lib.leon_header_decode_blocks(ctx.h, capi._ptr(pay, capi._u8p), capi._ptr(poff, capi._u64p), capi._ptr(pnr, capi._u32p),
+                            len(hblocks), first, len(first), capi._ptr(o, capi._u8p), cap, capi._ptr(out_off, capi._u64p), ctypes.byref(need), 0))):
+        best = None
+        for _ in range(2):
+            o = np.empty(cap, dtype=np.uint8)
+            t0 = time.perf_counter(); rc = call(o); dt = time.perf_counter() - t0
+            assert rc == 0, rc
+            best = dt if best is None else min(best, dt)
+        texts[name] = (round(best * 1e3, 1), bool(np.array_equal(o[:int(hoff[-1])], blob)))
+    streams["header_decode"] = {"headers": nh, "blocks": len(hblocks), "host_threads_ms": texts["host_threads"][0], "device_symbols_ms": texts["device_symbols"][0],
+                                "equal_input": texts["host_threads"][1] and texts["device_symbols"][1],
+                                "what": "leon_host_header_decode_blocks (all the CPUs of the quota) against leon_header_decode_blocks (symbols on the device, one wave per "
+                                        "block; text on the host threads), payloads in and text out in host memory, best of 2"}
+    del d_blob, d_hoff, hblocks, pay
+    ctx.reset_stream()
+
+    return streams
+
+
+def write_fastq(path, n, Lr, device):
+    """a synthetic FASTQ of n reads of the bench's generator (genome n*Lr/30, 1 % substitutions) with SRA-style headers and
+    structured qualities, built as fixed-width record matrices (reads grouped by the digit count of their index)"""
+    genome = gen_genome(max(n * Lr // 30, 10 * Lr), device)
+    qalpha = np.frombuffer(b"#5:?ABCDEFGHIJ", dtype=np.uint8)
+
+    def digits(v, d):
+        return ((v[:, None] // (10 ** np.arange(d - 1, -1, -1, dtype=np.int64))[None, :]) % 10 + 48).astype(np.uint8)
+    with open(path, "wb") as f:
+        for c0 in range((n + CHUNK - 1) // CHUNK):
+            m = min(CHUNK, n - c0 * CHUNK)
+            rd = gen_reads_chunk(genome, c0, CHUNK, 0.01, device, L=Lr)[:m].cpu().numpy()
+            rng = np.random.default_rng(c0)
+            x, y = rng.integers(10000, 100000, m), rng.integers(100000, 1000000, m)
+            q = qalpha[np.minimum(rng.integers(0, 14, (m, Lr)), rng.integers(4, 14, (m, 1)))]
+            idx = np.arange(c0 * CHUNK + 1, c0 * CHUNK + m + 1, dtype=np.int64)
+            lo = 0
+            while lo < m:
+                d = len(str(int(idx[lo])))
+                hi = min(m, lo + max(1, 10 ** d - int(idx[lo])))
+                parts = [b"@SRR387476.", digits(idx[lo:hi], d), b" HWI-ST1234:3:1101:", digits(x[lo:hi], 5), b":", digits(y[lo:hi], 6),
+                         b" length=%d\n" % Lr, rd[lo:hi], b"\n+\n", q[lo:hi], b"\n"]
+                w = sum(len(p) if isinstance(p, bytes) else p.shape[1] for p in parts)
+                rec = np.empty((hi - lo, w), dtype=np.uint8)
+                c = 0
+                for p in parts:
+                    if isinstance(p, bytes):
+                        rec[:, c:c + len(p)] = np.frombuffer(p, dtype=np.uint8)[None, :]
+                        c += len(p)
+                    else:
+                        rec[:, c:c + p.shape[1]] = p
+                        c += p.shape[1]
+                f.write(rec.tobytes())
+                lo = hi
+    del genome
+    torch.cuda.empty_cache()
+
+
+def end_to_end(n, device):
+    """the reference's own acceptance test through the C++ host mirror (/root/reference/scripts/simple_test.sh:51,54,62):
+    `leon -c -lossless` then `leon -d -test-file` on a synthetic FASTQ in /dev/shm; wall time of each command"""
+    import shutil
+    import subprocess
+    import tempfile
+    leon = os.path.join(ROOT, "leon_amd", "lib", "leon")
+    if not os.path.exists(leon):
+        return {"error": "leon_amd/lib/leon is not built"}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    work = tempfile.mkdtemp(prefix="leon_e2e_", dir=base)
+    fq = os.path.join(work, "reads.fastq")
+    out = {"reads": n, "read_len": L}
+    try:
+        t0 = time.time()
+        write_fastq(fq, n, L, device)
+        out["generate_s"] = round(time.time() - t0, 1)
+        out["fastq_bytes"] = os.path.getsize(fq)
+
+        def run(name, *args):
+            t = time.time()
+            r = subprocess.run([leon] + list(args), capture_output=True, text=True)
+            out[name + "_s"] = round(time.time() - t, 2)
+            out[name + "_rc"] = r.returncode
+            if r.returncode:
+                out[name + "_stderr"] = r.stderr[-400:]
+            return r
+        run("compress_lossless", "-file", fq, "-c", "-lossless")
+        out["leon_bytes"] = os.path.getsize(fq + ".leon") if os.path.exists(fq + ".leon") else None
+        r = run("decompress_test_file", "-file", fq + ".leon", "-d", "-test-file")
+        out["identical"] = r.returncode == 0 and "is identical to" in r.stdout
+        if out.get("compress_lossless_rc") == 0:
+            out["compress_MBps_of_file"] = round(out["fastq_bytes"] / 1e6 / out["compress_lossless_s"], 1)
+        if out["identical"]:
+            out["decompress_MBps_of_file"] = round(out["fastq_bytes"] / 1e6 / out["decompress_test_file_s"], 1)
+        out["what"] = ("leon -file X.fastq -c -lossless, then leon -file X.fastq.leon -d -test-file (byte comparison with the original), "
+                       "whole commands timed from outside: parse, k-mer counting, bloom, the three streams, HDF5 container")
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
 
 
 def _cpu_worker(args):

@@ -4,7 +4,7 @@
 #include "kernels.h"
 #include "host_rc.h"
 
-#include <hipcub/hipcub.hpp>
+#include "prim.h"
 
 #include <algorithm>
 #include <atomic>
@@ -455,9 +455,9 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipMemsetAsync(c->counters.as<uint32_t>() + 4, 0, 4, s));
     launch_read_slots(s, d_off, n, c->slot_off.as<uint64_t>(), c->counters.as<uint32_t>() + 4);
     size_t tmp_bytes = 0;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
+    HIPCHK(c, prim::ExclusiveSum(nullptr, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
     if (int rc = ensure_cub(c, tmp_bytes)) return rc;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
+    HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
     uint64_t n_slots = 0;
     uint32_t bad_offsets = 0;
     HIPCHK(c, hipMemcpyAsync(&n_slots, c->slot_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
@@ -515,7 +515,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     uint32_t* counters = c->counters.as<uint32_t>();            // [0],[1]: list counts
     uint32_t* lists[2] = { c->ulist0.as<uint32_t>(), c->ulist1.as<uint32_t>() };
     size_t scan_tmp = 0;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), W, s));
+    HIPCHK(c, prim::ExclusiveSum(nullptr, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), W, s));
     if (int rc = ensure_cub(c, scan_tmp)) return rc;
     c->poisoned = true;             // from here on the dictionary and the dictionary stream change: cleared on success
     for (uint64_t w0 = 0, w1 = 0; w0 < n; w0 = w1) {
@@ -552,7 +552,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         if (cnt0 > 0) {
             launch_final_pos(s, R, c->D, V, w0, w1, first_read_index);
             launch_ins_flags(s, V, w0, w1);
-            HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), w1 - w0, s));
+            HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), w1 - w0, s));
             uint32_t last_rank = 0, last_flag = 0;
             HIPCHK(c, hipMemcpyAsync(&last_rank, c->rank.as<uint32_t>() + (w1 - w0 - 1), 4, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipMemcpyAsync(&last_flag, V.ins_flag + (w1 - w0 - 1), 4, hipMemcpyDeviceToHost, s));
@@ -617,10 +617,10 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, c->sort_key2.ensure(nl * 8)); HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(nl * 4));
     hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
     size_t sort_tmp = 0;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
+    HIPCHK(c, prim::SortPairs(nullptr, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
                                                  c->perm2.as<uint32_t>(), nl, 0, 33, s));
     if (int rc = ensure_cub(c, sort_tmp)) return rc;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
+    HIPCHK(c, prim::SortPairs(c->cub_tmp.p, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
                                                  c->perm2.as<uint32_t>(), nl, 0, 33, s));
     HIPCHK(c, hipEventRecord(c->ev[3], s));
 
@@ -640,9 +640,9 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipMemsetAsync(c->sym_off.as<uint64_t>() + nl, 0, 8, s));
     launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(), r0, nl,
                    c->sym_off.as<uint64_t>(), c->nerr.as<uint32_t>(), nullptr);
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
+    HIPCHK(c, prim::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
     if (int rc = ensure_cub(c, tmp_bytes)) return rc;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
+    HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
     uint64_t n_syms = 0;
     HIPCHK(c, hipMemcpyAsync(&n_syms, c->sym_off.as<uint64_t>() + nl, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -781,10 +781,10 @@ int leon_dna_reserve(leon_dna_ctx* c, uint64_t max_reads, uint64_t max_bases) {
     HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
     HIPCHK(c, c->payload.ensure(max_bases / 12 + 4096));
     size_t t1 = 0, t2 = 0, t3 = 0;                               // the scans' and the sort's work space
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t1, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, c->stream));
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, t2, c->sort_key.as<uint64_t>(), c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>(), c->perm2.as<uint32_t>(),
+    HIPCHK(c, prim::ExclusiveSum(nullptr, t1, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, c->stream));
+    HIPCHK(c, prim::SortPairs(nullptr, t2, c->sort_key.as<uint64_t>(), c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>(), c->perm2.as<uint32_t>(),
                                                  n, 0, 33, c->stream));
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t3, c->ins_flag.as<uint32_t>(), c->rank.as<uint32_t>(), W, c->stream));
+    HIPCHK(c, prim::ExclusiveSum(nullptr, t3, c->ins_flag.as<uint32_t>(), c->rank.as<uint32_t>(), W, c->stream));
     if (int rc = ensure_cub(c, std::max(t1, std::max(t2, t3)))) return rc;
     if (max_bases / 12 + 4096 > c->h_payload_cap) {
         if (c->h_payload) HIPCHK(c, hipHostFree(c->h_payload));
@@ -841,9 +841,9 @@ static int header_batch_impl(leon_dna_ctx* c, const uint8_t* d_hdr, const uint64
         HIPCHK(c, hipMemsetAsync(c->sym_off.as<uint64_t>() + nl, 0, 8, s));
         launch_hdr_symbols(s, d_hdr, d_off + r0, nl, rpb, c->hdr_first.as<uint8_t>(), (uint32_t)first_len, c->sym_off.as<uint64_t>(), nullptr);
         size_t tmp_bytes = 0;
-        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
+        HIPCHK(c, prim::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
         if (int rc = ensure_cub(c, tmp_bytes)) return rc;
-        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
+        HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
         uint64_t n_syms = 0;
         HIPCHK(c, hipMemcpyAsync(&n_syms, c->sym_off.as<uint64_t>() + nl, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -936,9 +936,9 @@ int leon_qual_smooth_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const
     HIPCHK(c, hipMemsetAsync(c->counters.as<uint32_t>() + 4, 0, 4, s));
     launch_read_slots(s, d_off, n, c->slot_off.as<uint64_t>(), c->counters.as<uint32_t>() + 4);
     size_t tmp_bytes = 0;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
+    HIPCHK(c, prim::ExclusiveSum(nullptr, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
     if (int rc = ensure_cub(c, tmp_bytes)) return rc;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
+    HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
     uint64_t n_slots = 0;
     uint32_t bad_offsets = 0;
     HIPCHK(c, hipMemcpyAsync(&n_slots, c->slot_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));

@@ -237,13 +237,19 @@ template <bool SPIN> __device__ inline uint32_t dict_find_or_insert(const DictDe
         }
         if (hi == khi) {
             uint64_t lo = __hip_atomic_load(plo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // belt and braces: should the low word ever be seen after the high one, it still reads as the free slot's ~0;
-            // give it a moment before taking ~0 for a real low word (a k-mer ending in 32 G) and probing on
-            if (SPIN && lo == KEY_EMPTY && klo != KEY_EMPTY)
-                for (uint32_t spin = 0; lo == KEY_EMPTY && spin < 1024; spin++) {
+            // ORDERING ASSUMPTION: the inserter's two exchanges reach the slot's L2 channel in issue order, so a
+            // reader that sees the high word sees the low word.  That is observed behaviour of this memory system, not a
+            // documented guarantee, so it is checked, not trusted: a low word that still reads as the free slot's ~0 is given
+            // a moment, and if it stays ~0 the batch is FAILED through D.err (like the locked-slot timeout) -- probing on
+            // would insert the same k-mer twice and give a silently different dictionary.  (Not checkable for the one low
+            // word that IS ~0, a k-mer ending in 32 G: there ~0 is the answer either way.)
+            if (SPIN && lo == KEY_EMPTY && klo != KEY_EMPTY) {
+                for (uint32_t spin = 0; lo == KEY_EMPTY && spin < (1u << 16); spin++) {
                     __builtin_amdgcn_s_sleep(1);
                     lo = __hip_atomic_load(plo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                if (lo == KEY_EMPTY) { atomicExch(D.err, 1); return (uint32_t)slot; }
+            }
             if (lo == klo) return (uint32_t)slot;
         }
         slot = (slot + 1) & D.mask;

@@ -5,7 +5,7 @@
 #include "../../include/leon_dna.h"
 #include "kernels.h"
 
-#include <hipcub/hipcub.hpp>
+#include "prim.h"
 
 #include <algorithm>
 #include <string>
@@ -191,9 +191,9 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     KCHK(hipMemsetAsync(bad.p, 0, 4, s));
     launch_read_slots(s, d_offsets, n_reads, slot_off.as<uint64_t>(), bad.as<uint32_t>());
     size_t tb = 0;
-    KCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, slot_off.as<uint64_t>(), slot_off.as<uint64_t>(), n_reads + 1, s));
+    KCHK(prim::ExclusiveSum(nullptr, tb, slot_off.as<uint64_t>(), slot_off.as<uint64_t>(), n_reads + 1, s));
     KCHK(tmp.alloc(tb));
-    KCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, slot_off.as<uint64_t>(), slot_off.as<uint64_t>(), n_reads + 1, s));
+    KCHK(prim::ExclusiveSum(tmp.p, tb, slot_off.as<uint64_t>(), slot_off.as<uint64_t>(), n_reads + 1, s));
     uint64_t n_slots = 0;
     KCHK(hipMemcpy(&n_slots, slot_off.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
     uint32_t bad_offsets = 0;
@@ -209,9 +209,9 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     KCHK(pos.alloc((n_reads + 1) * 8));
     hipLaunchKernelGGL(k_positions, dim3(grid(n_reads)), dim3(256), 0, s, d_offsets, n_reads, k, pos.as<uint64_t>());
     Buf tmp2; size_t tb2 = 0;
-    KCHK(hipcub::DeviceReduce::Sum(nullptr, tb2, pos.as<uint64_t>(), pos.as<uint64_t>() + n_reads, n_reads, s));
+    KCHK(prim::Sum(nullptr, tb2, pos.as<uint64_t>(), pos.as<uint64_t>() + n_reads, n_reads, s));
     KCHK(tmp2.alloc(tb2));
-    KCHK(hipcub::DeviceReduce::Sum(tmp2.p, tb2, pos.as<uint64_t>(), pos.as<uint64_t>() + n_reads, n_reads, s));
+    KCHK(prim::Sum(tmp2.p, tb2, pos.as<uint64_t>(), pos.as<uint64_t>() + n_reads, n_reads, s));
     uint64_t total = 0;
     KCHK(hipMemcpy(&total, pos.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
     if (!total) return LEON_OK;
@@ -235,9 +235,9 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     KCHK(nsel.alloc(8)); KCHK(hist.alloc(256 * 8));
     KCHK(hipMemset(hist.p, 0, 256 * 8));
     size_t st = 0, st2 = 0, sl = 0;
-    if (W == 1) { KCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, st, keys.as<uint64_t>(), alt.as<uint64_t>(), cap, 0, 2 * k, s)); }
+    if (W == 1) { KCHK(prim::SortKeys(nullptr, st, keys.as<uint64_t>(), alt.as<uint64_t>(), cap, 0, 2 * k, s)); }
     else {
-        KCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, st, keys.as<uint64_t>(), alt.as<uint64_t>(), alt2.as<uint64_t>(), alt3.as<uint64_t>(), cap, 0, 64, s));
+        KCHK(prim::SortPairs(nullptr, st, keys.as<uint64_t>(), alt.as<uint64_t>(), alt2.as<uint64_t>(), alt3.as<uint64_t>(), cap, 0, 64, s));
         st2 = st;
     }
     KCHK(sort_tmp.alloc(std::max(st, st2)));
@@ -251,7 +251,7 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
 #define KCHK2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_create_error(std::string(#call) + ": " + hipGetErrorString(e_)); return fail_free(LEON_E_HIP); } } while (0)
     if (automatic) KCHK2(hipMalloc((void**)&out_cnt, out_cap));
     size_t scan_tb = 0;
-    KCHK2(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tb, pos.as<uint64_t>(), pos.as<uint64_t>(), n_reads + 1, s));
+    KCHK2(prim::ExclusiveSum(nullptr, scan_tb, pos.as<uint64_t>(), pos.as<uint64_t>(), n_reads + 1, s));
     Buf scan_tmp;
     KCHK2(scan_tmp.alloc(scan_tb));
     for (uint32_t part = 0; part < n_parts; part++) {
@@ -259,7 +259,7 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
         KCHK2(hipMemsetAsync(pos.as<uint64_t>() + n_reads, 0, 8, s));
         if (W == 1) hipLaunchKernelGGL((k_part_kmers<uint64_t, false>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), (uint64_t*)nullptr);
         else hipLaunchKernelGGL((k_part_kmers<u128, false>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), (uint64_t*)nullptr);
-        KCHK2(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_tb, pos.as<uint64_t>(), pos.as<uint64_t>(), n_reads + 1, s));
+        KCHK2(prim::ExclusiveSum(scan_tmp.p, scan_tb, pos.as<uint64_t>(), pos.as<uint64_t>(), n_reads + 1, s));
         uint64_t n = 0;
         KCHK2(hipMemcpy(&n, pos.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
         if (n > cap) { set_create_error("kmer_solid: a hash partition exceeds its buffer (very skewed k-mer spectrum); lower max_keys_per_pass"); return fail_free(LEON_E_OVERFLOW); }
@@ -270,13 +270,13 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
         if (!n) continue;
         uint64_t* sorted = nullptr;
         if (W == 1) {
-            KCHK2(hipcub::DeviceRadixSort::SortKeys(sort_tmp.p, st, keys.as<uint64_t>(), alt.as<uint64_t>(), n, 0, 2 * k, s));
+            KCHK2(prim::SortKeys(sort_tmp.p, st, keys.as<uint64_t>(), alt.as<uint64_t>(), n, 0, 2 * k, s));
             sorted = alt.as<uint64_t>();
         } else {                                              // 128-bit keys: LSD in two stable passes (low word, then high word)
             uint64_t* lo = alt.as<uint64_t>(); uint64_t* hi = lo + cap;
             hipLaunchKernelGGL(k_split_words, dim3(grid(n)), dim3(256), 0, s, keys.as<uint64_t>(), n, lo, hi);
-            KCHK2(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, st, lo, alt2.as<uint64_t>(), hi, alt3.as<uint64_t>(), n, 0, 64, s));     // by low
-            KCHK2(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, st, alt3.as<uint64_t>(), hi, alt2.as<uint64_t>(), lo, n, 0, 2 * k - 64 > 0 ? 2 * k - 64 : 1, s));   // by high (stable)
+            KCHK2(prim::SortPairs(sort_tmp.p, st, lo, alt2.as<uint64_t>(), hi, alt3.as<uint64_t>(), n, 0, 64, s));     // by low
+            KCHK2(prim::SortPairs(sort_tmp.p, st, alt3.as<uint64_t>(), hi, alt2.as<uint64_t>(), lo, n, 0, 2 * k - 64 > 0 ? 2 * k - 64 : 1, s));   // by high (stable)
             hipLaunchKernelGGL(k_join_words, dim3(grid(n)), dim3(256), 0, s, lo, hi, n, keys.as<uint64_t>());
             sorted = keys.as<uint64_t>();
         }
@@ -286,19 +286,19 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
         uint64_t* dst = (sorted == keys.as<uint64_t>()) ? alt.as<uint64_t>() : keys.as<uint64_t>();
         size_t need = 0;
         if (W == 1) {
-            KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need, sorted, flags.as<uint8_t>(), dst, nsel.as<uint64_t>(), n, s));
+            KCHK2(prim::Flagged(nullptr, need, sorted, flags.as<uint8_t>(), dst, nsel.as<uint64_t>(), n, s));
             if (need > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need)); sl = need; }
-            KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need, sorted, flags.as<uint8_t>(), dst, nsel.as<uint64_t>(), n, s));
+            KCHK2(prim::Flagged(sel_tmp.p, need, sorted, flags.as<uint8_t>(), dst, nsel.as<uint64_t>(), n, s));
         } else {
-            KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need, (Pair128*)sorted, flags.as<uint8_t>(), (Pair128*)dst, nsel.as<uint64_t>(), n, s));
+            KCHK2(prim::Flagged(nullptr, need, (Pair128*)sorted, flags.as<uint8_t>(), (Pair128*)dst, nsel.as<uint64_t>(), n, s));
             if (need > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need)); sl = need; }
-            KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need, (Pair128*)sorted, flags.as<uint8_t>(), (Pair128*)dst, nsel.as<uint64_t>(), n, s));
+            KCHK2(prim::Flagged(sel_tmp.p, need, (Pair128*)sorted, flags.as<uint8_t>(), (Pair128*)dst, nsel.as<uint64_t>(), n, s));
         }
         if (automatic) {                                        // the same heads' run lengths, in the same order
             size_t need2 = 0;
-            KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need2, runlen.as<uint8_t>(), flags.as<uint8_t>(), runsel.as<uint8_t>(), nsel.as<uint64_t>(), n, s));
+            KCHK2(prim::Flagged(nullptr, need2, runlen.as<uint8_t>(), flags.as<uint8_t>(), runsel.as<uint8_t>(), nsel.as<uint64_t>(), n, s));
             if (need2 > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need2)); sl = need2; }
-            KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need2, runlen.as<uint8_t>(), flags.as<uint8_t>(), runsel.as<uint8_t>(), nsel.as<uint64_t>(), n, s));
+            KCHK2(prim::Flagged(sel_tmp.p, need2, runlen.as<uint8_t>(), flags.as<uint8_t>(), runsel.as<uint8_t>(), nsel.as<uint64_t>(), n, s));
         }
         uint64_t ns = 0;
         KCHK2(hipMemcpy(&ns, nsel.p, 8, hipMemcpyDeviceToHost));
@@ -332,13 +332,13 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
             hipLaunchKernelGGL(k_flag_at_least, dim3(grid(out_n)), dim3(256), 0, s, out_cnt, out_n, cutoff, f2.as<uint8_t>());
             size_t need3 = 0;
             if (W == 1) {
-                KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need3, out, f2.as<uint8_t>(), kept.as<uint64_t>(), nsel.as<uint64_t>(), out_n, s));
+                KCHK2(prim::Flagged(nullptr, need3, out, f2.as<uint8_t>(), kept.as<uint64_t>(), nsel.as<uint64_t>(), out_n, s));
                 if (need3 > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need3)); sl = need3; }
-                KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need3, out, f2.as<uint8_t>(), kept.as<uint64_t>(), nsel.as<uint64_t>(), out_n, s));
+                KCHK2(prim::Flagged(sel_tmp.p, need3, out, f2.as<uint8_t>(), kept.as<uint64_t>(), nsel.as<uint64_t>(), out_n, s));
             } else {
-                KCHK2(hipcub::DeviceSelect::Flagged(nullptr, need3, (Pair128*)out, f2.as<uint8_t>(), (Pair128*)kept.p, nsel.as<uint64_t>(), out_n, s));
+                KCHK2(prim::Flagged(nullptr, need3, (Pair128*)out, f2.as<uint8_t>(), (Pair128*)kept.p, nsel.as<uint64_t>(), out_n, s));
                 if (need3 > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need3)); sl = need3; }
-                KCHK2(hipcub::DeviceSelect::Flagged(sel_tmp.p, need3, (Pair128*)out, f2.as<uint8_t>(), (Pair128*)kept.p, nsel.as<uint64_t>(), out_n, s));
+                KCHK2(prim::Flagged(sel_tmp.p, need3, (Pair128*)out, f2.as<uint8_t>(), (Pair128*)kept.p, nsel.as<uint64_t>(), out_n, s));
             }
             uint64_t nk = 0;
             KCHK2(hipMemcpy(&nk, nsel.p, 8, hipMemcpyDeviceToHost));

@@ -9,6 +9,51 @@
 
 namespace leon_host {
 
+static void put_varint(std::string& s, uint64_t v) { while (v >= 0x80) { s.push_back((char)(v | 0x80)); v >>= 7; } s.push_back((char)v); }
+
+std::string Bank::plusLines() const {
+    if (plus_default_ <= 0 && plus_exc_.empty()) return std::string();
+    std::string out(1, (char)plus_default_);
+    return out + plus_exc_;
+}
+
+PlusLines PlusLines::decode(const uint8_t* p, uint64_t n) {
+    PlusLines L;
+    if (!n) return L;
+    if (p[0] > 1) throw Exception("malformed '+'-line table");
+    L.def = p[0];
+    uint64_t at = 1, read = 0;
+    auto varint = [&]() -> uint64_t {
+        uint64_t v = 0;
+        for (uint32_t sh = 0;; sh += 7) {
+            if (at >= n || sh > 63) throw Exception("malformed '+'-line table");
+            const uint8_t c = p[at++];
+            v |= (uint64_t)(c & 0x7F) << sh;
+            if (!(c & 0x80)) return v;
+        }
+    };
+    while (at < n) {
+        const uint64_t d = varint();
+        if (!L.exc.empty() && d == 0) throw Exception("malformed '+'-line table");
+        read += d;
+        if (at >= n) throw Exception("malformed '+'-line table");
+        const uint8_t kind = p[at++];
+        if (kind > 2 || kind == L.def) throw Exception("malformed '+'-line table");
+        std::string text;
+        if (kind == 2) {
+            const uint64_t len = varint();
+            if (len > n - at) throw Exception("malformed '+'-line table");
+            text.assign(reinterpret_cast<const char*>(p) + at, len);
+            at += len;
+        }
+        L.exc.push_back(Exc{read, kind, std::move(text)});
+    }
+    return L;
+}
+size_t PlusLines::lower(uint64_t read) const {
+    return (size_t)(std::lower_bound(exc.begin(), exc.end(), read, [](const Exc& e, uint64_t r) { return e.read < r; }) - exc.begin());
+}
+
 Bank::Bank(const std::string& path) : path_(path), buf_(1 << 20) {
     struct stat st;
     if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) throw Exception("cannot open " + path);
@@ -27,7 +72,14 @@ bool Bank::getline(std::string& line) {
         if (buf_pos_ == buf_len_) {
             const int got = gzread((gzFile)gz_, buf_.data(), (unsigned)buf_.size());
             if (got < 0) { int e = 0; throw Exception(std::string("read error in ") + path_ + ": " + gzerror((gzFile)gz_, &e)); }
-            if (got == 0) break;
+            if (got == 0) {
+                // end of the data -- or of a TRUNCATED .gz, which zlib reports as 0 bytes + Z_BUF_ERROR after handing out
+                // what it could inflate: compressing that part and calling it success would lose the rest silently
+                int e = 0;
+                const char* msg = gzerror((gzFile)gz_, &e);
+                if (e != Z_OK && e != Z_STREAM_END) throw Exception(path_ + " is truncated or corrupt (" + (msg && *msg ? msg : "unexpected end of file") + ")");
+                break;
+            }
             buf_pos_ = 0; buf_len_ = (size_t)got;
         }
         const char* p = buf_.data() + buf_pos_;
@@ -84,12 +136,24 @@ uint64_t Bank::next(ReadBatch& b, uint64_t max_reads) {
         if (len == 0) continue;
         if (fastq_) {
             if (p[0] != '@') throw Exception("malformed FASTQ record " + std::to_string(n_read_ + 1) + " in " + path_);
+            const size_t hdr_at = b.headers.size(), hdr_len = len - 1;
             b.headers.append(p + 1, len - 1);
             if (!view(p, len)) throw Exception("truncated FASTQ record in " + path_);
             const size_t seq_len = len;
             b.bases.append(p, len);
             if (!view(p, len)) throw Exception("truncated FASTQ record in " + path_);
             if (len == 0 || p[0] != '+') throw Exception("malformed FASTQ record " + std::to_string(n_read_ + 1) + " in " + path_);
+            {   // the text after the '+': nothing, the header again, or something else
+                // (a bare '+' under an empty header is both "bare" and "the header again": whichever the file's default is)
+                const int kind = len == 1 ? (hdr_len == 0 && plus_default_ == 1 ? 1 : 0)
+                                          : (len - 1 == hdr_len && memcmp(p + 1, b.headers.data() + hdr_at, hdr_len) == 0) ? 1 : 2;
+                if (plus_default_ < 0) plus_default_ = kind == 2 ? 0 : kind;
+                if (kind != plus_default_) {
+                    put_varint(plus_exc_, n_read_ - plus_prev_); plus_prev_ = n_read_;
+                    plus_exc_.push_back((char)kind);
+                    if (kind == 2) { put_varint(plus_exc_, len - 1); plus_exc_.append(p + 1, len - 1); }
+                }
+            }
             if (!view(p, len)) throw Exception("truncated FASTQ record in " + path_);
             if (len != seq_len) throw Exception("FASTQ record " + std::to_string(n_read_ + 1) + " of " + path_ + ": quality and sequence lengths differ");
             b.quals.append(p, len);

@@ -30,6 +30,9 @@ public:
     // FASTA: the width every sequence line but a record's last has when the file wraps its sequences consistently, else 0
     // (sequences on one line, or lines of differing widths); valid once the whole file has been read
     uint64_t fastaLineWidth() const { return (wrap_seen_ && wrap_ok_ && !single_empty_ && single_max_ <= wrap_) ? wrap_ : 0; }
+    // FASTQ: what follows the '+' of every record's third line, as PlusLines::decode reads it back; empty when every record
+    // has a bare "+" (the usual case; nothing is stored then).  Valid once the whole file has been read.
+    std::string plusLines() const;
 private:
     bool getline(std::string& line);
     bool view(const char*& p, size_t& n);         // the next line where it lies (in the read buffer when it ends there), else assembled in spill_
@@ -42,6 +45,27 @@ private:
     uint64_t wrap_ = 0;
     bool wrap_seen_ = false, wrap_ok_ = true, single_empty_ = false;
     uint64_t single_max_ = 0;                     // longest sequence that sat on one line: must fit the wrap width too
+    int plus_default_ = -1;                       // kind of the first record's '+' line (0 bare, 1 repeats the header); -1: none seen
+    std::string plus_exc_;                        // the records that differ from it: varint(read index delta), kind, [varint(length), text]
+    uint64_t plus_prev_ = 0;
+};
+
+// The '+' lines of a FASTQ file (third line of a record): bare, or the header again (older Illumina / SRA dumps), or -- never
+// seen, but `diff` would see it -- any other text.  One default kind + the exceptions.
+struct PlusLines {
+    uint8_t def = 0;
+    struct Exc { uint64_t read; uint8_t kind; std::string text; };
+    std::vector<Exc> exc;                         // sorted by read
+    bool trivial() const { return def == 0 && exc.empty(); }
+    static PlusLines decode(const uint8_t* p, uint64_t n);        // throws leon_host::Exception on a malformed blob
+    // kind of read `read`'s line (0 bare, 1 header, 2 text); *hint walks the exceptions forwards over increasing reads
+    const Exc* find(uint64_t read, size_t* hint) const {
+        size_t i = *hint;
+        while (i < exc.size() && exc[i].read < read) i++;
+        *hint = i;
+        return (i < exc.size() && exc[i].read == read) ? &exc[i] : nullptr;
+    }
+    size_t lower(uint64_t read) const;            // first exception at or after `read`
 };
 
 }  // namespace leon_host

@@ -67,6 +67,18 @@ void load_hdf5() {
     BIND(Pcreate, "H5Pcreate"); BIND(Pset_obj_track_times, "H5Pset_obj_track_times"); BIND(Pclose, "H5Pclose"); BIND(Eset_auto2, "H5Eset_auto2");
 #undef BIND
     if (!ok) return;
+    // the typedefs above are the 1.10+ ABI (64-bit hid_t, the *_ID_g / *_g globals read below): an older library would be
+    // called with the wrong types
+    {
+        auto libversion = reinterpret_cast<herr_t (*)(unsigned*, unsigned*, unsigned*)>(sym("H5get_libversion"));
+        unsigned maj = 0, min = 0, rel = 0;
+        if (!ok) return;
+        if (libversion(&maj, &min, &rel) < 0 || maj != 1 || min < 10) {
+            g_load_error = "the HDF5 library found is version " + std::to_string(maj) + "." + std::to_string(min) + "." + std::to_string(rel) +
+                           "; 1.10 or later is needed (set LEON_HDF5_LIB to its path)";
+            return;
+        }
+    }
     if (g_h5.open() < 0) { g_load_error = "H5open failed"; return; }
     auto var = [&](const char* n) -> hid_t { void* p = sym(n); return p ? *reinterpret_cast<hid_t*>(p) : -1; };
     g_h5.T_U8 = var("H5T_STD_U8LE_g"); g_h5.T_U64 = var("H5T_STD_U64LE_g");

@@ -299,10 +299,22 @@ void Leon::executeCompression() {
     uint32_t abundance = (uint32_t)_abundance;
     if (_abundance == 0) (void)leon_kmer_auto_cutoff(hist, &abundance);
     const uint64_t tai = std::max<uint64_t>(n_solid * 12, 1000);         // NBITS_PER_KMER = 12 [RECALLED]
+    // the DNA stream goes to the device in batches of whole read blocks: the file at once up to 100 M reads, else 2 000 blocks
+    // (100 M reads) per leon_dna_encode_batch_device call -- the reads stay resident in HBM, the per-batch buffers are bounded
+    uint64_t batch_blocks = std::max<uint64_t>(std::min<uint64_t>(n_blocks, 2000), 1);
+    if (const char* e = getenv("LEON_BATCH_BLOCKS")) { const long v = atol(e); if (v > 0) batch_blocks = (uint64_t)v; }   // (tests: several batches on a small file)
+    uint64_t batch_max_reads = 0, batch_max_bases = 0;
+    for (uint64_t b0 = 0; b0 < n_blocks; b0 += batch_blocks) {
+        const uint64_t r0 = b0 * rpb, r1 = std::min<uint64_t>(n_reads, (b0 + batch_blocks) * rpb);
+        batch_max_reads = std::max(batch_max_reads, r1 - r0); batch_max_bases = std::max(batch_max_bases, offsets[r1] - offsets[r0]);
+    }
     std::vector<CtxPtr> ctx;
     for (int g = 0; g < n_gpus; g++) {
         ctx.push_back(make_ctx(k, tai, store[g]->device));
         check(ctx[g].get(), leon_dna_set_shard(ctx[g].get(), (uint32_t)g, (uint32_t)n_gpus), "leon_dna_set_shard");
+        // every per-batch buffer sized now, in one go, before the bloom is built and copied: the first (usually only) encode
+        // call then allocates nothing large
+        check(ctx[g].get(), leon_dna_reserve(ctx[g].get(), batch_max_reads, batch_max_bases), "leon_dna_reserve");
     }
     check(ctx[0].get(), leon_dna_bloom_insert_device(ctx[0].get(), d_solid, n_solid), "leon_dna_bloom_insert_device");
     uint64_t bloom_bytes = 0;
@@ -314,8 +326,6 @@ void Leon::executeCompression() {
 
     // ---- the DNA stream: Dispatcher::iterate(bank, DnaEncoder(this)) upstream, the device path here ----
     const auto t_dna = std::chrono::steady_clock::now();
-    uint64_t batch_blocks = n_blocks <= 2400 ? std::max<uint64_t>(n_blocks, 1) : 1000;           // whole file at once up to 120 M reads
-    if (const char* e = getenv("LEON_BATCH_BLOCKS")) { const long v = atol(e); if (v > 0) batch_blocks = (uint64_t)v; }   // (tests: several batches on a small file)
     std::vector<std::string> gpu_error(n_gpus);
     auto encode_on = [&](int g) {
         try {
@@ -415,6 +425,10 @@ void Leon::executeCompression() {
             table.push_back(wq.sizes[b]); table.push_back(wq.reads[b]); table.push_back(offsets[r1] - offsets[r0]);
         }
         out.putU64(DS_QUAL_TABLE, table.data(), table.size());
+    }
+    if (fastq && keep_header && keep_qual) {                     // '+' lines that repeat the header (or carry text): `diff` sees them (simple_test.sh:62)
+        const std::string plus = bank.plusLines();
+        if (!plus.empty()) out.putBytes(DS_PLUS_LINES, plus.data(), plus.size());
     }
     out.putBytes(DS_ANCHOR_DICT, dict, dict_size);
     out.putBytes(DS_BLOOM_BITS, bloom.data(), bloom.size());
@@ -520,6 +534,18 @@ void Leon::executeDecompression() {
     if (ofd.fd < 0) throw Exception("cannot write " + _outputFilename);
     ofd.path = _outputFilename;
     const bool fastq_out = !fasta_in && has_qual;               // "-noqual ... will decompress to fasta"
+    PlusLines plus;                                             // FASTQ '+' lines that are not bare (absent: all of them are)
+    if (fastq_out && has_header && in.exists(DS_PLUS_LINES)) {
+        const std::vector<uint8_t> blob = in.getBytes(DS_PLUS_LINES);
+        plus = PlusLines::decode(blob.data(), blob.size());
+        if (!plus.exc.empty() && plus.exc.back().read >= n_reads) throw Exception(_inputFilename + ": malformed '+'-line table");
+    }
+    // bytes a read's '+' line has after the '+': nothing, its header again, or its own text
+    auto plus_extra = [&plus](uint64_t read, uint64_t hl, size_t* hint) -> uint64_t {
+        const PlusLines::Exc* e = plus.exc.empty() ? nullptr : plus.find(read, hint);
+        const uint8_t kind = e ? e->kind : plus.def;
+        return kind == 1 ? hl : kind == 2 ? e->text.size() : 0;
+    };
     const uint64_t wrap = fasta_in ? params[P_FASTA_LINE_WIDTH] : 0;      // sequences wrapped at this width in the original (0: one line)
     const char lead = fastq_out ? '@' : '>';
 
@@ -569,10 +595,12 @@ void Leon::executeDecompression() {
         const uint64_t g_reads = R->g_reads;
         std::vector<uint64_t> rec_off(g_reads + 1, 0), base_at(g_reads + 1, 0);
         auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
+        size_t hint0 = plus.lower(R->read_index);
         for (uint64_t r = 0; r < g_reads; r++) {
             const uint64_t hl = has_header ? R->hdr_off[r + 1] - R->hdr_off[r] : std::to_string(R->read_index + r).size();
             if (fastq_out && R->qual_off[r + 1] - R->qual_off[r] != R->lens()[r]) throw Exception(_inputFilename + ": a read's quality and sequence lengths differ");
-            rec_off[r + 1] = rec_off[r] + 1 + hl + 1 + seq_text_len(R->lens()[r]) + (fastq_out ? 2 + (uint64_t)R->lens()[r] + 1 : 0);
+            rec_off[r + 1] = rec_off[r] + 1 + hl + 1 + seq_text_len(R->lens()[r]) + (fastq_out ? 2 + (uint64_t)R->lens()[r] + 1 : 0)
+                             + (plus.trivial() ? 0 : plus_extra(R->read_index + r, hl, &hint0));
             base_at[r + 1] = base_at[r] + R->lens()[r];
         }
         const uint64_t n_text = rec_off[g_reads];
@@ -582,6 +610,7 @@ void Leon::executeDecompression() {
         std::mutex err_mu;
         std::string werr;
         auto format_range = [&](uint64_t ra, uint64_t rb) {
+            size_t hint = plus.lower(R->read_index + ra);
             for (uint64_t r = ra; r < rb; r++) {
                 char* w = text.get() + rec_off[r];
                 *w++ = lead;
@@ -593,7 +622,16 @@ void Leon::executeDecompression() {
                 if (wrap && len > wrap) {
                     for (uint64_t o2 = 0; o2 < len; o2 += wrap) { const uint64_t m = std::min<uint64_t>(wrap, len - o2); memcpy(w, seq + o2, m); w += m; *w++ = '\n'; }
                 } else { memcpy(w, seq, len); w += len; *w++ = '\n'; }
-                if (fastq_out) { *w++ = '+'; *w++ = '\n'; memcpy(w, R->qual.data() + R->qual_off[r], len); w += len; *w++ = '\n'; }
+                if (fastq_out) {
+                    *w++ = '+';
+                    if (!plus.trivial()) {
+                        const PlusLines::Exc* e = plus.exc.empty() ? nullptr : plus.find(R->read_index + r, &hint);
+                        const uint8_t kind = e ? e->kind : plus.def;
+                        if (kind == 1) { const uint64_t hl = R->hdr_off[r + 1] - R->hdr_off[r]; memcpy(w, R->hdr.data() + R->hdr_off[r], hl); w += hl; }
+                        else if (kind == 2) { memcpy(w, e->text.data(), e->text.size()); w += e->text.size(); }
+                    }
+                    *w++ = '\n'; memcpy(w, R->qual.data() + R->qual_off[r], len); w += len; *w++ = '\n';
+                }
             }
             // this thread's share of the text goes out as soon as it is formatted
             uint64_t at = rec_off[ra];
@@ -727,13 +765,16 @@ void Leon::executeDecompression() {
                 const uint64_t g_reads = R->g_reads, g_bases = R->g_bases;
                 // the size of this round's text: where the next round's begins
                 uint64_t n_text = 0;
-                if (has_header && !wrap)                         // (the decoder has checked that the lengths add up to the block table's bases)
-                    n_text = 2 * g_reads + R->hdr_off[g_reads] + g_bases + g_reads + (fastq_out ? 3 * g_reads + g_bases : 0);
+                if (has_header && !wrap && plus.exc.empty())     // (the decoder has checked that the lengths add up to the block table's bases)
+                    n_text = 2 * g_reads + R->hdr_off[g_reads] + g_bases + g_reads + (fastq_out ? 3 * g_reads + g_bases : 0)
+                             + (plus.def == 1 ? R->hdr_off[g_reads] : 0);      // every '+' line repeats its header
                 else {
                     auto seq_text_len = [&](uint64_t len) -> uint64_t { return wrap && len > wrap ? len + (len + wrap - 1) / wrap : len + 1; };
+                    size_t hint = plus.lower(R->read_index);
                     for (uint64_t r = 0; r < g_reads; r++) {
                         const uint64_t hl = has_header ? R->hdr_off[r + 1] - R->hdr_off[r] : std::to_string(R->read_index + r).size();
-                        n_text += 1 + hl + 1 + seq_text_len(R->lens()[r]) + (fastq_out ? 2 + (uint64_t)R->lens()[r] + 1 : 0);
+                        n_text += 1 + hl + 1 + seq_text_len(R->lens()[r]) + (fastq_out ? 2 + (uint64_t)R->lens()[r] + 1 : 0)
+                                  + (plus.trivial() ? 0 : plus_extra(R->read_index + r, hl, &hint));
                     }
                 }
                 R->n_text = n_text; R->file_off = next_file_off;
@@ -867,7 +908,14 @@ int selftest_bank(const std::string& path) {
         mix(fnv_b, b.bases); mix(fnv_h, b.headers); mix(fnv_q, b.quals);
     }
     std::cout << "{\"fastq\": " << (fq ? "true" : "false") << ", \"reads\": " << n << ", \"bases\": " << nb << ", \"header_bytes\": " << nh << ", \"qual_bytes\": " << nq
-              << ", \"fasta_line_width\": " << bank.fastaLineWidth() << ", \"fnv_bases\": " << fnv_b << ", \"fnv_headers\": " << fnv_h << ", \"fnv_quals\": " << fnv_q << "}" << std::endl;
+              << ", \"fasta_line_width\": " << bank.fastaLineWidth() << ", \"fnv_bases\": " << fnv_b << ", \"fnv_headers\": " << fnv_h << ", \"fnv_quals\": " << fnv_q;
+    // the '+'-line table as the container stores it, read back the way -d reads it
+    const std::string plus = bank.plusLines();
+    const PlusLines L = PlusLines::decode(reinterpret_cast<const uint8_t*>(plus.data()), plus.size());
+    uint64_t text_bytes = 0;
+    for (const PlusLines::Exc& e : L.exc) text_bytes += e.text.size();
+    std::cout << ", \"plus\": {\"bytes\": " << plus.size() << ", \"default\": " << (int)L.def << ", \"exceptions\": " << L.exc.size() << ", \"first_exception\": "
+              << (L.exc.empty() ? -1ll : (long long)L.exc[0].read) << ", \"text_bytes\": " << text_bytes << "}}" << std::endl;
     return 0;
 }
 

@@ -26,7 +26,8 @@ int report(const leon_host::Exception& failure) {
 int main(int argc, char* argv[]) {
     if (wants_version(argc, argv)) {
         const std::string rule(44, '*');
-        std::cout << rule << "\n* leon_amd DNA encode path, C-ABI version " << leon_dna_abi_version() << "\n" << rule << std::endl;
+        std::cout << rule << "\n* leon_amd DNA encode path, C-ABI version " << leon_dna_abi_version()
+                  << "\n* .leon streams follow a restatement of gatb-core's\n* coders: byte parity with reference Leon is unverified\n" << rule << std::endl;
         return EXIT_FAILURE;
     }
     leon_host::Leon tool;

@@ -105,3 +105,112 @@ def test_full_size_properties(N_READS, K, L):
     hn[~np.isin(hn, np.frombuffer(b"ACGT", dtype=np.uint8))] = ord("N")
     assert np.array_equal(out, hn)
     capi.device_free(d_solid)
+
+
+def test_configuration_5_as_rank_0_of_8_sees_it():
+    """BASELINE configuration #5 -- 500 M x 250 bp, k = 63, 8 GPUs -- from the seat of ONE of its ranks, which is all a
+    one-GPU box can hold of it and exactly what a rank does under leon_dna_set_shard: ALL 500 M reads go through the
+    anchor resolution (replicated, file-order dictionary), rank 0's eighth of every batch's read blocks is walked and
+    coded, and rank 0 also carries the file-wide dictionary stream.  The reads are generated on the device batch by
+    batch (100 M reads = 25 GB of bases per leon_dna_encode_batch_device call) -- the file never exists as a whole.
+    Checked: block ids / sizes of the share; the first batch's share == the same blocks of a one-GPU run over the first
+    batch (the bytes do not depend on the sharding); decompress(compress(x)) == x on sampled blocks through the oracle's
+    decoder; the 7.2 G-symbol dictionary stream decodes to exactly the anchors the device inserted; 32-bit addresses,
+    dictionary capacity and the memory high-water mark.  LEON_CFG5="reads:batch" shrinks it for rehearsals."""
+    import time
+    import torch
+    import bench
+    import leon_amd
+    from leon_amd import capi
+    from leon_amd.shard import block_range
+    N, B = (int(v) for v in os.environ.get("LEON_CFG5", "500000000:100000000").split(":"))
+    K, L, WORLD, RANK = 63, 250, 8, 0
+    assert N % B == 0 and B % bench.CHUNK == 0 and B % RPB == 0
+    dev = torch.device("cuda", 0)
+    t_start = time.perf_counter()
+    G = N * L // 30
+    genome = bench.gen_genome(G, dev)
+    tai = (G - K + 1) * 12
+    ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai)
+    # the bloom: the genome's own k-mers (the step before the path; the device counter's hash partitions over 94 G k-mers are
+    # minutes of work and not what this test is about)
+    for lo in range(0, G - K + 1, 1 << 26):
+        km = bench.genome_kmers_chunk(genome, lo, min(G - K + 1, lo + (1 << 26)), K)
+        torch.cuda.synchronize()
+        ctx.bloom_insert_device(km.data_ptr(), km.shape[0])
+        del km
+    t_bloom = time.perf_counter() - t_start
+    ctx.set_shard(RANK, WORLD)
+    ctx.reserve(B, B * L)
+    buf = torch.empty((B, L), dtype=torch.uint8, device=dev)
+    off = (torch.arange(B + 1, dtype=torch.int64, device=dev) * L).contiguous()
+    bpb = B // RPB                                           # blocks per batch
+    lb0, lb1 = block_range(RANK, WORLD, bpb)                 # this rank's blocks of every batch
+    sample = {0: (0, 1, lb1 - 1), 1: (lb0 + 17,), N // B - 1: (lb1 - 1,)}     # batch -> blocks of the share kept for the round trip
+    kept_reads = {}
+
+    def fill(batch):
+        for c in range(B // bench.CHUNK):
+            buf[c * bench.CHUNK:(c + 1) * bench.CHUNK] = bench.gen_reads_chunk(genome, batch * (B // bench.CHUNK) + c, bench.CHUNK, 0.01, dev, L=L)
+        if batch == 0:                                       # a few N and a run of garbage reads inside the share
+            buf[123456, 40] = ord("N"); buf[1, 0:5] = ord("N")
+            g = torch.Generator(device=dev); g.manual_seed(9)
+            buf[60_000:60_200] = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=dev)[torch.randint(0, 4, (200, L), device=dev, generator=g)]
+        torch.cuda.synchronize()
+
+    blocks, stage, high_water = [], {}, 0
+    t_gen = t_enc = 0.0
+    for batch in range(N // B):
+        t0 = time.perf_counter()
+        fill(batch)
+        for b in sample.get(batch, ()):
+            kept_reads[batch * bpb + b] = buf[b * RPB:(b + 1) * RPB].cpu().numpy()
+        t1 = time.perf_counter()
+        got = ctx.encode_batch_device(buf.data_ptr(), off.data_ptr(), B)
+        t2 = time.perf_counter()
+        t_gen += t1 - t0; t_enc += t2 - t1
+        assert [g[0] for g in got] == list(range(batch * bpb + lb0, batch * bpb + lb1)) and all(g[2] == RPB for g in got)
+        blocks += got
+        st = ctx.stats()
+        assert st["n_reads"] == (lb1 - lb0) * RPB and st["n_bases"] == (lb1 - lb0) * RPB * L
+        for key, v in st.items():
+            if key.startswith("ms_") or key in ("resolve_rounds", "resolve_windows"):
+                stage[key] = stage.get(key, 0) + v
+        free_b, total_b = torch.cuda.mem_get_info()
+        high_water = max(high_water, total_b - free_b)
+    t0 = time.perf_counter()
+    d, na = ctx.finish()
+    t_finish = time.perf_counter() - t0
+    st = ctx.stats()
+    print("configuration #5, rank 0 of 8: %d reads in %d batches; bloom %.1f s, generation %.1f s, encode calls %.1f s + finish (dictionary chain) %.1f s; "
+          "device ms: pack %.0f resolve %.0f (replicated: all reads) sort %.0f walk %.0f symbols %.0f range coder %.0f d2h %.0f = %.0f; chain busy %.0f ms; "
+          "%d anchors, %d resolve rounds in %d windows; %d blocks, %.1f MB of payload + %.1f MB of dictionary stream; HBM high-water %.1f GB"
+          % (N, N // B, t_bloom, t_gen, t_enc, t_finish, stage["ms_pack"], stage["ms_resolve"], stage["ms_sort"], stage["ms_walk"], stage["ms_symbols"],
+             stage["ms_rangecoder"], stage["ms_d2h"], stage["ms_total"], st["ms_chain_busy"], na, stage["resolve_rounds"], stage["resolve_windows"],
+             len(blocks), sum(len(b[1]) for b in blocks) / 1e6, len(d) / 1e6, high_water / 1e9))
+    assert len(blocks) == (N // B) * (lb1 - lb0)
+    assert 0 < na < 2 ** 32 and 4 * na <= 2 ** 32          # 32-bit anchor addresses; the dictionary (load <= 1/4) stays within its 2^32 slots
+    assert high_water < 240e9, "a rank of configuration #5 must fit one MI355X (288 GB) with room to spare"
+    # the dictionary stream (rank 0 writes it) decodes to exactly what the device inserted, in insertion order
+    t0 = time.perf_counter()
+    anchors = capi.anchor_dict_decode(d, na, K)
+    t_dict = time.perf_counter() - t0
+    assert np.array_equal(anchors, ctx.anchor_kmers(na))
+    # decompress(compress(x)) == x on the sampled blocks, through the oracle's decoder
+    bl = O.Bloom(tai, K)
+    bl.set_bits(ctx.bloom_download())
+    by_id = {b[0]: b for b in blocks}
+    for bid, want in sorted(kept_reads.items()):
+        dec = O.decode_block(K, bl, anchors, by_id[bid][1], RPB, RPB * L + 16)
+        w = want.copy()
+        w[~np.isin(w, np.frombuffer(b"ACGT", dtype=np.uint8))] = ord("N")
+        assert b"".join(dec) == w.tobytes(), "block %d does not round-trip" % bid
+    del bl
+    # the share's bytes do not depend on the sharding: the first batch alone on one GPU gives the same first blocks
+    ctx.reset_stream()
+    ctx.set_shard(0, 1)
+    fill(0)
+    one = ctx.encode_batch_device(buf.data_ptr(), off.data_ptr(), B)
+    assert [(b[0], b[1]) for b in one[lb0:lb1]] == [(b[0], b[1]) for b in blocks[:lb1 - lb0]]
+    ctx.close()
+    print("dictionary decode %.1f s; whole test %.1f s" % (t_dict, time.perf_counter() - t_start))

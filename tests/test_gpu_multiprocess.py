@@ -1,8 +1,10 @@
 """-m gpu: the REAL N-process path of bench.py (BASELINE.json configuration #4's code: leon_dna_set_shard on every rank,
 the bloom built by rank 0 and broadcast, every rank resolving all reads and walking / coding its own block range, the
-merged block table) launched the way the driver launches it -- `python -m torch.distributed.run --nproc-per-node 2
-bench.py --gpus 2` -- on the one GPU of the test box, both ranks sharing device 0, collectives over gloo
-(LEON_BENCH_BACKEND=gloo: RCCL needs one device per rank, which only the driver's 8-GPU node has).
+merged block table) launched both ways the driver may launch it -- `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N`, and plain `python bench.py --gpus N` (which starts the former as a child before it touches the GPU) --
+on the one GPU of the test box, the ranks sharing device 0 (at most 4 of them: the box allows 6 processes on its card),
+collectives over gloo (LEON_BENCH_BACKEND=gloo: RCCL needs one device per rank, which only the driver's 8-GPU node has).
+The 8-way split itself runs in one process in test_gpu_parity.py::test_sharded_contexts_reproduce_the_single_stream.
 The ranks are fresh child processes of torch.distributed.run, itself a child that never touches the GPU.
 Asserts: union of the ranks' blocks == the single-process stream (checksum of block checksums), same dictionary stream."""
 import json
@@ -26,12 +28,14 @@ def _free_port():
     return p
 
 
-def _bench(world, extra_env=None):
+def _bench(world, extra_env=None, extra_args=(), launcher=True):
     env = dict(os.environ)
     env.update({"LEON_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     env.update(extra_env or {})
-    args = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--reads", str(READS), "--cpu-sample", "0", "--verify"]
-    if world == 1:
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(v, None)
+    args = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--reads", str(READS), "--cpu-sample", "0", "--e2e-reads", "0"] + list(extra_args)
+    if world == 1 or not launcher:
         cmd = [sys.executable] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
@@ -46,8 +50,8 @@ def _bench(world, extra_env=None):
 def test_two_and_three_process_runs_reproduce_the_single_process_stream():
     one = _bench(1)
     assert one["n_gpus"] == 1 and one["verify"]["n_blocks"] == READS // 50000
-    for world in (2, 3):
-        many = _bench(world)
+    for world, launcher, extra in ((2, True, ()), (3, False, ()), (4, True, ("--batch-reads", "700000"))):     # 4 ranks, three batches of 14 + 14 + 12 blocks
+        many = _bench(world, extra_args=extra, launcher=launcher)
         assert many["n_gpus"] == world and many["scaling"] == "strong"
         assert many["verify"]["blocks_per_rank"] and len(many["verify"]["blocks_per_rank"]) == world
         assert min(many["verify"]["blocks_per_rank"]) > 0
@@ -57,3 +61,27 @@ def test_two_and_three_process_runs_reproduce_the_single_process_stream():
         assert many["config"]["bloom_bytes"] == one["config"]["bloom_bytes"] and many["config"]["bloom_bcast_ms"] > 0
         for key in ("device_ms_max_over_ranks", "host_chain_ms", "value_device_only", "cold_first_step_ms"):
             assert many[key] > 0
+
+
+def test_default_bench_line_fills_every_key():
+    """the driver's `python bench.py` line: value beside the H2D-inclusive figure, verify, decode, end_to_end, roofline and
+    cpu_baseline -- none of them null at N = 1 (small sizes here; the keys and their checks are what is tested)"""
+    env = dict(os.environ)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(v, None)
+    cmd = [sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--reads", "1000000", "--batch-reads", "400000", "--cpu-sample", "100000",
+           "--e2e-reads", "200000"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    for key in ("value", "value_hbm_resident", "value_h2d_inclusive", "pcie_inclusive", "decode", "verify", "end_to_end", "roofline", "cpu_baseline"):
+        assert line[key] is not None, key
+    assert line["config"]["batches"] == 3 and line["value"] == line["value_hbm_resident"]
+    assert line["decode"]["equals_input"] is True
+    assert line["end_to_end"]["identical"] is True and line["end_to_end"]["compress_lossless_rc"] == 0
+    assert line["verify"]["n_blocks"] == 20
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+    assert "UNPINNED" in line["parity"]
+    # the same file as ONE batch: same bytes
+    one = _bench(1, extra_args=("--reads", "1000000"))
+    assert one["verify"]["blocks_sha256"] == line["verify"]["blocks_sha256"] and one["verify"]["dict_sha256"] == line["verify"]["dict_sha256"]

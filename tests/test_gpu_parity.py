@@ -265,7 +265,7 @@ def test_sharded_contexts_reproduce_the_single_stream():
     bases, off = common.synthetic(4000, 150, 15000, seed=51, n_rate=0.001)     # 14 blocks, the last partial
     bl, solid, tai = common.make_bloom(bases, off, k)
     ref = O.encode(bases, off, k, rpb, bl, trace=False)
-    for world in (2, 3, 5):
+    for world in (2, 3, 4, 5, 8):          # 8 = BASELINE configurations #4 / #5; the first batch's 6 blocks leave two of 8 ranks empty-handed
         got, dicts = [], []
         for rank in range(world):
             ctx = _ctx(k, rpb, tai, resolve_window=1000)

@@ -96,6 +96,10 @@ def test_bank_reader(leon_bin, tmp_path):
         r = run(leon_bin, "-selftest-bank", p)
         assert r.returncode == 0, r.stderr
         out[p] = json.loads(r.stdout)
+    # the '+' lines: bare in x.fastq (nothing to store), the header again in crlf.fastq (one byte: the default kind)
+    plus = {p: out[p].pop("plus") for p in out}
+    assert plus[fq] == {"bytes": 0, "default": 0, "exceptions": 0, "first_exception": -1, "text_bytes": 0} and plus[gz] == plus[fq]
+    assert plus[crlf] == {"bytes": 1, "default": 1, "exceptions": 0, "first_exception": -1, "text_bytes": 0}
     nb = sum(len(s) for _, s, _ in reads)
     assert out[fq]["fastq"] and out[fq]["reads"] == 4 and out[fq]["bases"] == nb and out[fq]["qual_bytes"] == nb
     assert out[fq]["header_bytes"] == sum(len(h) for h, _, _ in reads)
@@ -106,6 +110,24 @@ def test_bank_reader(leon_bin, tmp_path):
     r = run(leon_bin, "-selftest-bank", ragged)
     assert r.returncode == 0 and json.loads(r.stdout)["fasta_line_width"] == 0
     assert (out[fa]["fnv_bases"], out[fa]["fnv_headers"], out[fa]["bases"]) == (out[fq]["fnv_bases"], out[fq]["fnv_headers"], nb)
+    # mixed '+' lines: bare, the header again, other text -- the exceptions are kept against the first record's kind
+    mixed = str(tmp_path / "mixed.fastq")
+    open(mixed, "w").write("".join("@%s\n%s\n+%s\n%s\n" % (h, s, ("", h, "", "something else")[i], q) for i, (h, s, q) in enumerate(reads)))
+    r = run(leon_bin, "-selftest-bank", mixed)
+    assert r.returncode == 0 and json.loads(r.stdout)["plus"] == {"bytes": 1 + 2 + 2 + 1 + 14, "default": 0, "exceptions": 2, "first_exception": 1, "text_bytes": 14}
+    # a truncated .gz is an error, not a shorter file (zlib hands out what it could inflate, then 0 bytes + Z_BUF_ERROR)
+    big = str(tmp_path / "big.fastq.gz")
+    import random
+    rnd = random.Random(3)
+    with gzip.open(big, "wb") as f:
+        for i in range(20000):
+            sq = "".join(rnd.choice("ACGT") for _ in range(80))
+            f.write(("@r%d\n%s\n+\n%s\n" % (i, sq, "I" * 80)).encode())
+    assert json.loads(run(leon_bin, "-selftest-bank", big).stdout)["reads"] == 20000
+    blob = open(big, "rb").read()
+    open(big, "wb").write(blob[:len(blob) * 2 // 3])
+    r = run(leon_bin, "-selftest-bank", big)
+    assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: ") and "truncated" in r.stderr, r.stderr
     for bad in ("@r\nACGT\n+\nIII\n", "@r\nACGT\n", "ACGT\n", "@r\nACGT\nIIII\nIIII\n"):
         p = str(tmp_path / "bad.fq")
         open(p, "w").write(bad)
@@ -242,6 +264,21 @@ def test_reference_acceptance_test_lossless_fastq_gz(leon_bin, tmp_path):
     os.remove(fq)
     r = run(leon_bin, "-d", "-test-file", "-file", fq + ".leon")
     assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
+    # '+' lines that repeat the header (older Illumina / SRA dumps; simple_test.sh:62 is a byte diff): every record, then a mix of
+    # bare / repeated / other text, in rounds of one block so that the exceptions are found from the middle of the table
+    for name, plus in (("all", lambda i, h: h), ("mixed", lambda i, h: (b"", h, b"", b"", h, b"free text %d" % i)[i % 6] if i % 1000 < 6 else h)):
+        fp = str(tmp_path / ("plus_%s.fastq" % name))
+        with open(fp, "wb") as f:
+            for i, (h, sq, q) in enumerate(zip(heads, reads, quals)):
+                f.write(b"@" + h + b"\n" + sq + b"\n+" + plus(i, h) + b"\n" + q + b"\n")
+        r = run(leon_bin, "-c", "-lossless", "-file", fp, "-kmer-size", "25")
+        assert r.returncode == 0, r.stderr
+        assert "/leon/metadata/pluslines" in h5_names(fp + ".leon")
+        for env in (os.environ, dict(os.environ, LEON_DECODE_BLOCKS="1")):
+            r = run(leon_bin, "-d", "-test-file", "-file", fp + ".leon", env=env)
+            assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
+            assert run("cmp", fp, fp + ".d").returncode == 0
+    assert "/leon/metadata/pluslines" not in h5_names(fq + ".leon")          # bare '+' lines store nothing
 
 
 @pytest.mark.gpu
