@@ -13,7 +13,9 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <new>
+#include <algorithm>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -87,6 +89,168 @@ private:
     std::thread th_[kThreads];
 };
 
+
+// ---- the dictionary chain's feed -------------------------------------------------------------------------------
+// Everything the chain needs about symbol t EXCEPT the coder state is known before the chain gets there: the model is
+// order-0 with +1 updates, so a symbol's cumulative count lo and frequency fr are prefix counts of the symbols before it,
+// and the total is 5 + t.  Helper threads run ahead of the chain and turn the k-mers into one record per symbol:
+//     lo, fr and C = floor(fr * 2^64 / d), d = 5 + t + 1 the total of the NEXT symbol (one hardware division, fr < d).
+// With those the chain carries the QUOTIENT q(t) = floor(range / total) instead of the range.  The new range is q * fr, so
+//     floor(q * fr / d) = Phi           and   floor(q * fr * 2^8 / d) = (Phi << 8) | (Plo >> 56),     Phi:Plo = q * C,
+// exactly, unless the product's fraction is within q of the next integer (probability ~ q / 2^56: then, rarely, a division).
+// The next quotient so needs ONE multiply of the carried quotient and does not wait for the new range: the loop-carried
+// path is multiply, add, xor, compare, select (~7 cycles; the renormalisation test low ^ (low + range) < TOP is what bounds
+// it), with three multiplies per symbol, where carrying the range costs multiply-high, shift, select, multiply (~9) and four.
+struct ChainRec16 { uint64_t c; uint32_t lo, fr; };          // streams below 2^32 symbols (every count fits 32 bits)
+struct ChainRec24 { uint64_t c, lo, fr; };
+
+class ChainFeed {
+public:
+    static constexpr uint32_t kBufs = 16;
+    static constexpr uint64_t kPlainBelow = 512;               // symbols coded in the plain form at the start of a stream (m needs a total above 256)
+    struct View {
+        const void* recs = nullptr; uint64_t n_syms = 0;       // produced records (null for a plain segment): ChainRec16, or ChainRec24 when `wide`
+        bool wide = false;
+        const uint64_t* kmers = nullptr; uint32_t n_kmers = 0;
+        uint64_t t0 = 0;                                       // index of the segment's first symbol in the stream
+        uint64_t c_end[4] = {};                                // the model's counts (1 + occurrences of A, C, T, G) after the segment
+    };
+    explicit ChainFeed(uint32_t k) : k_(k), W_(k >= 32 ? 2u : 1u), seg_kmers_(std::max<uint32_t>(1, (1u << 15) / k)) {
+        uint32_t n = 5;
+        if (const char* e = getenv("LEON_CHAIN_HELPERS")) { const int v = atoi(e); if (v >= 1 && v <= 32) n = (uint32_t)v; }
+        n_threads_ = n;
+        for (auto& b : buf_) b.reset(new ChainRec24[(size_t)seg_kmers_ * k_]);
+    }
+    ~ChainFeed() { stop(); }
+    void start() {
+        if (running_) return;
+        quit_ = false;
+        for (uint32_t j = 0; j < n_threads_; j++) th_.emplace_back([this] { run(); });
+        running_ = true;
+    }
+    void stop() {
+        if (!running_) return;
+        { std::lock_guard<std::mutex> g(mu_); quit_ = true; }
+        cv_work_.notify_all(); cv_ready_.notify_all();
+        for (auto& t : th_) t.join();
+        th_.clear();
+        running_ = false;
+    }
+    // a new stream (every segment pushed so far must have been taken and released)
+    void reset_stream() {
+        std::lock_guard<std::mutex> g(mu_);
+        segs_.clear(); base_ = 0; next_claim_ = 0; next_take_ = 0; released_ = 0; prefix_upto_ = 0; t_pushed_ = 0;
+        for (auto& c : prefix_c_) c = 1;
+        for (auto& r : ready_) r = 0;
+    }
+    // `count` k-mers (W words each) that follow the ones pushed before; they must stay where they are until their segments
+    // have been released.  Returns the number of segments they were cut into.
+    uint32_t push(const uint64_t* kmers, size_t count) {
+        uint32_t n = 0;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            while (count) {
+                // the first symbols of a stream go in a short segment of their own, coded in the plain form
+                const bool plain = t_pushed_ < kPlainBelow;
+                const size_t take = plain ? std::min<size_t>(count, (kPlainBelow - t_pushed_ + k_ - 1) / k_) : std::min<size_t>(count, seg_kmers_);
+                Seg sg; sg.kmers = kmers; sg.n_kmers = (uint32_t)take; sg.plain = plain; sg.t0 = t_pushed_;
+                sg.wide = t_pushed_ + take * k_ + 8 >= (1ull << 32);
+                segs_.push_back(sg);
+                kmers += take * W_; count -= take; t_pushed_ += take * k_; n++;
+            }
+        }
+        cv_work_.notify_all();
+        return n;
+    }
+    // the next segment, in order; blocks until its records are there
+    void take(View& v) {
+        std::unique_lock<std::mutex> g(mu_);
+        const uint64_t s = next_take_++;
+        cv_ready_.wait(g, [&] { return ready_[s % kBufs] == s + 1; });
+        const Seg& sg = segs_[s - base_];
+        v.recs = sg.plain ? nullptr : buf_[s % kBufs].get();
+        v.wide = sg.wide;
+        v.n_syms = (uint64_t)sg.n_kmers * k_; v.kmers = sg.kmers; v.n_kmers = sg.n_kmers; v.t0 = sg.t0;
+        for (int i = 0; i < 4; i++) v.c_end[i] = sg.c_end[i];
+    }
+    void release() {                                           // the segment taken last is done: its buffer may be refilled
+        { std::lock_guard<std::mutex> g(mu_); released_++; while (base_ < released_ && !segs_.empty()) { segs_.pop_front(); base_++; } }
+        cv_work_.notify_all();
+    }
+private:
+    struct Seg { const uint64_t* kmers; uint32_t n_kmers; bool plain, wide; uint64_t t0; uint64_t c0[4], c_end[4]; };
+    // occurrences of the codes 1, 2, 3 in a k-mer's 2-bit groups (the unused high bits are zero: code 0 is the rest)
+    static inline void count_codes(uint64_t x, uint64_t* n) {
+        const uint64_t lo = x & 0x5555555555555555ull, hi = (x >> 1) & 0x5555555555555555ull;
+        n[1] += (uint64_t)__builtin_popcountll(lo & ~hi); n[2] += (uint64_t)__builtin_popcountll(hi & ~lo); n[3] += (uint64_t)__builtin_popcountll(lo & hi);
+    }
+    void run() {
+        for (;;) {
+            uint64_t s; Seg sg;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_work_.wait(g, [&] { return quit_ || (next_claim_ < base_ + segs_.size() && next_claim_ < released_ + kBufs); });
+                if (quit_) return;
+                s = next_claim_++;
+                sg = segs_[s - base_];
+            }
+            uint64_t h[4] = {0, 0, 0, 0};                       // the segment's histogram: what the segments after it need first
+            for (uint32_t a = 0; a < sg.n_kmers; a++) for (uint32_t w = 0; w < W_; w++) count_codes(sg.kmers[(size_t)a * W_ + w], h);
+            h[0] = (uint64_t)sg.n_kmers * k_ - h[1] - h[2] - h[3];
+            uint64_t c[4];
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_prefix_.wait(g, [&] { return quit_ || prefix_upto_ == s; });
+                if (quit_) return;
+                for (int i = 0; i < 4; i++) { c[i] = prefix_c_[i]; prefix_c_[i] += h[i]; }
+                prefix_upto_ = s + 1;
+                Seg& d = segs_[s - base_];
+                for (int i = 0; i < 4; i++) { d.c0[i] = c[i]; d.c_end[i] = prefix_c_[i]; }
+            }
+            cv_prefix_.notify_all();
+            if (!sg.plain) { if (sg.wide) fill(buf_[s % kBufs].get(), sg, c); else fill(reinterpret_cast<ChainRec16*>(buf_[s % kBufs].get()), sg, c); }
+            { std::lock_guard<std::mutex> g(mu_); ready_[s % kBufs] = s + 1; }
+            cv_ready_.notify_all();
+        }
+    }
+    static inline uint64_t scaled(uint64_t fr, uint64_t d) {   // floor(fr * 2^64 / d), fr < d
+#ifdef LEON_HOST_CHAIN_X86
+        uint64_t q, r;
+        asm("divq %[d]" : "=a"(q), "=d"(r) : "a"(0ull), "d"(fr), [d] "r"(d) : "cc");
+        return q;
+#else
+        return (uint64_t)((((unsigned __int128)fr) << 64) / d);
+#endif
+    }
+    template <typename Rec> void fill(Rec* out, const Seg& sg, uint64_t* c) const {
+        uint64_t d = 5 + sg.t0 + 1;                              // total of the symbol AFTER the one being recorded
+        for (uint32_t a = 0; a < sg.n_kmers; a++) {
+            const uint64_t* w = sg.kmers + (size_t)a * W_;
+            for (uint32_t i = 0; i < k_; i++, d++, out++) {
+                const uint32_t bit = 2 * (k_ - 1 - i);
+                const uint32_t sy = (uint32_t)(w[bit >> 6] >> (bit & 63)) & 3u;
+                const uint64_t c01 = c[0] + c[1];
+                const uint64_t lo = sy == 0 ? 0 : sy == 1 ? c[0] : sy == 2 ? c01 : c01 + c[2];
+                const uint64_t fr = c[sy];
+                out->c = scaled(fr, d);
+                out->lo = (decltype(out->lo))lo; out->fr = (decltype(out->fr))fr;
+                c[sy]++;
+            }
+        }
+    }
+    const uint32_t k_, W_, seg_kmers_;
+    uint32_t n_threads_ = 5;
+    std::unique_ptr<ChainRec24[]> buf_[kBufs];             // (holds either record type)
+    uint64_t ready_[kBufs] = {};                               // segment index + 1 a buffer currently holds
+    std::deque<Seg> segs_;                                     // segments pushed and not yet released; segs_[0] is segment base_
+    uint64_t base_ = 0, next_claim_ = 0, next_take_ = 0, released_ = 0, prefix_upto_ = 0, t_pushed_ = 0;
+    uint64_t prefix_c_[4] = {1, 1, 1, 1};                      // Order0Model::clear: every symbol starts with a count of 1
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_prefix_, cv_ready_;
+    bool quit_ = false, running_ = false;
+    std::vector<std::thread> th_;
+};
+
 // Order-0 adaptive model over {A,C,T,G,N} + carry-less 64-bit range coder, specialised for the dictionary
 // stream (5 symbols, cumulative counts updated branch-free, output written through a raw cursor): ~4-5 ns/symbol.
 // the coder's output: grows by doubling, is never zero-filled, keeps its capacity from one stream to the next (a
@@ -114,21 +278,14 @@ class AnchorDictCoder {
 public:
     AnchorDictCoder() { clear(); }
     void clear() {
-        low_ = 0; range_ = ~0ull; n_ = 0; buf_.clear(); w_ = 0; inv_ = nullptr;
+        low_ = 0; range_ = ~0ull; n_ = 0; buf_.clear(); w_ = 0;
         for (int i = 0; i <= 5; i++) cum_[i] = i;              // Order0Model::clear: _charRanges[i] = i
     }
-    void use_reciprocals(ReciprocalStream* r) { recips_ = r; }
     // `count` k-mers in the 2-bit code (W = 1 word per k-mer below k = 32, else low word then high word), first base in
-    // the highest bits (LargeInt::toString order)
+    // the highest bits (LargeInt::toString order), in the plain form: a division per symbol, the model kept here
     void encode_kmers(const uint64_t* w, size_t count, uint32_t k) {
         const uint32_t W = k >= 32 ? 2u : 1u;
-#ifdef LEON_HOST_CHAIN_X86
-        while (count && (!recips_ || n_ < 256)) { encode_kmer_plain(w, k); w += W; count--; }   // (the scaled reciprocal needs a total above 256)
-        if (!count) return;
-        if (W == 2) encode_chain<true>(w, count, k); else encode_chain<false>(w, count, k);
-#else
         for (; count; count--, w += W) encode_kmer_plain(w, k);
-#endif
     }
     inline void encode_kmer(const uint64_t* w, uint32_t k) { encode_kmers(w, 1, k); }
     inline void encode_kmer_plain(const uint64_t* w, uint32_t k) {
@@ -137,6 +294,19 @@ public:
             const uint32_t bit = 2 * (k - 1 - i);
             encode((uint32_t)(w[bit >> 6] >> (bit & 63)) & 3u);
         }
+    }
+    // one segment of the feed: its records when the helpers produced them, else (the first symbols of a stream; no x86) its k-mers
+    void encode_segment(const ChainFeed::View& v, uint32_t k) {
+#ifdef LEON_HOST_CHAIN_X86
+        if (v.recs) {
+            if (v.wide) encode_records(static_cast<const ChainRec24*>(v.recs), v.n_syms, v.t0);
+            else encode_records(static_cast<const ChainRec16*>(v.recs), v.n_syms, v.t0);
+            for (int i = 0; i < 4; i++) cum_[i + 1] = cum_[i] + v.c_end[i];     // the model as the plain form would have left it
+            cum_[5] = cum_[4] + 1;
+            return;
+        }
+#endif
+        encode_kmers(v.kmers, v.n_kmers, k);
     }
     void flush() {                                             // RangeEncoder::flush
         if (buf_.size() < w_ + 24) buf_.resize(w_ + 24);
@@ -148,78 +318,59 @@ public:
     uint64_t symbols() const { return n_; }
 private:
 #ifdef LEON_HOST_CHAIN_X86
-    // `count` k-mers through the latency-shaped chain; kTwo: k >= 32 (two words per k-mer)
-    template <bool kTwo> void encode_chain(const uint64_t* w, size_t count, uint32_t k) {
-        // The state carried from symbol to symbol is (low, range) BEFORE the renormalisation the
-        // previous symbol owes.  Its usual outcomes -- no byte, one byte -- are both formed and selected by conditional
-        // moves: with h = mulhi(range, m) the quotient is h >> 8 without the byte and h itself with it (range < 2^56
-        // there), so ONE multiply serves both.  The rare outcomes (two bytes at once, the carry-less coder's
-        // range < BOTTOM reset, a quotient one too small) leave through branches that are almost never taken.
-        // Loop-carried path: multiply-high, shift, select, multiply = ~9 cycles and no data-dependent branch, where
-        // the plain form has a division, a multiply and a ~25 %-taken renormalisation branch.  The model's cumulative
-        // counts live in two vector registers (one add each per symbol) and are read back through a small table.
-        alignas(16) static const uint64_t kInc[4][4] = {{1, 1, 1, 1}, {0, 1, 1, 1}, {0, 0, 1, 1}, {0, 0, 0, 1}};
-        alignas(16) uint64_t tbl[6] = {0, 0, cum_[1], cum_[2], cum_[3], cum_[4]};       // tbl[1 + c] = cum_[c]
-        __m128i ca = _mm_load_si128((const __m128i*)(tbl + 2)), cb = _mm_load_si128((const __m128i*)(tbl + 4));
-        uint64_t L = low_, R = range_, tot = 5 + n_;          // the model's total IS the symbol index + 5
+    // n symbols from their records (ChainFeed), the first one being symbol t0 of the stream.  The state carried from symbol
+    // to symbol is (q, L): the quotient floor(range / total) the NEXT symbol will use and the normalised low.  Per symbol:
+    //     Lu = L + q * lo, Tu = L + q * (lo + fr) (= Lu + the new range), x = Lu ^ Tu;   Phi:Plo = q * C
+    // the next quotient is Phi when no byte leaves and Phi8 = (Phi << 8) | (Plo >> 56) when exactly one does (x < TOP) -- both formed,
+    // selected by conditional moves.  The product's fraction within q of the next integer (see ChainFeed; rare), two bytes at
+    // once or the carry-less coder's range < BOTTOM reset take a division.
+    template <typename Rec> void encode_records(const Rec* r, uint64_t n, uint64_t t0) {
+        if (buf_.size() < w_ + n + 64) buf_.resize(buf_.size() * 2 + n + 4096);      // (a symbol emits one byte at most here; the rare path checks its room)
+        settle();
         uint8_t* p = buf_.data() + w_;
-        for (size_t a = 0; a < count; a++, w += kTwo ? 2 : 1) {
-            if ((size_t)(buf_.data() + buf_.size() - p) < 8 * (size_t)k + 16) {
-                const size_t used = (size_t)(p - buf_.data());
-                buf_.resize(buf_.size() * 2 + 8 * (size_t)k + 4096);
-                p = buf_.data() + used;
-            }
-            uint64_t x = w[0], xh = kTwo ? w[1] : 0;          // first base in the two highest bits of the (xh:)x register(s)
-            if (kTwo) { const uint32_t s = 128 - 2 * k; xh = s ? (xh << s) | (x >> (64 - s)) : xh; x <<= s; }
-            else x <<= 64 - 2 * k;
-            for (uint64_t tot_k = tot + k; tot < tot_k;) {
-                const uint64_t n = tot - 5, off = n % ReciprocalStream::kChunk;
-                if (off == 0 || !inv_) inv_ = recips_->take(n / ReciprocalStream::kChunk);
-                const uint64_t* ipb = inv_ + off - tot;        // ipb[tot] = the reciprocal of symbol n
-                const uint64_t left = ReciprocalStream::kChunk - off;
-                const uint64_t tot_e = left < tot_k - tot ? tot + left : tot_k;
-                for (; tot < tot_e; tot++) {
-                    uint32_t c;
-                    if (kTwo) { c = (uint32_t)(xh >> 62); xh = (xh << 2) | (x >> 62); x <<= 2; }
-                    else { c = (uint32_t)(x >> 62); x <<= 2; }
-                    const uint64_t lo = tbl[1 + c], fr = tbl[2 + c] - lo, m = ipb[tot];
-                    ca = _mm_add_epi64(ca, _mm_load_si128((const __m128i*)kInc[c]));       // Order0Model::update
-                    cb = _mm_add_epi64(cb, _mm_load_si128((const __m128i*)kInc[c] + 1));
-                    _mm_store_si128((__m128i*)(tbl + 2), ca);
-                    _mm_store_si128((__m128i*)(tbl + 4), cb);
-                    const uint64_t xr = L ^ (L + R);           // xr < TOP: the previous symbol owes (at least) one byte
-                    uint64_t q;
-                    // the branch-free form is valid for "no byte" and "exactly one byte" (the shifted test is xr << 8)
-                    if (__builtin_expect((xr >> 48) == 0 || R < kBottom, 0)) {
-                        while ((L ^ (L + R)) < kTop || (R < kBottom && ((R = (0 - L) & (kBottom - 1)), true))) {
-                            *p++ = (uint8_t)(L >> 56);
-                            R <<= 8;
-                            L <<= 8;
-                        }
-                        q = (uint64_t)(((unsigned __int128)R * m) >> 64) >> 8;
-                    } else {
-                        const uint64_t h = (uint64_t)(((unsigned __int128)R * m) >> 64);
-                        q = h >> 8;
-                        *p = (uint8_t)(L >> 56);
-                        // (q, R, L, p) = one byte ? (h, R << 8, L << 8, p + 1) : unchanged -- as conditional moves (a compiler
-                        // turns the selects back into the unpredictable branch this loop exists to avoid)
-                        asm("cmpq %[top], %[xr]\n\tcmovbq %[h], %[q]\n\tcmovbq %[R1], %[R]\n\tcmovbq %[L1], %[L]\n\tadcq $0, %[p]"
-                            : [q] "+r"(q), [R] "+r"(R), [L] "+r"(L), [p] "+r"(p)
-                            : [xr] "r"(xr), [top] "r"(kTop), [h] "r"(h), [R1] "r"(R << 8), [L1] "r"(L << 8)
-                            : "cc");
-                    }
-                    if (__builtin_expect(R - q * tot >= tot, 0)) {  // quotient one too small: probability < 2^-8
-                        asm volatile("" : "+r"(q));            // (keeps this a branch: as a select it would sit on the chain)
-                        q++;
-                    }
-                    R = q * fr;
-                    L += q * lo;
+        uint8_t* p_end = buf_.data() + buf_.size() - 32;
+        uint64_t L = low_, R = range_, tot1 = 5 + t0;          // tot1: the total the carried quotient was formed with ...
+        uint64_t q = R / tot1;
+        const Rec* const e = r + n;
+        for (; r < e; r++) {
+            tot1++;                                            // ... from here on, the total of the NEXT symbol
+            __builtin_prefetch(reinterpret_cast<const char*>(r) + 2048);      // (the records come from other cores' caches or from memory)
+            const uint64_t lo = r->lo, lf = lo + r->fr;
+            const uint64_t Lu = L + q * lo;
+            uint64_t Tu = L + q * lf;
+            asm("" : "+r"(Tu));                                // (the new range is Tu - Lu: a subtraction, not a fourth multiply)
+            const uint64_t Ru = Tu - Lu, x = Lu ^ Tu;
+            // (a second multiply, (q << 8) * C, instead of the double-word shift measured the same on Zen 5 -- 1.73 against 1.75 ns
+            // per symbol -- and costs Intel's single multiplier a slot)
+            const uint64_t q8 = q << 8;
+            const unsigned __int128 P = (unsigned __int128)q * r->c;
+            const uint64_t Phi = (uint64_t)(P >> 64), Plo = (uint64_t)P, Phi8 = (Phi << 8) | (Plo >> 56), Plo8 = Plo << 8;
+            if (__builtin_expect((x >> 48) == 0 || Ru < kBottom, 0)) {
+                L = Lu; R = Ru;
+                while ((L ^ (L + R)) < kTop || (R < kBottom && ((R = (0 - L) & (kBottom - 1)), true))) {
+                    if (p >= p_end) { const size_t used = (size_t)(p - buf_.data()); buf_.resize(buf_.size() * 2 + 4096); p = buf_.data() + used; p_end = buf_.data() + buf_.size() - 32; }
+                    *p++ = (uint8_t)(L >> 56);
+                    R <<= 8;
+                    L <<= 8;
                 }
+                q = R / tot1;
+                continue;
             }
+            uint64_t qn = Phi, Ln = Lu;
+            R = Ru;
+            *p = (uint8_t)(Lu >> 56);
+            // (qn, R, Ln, p) = one byte ? (Phi:Plo << 8, Ru << 8, Lu << 8, p + 1) : unchanged -- as conditional moves (a compiler
+            // turns the selects back into the unpredictable branch this loop exists to avoid)
+            asm("cmpq %[top], %[x]\n\tcmovbq %[A], %[qn]\n\tcmovbq %[R1], %[R]\n\tcmovbq %[L1], %[Ln]\n\tadcq $0, %[p]"
+                : [qn] "+r"(qn), [R] "+r"(R), [Ln] "+r"(Ln), [p] "+r"(p)
+                : [x] "r"(x), [top] "r"(kTop), [A] "r"(Phi8), [R1] "r"(Ru << 8), [L1] "r"(Lu << 8)
+                : "cc");
+            // in doubt (conservatively, for either outcome): the fraction of q * C / 2^64 (of q * C / 2^56) is within q of 1
+            if (__builtin_expect((Plo + q < q) | (Plo8 + q8 < q8), 0)) qn = R / tot1;
+            q = qn; L = Ln;
         }
         w_ = (size_t)(p - buf_.data());
-        low_ = L; range_ = R; n_ = tot - 5;
-        cum_[1] = tbl[2]; cum_[2] = tbl[3]; cum_[3] = tbl[4]; cum_[4] = tbl[5]; cum_[5] = tot;
+        low_ = L; range_ = R; n_ += n;
     }
 #endif
     // the renormalisation the last symbol owes (the state is kept un-normalised between symbols, see encode_kmer)
@@ -246,8 +397,6 @@ private:
     uint64_t low_, range_, n_, cum_[6];
     ByteBuf buf_;
     size_t w_;
-    ReciprocalStream* recips_ = nullptr;
-    const uint64_t* inv_ = nullptr;
 };
 
 // The inverse of AnchorDictCoder (Leon::decodeAnchorDict / RangeDecoder on _anchorDictModel(5) [RECALLED]): one serial
@@ -320,13 +469,16 @@ inline bool decode_anchor_dict(const uint8_t* p, uint64_t n, uint64_t n_anchors,
 // the worker that owns the coder: batches of anchor k-mers are queued in address order
 class AnchorDictWorker {
 public:
-    explicit AnchorDictWorker(uint32_t k) : k_(k) { coder_.use_reciprocals(&recips_); recips_.restart(); }
-    ~AnchorDictWorker() { stop(); recips_.stop(); }
+    explicit AnchorDictWorker(uint32_t k) : k_(k), feed_(k) {}
+    ~AnchorDictWorker() { stop(); feed_.stop(); }
     void push(std::vector<uint64_t>&& kmers) {
+        const uint32_t W = k_ >= 32 ? 2u : 1u;
         {
             std::lock_guard<std::mutex> g(mu_);
-            if (!running_) { running_ = true; quit_ = false; th_ = std::thread([this] { run(); }); }
-            q_.emplace_back(std::move(kmers));
+            if (!running_) { running_ = true; quit_ = false; feed_.start(); th_ = std::thread([this] { run(); }); }   // (threads only for contexts that code a dictionary)
+            q_.emplace_back(std::move(kmers), 0u);
+            // the helpers start on the batch's records at once (the vector's storage does not move with the deque's entry)
+            q_.back().second = feed_.push(q_.back().first.data(), q_.back().first.size() / W);
             pending_++;
         }
         cv_.notify_all();
@@ -345,13 +497,13 @@ public:
         th_.join();
         running_ = false;
     }
-    void reset() { drain(); coder_.clear(); recips_.restart(); busy_ms_ = 0; }
+    void reset() { drain(); coder_.clear(); feed_.reset_stream(); busy_ms_ = 0; }
     double busy_ms() const { return busy_ms_; }              // time spent coding since the last reset (read after drain())
     AnchorDictCoder& coder() { return coder_; }                // only after drain()
 private:
     void run() {
         for (;;) {
-            std::vector<uint64_t> batch;
+            std::pair<std::vector<uint64_t>, uint32_t> batch;
             {
                 std::unique_lock<std::mutex> g(mu_);
                 cv_.wait(g, [this] { return quit_ || !q_.empty(); });
@@ -359,9 +511,13 @@ private:
                 batch = std::move(q_.front());
                 q_.pop_front();
             }
-            const uint32_t W = k_ >= 32 ? 2u : 1u;
             const auto t0 = std::chrono::steady_clock::now();
-            coder_.encode_kmers(batch.data(), batch.size() / W, k_);
+            for (uint32_t sgm = 0; sgm < batch.second; sgm++) {
+                ChainFeed::View v;
+                feed_.take(v);
+                coder_.encode_segment(v, k_);
+                feed_.release();
+            }
             busy_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             {
                 std::lock_guard<std::mutex> g(mu_);
@@ -371,11 +527,11 @@ private:
         }
     }
     uint32_t k_;
-    ReciprocalStream recips_;
+    ChainFeed feed_;
     AnchorDictCoder coder_;
     std::mutex mu_;
     std::condition_variable cv_, cv_done_;
-    std::deque<std::vector<uint64_t>> q_;
+    std::deque<std::pair<std::vector<uint64_t>, uint32_t>> q_;
     uint64_t pending_ = 0;
     double busy_ms_ = 0;
     bool running_ = false, quit_ = false;
