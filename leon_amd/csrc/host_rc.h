@@ -119,12 +119,12 @@ public:
         uint32_t n = 5;
         if (const char* e = getenv("LEON_CHAIN_HELPERS")) { const int v = atoi(e); if (v >= 1 && v <= 32) n = (uint32_t)v; }
         n_threads_ = n;
-        for (auto& b : buf_) b.reset(new ChainRec24[(size_t)seg_kmers_ * k_]);
     }
     ~ChainFeed() { stop(); }
     void start() {
         if (running_) return;
         quit_ = false;
+        for (auto& b : buf_) if (!b) b.reset(new ChainRec24[(size_t)seg_kmers_ * k_]);      // (12 MB, only for contexts that code a dictionary)
         for (uint32_t j = 0; j < n_threads_; j++) th_.emplace_back([this] { run(); });
         running_ = true;
     }
