@@ -215,6 +215,11 @@ int leon_dna_reset_stream(leon_dna_ctx* ctx);
 
 int leon_dna_get_stats(const leon_dna_ctx* ctx, leon_dna_stats* out);
 
+/* Measurement hook (profiles/scripts/walk_order.py): the NEXT batch's reads are walked in the order of d_keys (one 48-bit key
+ * per read of the batch, device memory, the caller's until the call returns) instead of the order of their anchors' addresses.
+ * Changes which lanes share bloom sectors, never the bytes: walk events are indexed by read position. */
+int leon_dna_debug_walk_order(leon_dna_ctx* ctx, const uint64_t* d_keys);
+
 /* -- traces of the last batch (need LEON_F_KEEP_TRACE); for stage-wise parity tests -- */
 int leon_dna_trace_anchors(leon_dna_ctx* ctx, int32_t* anchor_pos, uint32_t* anchor_addr, uint8_t* flags,
                            uint64_t n_reads);

@@ -69,6 +69,7 @@ _EXPORTS = {
     "leon_dna_reset_stream": (C.c_int, [C.c_void_p]),
     "leon_dna_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "leon_dna_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "leon_dna_debug_walk_order": (C.c_int, [C.c_void_p, C.c_void_p]),
     "leon_kmer_solid_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                           C.POINTER(C.c_void_p), _u64p, _u64p]),
     "leon_kmer_solid": (C.c_int, [C.c_int, C.c_char_p, _u64p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _u64p, C.c_uint64,

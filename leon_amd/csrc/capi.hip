@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -98,6 +99,7 @@ struct leon_dna_ctx {
     uint64_t hdr_next_read = 0, hdr_next_block = 0;   // the header stream's own counters (leon_header_encode_batch)
     bool hdr_partial_seen = false;
     DevBuf hdr_first;
+    const uint64_t* walk_keys = nullptr;         // leon_dna_debug_walk_order: the next batch's walk order (measurement hook)
     uint32_t fbits_log2 = FBITS_LOG2;
     bool poisoned = false;                       // a batch failed after it had started to change the stream: LEON_E_STATE until reset_stream
     // batch buffers
@@ -185,15 +187,43 @@ ReadsDev reads_view(leon_dna_ctx* c, const uint64_t* d_off, uint64_t n) {
     return R;
 }
 
-// leon_dna_encode_batch's upload of the caller's bases, group by group, on its own host thread: the device packs and
-// resolves a group while the next ones are still crossing PCIe
+// leon_dna_encode_batch's upload of the caller's bases while the device already packs and resolves the groups that have
+// arrived.  The caller's memory is pageable: one hipMemcpy from it runs at 11-12 GB/s here (the runtime stages it through
+// ONE thread), a fifth of what PCIe carries.  So the staging is done here, by a few threads: each takes the next 16 MiB
+// piece of the byte range, copies it into one of its two pinned buffers and sends that to the device on its own stream.
 struct Upload {
-    std::atomic<uint64_t> reads_done{0};                       // reads whose bases are in HBM
-    std::atomic<int> failed{0};                                // 1: a copy failed; 2: the offsets do not describe one buffer
+    static constexpr uint64_t kPiece = 16ull << 20;
+    static constexpr uint32_t kThreads = 3;                    // 52-56 GB/s with 3 (PCIe's limit); more only take CPU time from the dictionary chain: 6 threads 1 079 ms per step, 3 threads 910
+    std::atomic<uint64_t> bytes_done{0};                       // bases [0, bytes_done) of the batch are in HBM
+    std::atomic<int> failed{0};                                // 1: a copy failed
     std::atomic<int> cancel{0};                                // set by the caller when the batch has failed: stop copying
-    std::thread th;
-    ~Upload() { if (th.joinable()) th.join(); }
+    std::atomic<uint64_t> next_piece{0};
+    std::vector<std::atomic<uint8_t>> piece_done;
+    std::mutex mu;
+    uint64_t prefix = 0, n_bytes = 0;
+    std::vector<std::thread> th;
+    explicit Upload(uint64_t bytes) : piece_done((bytes + kPiece - 1) / kPiece), n_bytes(bytes) { for (auto& f : piece_done) f.store(0); }
+    void publish(uint64_t piece) {
+        piece_done[piece].store(1, std::memory_order_release);
+        std::lock_guard<std::mutex> g(mu);
+        while (prefix < piece_done.size() && piece_done[prefix].load(std::memory_order_acquire)) prefix++;
+        bytes_done.store(std::min(n_bytes, prefix * kPiece), std::memory_order_release);
+    }
+    ~Upload() { for (auto& t : th) if (t.joinable()) t.join(); }
 };
+// the pinned staging buffers live as long as the process (allocating and pinning them costs tens of milliseconds)
+struct StagePool {
+    std::mutex mu;
+    std::vector<void*> free_bufs;
+    void* get() {
+        { std::lock_guard<std::mutex> g(mu); if (!free_bufs.empty()) { void* p = free_bufs.back(); free_bufs.pop_back(); return p; } }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, Upload::kPiece, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return p;
+    }
+    void put(void* p) { std::lock_guard<std::mutex> g(mu); free_bufs.push_back(p); }
+};
+StagePool g_stage;
 
 int ensure_cub(leon_dna_ctx* c, size_t bytes) { HIPCHK(c, c->cub_tmp.ensure(bytes)); return LEON_OK; }
 
@@ -391,21 +421,21 @@ int leon_dna_bloom_contains(leon_dna_ctx* c, const uint64_t* kmers, uint64_t n, 
 
 // ------------------------------------------------------------------------------------------------ encode
 static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
-                             uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up);
+                             uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up, const uint64_t* up_off);
 
 // A batch that fails before it has touched the stream (bad arguments, bad offsets, call order) leaves the context as it was.
 // One that fails later -- a HIP error, an internal bound, the sink -- leaves the dictionary, the dictionary-stream thread
 // and the caller's block sequence part-way through the batch: the context is poisoned and every call on the stream
 // returns LEON_E_STATE until leon_dna_reset_stream starts a new one.
 static int encode_batch_guarded(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
-                                uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up) {
+                                uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up, const uint64_t* up_off = nullptr) {
     if (!c) return LEON_E_INVALID;
     if (c->poisoned) return fail(c, LEON_E_STATE, "an earlier batch failed part-way: the stream is unusable until leon_dna_reset_stream");
     if (c->dc_pc.slots) {                                     // a context that goes back to encoding gives the decoder's table (up to 40 % of the HBM) back first
         (void)hipStreamSynchronize(c->stream);
         c->dc_cache.release(); c->dc_pc = PathCache{}; c->dc_filled = false;
     }
-    const int rc = encode_batch_impl(c, d_bases, d_off, n, first_read_index, sink, user, up);
+    const int rc = encode_batch_impl(c, d_bases, d_off, n, first_read_index, sink, user, up, up_off);
     if (rc != LEON_OK && c->poisoned) c->err += " (stream poisoned: leon_dna_reset_stream to go on)";
     return rc;
 }
@@ -427,7 +457,7 @@ static uint64_t group_end(uint64_t a, uint64_t n, uint64_t window, bool streamed
 }
 
 static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
-                             uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up) {
+                             uint64_t first_read_index, leon_block_sink sink, void* user, Upload* up, const uint64_t* up_off) {
     if (!c) return LEON_E_INVALID;
     if (c->finished) return fail(c, LEON_E_STATE, "encode_batch after finish");
     if (first_read_index != c->next_read) return fail(c, LEON_E_STATE, "first_read_index does not continue the stream");
@@ -477,8 +507,11 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     auto pack_group = [&]() -> int {
         const uint64_t a = packed_upto, b = group_end(a, n, c->cfg.resolve_window, up != nullptr);
         if (up) {
-            while (up->reads_done.load(std::memory_order_acquire) < b && !up->failed.load()) std::this_thread::yield();
-            if (up->failed.load() == 2) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
+            // the group's last base, from the caller's offsets: checked before it is waited for (whatever the entries between
+            // the group boundaries are, the device checks them one by one and refuses the batch)
+            const uint64_t want = up_off[b];
+            if (want < up_off[0] || want > up_off[n] || want < up_off[a]) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
+            while (up->bytes_done.load(std::memory_order_acquire) < want - up_off[0] && !up->failed.load()) std::this_thread::yield();
             if (up->failed.load()) return fail(c, LEON_E_HIP, "upload of the read bases failed");
         }
         if (c->pack_ev.size() < 2 * (size_t)(n_pack_ev + 1)) {
@@ -617,11 +650,16 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, c->sort_key2.ensure(nl * 8)); HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(nl * 4));
     hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
     size_t sort_tmp = 0;
-    HIPCHK(c, prim::SortPairs(nullptr, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
-                                                 c->perm2.as<uint32_t>(), nl, 0, 33, s));
+    // (measurement hook: another order of the reads in the walk changes which lanes share bloom sectors, never the bytes --
+    // events are indexed by read position)
+    const uint64_t* walk_key = c->walk_keys ? c->walk_keys + r0 : V.sort_key + r0;
+    const unsigned key_bits = c->walk_keys ? 48u : 33u;
+    c->walk_keys = nullptr;
+    HIPCHK(c, prim::SortPairs(nullptr, sort_tmp, walk_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
+                                                 c->perm2.as<uint32_t>(), nl, 0, key_bits, s));
     if (int rc = ensure_cub(c, sort_tmp)) return rc;
-    HIPCHK(c, prim::SortPairs(c->cub_tmp.p, sort_tmp, V.sort_key + r0, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
-                                                 c->perm2.as<uint32_t>(), nl, 0, 33, s));
+    HIPCHK(c, prim::SortPairs(c->cub_tmp.p, sort_tmp, walk_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
+                                                 c->perm2.as<uint32_t>(), nl, 0, key_bits, s));
     HIPCHK(c, hipEventRecord(c->ev[3], s));
 
     // ---- walk ----
@@ -727,25 +765,52 @@ int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t*
         launch_rebase_offsets(c->stream, c->in_off.as<uint64_t>(), n + 1, off[0]);
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    Upload up;
+    Upload up(nb);
     const int dev = c->device;
     uint8_t* dst = c->in_bases.as<uint8_t>();
-    const uint64_t window = c->cfg.resolve_window;
-    up.th = std::thread([&up, dev, dst, bases, off, n, window] {
-        if (hipSetDevice(dev) != hipSuccess) { up.failed.store(1); return; }
-        for (uint64_t a = 0; a < n && !up.cancel.load();) {
-            const uint64_t b = group_end(a, n, window, true);
-            // every copy stays inside [off[0], off[n]) of the caller's buffer and of in_bases, whatever the entries between
-            // the group boundaries are (the device checks those one by one and refuses the batch)
-            if (off[a] < off[0] || off[b] < off[a] || off[b] > off[n]) { up.failed.store(2); return; }
-            if (hipMemcpy(dst + (off[a] - off[0]), bases + off[a], off[b] - off[a], hipMemcpyHostToDevice) != hipSuccess) { up.failed.store(1); return; }
-            up.reads_done.store(b, std::memory_order_release);
-            a = b;
-        }
+    const uint8_t* src = bases + off[0];
+    static const uint32_t want_workers = [] { const char* e = getenv("LEON_UPLOAD_THREADS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (uint32_t)v : Upload::kThreads; }();
+    const uint32_t n_workers = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want_workers, up.piece_done.size()));
+    for (uint32_t w = 0; w < n_workers; w++)
+        up.th.emplace_back([&up, dev, dst, src, nb] {
+            hipStream_t st = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            void* buf[2] = {g_stage.get(), g_stage.get()};
+            uint64_t held[2] = {~0ull, ~0ull};                  // the piece a buffer's copy in flight belongs to
+            bool ok = buf[0] && buf[1] && hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            for (uint32_t turn = 0; ok && !up.cancel.load(); turn ^= 1) {
+                if (held[turn] != ~0ull) {                     // the buffer's previous piece has landed: publish it before refilling
+                    if (hipEventSynchronize(ev[turn]) != hipSuccess) { ok = false; break; }
+                    up.publish(held[turn]); held[turn] = ~0ull;
+                }
+                const uint64_t piece = up.next_piece.fetch_add(1);
+                if (piece >= up.piece_done.size()) break;
+                const uint64_t a = piece * Upload::kPiece, m = std::min<uint64_t>(Upload::kPiece, nb - a);
+                memcpy(buf[turn], src + a, m);
+                if (hipMemcpyAsync(dst + a, buf[turn], m, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[turn], st) != hipSuccess) { ok = false; break; }
+                held[turn] = piece;
+            }
+            for (int t = 0; t < 2 && ok; t++)
+                if (held[t] != ~0ull) { if (hipEventSynchronize(ev[t]) != hipSuccess) ok = false; else up.publish(held[t]); }
+            if (!ok && !up.cancel.load()) up.failed.store(1);
+            if (st) (void)hipStreamSynchronize(st);            // nothing of ours is in flight when the buffers go back
+            for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+            if (st) (void)hipStreamDestroy(st);
+            for (void* b : buf) if (b) g_stage.put(b);
+        });
+    static const bool trace_up = getenv("LEON_TRACE_UPLOAD") != nullptr;      // measurement aid: when the last base reached HBM
+    const auto t_up0 = std::chrono::steady_clock::now();
+    std::thread watcher;
+    if (trace_up) watcher = std::thread([&up, nb, t_up0] {
+        while (up.bytes_done.load() < nb && !up.failed.load() && !up.cancel.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count();
+        fprintf(stderr, "[leon upload] %.1f MB in %.1f ms = %.1f GB/s\n", nb / 1e6, ms, nb / 1e6 / ms);
     });
-    const int rc = encode_batch_guarded(c, dst, c->in_off.as<uint64_t>(), n, first_read_index, sink, user, &up);
+    const int rc = encode_batch_guarded(c, dst, c->in_off.as<uint64_t>(), n, first_read_index, sink, user, &up, off);
     if (rc != LEON_OK) up.cancel.store(1);
-    up.th.join();
+    for (auto& t : up.th) t.join();
+    if (watcher.joinable()) watcher.join();
     return rc;
 }
 
@@ -1030,6 +1095,12 @@ int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, ui
     *payload = c->anchor_worker->coder().data();
     *size = c->shard_rank == 0 ? c->anchor_worker->coder().size() : 0;      // the dictionary stream is rank 0's to write
     *n_anchors = c->n_anchors;
+    return LEON_OK;
+}
+
+int leon_dna_debug_walk_order(leon_dna_ctx* c, const uint64_t* d_keys) {
+    if (!c) return LEON_E_INVALID;
+    c->walk_keys = d_keys;
     return LEON_OK;
 }
 
