@@ -681,8 +681,12 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, prim::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
     if (int rc = ensure_cub(c, tmp_bytes)) return rc;
     HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
-    uint64_t n_syms = 0;
+    uint64_t n_syms = 0, max_block_syms = 0;
+    unsigned long long* d_max = reinterpret_cast<unsigned long long*>(c->counters.as<uint32_t>() + 8);
+    HIPCHK(c, hipMemsetAsync(d_max, 0, 8, s));
+    launch_max_block_syms(s, c->sym_off.as<uint64_t>(), nl, rpb, nbl, d_max);
     HIPCHK(c, hipMemcpyAsync(&n_syms, c->sym_off.as<uint64_t>() + nl, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&max_block_syms, d_max, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, c->syms.ensure(n_syms * 2 + 256));
     launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(), r0, nl,
@@ -698,7 +702,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
     HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
     launch_rc_encode(s, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, c->rc_out.as<uint8_t>(),
-                     c->out_off.as<uint64_t>(), c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>());
+                     c->out_off.as<uint64_t>(), c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>(), max_block_syms);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[7], s));
 
@@ -708,7 +712,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, nbl * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (errflag) return fail(c, LEON_E_OVERFLOW, errflag == 2 ? "a read block has 2^30 symbols or more"
+    if (errflag) return fail(c, LEON_E_OVERFLOW, errflag == 2 ? "a read block has 2^32 symbols or more"
                                                               : "range coder output exceeded its 3 bytes/symbol bound");
     for (uint64_t b = 0; b < nbl; b++) dst[b + 1] = dst[b] + sizes[b];
     const uint64_t payload_bytes = dst[nbl];
@@ -909,8 +913,12 @@ static int header_batch_impl(leon_dna_ctx* c, const uint8_t* d_hdr, const uint64
         HIPCHK(c, prim::ExclusiveSum(nullptr, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
         if (int rc = ensure_cub(c, tmp_bytes)) return rc;
         HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->sym_off.as<uint64_t>(), c->sym_off.as<uint64_t>(), nl + 1, s));
-        uint64_t n_syms = 0;
+        uint64_t n_syms = 0, max_block_syms = 0;
+        unsigned long long* d_max = reinterpret_cast<unsigned long long*>(c->counters.as<uint32_t>() + 8);
+        HIPCHK(c, hipMemsetAsync(d_max, 0, 8, s));
+        launch_max_block_syms(s, c->sym_off.as<uint64_t>(), nl, rpb, nbl, d_max);
         HIPCHK(c, hipMemcpyAsync(&n_syms, c->sym_off.as<uint64_t>() + nl, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&max_block_syms, d_max, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, c->syms.ensure(n_syms * 2 + 256));
         launch_hdr_symbols(s, d_hdr, d_off + r0, nl, rpb, c->hdr_first.as<uint8_t>(), (uint32_t)first_len, c->sym_off.as<uint64_t>(), c->syms.as<uint8_t>());
@@ -921,14 +929,14 @@ static int header_batch_impl(leon_dna_ctx* c, const uint8_t* d_hdr, const uint64
         HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
         HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
         launch_rc_encode(s, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, c->rc_out.as<uint8_t>(), c->out_off.as<uint64_t>(),
-                         c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>(), SMALL_SIZES_HEADER);
+                         c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>(), max_block_syms, SMALL_SIZES_HEADER);
         HIPCHK(c, hipGetLastError());
         std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
         int errflag = 0;
         HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, nbl * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        if (errflag) return fail(c, LEON_E_OVERFLOW, errflag == 2 ? "a header block has 2^30 symbols or more"
+        if (errflag) return fail(c, LEON_E_OVERFLOW, errflag == 2 ? "a header block has 2^32 symbols or more"
                                                                   : "range coder output exceeded its 3 bytes/symbol bound");
         for (uint64_t b = 0; b < nbl; b++) dst[b + 1] = dst[b] + sizes[b];
         const uint64_t payload_bytes = dst[nbl];
@@ -1068,7 +1076,7 @@ int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, ui
                 launch_anchor_symbols(s, c->anchor_kmers.as<uint64_t>(), c->n_anchors, c->cfg.kmer_size, dsyms.as<uint8_t>());
                 HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
                 launch_rc_encode(s, dsyms.as<uint8_t>(), dbegin.as<uint64_t>(), 1, dout.as<uint8_t>(), doff.as<uint64_t>(), dsize.as<uint64_t>(),
-                                 dscr.as<uint32_t>(), c->errflag.as<int>());
+                                 dscr.as<uint32_t>(), c->errflag.as<int>(), nsym);
                 HIPCHK(c, hipGetLastError());
                 HIPCHK(c, hipStreamSynchronize(s));
                 uint64_t sz = 0; int errflag = 0;
@@ -1284,12 +1292,12 @@ int leon_header_decode_blocks(leon_dna_ctx* c, const uint8_t* payloads, const ui
     if (!n_blocks) return LEON_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    // a block's share of the symbol buffer: generous for the headers sequencers write (a dozen symbols each); a block that
+    // a block's share of the symbol buffer: enough for the headers sequencers write (a dozen symbols each); a block that
     // needs more (free text in every header) sends the whole call to the host decoder -- same result, its speed
     std::vector<uint64_t> rel_off(n_blocks + 1), sym_begin(n_blocks + 1, 0);
     for (uint64_t b = 0; b < n_blocks; b++) {
         if (payload_off[b + 1] < payload_off[b]) return fail(c, LEON_E_INVALID, "payload offsets are not monotonic");
-        sym_begin[b + 1] = sym_begin[b] + 64ull * block_n_reads[b] + 4 * (payload_off[b + 1] - payload_off[b]) + 256;
+        sym_begin[b + 1] = sym_begin[b] + 24ull * block_n_reads[b] + 6 * (payload_off[b + 1] - payload_off[b]) + 256;   // (SRA-style headers: 12-17 symbols, ~6 bytes each)
     }
     for (uint64_t b = 0; b <= n_blocks; b++) rel_off[b] = payload_off[b] - payload_off[0];
     const uint64_t pay_bytes = rel_off[n_blocks], sym_cap = sym_begin[n_blocks];
@@ -1399,8 +1407,10 @@ int leon_rc_encode_streams(leon_dna_ctx* c, const uint8_t* syms, const uint64_t*
     HIPCHK(c, hipMemcpy(dbegin.p, begin, (n_streams + 1) * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(doff.p, off.data(), (n_streams + 1) * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
+    uint64_t longest = 0;
+    for (uint64_t b = 0; b < n_streams; b++) longest = std::max(longest, begin[b + 1] - begin[b]);
     launch_rc_encode(s, dsyms.as<uint8_t>(), dbegin.as<uint64_t>(), n_streams, dout.as<uint8_t>(), doff.as<uint64_t>(),
-                     dsize.as<uint64_t>(), dscr.as<uint32_t>(), c->errflag.as<int>());
+                     dsize.as<uint64_t>(), dscr.as<uint32_t>(), c->errflag.as<int>(), longest);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
     int errflag = 0;

@@ -969,6 +969,18 @@ void launch_block_ranges(hipStream_t s, const uint64_t* sym_off, uint64_t n_read
                        blk_begin, out_off);
 }
 
+// the longest block's symbol count: the host picks the range coder's instantiation by it (rc_kernels.hip)
+__global__ void k_max_block_syms(const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks, unsigned long long* out_max) {
+    for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r0 = b * rpb, r1 = r0 + rpb < n_reads ? r0 + rpb : n_reads;
+        atomicMax(out_max, (unsigned long long)(sym_off[r1] - sym_off[r0]));
+    }
+}
+void launch_max_block_syms(hipStream_t s, const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks, unsigned long long* out_max) {
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(k_max_block_syms, dim3(grid_for(n_blocks, 256)), dim3(256), 0, s, sym_off, n_reads, rpb, n_blocks, out_max);
+}
+
 __global__ void k_gather_payload(const uint8_t* out, const uint64_t* out_off, const uint64_t* dst_off, const uint64_t* sizes,
                                  uint64_t n_blocks, uint8_t* dst) {
     for (uint64_t b = blockIdx.y; b < n_blocks; b += gridDim.y) {

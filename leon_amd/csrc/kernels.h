@@ -93,11 +93,14 @@ void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const 
                     uint8_t* syms /*nullptr = count pass*/);
 void launch_block_ranges(hipStream_t s, const uint64_t* sym_off, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
                          uint64_t* blk_begin /*n_blocks+1*/, uint64_t* out_off /*n_blocks+1*/);
+void launch_max_block_syms(hipStream_t s, const uint64_t* sym_off /*offsets, n_reads+1*/, uint64_t n_reads, uint32_t rpb, uint64_t n_blocks,
+                           unsigned long long* out_max /*zeroed by the caller*/);
 // ---- range coder ----
 // small_sizes: alphabet sizes of the small models, a nibble per model id (SMALL_SIZES_DNA / SMALL_SIZES_HEADER)
+// max_block_syms: the longest block's symbol count (an upper bound will do): picks the instantiation that can divide exactly
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                       uint8_t* out, const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err,
-                      uint32_t small_sizes = SMALL_SIZES_DNA);
+                      uint64_t max_block_syms, uint32_t small_sizes = SMALL_SIZES_DNA);
 // ---- header stream (HeaderEncoder): records of every header against the previous one ----
 void launch_hdr_symbols(hipStream_t s, const uint8_t* hdr, const uint64_t* off, uint64_t n, uint32_t rpb, const uint8_t* first,
                         uint32_t first_len, uint64_t* sym_off /*count or offsets*/, uint8_t* syms /*nullptr = count pass*/);

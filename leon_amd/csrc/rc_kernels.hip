@@ -27,10 +27,12 @@ __host__ __device__ constexpr uint32_t rc_waves(uint32_t g) { return g + 1 + (g 
 // in its lanes 0..G-1 (lane = block).  A chain step costs the same issue slots whether one lane or eight are active, so
 // a CU that holds 8 blocks runs ONE chain instruction stream instead of eight; the step itself is branch-free in the
 // usual cases (0..2 bytes leave, no range < BOTTOM reset) and falls back to RangeEncoder::encode's loop per lane otherwise.
-template <uint32_t G, uint32_t RC_NSLOT>
+// BIGOK: some block of the launch is long enough for a model's total to reach 2^30 (the host knows the blocks' symbol counts):
+// that instantiation also carries the exact-division steps, tile by tile; the other one is the plain fast chain.
+template <uint32_t G, uint32_t RC_NSLOT, bool BIGOK>
 __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                                                             uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
-                                                            uint32_t* scratch, int* err, uint32_t small_sizes) {
+                                                            uint32_t* scratch, int* err, uint32_t small_sizes, uint32_t fast_total) {
     constexpr uint32_t MW = RC_SMALL_WORDS + RC_NSLOT * RC_STRIDE;
     __shared__ uint32_t models_all[G * MW];
     // a step's record: {cumLow, freq, total, cumLow + freq} and the total's 64-bit reciprocal -- two LDS reads for the coder (its
@@ -39,6 +41,7 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
     __shared__ uint2 ring_b[G][2][RC_RING];
     __shared__ uint8_t slotmap_all[G][RC_NNUM];
     __shared__ uint32_t ntiles_s[G];
+    __shared__ uint32_t tile_big[BIGOK ? G : 1][2];              // a total of fast_total or more in the tile: the coder divides exactly
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool is_coder = wave == 0, is_idle = wave != 0 && (wave & 3u) == 0;
@@ -60,7 +63,7 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
         bool valid = (is_coder ? lane < G : !is_idle) && b < n_blocks;
         uint64_t s0 = 0, s1 = 0;
         if (valid) { s0 = blk_begin[b]; s1 = blk_begin[b + 1]; }
-        if (valid && s1 - s0 >= RC_MAX_TOTAL - 256) {            // totals must stay below 2^30 for the chain's 32-bit fix-up
+        if (valid && s1 - s0 >= 0xFFFFFF00ull) {                 // the models' counts are 32-bit words (upstream's are 64-bit [RECALLED]: it would go on)
             if (is_coder || lane == 0) atomicExch(err, 2);
             if (is_coder) out_size[b] = 0;
             valid = false;
@@ -215,10 +218,15 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                     const uint64_t inv = ~0ull / (uint64_t)tot;        // per lane, off the serial chains
                     ring_a[mi][t & 1][lane] = make_uint4(lo, hi - lo, tot, hi);
                     ring_b[mi][t & 1][lane] = make_uint2((uint32_t)inv, (uint32_t)(inv >> 32));
+                    if (BIGOK) {
+                        const bool big = __ballot(tot >= fast_total) != 0;   // (the chain's 32-bit fix-up needs totals below 2^30)
+                        if (lane == 0) tile_big[mi][t & 1] = big ? 1u : 0u;
+                    }
                 } else if (t < T) {
                     // the group's longer blocks go on: records that leave a chain as it is (cumLow 0, freq = total = 1)
                     ring_a[mi][t & 1][lane] = make_uint4(0u, 1u, 1u, 1u);
                     ring_b[mi][t & 1][lane] = make_uint2(~0u, ~0u);
+                    if (BIGOK && lane == 0) tile_big[mi][t & 1] = 0u;
                 }
             } else if (t > 0) {
                 // =================== coder: tile t-1 of every block of the group, lane = block ===================
@@ -228,6 +236,10 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                     const uint2* rb = &ring_b[lane][(t - 1) & 1][0];
                     uint4 pa = ra[0];
                     uint2 pb = rb[0];
+                    // (a tile in which some block's total has reached fast_total takes the same steps with the exact division)
+                    bool any_big = false;
+                    if (BIGOK) any_big = __ballot(tile_big[lane < G ? lane : 0][(t - 1) & 1] != 0 && lane < G) != 0;
+                    if (!BIGOK || __builtin_expect(!any_big, 1)) {
 #pragma unroll 4
                     for (uint32_t j = 0; j < 64; j++) {
                         const uint32_t s_lo = pa.x, s_fr = pa.y, s_tot = pa.z, s_hc = pa.w, b0 = pb.x, b1 = pb.y;
@@ -235,14 +247,18 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                         pa = ra[jn]; pb = rb[jn];
                         // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
                         // total < 2^30), fixed up on the low word
-                        const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
-                        uint64_t q = (uint64_t)r1 * b1 + __umulhi(r1, b0);
-                        q += __umulhi(r0, b1);
-                        const uint32_t rem = r0 - (uint32_t)q * s_tot;              // true remainder < 4 * tot < 2^32
-                        const uint32_t t2 = s_tot << 1, t3 = t2 + s_tot;
-                        uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
-                        asm volatile("" : "+v"(e));                                 // (one 64-bit add, not three)
-                        q += e;
+                        uint64_t q;
+                        if (false) q = range / (uint64_t)s_tot;                       // totals of 2^30 and more: the exact (slow) division
+                        else {
+                            const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
+                            q = (uint64_t)r1 * b1 + __umulhi(r1, b0);
+                            q += __umulhi(r0, b1);
+                            const uint32_t rem = r0 - (uint32_t)q * s_tot;          // true remainder < 4 * tot < 2^32
+                            const uint32_t t2 = s_tot << 1, t3 = t2 + s_tot;
+                            uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
+                            asm volatile("" : "+v"(e));                             // (one 64-bit add, not three)
+                            q += e;
+                        }
                         const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
                         // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq)
                         uint64_t top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
@@ -271,6 +287,55 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                         }
                         low = low_n; range = range_n; nout = nout_n;
                     }
+                    } else {
+#pragma unroll 1
+                    for (uint32_t j = 0; j < 64; j++) {
+                        const uint32_t s_lo = pa.x, s_fr = pa.y, s_tot = pa.z, s_hc = pa.w, b0 = pb.x, b1 = pb.y;
+                        const uint32_t jn = j + 1;                                 // next step's record, fetched under this step
+                        pa = ra[jn]; pb = rb[jn];
+                        // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
+                        // total < 2^30), fixed up on the low word
+                        uint64_t q;
+                        if (true) q = range / (uint64_t)s_tot;                       // totals of 2^30 and more: the exact (slow) division
+                        else {
+                            const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
+                            q = (uint64_t)r1 * b1 + __umulhi(r1, b0);
+                            q += __umulhi(r0, b1);
+                            const uint32_t rem = r0 - (uint32_t)q * s_tot;          // true remainder < 4 * tot < 2^32
+                            const uint32_t t2 = s_tot << 1, t3 = t2 + s_tot;
+                            uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
+                            asm volatile("" : "+v"(e));                             // (one 64-bit add, not three)
+                            q += e;
+                        }
+                        const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
+                        // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq)
+                        uint64_t top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
+                        low = (uint64_t)q0 * s_lo + low;            low += (uint64_t)(q1 * s_lo) << 32;
+                        range = (uint64_t)q0 * s_fr;                range += (uint64_t)(q1 * s_fr) << 32;
+                        // RangeEncoder::encode's while loop.  Usual case: low and low + range agree on their top 0..2
+                        // bytes and the shifted range stays >= BOTTOM: those bytes leave at once -- one unaligned 4-byte
+                        // store at the cursor (what lies past the cursor is overwritten by the stores that follow)
+                        const uint32_t lh = (uint32_t)(low >> 32);
+                        const uint32_t xh = lh ^ (uint32_t)(top >> 32);
+                        const uint32_t sh = (uint32_t)__builtin_clz(xh | 1u) & 24u;
+                        const uint64_t range_s = range << sh;
+                        const bool rare = xh < 256u || (uint32_t)(range_s >> 32) < (1u << 16);
+                        *(uint32_t*)(dst + (nout < cap4 ? nout : cap4)) = __builtin_bswap32(lh);
+                        uint64_t low_n = low << sh, range_n = range_s;
+                        uint32_t nout_n = nout + (sh >> 3);
+                        if (__builtin_expect(rare, 0)) {
+                            low_n = low; range_n = range; nout_n = nout;
+                            while ((low_n ^ (low_n + range_n)) < (1ull << 56) ||
+                                   (range_n < RC_BOTTOM && ((range_n = (0 - low_n) & (RC_BOTTOM - 1)), true))) {
+                                dst[nout_n < cap4 ? nout_n : cap4] = (uint8_t)(low_n >> 56);
+                                nout_n++;
+                                range_n <<= 8;
+                                low_n <<= 8;
+                            }
+                        }
+                        low = low_n; range = range_n; nout = nout_n;
+                    }
+                    }
                 }
             }
             __syncthreads();
@@ -289,7 +354,7 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
 }
 
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint8_t* out,
-                      const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err, uint32_t small_sizes) {
+                      const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err, uint64_t max_block_syms, uint32_t small_sizes) {
     if (!n_blocks) return;
     // blocks per workgroup: as few as keeps every block resident on the 256 CUs (LDS: 8 blocks of 19.6 KB per CU)
     const uint64_t per_cu = (n_blocks + 255) / 256;
@@ -298,11 +363,17 @@ void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_be
     if (force) { int v = atoi(force); if (v == 1 || v == 2 || v == 4 || v == 8) G = (uint32_t)v; }
     const uint64_t n_groups = (n_blocks + G - 1) / G;
     const uint32_t g = (uint32_t)std::min<uint64_t>(n_groups, 256ull * (8 / G));
-#define RC_LAUNCH(GG, N) hipLaunchKernelGGL((k_rc_encode<GG, N>), dim3(g), dim3(64 * rc_waves(GG)), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err, small_sizes)
-    if (G == 1) RC_LAUNCH(1, RC_NSLOT_BIG);
-    else if (G == 2) RC_LAUNCH(2, RC_NSLOT_BIG);
-    else if (G == 4) RC_LAUNCH(4, RC_NSLOT_BIG);
-    else RC_LAUNCH(8, RC_NSLOT_SMALL);
+    // totals at which the coder switches to the exact division (test hook: a low value sends ordinary data down that path)
+    uint32_t fast_total = RC_MAX_TOTAL;
+    if (const char* e = getenv("LEON_RC_FAST_TOTAL_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 30) fast_total = 1u << v; }
+    const bool big = max_block_syms + 512 >= fast_total;      // (a model's total is at most its block's symbol count + 256)
+#define RC_LAUNCH(GG, N, B) hipLaunchKernelGGL((k_rc_encode<GG, N, B>), dim3(g), dim3(64 * rc_waves(GG)), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err, small_sizes, fast_total)
+#define RC_PICK(GG, N) do { if (big) RC_LAUNCH(GG, N, true); else RC_LAUNCH(GG, N, false); } while (0)
+    if (G == 1) RC_PICK(1, RC_NSLOT_BIG);
+    else if (G == 2) RC_PICK(2, RC_NSLOT_BIG);
+    else if (G == 4) RC_PICK(4, RC_NSLOT_BIG);
+    else RC_PICK(8, RC_NSLOT_SMALL);
+#undef RC_PICK
 #undef RC_LAUNCH
 }
 

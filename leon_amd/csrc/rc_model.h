@@ -15,7 +15,7 @@ constexpr uint32_t RC_NNUM = N_NUM_GROUPS * MODELS_PER_NUMERIC;   // 72
 constexpr uint32_t RC_GLOBAL = 0x80000000u;  // model lives in the global overflow area (more than RC_NSLOT numeric models)
 constexpr uint64_t RC_BOTTOM = 1ull << 48;
 constexpr uint32_t RC_RING = 65;
-constexpr uint32_t RC_MAX_TOTAL = 1u << 30;  // chain arithmetic assumes total < 2^30 (checked by the host per block)
+constexpr uint32_t RC_MAX_TOTAL = 1u << 30;  // the coder's multiply-high + 32-bit fix-up needs totals below this; from there on it divides exactly (per tile)
 
 
 // A model keeps the cumulative count F(x) = H[x>>4] + Lw[x], x in 0..256 (F(256) = H[16] + the zero word).

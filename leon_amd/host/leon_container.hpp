@@ -24,7 +24,7 @@ constexpr const char* DS_PARAMS = "leon/metadata/params";              // u64[PA
 constexpr const char* DS_FIRST_HEADER = "leon/metadata/firstheader";   // u8[]: the file's first header, plain
 constexpr const char* DS_PLUS_LINES = "leon/metadata/pluslines";       // u8[]: FASTQ '+' lines that are not bare (bank.hpp PlusLines); absent = all bare
 constexpr const char* DS_DNA_TABLE = "leon/metadata/dna_blocksizes";   // u64[3 n]: payload bytes, reads, bases per block
-constexpr const char* DS_HEADER_TABLE = "leon/metadata/header_blocksizes";   // u64[2 n]: payload bytes, reads
+constexpr const char* DS_HEADER_TABLE = "leon/metadata/header_blocksizes";   // u64[3 n]: payload bytes, reads, bytes of header text
 constexpr const char* DS_QUAL_TABLE = "leon/metadata/qual_blocksizes";       // u64[3 n]: payload bytes, reads, quality bytes
 constexpr const char* DS_ANCHOR_DICT = "leon/anchors/dict";            // u8[]: the anchor-dictionary stream
 constexpr const char* DS_BLOOM_BITS = "bloom/bits";                    // u8[nchar]

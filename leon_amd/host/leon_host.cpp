@@ -229,6 +229,7 @@ void Leon::executeCompression() {
     std::vector<uint64_t> offsets(1, 0);                         // base offsets of every read, absolute in the resident copy
     std::string first_header;
     uint64_t n_reads = 0, header_bytes = 0, qual_bytes = 0;
+    std::vector<uint64_t> hdr_text;                              // bytes of header text per read block: the decoder sizes its buffers from it
     const uint64_t batch_reads = 64ull * rpb;
     ReadBatch batch;
     std::future<void> qual_job;
@@ -256,6 +257,7 @@ void Leon::executeCompression() {
                                                                reinterpret_cast<const uint8_t*>(first_header.data()), first_header.size(), StreamWriter::sink, &wh),
                        wh, "leon_header_encode_batch");
             header_bytes += batch.headers.size();
+            for (uint64_t r = 0; r < got; r += rpb) hdr_text.push_back(batch.header_off[std::min<uint64_t>(got, r + rpb)] - batch.header_off[r]);   // (batches are whole blocks but the last)
         }
         qual_bytes += batch.quals.size();
         if (keep_qual && _lossless) {                            // deflated on the host threads while the next batch is being parsed
@@ -414,7 +416,7 @@ void Leon::executeCompression() {
     out.putU64(DS_DNA_TABLE, table.data(), table.size());
     if (keep_header) {
         table.clear();
-        for (uint64_t b = 0; b < n_blocks; b++) { table.push_back(wh.sizes[b]); table.push_back(wh.reads[b]); }
+        for (uint64_t b = 0; b < n_blocks; b++) { table.push_back(wh.sizes[b]); table.push_back(wh.reads[b]); table.push_back(hdr_text[b]); }
         out.putU64(DS_HEADER_TABLE, table.data(), table.size());
         out.putBytes(DS_FIRST_HEADER, first_header.data(), first_header.size());
     }
@@ -487,8 +489,11 @@ void Leon::executeDecompression() {
     if (has_header) {
         thdr = in.getU64(DS_HEADER_TABLE);
         first_header = in.getBytes(DS_FIRST_HEADER);
-        if (thdr.size() != 2 * n_blocks) throw Exception(_inputFilename + ": the header block table does not match the read count");
-        for (uint64_t b = 0; b < n_blocks; b++) if (thdr[2 * b + 1] != tdna[3 * b + 1]) throw Exception(_inputFilename + ": header and DNA blocks disagree");
+        if (thdr.size() != 3 * n_blocks) throw Exception(_inputFilename + ": the header block table does not match the read count");
+        for (uint64_t b = 0; b < n_blocks; b++) {
+            if (thdr[3 * b + 1] != tdna[3 * b + 1]) throw Exception(_inputFilename + ": header and DNA blocks disagree");
+            if (thdr[3 * b + 2] > (1ull << 40)) throw Exception(_inputFilename + ": the header block table does not add up");      // (buffers are sized from it)
+        }
     }
     if (has_qual) {
         tqual = in.getU64(DS_QUAL_TABLE);
@@ -575,7 +580,7 @@ void Leon::executeDecompression() {
     // what one round hands from the decoding stage to the writing stage
     struct DnaGroup { RawBytes bases; std::unique_ptr<uint32_t[]> lens; };   // the DNA blocks of one device call: the bases and lengths of its rounds
     struct Round {
-        uint64_t read_index = 0, file_off = 0, g_reads = 0, g_bases = 0, n_text = 0, nb = 0;
+        uint64_t read_index = 0, file_off = 0, g_reads = 0, g_bases = 0, n_text = 0, nb = 0, hdr_text_bytes = 0;
         std::shared_ptr<DnaGroup> dna; uint64_t base0 = 0, read0 = 0;   // this round's share of them
         const uint8_t* bases() const { return dna->bases.p.get() + base0; }
         const uint32_t* lens() const { return dna->lens.get() + read0; }
@@ -700,14 +705,16 @@ void Leon::executeDecompression() {
             for (uint64_t b = 0; b < nb; b++) { g_reads += R->blk_reads[b]; g_bases += R->blk_bases[b]; }
             R->read_index = read_index; R->g_reads = g_reads; R->g_bases = g_bases;
             R->dna = G; R->base0 = base0; R->read0 = read0;
-            if (has_header) gather(GROUP_HEADER, thdr, 2, g0, nb, R->pay_h, R->off_h);
+            if (has_header) gather(GROUP_HEADER, thdr, 3, g0, nb, R->pay_h, R->off_h);
             if (fastq_out) gather(GROUP_QUAL, tqual, 3, g0, nb, R->pay_q, R->off_q);
             R->hdr_off.assign(g_reads + 1, 0); R->qual_off.assign(g_reads + 1, 0);
+            R->hdr_text_bytes = 64;
+            if (has_header) for (uint64_t b = 0; b < nb; b++) R->hdr_text_bytes += thdr[3 * (g0 + b) + 2];
             // stage B
             std::shared_future<void> host_job = std::async(std::launch::async, [&, R, host_before] {
                 if (host_before.valid()) host_before.wait();
                 auto th = std::chrono::steady_clock::now();
-                const uint64_t nb = R->nb, g_reads = R->g_reads, g_bases = R->g_bases;
+                const uint64_t nb = R->nb, g_bases = R->g_bases;
                 const bool on_device = has_header && nb >= header_blocks_on_device;
                 auto decode_quals = [&] {
                     R->qual.resize(g_bases + 1);
@@ -719,7 +726,7 @@ void Leon::executeDecompression() {
                 if (fastq_out && on_device) quals_beside = std::async(std::launch::async, decode_quals);
                 if (has_header) {
                     uint64_t need = 0;
-                    R->hdr.resize(std::max<uint64_t>(64 * g_reads, 64));
+                    R->hdr.resize(R->hdr_text_bytes);             // from the block table (a wrong entry only costs the second call below)
                     // A round of many blocks: the stream's symbols on the device (its own context and stream, beside the DNA blocks: a
                     // block is a serial chain there too, ~1.3 s for 50 000 headers, but all of them at once) and the text on the host
                     // threads.  A few hundred blocks: the host threads alone are quicker (10 M headers in 200 blocks: 0.62 s against 1.27 s).

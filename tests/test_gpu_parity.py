@@ -104,6 +104,23 @@ def test_range_coder_streams():
     ctx.close()
 
 
+def test_range_coder_exact_division_path(monkeypatch):
+    """totals of 2^30 and more (a block with a billion symbols on one model: long reads) leave the coder's multiply-high +
+    32-bit fix-up for an exact division, tile by tile.  The switch-over total is lowered here (test hook) so that ordinary
+    streams and a whole encode take that path after their first few hundred symbols: same bytes as the oracle."""
+    monkeypatch.setenv("LEON_RC_FAST_TOTAL_LOG2", "8")
+    rng = np.random.default_rng(11)
+    syms, begin, sizes = _random_symbol_streams(rng, 9, 9000)
+    ctx = _ctx(31, 1000, 1000)
+    got = ctx.rc_encode_streams(syms, begin)
+    for i in range(len(begin) - 1):
+        a, b = int(begin[i]), int(begin[i + 1])
+        assert got[i] == O.rc_encode_stream(syms[2 * a:2 * b:2], syms[2 * a + 1:2 * b:2], sizes), "stream %d differs" % i
+    ctx.close()
+    bases, off = common.synthetic(3000, 150, 9000, seed=29, n_rate=0.001)
+    _full_compare(bases, off, 31, 700)
+
+
 def _full_compare(bases, off, k, rpb, window=0, batches=1, bloom=None):
     bl, solid, tai = bloom if bloom is not None else common.make_bloom(bases, off, k)
     ref = O.encode(bases, off, k, rpb, bl)
