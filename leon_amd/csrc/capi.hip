@@ -3,6 +3,7 @@
 #include "../../include/leon_dna.h"
 #include "kernels.h"
 #include "host_rc.h"
+#include "staging.h"
 
 #include "prim.h"
 
@@ -192,8 +193,8 @@ ReadsDev reads_view(leon_dna_ctx* c, const uint64_t* d_off, uint64_t n) {
 // ONE thread), a fifth of what PCIe carries.  So the staging is done here, by a few threads: each takes the next 16 MiB
 // piece of the byte range, copies it into one of its two pinned buffers and sends that to the device on its own stream.
 struct Upload {
-    static constexpr uint64_t kPiece = 16ull << 20;
-    static constexpr uint32_t kThreads = 3;                    // 52-56 GB/s with 3 (PCIe's limit); more only take CPU time from the dictionary chain: 6 threads 1 079 ms per step, 3 threads 910
+    static constexpr uint64_t kPiece = kStagePiece;             // (staging.h; 3 threads reach PCIe's 52-56 GB/s, more only take CPU time from the dictionary
+                                                                //  chain: 6 threads 1 079 ms per step, 3 threads 910)
     std::atomic<uint64_t> bytes_done{0};                       // bases [0, bytes_done) of the batch are in HBM
     std::atomic<int> failed{0};                                // 1: a copy failed
     std::atomic<int> cancel{0};                                // set by the caller when the batch has failed: stop copying
@@ -211,20 +212,6 @@ struct Upload {
     }
     ~Upload() { for (auto& t : th) if (t.joinable()) t.join(); }
 };
-// the pinned staging buffers live as long as the process (allocating and pinning them costs tens of milliseconds)
-struct StagePool {
-    std::mutex mu;
-    std::vector<void*> free_bufs;
-    void* get() {
-        { std::lock_guard<std::mutex> g(mu); if (!free_bufs.empty()) { void* p = free_bufs.back(); free_bufs.pop_back(); return p; } }
-        void* p = nullptr;
-        if (hipHostMalloc(&p, Upload::kPiece, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        return p;
-    }
-    void put(void* p) { std::lock_guard<std::mutex> g(mu); free_bufs.push_back(p); }
-};
-StagePool g_stage;
-
 int ensure_cub(leon_dna_ctx* c, size_t bytes) { HIPCHK(c, c->cub_tmp.ensure(bytes)); return LEON_OK; }
 
 }  // namespace
@@ -340,7 +327,7 @@ int leon_dna_bloom_upload(leon_dna_ctx* c, const uint8_t* bits, uint64_t n) {
     if (!c || !bits) return LEON_E_INVALID;
     if (n != c->bloom_nchar) return fail(c, LEON_E_INVALID, "bloom_upload: size differs from leon_dna_bloom_nbytes");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(c->d_bloom, bits, n, hipMemcpyHostToDevice));
+    HIPCHK(c, staged_h2d(c->device, c->d_bloom, bits, n));
     return LEON_OK;
 }
 int leon_dna_bloom_download(leon_dna_ctx* c, uint8_t* bits, uint64_t n) {
@@ -348,7 +335,7 @@ int leon_dna_bloom_download(leon_dna_ctx* c, uint8_t* bits, uint64_t n) {
     if (n != c->bloom_nchar) return fail(c, LEON_E_INVALID, "bloom_download: size differs from leon_dna_bloom_nbytes");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(bits, c->d_bloom, n, hipMemcpyDeviceToHost));
+    HIPCHK(c, staged_d2h(c->device, bits, c->d_bloom, n));
     return LEON_OK;
 }
 int leon_dna_bloom_clear(leon_dna_ctx* c) {
@@ -446,14 +433,15 @@ int leon_dna_encode_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const 
 }
 
 // reads [0, group_end(a)) are packed (and, through the host entry point, uploaded) together: the first resolution window
-// alone, so that the device and the dictionary chain start at once, then groups of 8 windows (everything that is left
-// when the bases are in HBM already)
+// alone, so that the device and the dictionary chain start at once, then groups of 8 windows
 // (the first window itself is short -- first_window() reads -- so that the first anchors reach the host chain, the longest
 // single piece of a step, a few milliseconds after the call starts; the result does not depend on where windows end)
 static uint64_t first_window(uint64_t window) { return std::min<uint64_t>(window, 1ull << 17); }
-static uint64_t group_end(uint64_t a, uint64_t n, uint64_t window, bool streamed) {
+static uint64_t group_end(uint64_t a, uint64_t n, uint64_t window, bool /*streamed*/) {
     if (a == 0) return std::min(n, first_window(window));
-    return streamed ? std::min(n, a + 8 * window) : n;
+    // (resident input used to pack everything that was left in one go: 9.6 ms at 100 M reads between the first window and the
+    // second, during which the dictionary chain ran out of the first window's anchors and idled)
+    return std::min(n, a + 8 * window);
 }
 
 static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
@@ -469,6 +457,11 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->stats = leon_dna_stats{};
+    static const bool trace_step = getenv("LEON_TRACE_STEP") != nullptr;   // measurement aid: host time of a batch's first milestones, on stderr
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (trace_step) fprintf(stderr, "[leon step] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count());
+    };
 
     // ---- sizes ----
     uint64_t off_first = 0, off_last = 0;
@@ -494,6 +487,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipMemcpyAsync(&bad_offsets, c->counters.as<uint32_t>() + 4, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (bad_offsets) return fail(c, LEON_E_INVALID, "offsets are not monotonic (or a read is longer than 2^31 bases)");
+    mark("offsets checked, slots scanned");
     HIPCHK(c, c->packed.ensure((n_slots * 2 + 16) * 4));     // wave loads reach 12 dwords past a pass start
     HIPCHK(c, c->nmask.ensure((n_slots + 4) * 4));
     HIPCHK(c, c->rlen.ensure(n * 4));
@@ -608,6 +602,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
                 HIPCHK(c, hipMemcpyAsync(fresh.data(), c->anchor_kmers.as<uint64_t>() + c->n_anchors * KW, n_new * 8 * KW, hipMemcpyDeviceToHost, s));
                 HIPCHK(c, hipStreamSynchronize(s));
                 c->anchor_worker->push(std::move(fresh));
+                if (w0 == 0) mark("first window's anchors to the chain");
             }
             c->n_anchors += n_new;
         }
@@ -617,6 +612,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
+    mark("resolution launched to its end");
     // ---- this rank's share of the batch: a contiguous range of whole blocks (all of it when not sharded) ----
     uint64_t lb0 = 0, lb1 = n_blocks;
     if (c->shard_world > 1) {
@@ -773,35 +769,27 @@ int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t*
     const int dev = c->device;
     uint8_t* dst = c->in_bases.as<uint8_t>();
     const uint8_t* src = bases + off[0];
-    static const uint32_t want_workers = [] { const char* e = getenv("LEON_UPLOAD_THREADS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (uint32_t)v : Upload::kThreads; }();
-    const uint32_t n_workers = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want_workers, up.piece_done.size()));
+    const uint32_t n_workers = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(stage_threads(), up.piece_done.size()));
     for (uint32_t w = 0; w < n_workers; w++)
         up.th.emplace_back([&up, dev, dst, src, nb] {
-            hipStream_t st = nullptr;
-            hipEvent_t ev[2] = {nullptr, nullptr};
-            void* buf[2] = {g_stage.get(), g_stage.get()};
+            StageLane L(dev);
             uint64_t held[2] = {~0ull, ~0ull};                  // the piece a buffer's copy in flight belongs to
-            bool ok = buf[0] && buf[1] && hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
-                      hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            bool ok = L.ok;
             for (uint32_t turn = 0; ok && !up.cancel.load(); turn ^= 1) {
                 if (held[turn] != ~0ull) {                     // the buffer's previous piece has landed: publish it before refilling
-                    if (hipEventSynchronize(ev[turn]) != hipSuccess) { ok = false; break; }
+                    if (hipEventSynchronize(L.ev[turn]) != hipSuccess) { ok = false; break; }
                     up.publish(held[turn]); held[turn] = ~0ull;
                 }
                 const uint64_t piece = up.next_piece.fetch_add(1);
                 if (piece >= up.piece_done.size()) break;
                 const uint64_t a = piece * Upload::kPiece, m = std::min<uint64_t>(Upload::kPiece, nb - a);
-                memcpy(buf[turn], src + a, m);
-                if (hipMemcpyAsync(dst + a, buf[turn], m, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[turn], st) != hipSuccess) { ok = false; break; }
+                memcpy(L.buf[turn], src + a, m);
+                if (hipMemcpyAsync(dst + a, L.buf[turn], m, hipMemcpyHostToDevice, L.st) != hipSuccess || hipEventRecord(L.ev[turn], L.st) != hipSuccess) { ok = false; break; }
                 held[turn] = piece;
             }
             for (int t = 0; t < 2 && ok; t++)
-                if (held[t] != ~0ull) { if (hipEventSynchronize(ev[t]) != hipSuccess) ok = false; else up.publish(held[t]); }
+                if (held[t] != ~0ull) { if (hipEventSynchronize(L.ev[t]) != hipSuccess) ok = false; else up.publish(held[t]); }
             if (!ok && !up.cancel.load()) up.failed.store(1);
-            if (st) (void)hipStreamSynchronize(st);            // nothing of ours is in flight when the buffers go back
-            for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-            if (st) (void)hipStreamDestroy(st);
-            for (void* b : buf) if (b) g_stage.put(b);
         });
     static const bool trace_up = getenv("LEON_TRACE_UPLOAD") != nullptr;      // measurement aid: when the last base reached HBM
     const auto t_up0 = std::chrono::steady_clock::now();
@@ -1122,6 +1110,9 @@ int leon_dna_set_shard(leon_dna_ctx* c, uint32_t rank, uint32_t world) {
 
 int leon_dna_reset_stream(leon_dna_ctx* c) {
     if (!c) return LEON_E_INVALID;
+    static const bool trace_step = getenv("LEON_TRACE_STEP") != nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
+    struct Done { bool on; std::chrono::steady_clock::time_point t0; ~Done() { if (on) fprintf(stderr, "[leon step] %-34s %8.2f ms\n", "reset_stream", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } } done{trace_step, t_enter};
     c->anchor_worker->reset();
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1228,7 +1219,7 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     std::vector<uint64_t> rel_off(n_blocks + 1);
     for (uint64_t b = 0; b <= n_blocks; b++) rel_off[b] = payload_off[b] - payload_off[0];
     if (n_anchors) HIPCHK(c, hipMemcpyAsync(d_anchors.p, anchors, n_anchors * W * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(d_pay.p, payloads + payload_off[0], pay_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, staged_h2d(c->device, d_pay.p, payloads + payload_off[0], pay_bytes));
     HIPCHK(c, hipMemsetAsync((uint8_t*)d_pay.p + pay_bytes, 0, 1024, s));
     HIPCHK(c, hipMemcpyAsync(d_off.p, rel_off.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_nreads.p, block_n_reads, n_blocks * 4, hipMemcpyHostToDevice, s));
@@ -1270,8 +1261,8 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
                          : err[0] == 4 ? "the payload ends before its reads do" : "too many N / error positions in one read";
         return fail(c, LEON_E_INVALID, std::string("block ") + std::to_string(err[1]) + " does not decode: " + what);
     }
-    HIPCHK(c, hipMemcpy(out_bases, d_out.p, out0[n_blocks], hipMemcpyDeviceToHost));
-    if (read0[n_blocks]) HIPCHK(c, hipMemcpy(out_len, d_len.p, read0[n_blocks] * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, staged_d2h(c->device, out_bases, d_out.p, out0[n_blocks]));     // gigabytes into the caller's pageable memory: at PCIe's rate (staging.h)
+    if (read0[n_blocks]) HIPCHK(c, staged_d2h(c->device, out_len, d_len.p, read0[n_blocks] * 4));
     lap("bases to the host");
     return LEON_OK;
 }
@@ -1306,7 +1297,7 @@ int leon_header_decode_blocks(leon_dna_ctx* c, const uint8_t* payloads, const ui
     HIPCHK(c, d_off.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_nreads.ensure(n_blocks * 4));
     HIPCHK(c, d_begin.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_count.ensure(n_blocks * 8));
     HIPCHK(c, d_syms.ensure(sym_cap + 64)); HIPCHK(c, d_err.ensure(16));
-    HIPCHK(c, hipMemcpyAsync(d_pay.p, payloads + payload_off[0], pay_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, staged_h2d(c->device, d_pay.p, payloads + payload_off[0], pay_bytes));
     HIPCHK(c, hipMemsetAsync((uint8_t*)d_pay.p + pay_bytes, 0, 1024, s));
     HIPCHK(c, hipMemcpyAsync(d_off.p, rel_off.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_nreads.p, block_n_reads, n_blocks * 4, hipMemcpyHostToDevice, s));

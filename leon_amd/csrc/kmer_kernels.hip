@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 #include "prim.h"
+#include "staging.h"
 
 #include <algorithm>
 #include <string>
@@ -134,7 +135,7 @@ int leon_device_alloc(int device_id, uint64_t bytes, void** d_ptr) {
 int leon_device_upload(int device_id, void* d_dst, const void* src, uint64_t bytes) {
     if (bytes && (!d_dst || !src)) return LEON_E_INVALID;
     KCHK(hipSetDevice(device_id));
-    if (bytes) KCHK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    if (bytes) KCHK(staged_h2d(device_id, d_dst, src, bytes));
     return LEON_OK;
 }
 int leon_device_copy(int device_id, void* d_dst, const void* d_src, uint64_t bytes) {
@@ -147,7 +148,7 @@ int leon_device_copy(int device_id, void* d_dst, const void* d_src, uint64_t byt
 int leon_device_download(int device_id, void* dst, const void* d_src, uint64_t bytes) {
     if (bytes && (!dst || !d_src)) return LEON_E_INVALID;
     KCHK(hipSetDevice(device_id));
-    if (bytes) KCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    if (bytes) KCHK(staged_d2h(device_id, dst, d_src, bytes));          // (at PCIe's rate for large copies: staging.h)
     return LEON_OK;
 }
 

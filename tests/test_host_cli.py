@@ -269,7 +269,7 @@ def test_reference_acceptance_test_lossless_fastq_gz(leon_bin, tmp_path):
     for name, plus in (("all", lambda i, h: h), ("mixed", lambda i, h: (b"", h, b"", b"", h, b"free text %d" % i)[i % 6] if i % 1000 < 6 else h)):
         fp = str(tmp_path / ("plus_%s.fastq" % name))
         with open(fp, "wb") as f:
-            for i, (h, sq, q) in enumerate(zip(heads, reads, quals)):
+            for i, (h, sq, q) in enumerate(zip(heads[:60000], reads, quals)):               # two read blocks
                 f.write(b"@" + h + b"\n" + sq + b"\n+" + plus(i, h) + b"\n" + q + b"\n")
         r = run(leon_bin, "-c", "-lossless", "-file", fp, "-kmer-size", "25")
         assert r.returncode == 0, r.stderr
