@@ -60,14 +60,14 @@ def parse():
     ap.add_argument("--err", type=float, default=0.01)
     ap.add_argument("--kmer-max-keys", type=int, default=0, help="k-mers sorted per pass by the solid k-mer counter (0 = sized by the library)")
     ap.add_argument("--quick", action="store_true",
-                    help="only the timed steps, roofline and cpu_baseline: skip pcie_inclusive / verify / decode / end_to_end")
+                    help="only the timed steps, roofline and cpu_baseline: skip pcie_inclusive / verify / decode / streams / end_to_end")
     ap.add_argument("--decode", action="store_true", help="(always on at N = 1 unless --quick) decode the whole file on the device and compare it with the input")
     ap.add_argument("--verify", action="store_true", help="(always on unless --quick) one more UNTIMED step whose sink hashes every block")
     ap.add_argument("--host-input", action="store_true", help="(always on at N = 1 unless --quick) one step through leon_dna_encode_batch, PCIe included")
     ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("LEON_BENCH_E2E_READS", 10_000_000)),
                     help="reads of the FASTQ that `end_to_end` takes through the leon CLI (0 = skip)")
     ap.add_argument("--streams", action="store_true",
-                    help="also time the kernels of the streams either side of the DNA stream on device-resident synthetic data: the header "
+                    help="(always on at N = 1 unless --quick) also time the kernels of the streams either side of the DNA stream on device-resident synthetic data: the header "
                          "stream (records + range coder, 10 M SRA-style headers) and the lossy quality smoothing (the workload's reads); "
                          "reported as `streams`, never as value")
     return ap.parse_args()
@@ -435,7 +435,7 @@ def main():
         ctx.reset_stream()
 
     streams = None
-    if a.streams and world == 1:
+    if (a.streams or extras) and world == 1:
         streams = bench_streams(ctx, capi, reads, offsets, n_total, device)
 
     e2e = None
@@ -507,16 +507,9 @@ def bench_streams(ctx, capi, reads, offsets, n_total, device):
     del quals
     # header stream: 10 M SRA-style headers resident in HBM -> records (one lane per header) -> k_rc_encode
     nh = min(10_000_000, n_total)
-    rng = np.random.default_rng(7)
-    idx = np.arange(1, nh + 1)
-    heads = np.char.add(np.char.add(b"SRR387476.", idx.astype("S")),
-                        np.char.add(b" HWI-ST1234:3:1101:", np.char.add(rng.integers(1000, 20000, nh).astype("S"),
-                                    np.char.add(b":", np.char.add(rng.integers(1000, 200000, nh).astype("S"), b" length=150")))))
-    lens = np.char.str_len(heads).astype(np.int64)
-    blob = np.frombuffer(b"".join(heads.tolist()), dtype=np.uint8)
-    hoff = np.zeros(nh + 1, dtype=np.int64); hoff[1:] = np.cumsum(lens)
+    blob, hoff = sra_headers(nh, seed=7)
     d_blob = torch.from_numpy(blob.copy()).to(device); d_hoff = torch.from_numpy(hoff).to(device)
-    first = heads[0]
+    first = blob[:int(hoff[1])].tobytes()
     hbytes = [0]
     hsink = capi.SINK(lambda user, bid, ptr, size, nreads: (hbytes.__setitem__(0, hbytes[0] + size), 0)[1])
     best = None
@@ -564,6 +557,48 @@ def bench_streams(ctx, capi, reads, offsets, n_total, device):
     return streams
 
 
+def _digits(v, d):
+    """the d decimal digits of every entry of v as ASCII, most significant first (division by the constant 10, column by column:
+    numpy's broadcast int64 division by an array of powers is two orders of magnitude slower)"""
+    out = np.empty((len(v), d), dtype=np.uint8)
+    v = np.asarray(v, dtype=np.int64).copy()
+    for j in range(d - 1, -1, -1):
+        q = v // 10
+        out[:, j] = (v - q * 10 + 48).astype(np.uint8)
+        v = q
+    return out
+
+
+def sra_headers(n, seed=7, L_field=150):
+    """n SRA-style header texts (`SRR387476.<i> HWI-ST1234:3:1101:<x>:<y> length=150`) back to back + their offsets, built as
+    fixed-width matrices per digit count of the index (numpy's char routines take a minute for 10 M of them)"""
+    rng = np.random.default_rng(seed)
+    x, y = rng.integers(10000, 100000, n), rng.integers(100000, 1000000, n)
+    idx = np.arange(1, n + 1, dtype=np.int64)
+
+    def digits(v, d):
+        return _digits(v, d)
+    parts, lens = [], np.empty(n, dtype=np.int64)
+    lo = 0
+    while lo < n:
+        d = len(str(int(idx[lo])))
+        hi = min(n, lo + max(1, 10 ** d - int(idx[lo])))
+        cols = [b"SRR387476.", digits(idx[lo:hi], d), b" HWI-ST1234:3:1101:", digits(x[lo:hi], 5), b":", digits(y[lo:hi], 6), b" length=%d" % L_field]
+        w = sum(len(c) if isinstance(c, bytes) else c.shape[1] for c in cols)
+        rec = np.empty((hi - lo, w), dtype=np.uint8)
+        c0 = 0
+        for c in cols:
+            if isinstance(c, bytes):
+                rec[:, c0:c0 + len(c)] = np.frombuffer(c, dtype=np.uint8)[None, :]; c0 += len(c)
+            else:
+                rec[:, c0:c0 + c.shape[1]] = c; c0 += c.shape[1]
+        parts.append(rec.reshape(-1)); lens[lo:hi] = w
+        lo = hi
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    return np.concatenate(parts), off
+
+
 def write_fastq(path, n, Lr, device):
     """a synthetic FASTQ of n reads of the bench's generator (genome n*Lr/30, 1 % substitutions) with SRA-style headers and
     structured qualities, built as fixed-width record matrices (reads grouped by the digit count of their index)"""
@@ -571,7 +606,7 @@ def write_fastq(path, n, Lr, device):
     qalpha = np.frombuffer(b"#5:?ABCDEFGHIJ", dtype=np.uint8)
 
     def digits(v, d):
-        return ((v[:, None] // (10 ** np.arange(d - 1, -1, -1, dtype=np.int64))[None, :]) % 10 + 48).astype(np.uint8)
+        return _digits(v, d)
     with open(path, "wb") as f:
         for c0 in range((n + CHUNK - 1) // CHUNK):
             m = min(CHUNK, n - c0 * CHUNK)

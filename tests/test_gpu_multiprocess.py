@@ -74,12 +74,13 @@ def test_default_bench_line_fills_every_key():
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-4000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    for key in ("value", "value_hbm_resident", "value_h2d_inclusive", "pcie_inclusive", "decode", "verify", "end_to_end", "roofline", "cpu_baseline"):
+    for key in ("value", "value_hbm_resident", "value_h2d_inclusive", "pcie_inclusive", "decode", "verify", "streams", "end_to_end", "roofline", "cpu_baseline"):
         assert line[key] is not None, key
     assert line["config"]["batches"] == 3 and line["value"] == line["value_hbm_resident"]
     assert line["decode"]["equals_input"] is True
     assert line["end_to_end"]["identical"] is True and line["end_to_end"]["compress_lossless_rc"] == 0
     assert line["verify"]["n_blocks"] == 20
+    assert line["streams"]["header_decode"]["equal_input"] is True and line["streams"]["qual_smooth"]["MBps"] > 0
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
     assert "UNPINNED" in line["parity"]
     # the same file as ONE batch: same bytes
