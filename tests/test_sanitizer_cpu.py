@@ -30,3 +30,22 @@ def test_host_decoders_under_asan_ubsan(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_fuzz_host_streams.py"), so], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "header decoder under ASan/UBSan: ok" in r.stdout and "quality decoder under ASan/UBSan: ok" in r.stdout
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_dictionary_chain_worker_under_sanitizers(tmp_path, san):
+    """the dictionary chain of round 3 is a small pipeline of threads (helpers that prepare per-symbol records in a ring of
+    buffers, the chain that consumes them; host_rc.h): ThreadSanitizer and ASan/UBSan over the whole worker, one- and two-word
+    k-mers, streams long enough to go round the ring several times"""
+    if not _lib("libtsan.so" if san == "thread" else "libasan.so"):
+        pytest.skip("no sanitizer runtime in this toolchain")
+    exe = str(tmp_path / "chain_san")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-o", exe,
+                           os.path.join(ROOT, "profiles", "scripts", "chain_ab", "ab_new.cpp"), "-lpthread"])
+    for n, k in ((60000, 31), (30000, 63)):                  # ~1.9 M symbols each: 58 segments through 16 buffers
+        r = subprocess.run([exe, str(n), str(k)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
+        out = r.stdout + r.stderr
+        assert r.returncode == 0 and "Sanitizer" not in out and "runtime error" not in out, out[-3000:]
+        fnv = {l.split("fnv")[1].strip() for l in r.stdout.splitlines() if "fnv" in l}
+        assert len(fnv) == 1, "three runs of the same stream must give the same bytes: %s" % fnv
