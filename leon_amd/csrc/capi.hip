@@ -760,7 +760,7 @@ int leon_dna_encode_batch(leon_dna_ctx* c, const uint8_t* bases, const uint64_t*
     HIPCHK(c, c->in_off.ensure((n + 1) * 8));
     // offsets first (rebased on the device so that they index the device copy of the bases), then the bases group by
     // group on an uploader thread while the device already works on the groups that have arrived
-    HIPCHK(c, hipMemcpy(c->in_off.p, off, (n + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, staged_h2d(c->device, c->in_off.p, off, (n + 1) * 8));      // (800 MB at 100 M reads: 73 ms as one hipMemcpy from pageable memory, 15 staged)
     if (off[0]) {
         launch_rebase_offsets(c->stream, c->in_off.as<uint64_t>(), n + 1, off[0]);
         HIPCHK(c, hipStreamSynchronize(c->stream));
