@@ -116,7 +116,8 @@ public:
         uint64_t c_end[4] = {};                                // the model's counts (1 + occurrences of A, C, T, G) after the segment
     };
     explicit ChainFeed(uint32_t k) : k_(k), W_(k >= 32 ? 2u : 1u), seg_kmers_(std::max<uint32_t>(1, (1u << 15) / k)) {
-        uint32_t n = 5;
+        uint32_t n = 5;                                        // ~4.8 ns per record and helper inside the library: 3 just keep ahead of the chain, 5 leave a margin;
+                                                               // more only lower the clock the chain's core gets (8 helpers: +9 % on its time)
         if (const char* e = getenv("LEON_CHAIN_HELPERS")) { const int v = atoi(e); if (v >= 1 && v <= 32) n = (uint32_t)v; }
         n_threads_ = n;
     }
@@ -222,21 +223,24 @@ private:
         return (uint64_t)((((unsigned __int128)fr) << 64) / d);
 #endif
     }
+    // (the cumulative counts stay in registers and the k-mer is shifted out two bits at a time: 3.0 ns per record on the EPYC 9575F
+    // against 5.3-6.5 with the counts in an array and a variable shift per base -- profiles/scripts/chain_ab/ab_fill.cpp; what is
+    // left is the division.  A double-precision estimate with an exact fix-up instead of it: 2.5 ns under g++, 5.2 under clang.)
     template <typename Rec> void fill(Rec* out, const Seg& sg, uint64_t* c) const {
         uint64_t d = 5 + sg.t0 + 1;                              // total of the symbol AFTER the one being recorded
+        uint64_t cum[5] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2], c[0] + c[1] + c[2] + c[3]};   // cum[j] = counts of the symbols below j
         for (uint32_t a = 0; a < sg.n_kmers; a++) {
             const uint64_t* w = sg.kmers + (size_t)a * W_;
-            for (uint32_t i = 0; i < k_; i++, d++, out++) {
-                const uint32_t bit = 2 * (k_ - 1 - i);
-                const uint32_t sy = (uint32_t)(w[bit >> 6] >> (bit & 63)) & 3u;
-                const uint64_t c01 = c[0] + c[1];
-                const uint64_t lo = sy == 0 ? 0 : sy == 1 ? c[0] : sy == 2 ? c01 : c01 + c[2];
-                const uint64_t fr = c[sy];
+            unsigned __int128 x = W_ == 2 ? (((unsigned __int128)w[1] << 64) | w[0]) << (128 - 2 * k_) : (unsigned __int128)w[0] << (128 - 2 * k_);
+            for (uint32_t i = 0; i < k_; i++, d++, out++, x <<= 2) {    // first base in the two highest bits
+                const uint32_t sy = (uint32_t)(x >> 126);
+                const uint64_t lo = cum[sy], fr = cum[sy + 1] - lo;
                 out->c = scaled(fr, d);
                 out->lo = (decltype(out->lo))lo; out->fr = (decltype(out->fr))fr;
-                c[sy]++;
+                cum[1] += sy < 1; cum[2] += sy < 2; cum[3] += sy < 3; cum[4]++;
             }
         }
+        c[0] = cum[1]; c[1] = cum[2] - cum[1]; c[2] = cum[3] - cum[2]; c[3] = cum[4] - cum[3];
     }
     const uint32_t k_, W_, seg_kmers_;
     uint32_t n_threads_ = 5;
