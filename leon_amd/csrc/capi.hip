@@ -112,6 +112,7 @@ struct leon_dna_ctx {
     uint64_t last_n = 0, last_bases = 0;
     // decoder: the path cache (decode_kernels.hip) lives as long as the bloom it was learnt from
     DevBuf dc_cache;
+    DevBuf dc_out, dc_pay, dc_len, dc_pool, dc_scr;   // a decode call's large buffers, kept from call to call (a fresh 15 GB allocation waits 0.3 s for the driver to wipe it)
     PathCache dc_pc{};
     uint64_t dc_bloom_fp = 0;                    // fingerprint of the bloom bits the cache's entries were derived from
     bool dc_filled = false;
@@ -305,7 +306,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
                        &c->status, &c->hit_pos, &c->hit_slot, &c->cand_pos, &c->cand_slot, &c->anchor_pos, &c->anchor_addr,
                        &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
                        &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
-                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->fbits, &c->pbits, &c->hdr_first, &c->dc_cache };
+                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->fbits, &c->pbits, &c->hdr_first, &c->dc_cache, &c->dc_out, &c->dc_pay, &c->dc_len, &c->dc_pool, &c->dc_scr };
     for (DevBuf* b : bufs) b->release();
     if (c->d_bloom) (void)hipFree(c->d_bloom);
     if (c->d_rv16) (void)hipFree(c->d_rv16);
@@ -422,6 +423,7 @@ static int encode_batch_guarded(leon_dna_ctx* c, const uint8_t* d_bases, const u
         (void)hipStreamSynchronize(c->stream);
         c->dc_cache.release(); c->dc_pc = PathCache{}; c->dc_filled = false;
     }
+    for (DevBuf* b : { &c->dc_out, &c->dc_pay, &c->dc_len, &c->dc_pool, &c->dc_scr }) b->release();
     const int rc = encode_batch_impl(c, d_bases, d_off, n, first_read_index, sink, user, up, up_off);
     if (rc != LEON_OK && c->poisoned) c->err += " (stream poisoned: leon_dna_reset_stream to go on)";
     return rc;
@@ -1174,7 +1176,8 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     }
     if (out0[n_blocks] > out_cap) return fail(c, LEON_E_INVALID, "output capacity below the sum of block_n_bases");
     const uint64_t pay_bytes = payload_off[n_blocks] - payload_off[0];
-    TmpBuf d_anchors, d_pay, d_off, d_nreads, d_read0, d_out0, d_out, d_len, d_scr, d_err, d_pool;
+    TmpBuf d_anchors, d_off, d_nreads, d_read0, d_out0, d_err;
+    DevBuf &d_pay = c->dc_pay, &d_out = c->dc_out, &d_len = c->dc_len, &d_scr = c->dc_scr, &d_pool = c->dc_pool;
     HIPCHK(c, d_anchors.ensure(std::max<uint64_t>(n_anchors * W, 1) * 8));
     HIPCHK(c, d_pay.ensure(pay_bytes + 1024));                 // the payload window reads up to 256 + 3 bytes past a block's end
     HIPCHK(c, d_off.ensure((n_blocks + 1) * 8)); HIPCHK(c, d_nreads.ensure(n_blocks * 4));
