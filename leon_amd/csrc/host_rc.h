@@ -405,63 +405,96 @@ private:
 
 // The inverse of AnchorDictCoder (Leon::decodeAnchorDict / RangeDecoder on _anchorDictModel(5) [RECALLED]): one serial
 // chain again, on a host core.  k symbols per anchor, first base in the highest bits.  Returns false on a corrupt stream.
-// range / total uses the encoder's reciprocal stream (the total is 5 + t here too); the decoder's second division,
-// (code - low) / range, is replaced by four multiplies: the symbol is the number of cumulative counts c with
-// c * range <= code - low.
+// Here the symbol is not known ahead, so nothing but the reciprocal of the total (5 + t, whatever the data) can be prepared by
+// helpers; but a step has only four outcomes.  With r = floor(range / total) carried from the step before:
+//     p_j = r * cum[j] (five products); the symbol is the number of j with p_j <= code - low (no second division);
+//     its new range is one of R_s = p_(s+1) - p_s, and the NEXT quotient floor(R_s / total') is formed for ALL FOUR beside the
+//     comparisons (multiply-high by the next total's scaled reciprocal: h >> 8 when no byte leaves, h when one does),
+// so that once the symbol is known only selections remain: symbol -> (low, range, h), then the renormalisation test -> (r, low,
+// code).  The carried path is multiply, compare, select, add, xor, compare, select (~12 cycles); computing the quotient after
+// the symbol (multiply-high, shift, multiply, compare, four selects, subtract, add, xor, compare, select) was ~19.
 inline bool decode_anchor_dict(const uint8_t* p, uint64_t n, uint64_t n_anchors, uint32_t k, uint64_t* out) {
     constexpr uint64_t kTop = 1ull << 56, kBottom = 1ull << 48;
     const uint32_t W = k >= 32 ? 2u : 1u;
     uint64_t low = 0, range = ~0ull, code = 0, i = 0, t = 0, cum[6] = {0, 1, 2, 3, 4, 5};
     for (int b = 0; b < 8; b++) code = (code << 8) | (i < n ? p[i] : 0), i++;
     ReciprocalStream recips;
+    const bool use_inv = n_anchors * (uint64_t)k > (1u << 16);     // (not worth three threads for a handful of symbols)
+    if (use_inv) recips.restart();
     const uint64_t* inv = nullptr;
-    if (n_anchors * (uint64_t)k > (1u << 16)) recips.restart();   // (not worth three threads for a handful of symbols)
-    const bool use_inv = n_anchors * (uint64_t)k > (1u << 16);
+    uint64_t inv_chunk = ~0ull;
+    auto recip_of_symbol = [&](uint64_t tt) -> uint64_t {            // floor((2^72 - 1) / (5 + tt)); symbols are asked for in increasing order
+        const uint64_t c = tt / ReciprocalStream::kChunk;
+        if (c != inv_chunk) { inv = recips.take(c); inv_chunk = c; }
+        return inv[tt % ReciprocalStream::kChunk];
+    };
+    auto next_byte = [&]() -> uint64_t { const uint64_t v = i < n ? p[i] : 0; i++; return v; };
+    uint64_t r = 0;                                             // floor(range / total) of the symbol about to be decoded, when r_valid
+    bool r_valid = false;
     for (uint64_t a = 0; a < n_anchors; a++) {
         unsigned __int128 km = 0;
         for (uint32_t j = 0; j < k; j++, t++) {
             const uint64_t tot = 5 + t;
-            uint64_t r;
-            if (use_inv && t >= 256) {
-                const uint64_t off = t % ReciprocalStream::kChunk;
-                if (off == 0 || !inv) inv = recips.take(t / ReciprocalStream::kChunk);
-                r = (uint64_t)(((unsigned __int128)range * inv[off]) >> 64) >> 8;     // floor(range / tot) or one less
-                if (range - r * tot >= tot) r++;
-            } else r = range / tot;
+            if (!r_valid) r = range / tot;
             if (r == 0) return false;
-            // the symbol is the number of cumulative counts c with c * r <= code - low; the five products also are the
-            // new low and range (no second multiply, no division).  Selected with conditional moves: the symbol is as good
-            // as random, a branch on it would be mispredicted three times out of four
+            // the symbol is the number of cumulative counts c with c * r <= code - low; the products also are the new low and
+            // the candidates of the new range
             const uint64_t d = code - low;
-            const uint64_t p1 = r * cum[1], p2 = r * cum[2], p3 = r * cum[3], p4 = r * cum[4], p5 = r * tot;
-            const uint64_t g1 = d >= p1, g2 = d >= p2, g3 = d >= p3, g4 = d >= p4;
-            const uint32_t c = (uint32_t)(g1 + g2 + g3 + g4);
-            uint64_t lo = g1 ? p1 : 0, hi = g1 ? p2 : p1;
-            lo = g2 ? p2 : lo; hi = g2 ? p3 : hi;
-            lo = g3 ? p3 : lo; hi = g3 ? p4 : hi;
-            lo = g4 ? p4 : lo; hi = g4 ? p5 : hi;
+            const uint64_t p1 = r * cum[1], p2 = r * cum[2], p3 = r * cum[3], p4 = r * cum[4];
+            const bool g1 = d >= p1, g2 = d >= p2, g3 = d >= p3, g4 = d >= p4;
+            if (g4) return false;                              // an N inside an anchor: not a stream this coder wrote
+            const uint64_t R0 = p1, R1 = p2 - p1, R2 = p3 - p2, R3 = p4 - p3;
+            const uint32_t c = (uint32_t)g1 + (uint32_t)g2 + (uint32_t)g3;
+            uint64_t lo, R, h = 0;
+            const bool fast = use_inv && t >= 256;
+            if (fast) {
+                const uint64_t m1 = recip_of_symbol(t + 1);
+                uint64_t h0 = (uint64_t)(((unsigned __int128)R0 * m1) >> 64), h1 = (uint64_t)(((unsigned __int128)R1 * m1) >> 64);
+                uint64_t h2 = (uint64_t)(((unsigned __int128)R2 * m1) >> 64), h3 = (uint64_t)(((unsigned __int128)R3 * m1) >> 64);
+                // (clang selects the range first and multiplies once; forcing the four products apart, as written, is slower: 5.4 against
+                //  4.7 ns per symbol on the EPYC 9575F -- the step is bound by its ~45 instructions, not by this dependency)
+                // selected by the symbol, as a tree of conditional moves: the symbol is as good as random, a branch on it would be
+                // mispredicted three times out of four
+                const uint64_t lo_a = g1 ? p1 : 0, R_a = g1 ? R1 : R0, h_a = g1 ? h1 : h0;      // symbol 0 or 1
+                const uint64_t lo_b = g3 ? p3 : p2, R_b = g3 ? R3 : R2, h_b = g3 ? h3 : h2;     // symbol 2 or 3
+                lo = g2 ? lo_b : lo_a; R = g2 ? R_b : R_a; h = g2 ? h_b : h_a;
+            } else {
+                lo = g3 ? p3 : g2 ? p2 : g1 ? p1 : 0;
+                R = g3 ? R3 : g2 ? R2 : g1 ? R1 : R0;
+            }
             low += lo;
-            range = hi - lo;
+            range = R;
             // renormalisation: nothing or one byte in the usual case, both formed and selected without a branch (a byte leaves
             // after every fourth symbol or so: as a branch that is a misprediction per byte); the rare cases take the loop
-            {
-                const uint64_t x = low ^ (low + range);
-                const bool one = x < kTop;                       // the top byte is settled
-                const uint64_t low1 = low << 8, range1 = range << 8, code1 = (code << 8) | (i < n ? p[i] : 0);
-                const uint64_t x1 = low1 ^ (low1 + range1);
-                if (__builtin_expect((one && (x1 < kTop || range1 < kBottom)) || (!one && range < kBottom), 0)) {
-                    while ((low ^ (low + range)) < kTop || (range < kBottom && ((range = (0 - low) & (kBottom - 1)), true))) {
-                        code = (code << 8) | (i < n ? p[i] : 0); i++;
-                        range <<= 8;
-                        low <<= 8;
-                        if (i > n + 16) return false;              // far past the end: not a stream this coder wrote (a range of 0 would spin here)
-                    }
-                } else {
-                    low = one ? low1 : low; range = one ? range1 : range; code = one ? code1 : code; i += one;
+            const uint64_t x = low ^ (low + range);
+            if (__builtin_expect(!fast || (x >> 48) == 0 || range < kBottom, 0)) {
+                while ((low ^ (low + range)) < kTop || (range < kBottom && ((range = (0 - low) & (kBottom - 1)), true))) {
+                    code = (code << 8) | next_byte();
+                    range <<= 8;
+                    low <<= 8;
+                    if (i > n + 16) return false;                  // far past the end: not a stream this coder wrote (a range of 0 would spin here)
                 }
+                r_valid = false;
+            } else {
+                // x < TOP: the top byte is settled, exactly one byte leaves (x >= 2^48 here)
+                const uint64_t byte = i < n ? p[i] : 0;
+                const uint64_t tot1 = tot + 1;
+                uint64_t rn = h >> 8;
+#ifdef LEON_HOST_CHAIN_X86
+                // (rn, range, low, code, i) = one byte ? (h, range << 8, low << 8, code << 8 | byte, i + 1) : unchanged -- as conditional
+                // moves (the compiler makes a branch of the selects, mispredicted at every byte: 4.7 against 5.5 ns per symbol for nothing)
+                asm("cmpq %[top], %[x]\n\tcmovbq %[h], %[rn]\n\tcmovbq %[R8], %[rg]\n\tcmovbq %[L8], %[lw]\n\tcmovbq %[C8], %[cd]\n\tadcq $0, %[i]"
+                    : [rn] "+r"(rn), [rg] "+r"(range), [lw] "+r"(low), [cd] "+r"(code), [i] "+r"(i)
+                    : [x] "r"(x), [top] "r"(kTop), [h] "r"(h), [R8] "r"(range << 8), [L8] "r"(low << 8), [C8] "r"((code << 8) | byte)
+                    : "cc");
+#else
+                const bool one = x < kTop;
+                rn = one ? h : rn; range = one ? range << 8 : range; low = one ? low << 8 : low; code = one ? (code << 8) | byte : code; i += one;
+#endif
+                if (__builtin_expect(range - rn * tot1 >= tot1, 0)) rn++;          // the scaled reciprocal's quotient is one short with probability < 2^-8
+                r = rn; r_valid = true;
             }
-            cum[1] += (uint64_t)(c < 1); cum[2] += (uint64_t)(c < 2); cum[3] += (uint64_t)(c < 3); cum[4] += (uint64_t)(c < 4);   // Order0Model::update, branch-free
-            if (c > 3) return false;                           // an N inside an anchor: not a stream this coder wrote
+            cum[1] += (uint64_t)(c < 1); cum[2] += (uint64_t)(c < 2); cum[3] += (uint64_t)(c < 3); cum[4] += 1; cum[5] += 1;   // Order0Model::update, branch-free
             km = (km << 2) | c;
         }
         out[a * W] = (uint64_t)km;
