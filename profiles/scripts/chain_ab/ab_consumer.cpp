@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     {   // a cache-resident stretch of records, over and over (the state keeps evolving; output discarded by rewinding)
         AnchorDictCoder cd;
         cd.encode_kmers(km.data(), 20, k);
-        const size_t m = 60000, start = 1000000 * (size_t)k;
+        const size_t m = 60000, start = (n > 1100000 ? 1000000 : n / 2) * (size_t)k;
         auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < 300; i++) { cd.w_ = 0; cd.encode_records(recs.data() + start, m, start); }
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
