@@ -76,7 +76,7 @@ def test_host_anchor_dict_stream_matches_oracle(lib):
     from leon_amd import capi
     rng = np.random.default_rng(3)
     sizes = [2, 5, 5, 2, 3, 3, 3, 2] + [256] * 72
-    for k, n in [(31, 0), (31, 1), (31, 700), (21, 3000), (5, 10), (32, 50), (63, 900), (31, 30000)]:   # last: > 3 reciprocal chunks
+    for k, n in [(31, 0), (31, 1), (31, 700), (21, 3000), (5, 10), (32, 50), (33, 4000), (47, 2500), (63, 900), (31, 30000), (63, 20000)]:   # the last two: 29 and 39 segments of records through the feed's 16 buffers
         ints = [(int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 1 << 62)) << 62)) & ((1 << (2 * k)) - 1) for _ in range(n)]
         w = O.kwords(k)
         kmers = np.array([[x & 0xFFFFFFFFFFFFFFFF, x >> 64][:w] for x in ints], dtype=np.uint64).reshape(-1)
