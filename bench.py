@@ -183,7 +183,10 @@ def main():
         local = local % max(n_dev, 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # (LEON_BENCH_FORCE_DIST=1: a one-rank run under torch.distributed.run still goes through the process group, the RCCL broadcast
+    # of the bloom and the reductions -- the N > 1 code on the one GPU a test box has)
+    use_dist = world > 1 or (os.environ.get("LEON_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("LEON_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI; gloo only to rehearse
         if backend == "nccl":
@@ -214,7 +217,7 @@ def main():
         del chunk
     offsets = (torch.arange(n_total + 1, dtype=torch.int64, device=device) * L).contiguous()
     torch.cuda.synchronize()
-    if world > 1:                            # the replicated anchor resolution needs the SAME reads on every rank
+    if use_dist:                            # the replicated anchor resolution needs the SAME reads on every rank
         chk = torch.stack([reads[::97].sum(dtype=torch.int64), reads[-1].sum(dtype=torch.int64)])
         lo_, hi_ = chk.clone(), chk.clone()
         dist.all_reduce(lo_, op=dist.ReduceOp.MIN); dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
@@ -235,7 +238,7 @@ def main():
     else:
         n_solid_t[0] = G - K + 1
     count_s = time.time() - t_b
-    if world > 1:
+    if use_dist:
         dist.broadcast(n_solid_t, src=0)
     n_solid = int(n_solid_t.item())
     tai = n_solid * BITS_PER_KMER
@@ -257,7 +260,7 @@ def main():
                 ctx.bloom_insert_device(km.data_ptr(), km.shape[0])
                 del km
     del genome
-    if world > 1:                           # RCCL broadcast of the bloom over xGMI, device to device
+    if use_dist:                           # RCCL broadcast of the bloom over xGMI, device to device
         bits = torch.empty(nbytes, dtype=torch.uint8, device=device)
         if rank == 0:
             ctx.bloom_download_device(bits.data_ptr(), nbytes)
@@ -302,7 +305,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -331,7 +334,7 @@ def main():
         stage = acc
     # max over ranks: whole step, device stages alone (HIP events on each rank's stream), cold first step
     red = torch.tensor([sum(times), float(np.mean(dev_ms)), cold_ms[0]], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     total_s, device_ms_max, cold_first_step_ms = float(red[0].item()), float(red[1].item()), float(red[2].item())
     ms_per_step = total_s / a.steps * 1e3
@@ -350,7 +353,7 @@ def main():
         encode_stream(hcb)
         dstream, na_v = ctx.finish()
         tables = [mine]
-        if world > 1:
+        if use_dist:
             tables = [None] * world
             dist.all_gather_object(tables, mine)
         if rank == 0:
@@ -487,7 +490,7 @@ def main():
         }
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -86,3 +86,22 @@ def test_default_bench_line_fills_every_key():
     # the same file as ONE batch: same bytes
     one = _bench(1, extra_args=("--reads", "1000000"))
     assert one["verify"]["blocks_sha256"] == line["verify"]["blocks_sha256"] and one["verify"]["dict_sha256"] == line["verify"]["dict_sha256"]
+
+
+def test_rccl_path_with_one_rank():
+    """RCCL itself (backend nccl) needs one device per rank, so more than one rank cannot run on the test box's one GPU; but the
+    N > 1 CODE can: one rank under torch.distributed.run with LEON_BENCH_FORCE_DIST=1 goes through init_process_group("nccl",
+    device_id=...), the device-to-device broadcast of the bloom, the reductions, the gather of the block tables and the barriers
+    -- every RCCL call the 8-GPU run makes, with a world of one.  Same bytes as the plain run."""
+    env = dict(os.environ, LEON_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LEON_BENCH_BACKEND"):
+        env.pop(v, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "0", "--reads", str(READS),
+           "--cpu-sample", "0", "--quick", "--verify"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["bloom_bcast_ms"] > 0            # the broadcast ran (through RCCL)
+    plain = _bench(1, extra_args=("--quick", "--verify"))
+    assert line["verify"]["blocks_sha256"] == plain["verify"]["blocks_sha256"] and line["verify"]["dict_sha256"] == plain["verify"]["dict_sha256"]
