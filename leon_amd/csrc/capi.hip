@@ -459,6 +459,8 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->stats = leon_dna_stats{};
+    const uint64_t* const walk_keys = c->walk_keys;              // (leon_dna_debug_walk_order applies to THIS batch only, whatever becomes of it)
+    c->walk_keys = nullptr;
     static const bool trace_step = getenv("LEON_TRACE_STEP") != nullptr;   // measurement aid: host time of a batch's first milestones, on stderr
     const auto t_enter = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
@@ -650,9 +652,8 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     size_t sort_tmp = 0;
     // (measurement hook: another order of the reads in the walk changes which lanes share bloom sectors, never the bytes --
     // events are indexed by read position)
-    const uint64_t* walk_key = c->walk_keys ? c->walk_keys + r0 : V.sort_key + r0;
-    const unsigned key_bits = c->walk_keys ? 48u : 33u;
-    c->walk_keys = nullptr;
+    const uint64_t* walk_key = walk_keys ? walk_keys + r0 : V.sort_key + r0;
+    const unsigned key_bits = walk_keys ? 48u : 33u;
     HIPCHK(c, prim::SortPairs(nullptr, sort_tmp, walk_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
                                                  c->perm2.as<uint32_t>(), nl, 0, key_bits, s));
     if (int rc = ensure_cub(c, sort_tmp)) return rc;
