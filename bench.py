@@ -388,8 +388,19 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": int(traffic) if traffic else None, "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(walk_avg_ms, 3), "launches_per_step": n_launch}
 
-    pcie = None
-    if (a.host_input or extras) and world == 1:
+    # What follows is reported beside `value`, never as it, and must never cost the line: an extra that fails is reported as
+    # {"error": ...} and the stream is reset for the next one.  (World 1 only: nothing here waits for another rank.)
+    def guarded(fn):
+        try:
+            return fn()
+        except Exception as e:                                   # noqa: BLE001 -- whatever it was, the headline numbers stand
+            try:
+                ctx.reset_stream()
+            except Exception:                                    # noqa: BLE001
+                pass
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+    def do_pcie():
         h_reads = reads.cpu().numpy()
         h_off = offsets.cpu().numpy().astype(np.uint64)
         h_batches = [(h_reads[lo:hi].reshape(-1), np.ascontiguousarray(h_off[lo:hi + 1] - h_off[lo])) for lo, hi in batches]   # (views + offsets, made outside the timed region)
@@ -406,21 +417,19 @@ def main():
             h_times.append(time.perf_counter() - t0)
         dt = h_times[-1]
         h_st = ctx.stats()
-        pcie = {"value": round(n_total * L / 1e6 / dt, 1), "unit": "MB/s", "ms": round(dt * 1e3, 1), "first_call_ms": round(h_times[0] * 1e3, 1),
+        return {"value": round(n_total * L / 1e6 / dt, 1), "unit": "MB/s", "ms": round(dt * 1e3, 1), "first_call_ms": round(h_times[0] * 1e3, 1),
                 "last_batch_device_ms": round(h_st["ms_total"], 1), "last_batch_resolve_ms": round(h_st["ms_resolve"], 1), "chain_busy_ms": round(h_st["ms_chain_busy"], 1),
                 "what": "SURVEY 8(d)'s form of the metric: one step through leon_dna_encode_batch, reads and offsets in pageable host "
                         "memory, H2D inside the timed region (three staging threads copy 16 MiB pieces through pinned buffers at PCIe's rate while "
                         "the device packs and resolves what has arrived); second of two calls"}
-        del h_reads, h_off, h_batches
 
-    decode = None
-    if (a.decode or extras) and world == 1:
+    def do_decode():
         kept = []
         keep = capi.SINK(lambda user, bid, ptr, size, nreads: (kept.append((int(bid), ctypes.string_at(ptr, size), int(nreads))), 0)[1])
         encode_stream(keep)
-        dstream, n_anchors = ctx.finish()
+        dstream, n_anch = ctx.finish()
         t0 = time.perf_counter()
-        anchors = capi.anchor_dict_decode(dstream, n_anchors, K)
+        anchors = capi.anchor_dict_decode(dstream, n_anch, K)
         t1 = time.perf_counter()
         out_bases, out_lens = ctx.decode_blocks_raw(anchors, kept, [b[2] * L for b in kept])
         t2 = time.perf_counter()
@@ -432,32 +441,25 @@ def main():
         out_bases, out_lens = ctx.decode_blocks_raw(anchors, kept, [b[2] * L for b in kept])
         t3 = time.perf_counter()
         same = same and bool(np.array_equal(out_bases, ref)) and bool(np.all(out_lens == L))
-        decode = {"value": round(n_total * L / 1e6 / (t2 - t0), 1), "unit": "MB/s", "dictionary_s": round(t1 - t0, 2),
-                  "blocks_s": round(t2 - t1, 2), "blocks_MBps": round(n_total * L / 1e6 / (t2 - t1), 1),
-                  "blocks_s_second_call": round(t3 - t2b, 2), "equals_input": same,
-                  "what": "leon_host_anchor_dict_decode (one host core) then leon_dna_decode_blocks (one wave per block, path cache "
-                          "in HBM), payloads in host memory, bases back in host memory; every base compared with the input"}
-        del kept, out_bases, out_lens, ref, anchors, dstream
         ctx.reset_stream()
+        return {"value": round(n_total * L / 1e6 / (t2 - t0), 1), "unit": "MB/s", "dictionary_s": round(t1 - t0, 2),
+                "blocks_s": round(t2 - t1, 2), "blocks_MBps": round(n_total * L / 1e6 / (t2 - t1), 1),
+                "blocks_s_second_call": round(t3 - t2b, 2), "equals_input": same,
+                "what": "leon_host_anchor_dict_decode (one host core) then leon_dna_decode_blocks (one wave per block, path cache "
+                        "in HBM), payloads in host memory, bases back in host memory; every base compared with the input"}
 
-    streams = None
-    if (a.streams or extras) and world == 1:
-        streams = bench_streams(ctx, capi, reads, offsets, n_total, device)
-
-    e2e = None
-    if extras and world == 1 and rank == 0 and a.e2e_reads > 0:
-        e2e = end_to_end(min(a.e2e_reads, n_total), device)
-
-    cpu = None
-    if rank == 0 and world == 1 and a.cpu_sample > 0:
-        cpu = cpu_baseline(ctx, reads, min(a.cpu_sample, n_total))
+    pcie = guarded(do_pcie) if (a.host_input or extras) and world == 1 else None
+    decode = guarded(do_decode) if (a.decode or extras) and world == 1 else None
+    streams = guarded(lambda: bench_streams(ctx, capi, reads, offsets, n_total, device)) if (a.streams or extras) and world == 1 else None
+    e2e = guarded(lambda: end_to_end(min(a.e2e_reads, n_total), device)) if extras and world == 1 and rank == 0 and a.e2e_reads > 0 else None
+    cpu = guarded(lambda: cpu_baseline(ctx, reads, min(a.cpu_sample, n_total))) if rank == 0 and world == 1 and a.cpu_sample > 0 else None
 
     if rank == 0:
         out = {
             "metric": "compressed input MB/s (DNA encode path)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
             "value_hbm_resident": round(value, 1),
-            "value_h2d_inclusive": pcie["value"] if pcie else None,
+            "value_h2d_inclusive": pcie.get("value") if pcie else None,
             "cold_first_step_ms": round(cold_first_step_ms, 2),
             # the multi-GPU truth: the job also waits for the file-wide dictionary stream, one serial
             # chain on a host core of rank 0 whatever N is; the device stages are what shards
@@ -652,7 +654,10 @@ def end_to_end(n, device):
     leon = os.path.join(ROOT, "leon_amd", "lib", "leon")
     if not os.path.exists(leon):
         return {"error": "leon_amd/lib/leon is not built"}
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    need = 3 * n * (2 * L + 70)                                # the FASTQ, its .leon and the restored copy
+    base = next((d for d in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need), None)
+    if base is None:
+        return {"error": "no directory with %d MB free for the FASTQ" % (need >> 20)}
     work = tempfile.mkdtemp(prefix="leon_e2e_", dir=base)
     fq = os.path.join(work, "reads.fastq")
     out = {"reads": n, "read_len": L}
