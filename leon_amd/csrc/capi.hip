@@ -1016,7 +1016,26 @@ int leon_qual_smooth_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const
     HIPCHK(c, hipMemsetAsync(c->packed.as<uint32_t>() + n_slots * 2, 0, 64, s));
     launch_pack(s, d_bases, d_off, c->slot_off.as<uint64_t>(), n, c->packed.as<uint32_t>(), c->nmask.as<uint32_t>(), c->rlen.as<uint32_t>(),
                 c->ncount.as<uint32_t>());
-    launch_qual_smooth(s, reads_view(c, d_off, n), c->B, c->d_rv16, d_quals);
+    // large batches: the probes shared between the reads of a locus (hdr_kernels.hip) -- a minimizer per read, one sort, one lane per
+    // read in that order, then the rewrite; small ones (and LEON_QUAL_ORDER=0, the measurement reference): every read for itself
+    const char* qo = getenv("LEON_QUAL_ORDER");
+    const bool in_file_order = qo && atoi(qo) == 0;
+    const ReadsDev R = reads_view(c, d_off, n);
+    if (!in_file_order && n >= 256) {
+        HIPCHK(c, c->sort_key.ensure(n * 4)); HIPCHK(c, c->sort_key2.ensure(n * 4));
+        HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(n * 4));
+        HIPCHK(c, c->hit_pos.ensure(n * 4));                    // (the minimizers' positions; the encode's per-read arrays are free between batches)
+        HIPCHK(c, c->events.ensure((n_slots + 4) * 4));         // (the flags)
+        HIPCHK(c, hipMemsetAsync(c->events.p, 0, (n_slots + 4) * 4, s));
+        launch_read_minimizer(s, R, c->sort_key.as<uint32_t>(), c->hit_pos.as<uint32_t>());
+        hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
+        size_t sort_tmp = 0;
+        HIPCHK(c, prim::SortPairs(nullptr, sort_tmp, c->sort_key.as<uint32_t>(), c->sort_key2.as<uint32_t>(), c->perm.as<uint32_t>(), c->perm2.as<uint32_t>(), n, 0, 32, s));
+        if (int rc = ensure_cub(c, sort_tmp)) return rc;
+        HIPCHK(c, prim::SortPairs(c->cub_tmp.p, sort_tmp, c->sort_key.as<uint32_t>(), c->sort_key2.as<uint32_t>(), c->perm.as<uint32_t>(), c->perm2.as<uint32_t>(), n, 0, 32, s));
+        launch_solid_flags(s, R, c->B, c->d_rv16, c->perm2.as<uint32_t>(), c->hit_pos.as<uint32_t>(), c->events.as<uint32_t>());
+        launch_qual_rewrite(s, R, c->events.as<uint32_t>(), d_quals);
+    } else launch_qual_smooth(s, R, c->B, c->d_rv16, d_quals);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(s));
     return LEON_OK;

@@ -141,6 +141,140 @@ void launch_hdr_symbols(hipStream_t s, const uint8_t* hdr, const uint64_t* off, 
 // ================================================================================================
 namespace leon {
 
+// ---- the smoothing's bloom probes, shared between the reads of a locus ----
+// In file order every k-mer of every read costs its random sectors (100 M reads: 1.1 s at the chip's rate; taking the reads in a
+// better ORDER alone gives 7 %: a read's sectors are gone from L2 long before its neighbour is looked at).
+// The walk shares probes because the reads of an anchor sit in neighbouring lanes and step through the same genome k-mers in the
+// same instruction.  The same here, without the dictionary: every read is anchored on its MINIMIZER (its canonical k-mer of
+// smallest hash); reads are sorted by it, one lane per read, and every lane goes through its k-mers outwards from the minimizer,
+// one step to either side per iteration, the side towards the canonical k-mer's "right" first whatever the read's strand -- so at
+// iteration g all reads that share a minimizer ask for the SAME genome k-mer, and identical addresses coalesce in the wave's own
+// memory instruction.  The flags (k-mer solid or not, one bit per position) go to an array laid out like the N mask; a second,
+// streaming kernel turns them into coverages and rewrites the qualities.  Measured at 100 M x 150 bp: 1 106 -> 580 ms, FETCH_SIZE
+// 1.76 TB = 2.3 sectors per k-mer position; what is left is mostly the reads whose minimizer a sequencing error destroyed (a
+// quarter of them at 1 % errors, k = 31): they land in clusters of their own, and the k-mers over errors, which no read shares.
+template <typename K>
+__global__ void __launch_bounds__(256) k_read_minimizer(ReadsDev R, uint32_t* key, uint32_t* mpos) {
+    const uint32_t lane = lane_id(), k = R.k;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < R.n; i += nwaves) {
+        const uint32_t len = R.len[i];
+        if (len < k) { if (lane == 0) { key[i] = 0xFFFFFFFFu; mpos[i] = 0; } continue; }     // reads shorter than k: last, untouched
+        const uint32_t nk = len - k + 1;
+        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+        uint64_t best = ~0ull;                                   // (hash << 32) | position: the smallest hash, its first position
+        for (uint32_t base = 0; base < nk; base += 64) {
+            const uint32_t p = base + lane;
+            const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
+            const uint64_t cand = ((uint64_t)(key_hash(cn) >> 33) << 32) | p;
+            if (p < nk && cand < best) best = cand;
+        }
+        for (int d = 32; d; d >>= 1) {
+            const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, d);
+            best = o < best ? o : best;
+        }
+        if (lane == 0) {
+            const uint32_t m = (uint32_t)best;
+            const K km = kmer_at<K>(pk, m, k);
+            const uint32_t fwd = km <= revcomp(km, k) ? 1u : 0u;   // the read carries the minimizer in its canonical orientation
+            key[i] = (uint32_t)(best >> 32);
+            mpos[i] = (m << 1) | fwd;
+        }
+    }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_solid_flags(ReadsDev R, BloomDev B, const uint16_t* rv16g, const uint32_t* perm, const uint32_t* mpos,
+                                                    uint32_t* flags) {
+    __shared__ uint16_t rv16[256];
+    load_rv16(rv16, rv16g);
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= R.n) return;
+    const uint32_t i = perm[t], k = R.k, len = R.len[i];
+    if (len < k) return;
+    const uint32_t nk = len - k + 1, m = mpos[i] >> 1;
+    const bool fwd = (mpos[i] & 1u) != 0;
+    const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+    uint32_t* fl = flags + R.slot_off[i];
+    const K mask = kmask<K>(k);
+    const uint32_t top = 2 * (k - 1);
+    // side P goes to higher positions, side M to lower ones; each keeps its k-mer, the reverse complement and a word of the read
+    K xP = kmer_at<K>(pk, m, k), rP = revcomp(xP, k), xM = xP, rM = rP;
+    uint32_t wP = 0, wP_idx = 0xFFFFFFFFu, wM = 0, wM_idx = 0xFFFFFFFFu;
+    // flags collected per 32-position word and side, handed over when the side moves on to another word
+    uint32_t aP = 0, aP_idx = m >> 5, aM = 0, aM_idx = m >> 5;
+    if (bloom_contains_xr<K>(B, rv16, xP, rP)) aP |= 1u << (m & 31);
+    const uint32_t nP = nk - 1 - m, nM = m, nmax = nP > nM ? nP : nM;
+    for (uint32_t g = 1; g <= nmax; g++) {
+        // "A" = the side towards the canonical minimizer's right (P for a read that carries it forwards, M otherwise), "B" = the other
+        const bool onP = g <= nP, onM = g <= nM;
+        if (onP) {                                               // position m + g: the new last base is m + g + k - 1
+            const uint32_t q = m + g + k - 1;
+            if ((q >> 4) != wP_idx) { wP_idx = q >> 4; wP = pk[wP_idx]; }
+            const uint32_t b = (wP >> (30 - 2 * (q & 15))) & 3u;
+            xP = ((xP << 2) | (K)b) & mask;
+            rP = (rP >> 2) | ((K)(b ^ 2u) << top);
+        }
+        if (onM) {                                               // position m - g: the new first base is m - g
+            const uint32_t q = m - g;
+            if ((q >> 4) != wM_idx) { wM_idx = q >> 4; wM = pk[wM_idx]; }
+            const uint32_t b = (wM >> (30 - 2 * (q & 15))) & 3u;
+            xM = (xM >> 2) | ((K)b << top);
+            rM = ((rM << 2) | (K)(b ^ 2u)) & mask;
+        }
+        const bool onA = fwd ? onP : onM, onB = fwd ? onM : onP;
+        // (both sides' first hashes in flight together, then the rest of both: measured, no different -- 487 against 471 ms; the
+        // kernel is bound by its sectors, 1.76 TB at 100 M reads, not by their latency)
+        const bool sA = onA && bloom_contains_xr<K>(B, rv16, fwd ? xP : xM, fwd ? rP : rM);
+        const bool sB = onB && bloom_contains_xr<K>(B, rv16, fwd ? xM : xP, fwd ? rM : rP);
+        const bool sP = fwd ? sA : sB, sM = fwd ? sB : sA;
+        if (onP) {
+            const uint32_t p = m + g;
+            if ((p >> 5) != aP_idx) { if (aP) atomicOr(fl + aP_idx, aP); aP = 0; aP_idx = p >> 5; }
+            if (sP) aP |= 1u << (p & 31);
+        }
+        if (onM) {
+            const uint32_t p = m - g;
+            if ((p >> 5) != aM_idx) { if (aM) atomicOr(fl + aM_idx, aM); aM = 0; aM_idx = p >> 5; }
+            if (sM) aM |= 1u << (p & 31);
+        }
+    }
+    if (aP) atomicOr(fl + aP_idx, aP);
+    if (aM) atomicOr(fl + aM_idx, aM);
+}
+
+// coverages from the flags, qualities rewritten: one wave per read, lane = position (DnaEncoder::smoothQuals as restated in DESIGN 1.4)
+__global__ void __launch_bounds__(256) k_qual_rewrite(ReadsDev R, const uint32_t* flags, uint8_t* quals) {
+    const uint32_t lane = lane_id(), k = R.k;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < R.n; i += nwaves) {
+        const uint32_t len = R.len[i];
+        if (len < k) continue;
+        const uint32_t* fl = flags + R.slot_off[i];
+        uint8_t* q = quals + (R.base_off[i] - R.base_off[0]);
+        unsigned long long prev = 0;                              // solid flags of k-mer positions [base - 64, base)
+        for (uint32_t base = 0; base < len; base += 64) {
+            const uint32_t p = base + lane;
+            // positions [base, base + 64): two words of the read's flag array (it has a word per 32-base slot; bits past the
+            // last k-mer are zero)
+            const uint32_t nw = (len + 31) >> 5, w0 = base >> 5;
+            const unsigned long long cur = (unsigned long long)(w0 < nw ? fl[w0] : 0u) | ((unsigned long long)(w0 + 1 < nw ? fl[w0 + 1] : 0u) << 32);
+            if (p < len) {
+                const unsigned __int128 both = ((unsigned __int128)cur << 64) | prev;
+                const uint32_t lo = lane + 65 - k;                // k <= 63: lo >= 2
+                const unsigned __int128 win = (both >> lo) & ((((unsigned __int128)1) << k) - 1);
+                const uint32_t cover = (uint32_t)__popcll((unsigned long long)win) + (uint32_t)__popcll((unsigned long long)(win >> 64));
+                const uint8_t c = q[p];
+                if (cover >= 2u || c > (uint8_t)'@') q[p] = (uint8_t)'@';
+            }
+            prev = cur;
+        }
+    }
+}
+
+// the smoothing in file order, every read probing for itself: small batches, and the measurement reference (LEON_QUAL_ORDER=0)
 template <typename K>
 __global__ void __launch_bounds__(256) k_qual_smooth(ReadsDev R, BloomDev B, const uint16_t* rv16g, uint8_t* quals) {
     __shared__ uint16_t rv16[256];
@@ -175,12 +309,26 @@ __global__ void __launch_bounds__(256) k_qual_smooth(ReadsDev R, BloomDev B, con
         }
     }
 }
+static uint32_t wave_grid(uint64_t n) { uint64_t g = (n + 3) / 4; return (uint32_t)(g > 256 * 16 ? 256 * 16 : g); }
+void launch_read_minimizer(hipStream_t s, ReadsDev R, uint32_t* key, uint32_t* mpos) {
+    if (!R.n) return;
+    if (R.k >= 32) hipLaunchKernelGGL(k_read_minimizer<u128>, dim3(wave_grid(R.n)), dim3(256), 0, s, R, key, mpos);
+    else hipLaunchKernelGGL(k_read_minimizer<uint64_t>, dim3(wave_grid(R.n)), dim3(256), 0, s, R, key, mpos);
+}
+void launch_solid_flags(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const uint32_t* perm, const uint32_t* mpos, uint32_t* flags) {
+    if (!R.n) return;
+    const uint32_t g = (uint32_t)((R.n + 255) / 256);
+    if (R.k >= 32) hipLaunchKernelGGL(k_solid_flags<u128>, dim3(g), dim3(256), 0, s, R, B, rv16, perm, mpos, flags);
+    else hipLaunchKernelGGL(k_solid_flags<uint64_t>, dim3(g), dim3(256), 0, s, R, B, rv16, perm, mpos, flags);
+}
+void launch_qual_rewrite(hipStream_t s, ReadsDev R, const uint32_t* flags, uint8_t* quals) {
+    if (!R.n) return;
+    hipLaunchKernelGGL(k_qual_rewrite, dim3(wave_grid(R.n)), dim3(256), 0, s, R, flags, quals);
+}
 void launch_qual_smooth(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, uint8_t* quals) {
     if (!R.n) return;
-    uint64_t g = (R.n + 3) / 4;
-    if (g > 256 * 16) g = 256 * 16;
-    if (R.k >= 32) hipLaunchKernelGGL(k_qual_smooth<u128>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, quals);
-    else hipLaunchKernelGGL(k_qual_smooth<uint64_t>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, quals);
+    if (R.k >= 32) hipLaunchKernelGGL(k_qual_smooth<u128>, dim3(wave_grid(R.n)), dim3(256), 0, s, R, B, rv16, quals);
+    else hipLaunchKernelGGL(k_qual_smooth<uint64_t>, dim3(wave_grid(R.n)), dim3(256), 0, s, R, B, rv16, quals);
 }
 
 }  // namespace leon

@@ -109,7 +109,12 @@ void launch_gather_payload(hipStream_t s, const uint8_t* out, const uint64_t* ou
                            const uint64_t* sizes, uint64_t n_blocks, uint8_t* dst);
 
 // ---- quality stream, lossy form: DnaEncoder::smoothQuals over packed reads, quals in place (indexed like the bases) ----
-void launch_qual_smooth(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, uint8_t* quals);
+void launch_qual_smooth(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, uint8_t* quals);     // file order, every read probes for itself
+// the same with the probes shared between the reads of a locus: minimizer per read -> (caller sorts) -> solid flags -> rewrite
+void launch_read_minimizer(hipStream_t s, ReadsDev R, uint32_t* key /*its hash, 31 bits; 0xFFFFFFFF for reads shorter than k*/, uint32_t* mpos /*position << 1 | forward*/);
+void launch_solid_flags(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const uint32_t* perm, const uint32_t* mpos,
+                        uint32_t* flags /*a word per 32-base slot like nmask, zeroed*/);
+void launch_qual_rewrite(hipStream_t s, ReadsDev R, const uint32_t* flags, uint8_t* quals);
 // ---- decoder (DnaDecoder) ----
 // what the decoding waves have learnt from the bloom, shared in HBM (decode_kernels.hip): 64-byte buckets of write-once slots
 struct PathCache { uint64_t* slots; uint64_t bucket_mask; };          // slots == nullptr: off

@@ -353,12 +353,13 @@ void Leon::executeCompression() {
     // ---- lossy qualities (the default): smoothed against the bloom on the device, then the same zlib blocks ----
     if (keep_qual && !_lossless && qstore && qstore->n_bases == n_bases) {
         // smoothed where they lie, then back to the host chunk by chunk: chunk i is deflated by the host threads while
-        // chunk i + 1 is smoothed and copied
+        // chunk i + 1 is copied
+        // ONE call over the whole file: the library smooths the reads in the order of their minimizers, so that reads of the same
+        // locus follow one another and share their bloom probes in cache -- which needs them all in one call
+        check(ctx[0].get(), leon_qual_smooth_batch_device(ctx[0].get(), store[0]->d_bases, store[0]->d_off, n_reads, qstore->d_bases), "leon_qual_smooth_batch_device");
         for (uint64_t r = 0; r < n_reads;) {
             const uint64_t got = std::min<uint64_t>(batch_reads, n_reads - r);
             const uint64_t nb = offsets[r + got] - offsets[r];
-            check(ctx[0].get(), leon_qual_smooth_batch_device(ctx[0].get(), store[0]->d_bases, store[0]->d_off + r, got, qstore->d_bases + offsets[r]),
-                  "leon_qual_smooth_batch_device");
             auto quals = std::make_shared<std::string>();
             quals->resize(nb);
             if (nb) check(nullptr, leon_device_download(store[0]->device, &(*quals)[0], qstore->d_bases + offsets[r], nb), "leon_device_download");

@@ -82,8 +82,8 @@ def test_header_stream_batches_shards_and_state():
 
 
 @pytest.mark.parametrize("k,kw", [(31, dict(n_rate=0.003, err=0.02)), (21, dict(ragged=True, n_rate=0.001)), (47, dict(err=0.03)), (63, dict())])
-def test_lossy_quality_smoothing_equals_the_oracle(k, kw):
-    """leon_qual_smooth_batch (DnaEncoder::smoothQuals on the device, one wave per read) == the CPU restatement, every byte"""
+def test_lossy_quality_smoothing_equals_the_oracle(k, kw, monkeypatch):
+    """leon_qual_smooth_batch (DnaEncoder::smoothQuals on the device) == the CPU restatement, every byte, whichever way the device goes through the reads"""
     import common
     bases, off = common.synthetic(1500, 150 if k < 60 else 220, 9000, seed=31 + k, **kw)
     n = len(off) - 1
@@ -94,11 +94,16 @@ def test_lossy_quality_smoothing_equals_the_oracle(k, kw):
     import leon_amd
     ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=500, bloom_tai=tai)
     ctx.bloom_upload(bl.bits)
-    got = ctx.qual_smooth_batch(bases, off, b"".join(quals))
+    got = ctx.qual_smooth_batch(bases, off, b"".join(quals))        # the probes shared between the reads of a locus (minimizer order)
     want = b"".join(O.qual_smooth(bl, k, r, q) for r, q in zip(reads, quals))
     assert len(got) == len(want)
     assert got == want
     assert want != b"".join(quals)                                  # something was smoothed
+    monkeypatch.setenv("LEON_QUAL_ORDER", "0")                      # every read probing for itself, in file order: the same bytes
+    assert ctx.qual_smooth_batch(bases, off, b"".join(quals)) == want
+    monkeypatch.delenv("LEON_QUAL_ORDER")
+    few = 100                                                       # a batch too small for the sort: file order again
+    assert ctx.qual_smooth_batch(bases, off[:few + 1], b"".join(quals[:few])) == b"".join(O.qual_smooth(bl, k, r, q) for r, q in zip(reads[:few], quals[:few]))
     assert ctx.qual_smooth_batch(b"", np.zeros(1, dtype=np.uint64), b"") == b""
     ctx.close()
 
