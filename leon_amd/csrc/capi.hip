@@ -110,6 +110,7 @@ struct leon_dna_ctx {
     DevBuf blk_begin, out_off, out_size, rc_out, rc_scratch, dst_off, payload, errflag, nerr, wbits, fbits, pbits;
     void* h_payload = nullptr; size_t h_payload_cap = 0;
     uint64_t last_n = 0, last_bases = 0;
+    const void* last_d_bases = nullptr; const void* last_d_off = nullptr;      // the last encoded batch: its anchors can serve the smoothing of the same reads
     // decoder: the path cache (decode_kernels.hip) lives as long as the bloom it was learnt from
     DevBuf dc_cache;
     DevBuf dc_out, dc_pay, dc_len, dc_pool, dc_scr;   // a decode call's large buffers, kept from call to call (a fresh 15 GB allocation waits 0.3 s for the driver to wipe it)
@@ -636,6 +637,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     auto ms = [&](int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, c->ev[a], c->ev[b]); return v; };
     c->stats.n_reads = nl; c->stats.n_bases = nl_bases; c->stats.n_blocks = nbl; c->stats.n_anchors = c->n_anchors;
     c->last_n = n; c->last_bases = nl_bases;
+    c->last_d_bases = d_bases; c->last_d_off = d_off;
     if (nl == 0) {                                            // nothing of this batch is ours to encode
         HIPCHK(c, hipStreamSynchronize(s));
         float pack2 = 0; for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
@@ -1027,7 +1029,14 @@ int leon_qual_smooth_batch_device(leon_dna_ctx* c, const uint8_t* d_bases, const
         HIPCHK(c, c->hit_pos.ensure(n * 4));                    // (the minimizers' positions; the encode's per-read arrays are free between batches)
         HIPCHK(c, c->events.ensure((n_slots + 4) * 4));         // (the flags)
         HIPCHK(c, hipMemsetAsync(c->events.p, 0, (n_slots + 4) * 4, s));
-        launch_read_minimizer(s, R, c->sort_key.as<uint32_t>(), c->hit_pos.as<uint32_t>());
+        // the reads of the batch this context encoded last (the CLI smooths a file right after its DNA stream): their ANCHORS are
+        // at hand and serve better than minimizers -- a read with a sequencing error in its minimizer lands in a cluster of its
+        // own, one with an error in an anchor k-mer simply has another anchor.  (Which k-mer a read is aligned on only decides
+        // who shares probes with whom, never a flag: stale anchors would cost time, not bytes; positions are range-checked.)
+        const bool anchors = n == c->last_n && d_bases == c->last_d_bases && d_off == c->last_d_off && c->shard_world == 1 && !c->poisoned;
+        if (anchors) launch_mpos_from_anchors(s, R, c->anchor_pos.as<int32_t>(), c->anchor_addr.as<uint32_t>(), c->flags.as<uint8_t>(),
+                                              c->sort_key.as<uint32_t>(), c->hit_pos.as<uint32_t>());
+        else launch_read_minimizer(s, R, c->sort_key.as<uint32_t>(), c->hit_pos.as<uint32_t>());
         hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
         size_t sort_tmp = 0;
         HIPCHK(c, prim::SortPairs(nullptr, sort_tmp, c->sort_key.as<uint32_t>(), c->sort_key2.as<uint32_t>(), c->perm.as<uint32_t>(), c->perm2.as<uint32_t>(), n, 0, 32, s));
@@ -1147,7 +1156,7 @@ int leon_dna_reset_stream(leon_dna_ctx* c) {
     c->n_keys = 0; c->n_anchors = 0;
     c->next_read = 0; c->next_block = 0; c->partial_seen = false; c->finished = false; c->poisoned = false;
     c->hdr_next_read = 0; c->hdr_next_block = 0; c->hdr_partial_seen = false;
-    c->last_n = 0; c->last_bases = 0;
+    c->last_n = 0; c->last_bases = 0; c->last_d_bases = c->last_d_off = nullptr;
     return LEON_OK;
 }
 

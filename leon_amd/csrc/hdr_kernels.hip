@@ -6,6 +6,7 @@
 // serial part is left to k_rc_encode (rc_kernels.hip) with this stream's model set.  The record layout is the one
 // DESIGN.md section 1.3 states; the tests compare payload bytes with the CPU restatement of the same rules.
 #include "kernels.h"
+#include <algorithm>
 
 namespace leon {
 
@@ -182,6 +183,20 @@ __global__ void __launch_bounds__(256) k_read_minimizer(ReadsDev R, uint32_t* ke
             mpos[i] = (m << 1) | fwd;
         }
     }
+}
+
+__global__ void k_mpos_from_anchors(ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr, const uint8_t* flags, uint32_t* key, uint32_t* mpos) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < R.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t len = R.len[i], k = R.k;
+        const int32_t a = anchor_pos[i];
+        if (len < k) { key[i] = 0xFFFFFFFFu; mpos[i] = 0; }
+        else if (a < 0 || (uint32_t)a > len - k) { key[i] = 0xFFFFFFFEu; mpos[i] = 1; }          // no (usable) anchor: on its own, from its first k-mer
+        else { key[i] = anchor_addr[i]; mpos[i] = ((uint32_t)a << 1) | ((flags[i] & 1u) ? 0u : 1u); }   // flags bit 0: the anchor is reverse-complemented in the read
+    }
+}
+void launch_mpos_from_anchors(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr, const uint8_t* flags, uint32_t* key, uint32_t* mpos) {
+    if (!R.n) return;
+    hipLaunchKernelGGL(k_mpos_from_anchors, dim3((uint32_t)std::min<uint64_t>((R.n + 255) / 256, 8192)), dim3(256), 0, s, R, anchor_pos, anchor_addr, flags, key, mpos);
 }
 
 template <typename K>

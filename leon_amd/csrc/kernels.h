@@ -112,6 +112,8 @@ void launch_gather_payload(hipStream_t s, const uint8_t* out, const uint64_t* ou
 void launch_qual_smooth(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, uint8_t* quals);     // file order, every read probes for itself
 // the same with the probes shared between the reads of a locus: minimizer per read -> (caller sorts) -> solid flags -> rewrite
 void launch_read_minimizer(hipStream_t s, ReadsDev R, uint32_t* key /*its hash, 31 bits; 0xFFFFFFFF for reads shorter than k*/, uint32_t* mpos /*position << 1 | forward*/);
+// ... or, for reads whose anchors are known, the anchor in the minimizer's place (key = the anchor's address)
+void launch_mpos_from_anchors(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr, const uint8_t* flags, uint32_t* key, uint32_t* mpos);
 void launch_solid_flags(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const uint32_t* perm, const uint32_t* mpos,
                         uint32_t* flags /*a word per 32-base slot like nmask, zeroed*/);
 void launch_qual_rewrite(hipStream_t s, ReadsDev R, const uint32_t* flags, uint8_t* quals);

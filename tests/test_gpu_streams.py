@@ -102,6 +102,11 @@ def test_lossy_quality_smoothing_equals_the_oracle(k, kw, monkeypatch):
     monkeypatch.setenv("LEON_QUAL_ORDER", "0")                      # every read probing for itself, in file order: the same bytes
     assert ctx.qual_smooth_batch(bases, off, b"".join(quals)) == want
     monkeypatch.delenv("LEON_QUAL_ORDER")
+    ctx.reset_stream()                                              # after an encode of the same reads the device aligns them on their ANCHORS instead
+    ctx.encode_batch(bases, off)
+    ctx.finish()
+    assert ctx.qual_smooth_batch(bases, off, b"".join(quals)) == want
+    ctx.reset_stream()
     few = 100                                                       # a batch too small for the sort: file order again
     assert ctx.qual_smooth_batch(bases, off[:few + 1], b"".join(quals[:few])) == b"".join(O.qual_smooth(bl, k, r, q) for r, q in zip(reads[:few], quals[:few]))
     assert ctx.qual_smooth_batch(b"", np.zeros(1, dtype=np.uint64), b"") == b""
