@@ -486,6 +486,8 @@ def main():
             "end_to_end": e2e,
             "streams": streams,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
+            # `value` is the host chain's (one core of rank 0): which CPU that was, and what a dictionary symbol cost on it
+            "host": host_info(stage["ms_chain_busy"], n_anchors * K),
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
                       "symbols": int(stage["n_symbols"]), "resolve_rounds": int(stage["resolve_rounds"]),
                       "bits_per_base": round(8.0 * (payload[0] + dict_bytes) / (max(n_local, 1) * L), 4)},
@@ -495,6 +497,20 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_info(chain_ms, chain_symbols):
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu": model, "cpus_allowed": len(os.sched_getaffinity(0)),
+            "chain_ns_per_symbol": round(chain_ms * 1e6 / chain_symbols, 3) if chain_symbols else None}
 
 
 def bench_streams(ctx, capi, reads, offsets, n_total, device):

@@ -83,6 +83,7 @@ def test_default_bench_line_fills_every_key():
     assert line["streams"]["header_decode"]["equal_input"] is True and line["streams"]["qual_smooth"]["MBps"] > 0
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
     assert "UNPINNED" in line["parity"]
+    assert line["host"]["cpus_allowed"] >= 1 and line["host"]["chain_ns_per_symbol"] > 0
     # the same file as ONE batch: same bytes
     one = _bench(1, extra_args=("--reads", "1000000"))
     assert one["verify"]["blocks_sha256"] == line["verify"]["blocks_sha256"] and one["verify"]["dict_sha256"] == line["verify"]["dict_sha256"]
