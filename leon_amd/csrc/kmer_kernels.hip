@@ -9,6 +9,8 @@
 #include "staging.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -17,25 +19,63 @@ void set_create_error(const std::string& msg);   // capi.hip: message behind leo
 
 namespace {
 
-// k-mers of partition `part` (of n_parts, by hash).  EMIT = false: counts[i] = how many read i contributes;
-// EMIT = true: they are written at keys[start[i] ...] (start = exclusive scan of the counts): no atomics, exact sizes.
-template <typename K, bool EMIT>
-__global__ void __launch_bounds__(256) k_part_kmers(ReadsDev R, uint32_t n_parts, uint32_t part, uint64_t* counts_or_start, uint64_t* keys) {
+// k-mers of partition `part` (of n_parts, by hash), in ONE pass over the reads.  The order of a partition's k-mers does not
+// matter -- the sort follows -- so a wave takes the buffer chunk by chunk (PART_CHUNK slots, one atomic add on the cursor per
+// chunk) and writes what it selects behind one another inside its chunk; what a chunk has left when the next 64 positions might not
+// fit, and at the wave's end, is filled with a key no k-mer has (all ones: a canonical k-mer is never all G, its reverse
+// complement all C is smaller), which the sort moves to the end of the partition; *npad counts them.  Round 2 counted per
+// read, scanned, then emitted at exact offsets: two passes of ~36 ms per partition at 100 M reads, half of the counter's time.
+// (Measured on the way: staging the k-mers in LDS and flushing them in full lines, 64 ms per pass with 256 k-mers per flush
+// -- 5.6 M atomic adds on one address go through one L2 channel one after the other -- and 52 ms with 1 024.)
+// *cursor may run past cap (nothing is written there): the caller checks.
+constexpr uint32_t PART_CHUNK = 1024;
+// the partition of a canonical k-mer: every pass asks it of every k-mer of the input, so it is a few 32-bit operations (a
+// multiply per word, one mixing round, a multiply-high for the range) rather than the 64-bit mixer and a modulo by a run-time
+// divisor, which were most of the pass's instructions (40 -> ... ms per pass at 100 M reads).  Any function of the canonical
+// k-mer does; this one only has to spread the k-mers evenly (the buffers have a quarter of slack).
+__device__ inline uint32_t part_mix(uint32_t x) { x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13; return x; }
+__device__ inline uint32_t part_of(uint64_t c, uint32_t n_parts) {
+    return __umulhi(part_mix((uint32_t)c * 0x9E3779B1u + (uint32_t)(c >> 32) * 0x85EBCA77u), n_parts);
+}
+__device__ inline uint32_t part_of(u128 c, uint32_t n_parts) {
+    const uint64_t lo = (uint64_t)c, hi = (uint64_t)(c >> 64);
+    return __umulhi(part_mix((uint32_t)lo * 0x9E3779B1u + (uint32_t)(lo >> 32) * 0x85EBCA77u + (uint32_t)hi * 0xC2B2AE3Du + (uint32_t)(hi >> 32) * 0x27D4EB2Fu), n_parts);
+}
+template <typename K>
+__global__ void __launch_bounds__(256) k_part_kmers(ReadsDev R, uint32_t n_parts, uint32_t part, uint64_t* keys, uint64_t cap, unsigned long long* cursor,
+                                                    unsigned long long* npad) {
     const uint32_t lane = lane_id(), k = R.k;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t i = wave; i < R.n; i += nwaves) {
-        const uint32_t len = R.len[i];
-        uint64_t at = EMIT ? counts_or_start[i] : 0;
+    uint64_t at = 0, end = 0, pads = 0;                         // wave-uniform: the chunk's next free slot and its end
+    auto pad = [&]() {
+        for (uint64_t i = at + lane; i < end; i += 64)
+            if (i < cap) store_kmer(keys + i * KT<K>::W, ~(K)0);
+        pads += end - at;
+    };
+    // a wave's reads come one after the other, and each needs its length, its slot and then its first dwords: the next read's
+    // are asked for while the current one is worked on (two dependent round trips per read otherwise, with nothing beside them)
+    uint64_t i = wave;
+    uint32_t len = 0, ncnt = 0, words0 = 0;
+    uint64_t so = 0;
+    if (i < R.n) { len = R.len[i]; so = R.slot_off[i]; ncnt = R.n_count[i]; words0 = pass_words(R.packed + 2 * so, 0, lane); }
+    while (i < R.n) {
+        const uint64_t inext = i + nwaves;
+        uint32_t len_n = 0, ncnt_n = 0;
+        uint64_t so_n = 0;
+        if (inext < R.n) { len_n = R.len[inext]; so_n = R.slot_off[inext]; ncnt_n = R.n_count[inext]; }
+        uint32_t words_n = 0;
         if (len >= k) {
-            const uint32_t* pk = R.packed + 2 * R.slot_off[i];
-            const uint32_t* nm = R.nmask + R.slot_off[i];
-            const bool hasN = R.n_count[i] != 0;
+            const uint32_t* pk = R.packed + 2 * so;
+            const uint32_t* nm = R.nmask + so;
+            const bool hasN = ncnt != 0;
             const uint32_t nk = len - k + 1;
             for (uint32_t base = 0; base < nk; base += 64) {
+                const uint32_t words = base == 0 ? words0 : pass_words(pk, base, lane);
+                if (base + 64 >= nk && inext < R.n) words_n = pass_words(R.packed + 2 * so_n, 0, lane);   // (the next read's slot is here by now)
                 const uint32_t p = base + lane;
                 bool valid = p < nk;
-                const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, valid ? p : nk - 1, k);
+                const K cn = canon_from_words<K>(words, base, valid ? p : nk - 1, k);
                 if (valid && hasN) {                          // any N in [p, p + k) ?
                     for (uint32_t d = p >> 5; d <= (p + k - 1) >> 5 && valid; d++) {
                         const uint32_t lo = d == (p >> 5) ? (p & 31) : 0, hi = d == ((p + k - 1) >> 5) ? ((p + k - 1) & 31) : 31;
@@ -43,14 +83,27 @@ __global__ void __launch_bounds__(256) k_part_kmers(ReadsDev R, uint32_t n_parts
                         if (nm[d] & m) valid = false;
                     }
                 }
-                if (valid && n_parts > 1) valid = (uint32_t)((key_hash(cn) >> 40) % n_parts) == part;
+                if (valid && n_parts > 1) valid = part_of(cn, n_parts) == part;
                 const unsigned long long b = __ballot(valid);
-                if (EMIT && valid) store_kmer(keys + (at + __popcll(b & ((1ull << lane) - 1))) * KT<K>::W, cn);
-                at += __popcll(b);
+                const uint32_t c = (uint32_t)__popcll(b);
+                if (!c) continue;
+                if (at + c > end) {                           // the next chunk
+                    pad();
+                    unsigned long long nb = 0;
+                    if (lane == 0) nb = atomicAdd(cursor, (unsigned long long)PART_CHUNK);
+                    nb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(nb >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
+                    at = nb; end = nb + PART_CHUNK;
+                }
+                const uint64_t slot = at + (uint32_t)__popcll(b & ((1ull << lane) - 1));
+                if (valid && slot < cap) store_kmer(keys + slot * KT<K>::W, cn);
+                at += c;
             }
-        }
-        if (!EMIT && lane == 0) counts_or_start[i] = at;
+        } else if (inext < R.n) words_n = pass_words(R.packed + 2 * so_n, 0, lane);
+        i = inext; len = len_n; so = so_n; ncnt = ncnt_n; words0 = words_n;
     }
+    pad();
+    if (lane == 0 && pads) atomicAdd(npad, (unsigned long long)pads);
 }
 
 __global__ void k_positions(const uint64_t* off, uint64_t n, uint32_t k, uint64_t* out) {
@@ -86,6 +139,51 @@ __global__ void __launch_bounds__(256) k_flag_runs(const uint64_t* keys, uint64_
     }
     __syncthreads();
     if (hist && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+// ---- compaction of the flagged heads, in order: per-tile counts, a scan of the (few) tile counts, then every tile writes its own ----
+// (rocPRIM's select took 22-27 ms per partition of 2^30 keys, ten times the bandwidth's time: the flags are sparse -- one key in
+// twenty-five is the head of a solid run -- and byte flags of 8 items are one 64-bit load here)
+constexpr uint32_t CT_TILE = 256 * 8;
+__device__ inline uint64_t ct_flags8(const uint8_t* flags, uint64_t i0, uint64_t n) {
+    if (i0 + 8 <= n) return *(const uint64_t*)(flags + i0) & 0x0101010101010101ull;
+    uint64_t x = 0;
+    for (uint32_t j = 0; j < 8 && i0 + j < n; j++) x |= (uint64_t)(flags[i0 + j] & 1u) << (8 * j);
+    return x;
+}
+__device__ inline uint32_t ct_wave_incl(uint32_t c, uint32_t lane) {                // inclusive scan over the wave's lanes
+    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)c, d); if (lane >= d) c += o; }
+    return c;
+}
+__global__ void __launch_bounds__(256) k_tile_counts(const uint8_t* flags, uint64_t n, uint64_t* counts) {
+    __shared__ uint32_t part[4];
+    const uint64_t i0 = blockIdx.x * (uint64_t)CT_TILE + threadIdx.x * 8;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = i0 < n ? (uint32_t)__popcll(ct_flags8(flags, i0, n)) : 0u;
+    const uint32_t inc = ct_wave_incl(c, lane);
+    if (lane == 63) part[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = (uint64_t)part[0] + part[1] + part[2] + part[3];
+}
+template <uint32_t W>
+__global__ void __launch_bounds__(256) k_tile_compact(const uint8_t* flags, uint64_t n, const uint64_t* tile_off, const uint64_t* keys, uint64_t* dst,
+                                                       const uint8_t* runlen, uint8_t* runsel) {
+    __shared__ uint32_t part[4];
+    const uint64_t i0 = blockIdx.x * (uint64_t)CT_TILE + threadIdx.x * 8;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint64_t x = i0 < n ? ct_flags8(flags, i0, n) : 0ull;
+    const uint32_t c = (uint32_t)__popcll(x);
+    const uint32_t inc = ct_wave_incl(c, lane);
+    if (lane == 63) part[w] = inc;
+    __syncthreads();
+    uint64_t at = tile_off[blockIdx.x] + (inc - c);
+    for (uint32_t v = 0; v < w; v++) at += part[v];
+    for (uint64_t m = x; m; m &= m - 1) {
+        const uint64_t i = i0 + ((uint32_t)__builtin_ctzll(m) >> 3);
+        dst[at * W] = keys[i * W];
+        if (W == 2) dst[at * W + 1] = keys[i * W + 1];
+        if (runlen) runsel[at] = runlen[i];
+        at++;
+    }
 }
 __global__ void k_flag_at_least(const uint8_t* counts, uint64_t n, uint32_t T, uint8_t* flags) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) flags[i] = counts[i] >= T ? 1 : 0;
@@ -227,7 +325,9 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     }
     uint32_t n_parts = (uint32_t)((total + max_keys_per_pass - 1) / max_keys_per_pass);
     if (n_parts < 1) n_parts = 1;
-    const uint64_t cap = n_parts == 1 ? total : (uint64_t)(total / n_parts * 1.25) + (1u << 20);
+    const uint32_t part_grid = grid(n_reads, 4, 256 * 16);
+    // (every wave of the partition pass leaves at most one chunk partly used, and up to 63 slots at the end of each chunk)
+    const uint64_t cap = (n_parts == 1 ? total : (uint64_t)(total / n_parts * 1.25) + (1u << 20)) + (uint64_t)part_grid * 4 * PART_CHUNK + total / n_parts / 8;
     // ---- per-partition buffers ----
     Buf keys, alt, alt2, alt3, flags, nsel, hist, sort_tmp, sel_tmp, runlen, runsel;
     KCHK(keys.alloc(cap * 8 * W)); KCHK(alt.alloc(cap * 8 * W)); KCHK(flags.alloc(cap));
@@ -251,58 +351,51 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     const bool want_hist = histogram != nullptr || automatic;
 #define KCHK2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_create_error(std::string(#call) + ": " + hipGetErrorString(e_)); return fail_free(LEON_E_HIP); } } while (0)
     if (automatic) KCHK2(hipMalloc((void**)&out_cnt, out_cap));
-    size_t scan_tb = 0;
-    KCHK2(prim::ExclusiveSum(nullptr, scan_tb, pos.as<uint64_t>(), pos.as<uint64_t>(), n_reads + 1, s));
-    Buf scan_tmp;
-    KCHK2(scan_tmp.alloc(scan_tb));
+    Buf cursor, tile_cnt, tile_tmp;
+    KCHK2(cursor.alloc(16));
+    const size_t max_tiles = (size_t)(cap / CT_TILE) + 2;
+    KCHK2(tile_cnt.alloc(max_tiles * 8));
+    size_t tile_tb = 0;
+    KCHK2(prim::ExclusiveSum(nullptr, tile_tb, tile_cnt.as<uint64_t>(), tile_cnt.as<uint64_t>(), max_tiles, s));
+    KCHK2(tile_tmp.alloc(tile_tb));
+    const bool trace = getenv("LEON_TRACE_KMER") != nullptr;
     for (uint32_t part = 0; part < n_parts; part++) {
-        // count per read, scan, emit at exact offsets (pos[] is reused: n_reads + 1 entries)
-        KCHK2(hipMemsetAsync(pos.as<uint64_t>() + n_reads, 0, 8, s));
-        if (W == 1) hipLaunchKernelGGL((k_part_kmers<uint64_t, false>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), (uint64_t*)nullptr);
-        else hipLaunchKernelGGL((k_part_kmers<u128, false>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), (uint64_t*)nullptr);
-        KCHK2(prim::ExclusiveSum(scan_tmp.p, scan_tb, pos.as<uint64_t>(), pos.as<uint64_t>(), n_reads + 1, s));
-        uint64_t n = 0;
-        KCHK2(hipMemcpy(&n, pos.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost));
-        if (n > cap) { set_create_error("kmer_solid: a hash partition exceeds its buffer (very skewed k-mer spectrum); lower max_keys_per_pass"); return fail_free(LEON_E_OVERFLOW); }
-        if (n) {
-            if (W == 1) hipLaunchKernelGGL((k_part_kmers<uint64_t, true>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), keys.as<uint64_t>());
-            else hipLaunchKernelGGL((k_part_kmers<u128, true>), dim3(grid(n_reads, 4, 256 * 16)), dim3(256), 0, s, R, n_parts, part, pos.as<uint64_t>(), keys.as<uint64_t>());
-        }
+        // one pass: the partition's k-mers in whatever order the waves' chunks make it (the sort follows), padded with all-ones keys
+        KCHK2(hipMemsetAsync(cursor.p, 0, 16, s));
+        if (W == 1) hipLaunchKernelGGL((k_part_kmers<uint64_t>), dim3(part_grid), dim3(256), 0, s, R, n_parts, part, keys.as<uint64_t>(), cap, cursor.as<unsigned long long>(), cursor.as<unsigned long long>() + 1);
+        else hipLaunchKernelGGL((k_part_kmers<u128>), dim3(part_grid), dim3(256), 0, s, R, n_parts, part, keys.as<uint64_t>(), cap, cursor.as<unsigned long long>(), cursor.as<unsigned long long>() + 1);
+        uint64_t cur[2] = {0, 0};
+        KCHK2(hipMemcpy(cur, cursor.p, 16, hipMemcpyDeviceToHost));
+        if (cur[0] > cap) { set_create_error("kmer_solid: a hash partition exceeds its buffer (very skewed k-mer spectrum); lower max_keys_per_pass"); return fail_free(LEON_E_OVERFLOW); }
+        const uint64_t n_all = cur[0], n = cur[0] - cur[1];      // with and without the padding, which sorts to the end
+        if (trace) fprintf(stderr, "[leon kmer] partition %u of %u: %llu k-mers (+ %llu of padding), buffer %llu\n", part, n_parts, (unsigned long long)n, (unsigned long long)cur[1], (unsigned long long)cap);
         if (!n) continue;
         uint64_t* sorted = nullptr;
         if (W == 1) {
-            KCHK2(prim::SortKeys(sort_tmp.p, st, keys.as<uint64_t>(), alt.as<uint64_t>(), n, 0, 2 * k, s));
+            KCHK2(prim::SortKeys(sort_tmp.p, st, keys.as<uint64_t>(), alt.as<uint64_t>(), n_all, 0, 2 * k, s));
             sorted = alt.as<uint64_t>();
         } else {                                              // 128-bit keys: LSD in two stable passes (low word, then high word)
             uint64_t* lo = alt.as<uint64_t>(); uint64_t* hi = lo + cap;
-            hipLaunchKernelGGL(k_split_words, dim3(grid(n)), dim3(256), 0, s, keys.as<uint64_t>(), n, lo, hi);
-            KCHK2(prim::SortPairs(sort_tmp.p, st, lo, alt2.as<uint64_t>(), hi, alt3.as<uint64_t>(), n, 0, 64, s));     // by low
-            KCHK2(prim::SortPairs(sort_tmp.p, st, alt3.as<uint64_t>(), hi, alt2.as<uint64_t>(), lo, n, 0, 2 * k - 64 > 0 ? 2 * k - 64 : 1, s));   // by high (stable)
-            hipLaunchKernelGGL(k_join_words, dim3(grid(n)), dim3(256), 0, s, lo, hi, n, keys.as<uint64_t>());
+            hipLaunchKernelGGL(k_split_words, dim3(grid(n_all)), dim3(256), 0, s, keys.as<uint64_t>(), n_all, lo, hi);
+            KCHK2(prim::SortPairs(sort_tmp.p, st, lo, alt2.as<uint64_t>(), hi, alt3.as<uint64_t>(), n_all, 0, 64, s));     // by low
+            KCHK2(prim::SortPairs(sort_tmp.p, st, alt3.as<uint64_t>(), hi, alt2.as<uint64_t>(), lo, n_all, 0, 2 * k - 64 > 0 ? 2 * k - 64 : 1, s));   // by high (stable)
+            hipLaunchKernelGGL(k_join_words, dim3(grid(n_all)), dim3(256), 0, s, lo, hi, n_all, keys.as<uint64_t>());
             sorted = keys.as<uint64_t>();
         }
         if (W == 1) hipLaunchKernelGGL(k_flag_runs<1>, dim3(grid(n)), dim3(256), 0, s, sorted, n, min_abundance, flags.as<uint8_t>(), want_hist ? hist.as<unsigned long long>() : nullptr, runlen.as<uint8_t>());
         else hipLaunchKernelGGL(k_flag_runs<2>, dim3(grid(n)), dim3(256), 0, s, sorted, n, min_abundance, flags.as<uint8_t>(), want_hist ? hist.as<unsigned long long>() : nullptr, runlen.as<uint8_t>());
         // compact the heads of solid runs behind what earlier partitions produced
         uint64_t* dst = (sorted == keys.as<uint64_t>()) ? alt.as<uint64_t>() : keys.as<uint64_t>();
-        size_t need = 0;
-        if (W == 1) {
-            KCHK2(prim::Flagged(nullptr, need, sorted, flags.as<uint8_t>(), dst, nsel.as<uint64_t>(), n, s));
-            if (need > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need)); sl = need; }
-            KCHK2(prim::Flagged(sel_tmp.p, need, sorted, flags.as<uint8_t>(), dst, nsel.as<uint64_t>(), n, s));
-        } else {
-            KCHK2(prim::Flagged(nullptr, need, (Pair128*)sorted, flags.as<uint8_t>(), (Pair128*)dst, nsel.as<uint64_t>(), n, s));
-            if (need > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need)); sl = need; }
-            KCHK2(prim::Flagged(sel_tmp.p, need, (Pair128*)sorted, flags.as<uint8_t>(), (Pair128*)dst, nsel.as<uint64_t>(), n, s));
-        }
-        if (automatic) {                                        // the same heads' run lengths, in the same order
-            size_t need2 = 0;
-            KCHK2(prim::Flagged(nullptr, need2, runlen.as<uint8_t>(), flags.as<uint8_t>(), runsel.as<uint8_t>(), nsel.as<uint64_t>(), n, s));
-            if (need2 > sl) { if (sel_tmp.p) { (void)hipFree(sel_tmp.p); sel_tmp.p = nullptr; } KCHK2(sel_tmp.alloc(need2)); sl = need2; }
-            KCHK2(prim::Flagged(sel_tmp.p, need2, runlen.as<uint8_t>(), flags.as<uint8_t>(), runsel.as<uint8_t>(), nsel.as<uint64_t>(), n, s));
-        }
+        const uint32_t n_tiles = (uint32_t)((n + CT_TILE - 1) / CT_TILE);
+        KCHK2(hipMemsetAsync(tile_cnt.as<uint64_t>() + n_tiles, 0, 8, s));
+        hipLaunchKernelGGL(k_tile_counts, dim3(n_tiles), dim3(256), 0, s, flags.as<uint8_t>(), n, tile_cnt.as<uint64_t>());
+        KCHK2(prim::ExclusiveSum(tile_tmp.p, tile_tb, tile_cnt.as<uint64_t>(), tile_cnt.as<uint64_t>(), (size_t)n_tiles + 1, s));
+        if (W == 1) hipLaunchKernelGGL(k_tile_compact<1>, dim3(n_tiles), dim3(256), 0, s, flags.as<uint8_t>(), n, tile_cnt.as<uint64_t>(), sorted, dst,
+                                       automatic ? runlen.as<uint8_t>() : (const uint8_t*)nullptr, runsel.as<uint8_t>());
+        else hipLaunchKernelGGL(k_tile_compact<2>, dim3(n_tiles), dim3(256), 0, s, flags.as<uint8_t>(), n, tile_cnt.as<uint64_t>(), sorted, dst,
+                                automatic ? runlen.as<uint8_t>() : (const uint8_t*)nullptr, runsel.as<uint8_t>());
         uint64_t ns = 0;
-        KCHK2(hipMemcpy(&ns, nsel.p, 8, hipMemcpyDeviceToHost));
+        KCHK2(hipMemcpy(&ns, tile_cnt.as<uint64_t>() + n_tiles, 8, hipMemcpyDeviceToHost));
         if (out_n + ns > out_cap) {
             uint64_t nc = std::max(out_cap * 2, out_n + ns);
             uint64_t* bigger = nullptr;
