@@ -9,6 +9,7 @@
 #include "staging.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -198,8 +199,26 @@ struct Pair128 { uint64_t lo, hi; };
 
 struct Buf {
     void* p = nullptr;
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) {
+        static const bool trace = getenv("LEON_TRACE_ALLOC") != nullptr;       // (as in capi.hip: allocations of 1 ms or more on stderr)
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (trace) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms >= 1.0) fprintf(stderr, "[leon alloc] kmer: %.1f MB in %.1f ms\n", bytes / 1e6, ms);
+        }
+        return e;
+    }
+    ~Buf() {
+        if (!p) return;
+        static const bool trace = getenv("LEON_TRACE_ALLOC") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        (void)hipFree(p);
+        if (trace) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms >= 1.0) fprintf(stderr, "[leon alloc] kmer: free in %.1f ms\n", ms);
+        }
+    }
     template <typename T> T* as() { return (T*)p; }
 };
 uint32_t grid(uint64_t n, uint32_t per = 256, uint32_t cap = 8192) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + per - 1) / per, cap)); }
