@@ -428,6 +428,25 @@ def test_device_solid_kmer_counting(k, min_ab, maxkeys):
     ctx.close()
 
 
+@pytest.mark.parametrize("k", [5, 31, 32, 63])
+def test_solid_kmer_counting_homopolymers_and_padding(k):
+    """the counter pads its partition buffers with the all-ones key (all G), which must never be a canonical k-mer nor be
+    counted: reads of all G / all C / all A / all T beside ordinary ones, several partitions, inputs smaller than one chunk"""
+    from leon_amd import capi
+    bases, off = common.synthetic(300, 100, 2000, seed=500 + k)
+    reads = [bytes(bases[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    reads += [b"G" * 90] * 5 + [b"C" * 90] * 4 + [b"A" * 70] * 3 + [b"T" * 70] * 3 + [b"G" * (k - 1)] + [b"ACGT" * 30] * 2
+    b2, o2 = O.reads_to_arrays(reads)
+    for maxkeys in (0, 3000):
+        for min_ab in (1, 3):
+            exp = O.count_solid(b2, o2, k, min_ab)
+            got, hist = capi.kmer_solid(b2, o2, k, min_ab, with_histogram=True, max_keys_per_pass=maxkeys)
+            assert sorted(O.kmers_to_ints(got, k)) == sorted(O.kmers_to_ints(exp, k)), (k, maxkeys, min_ab)
+            assert int(hist.sum()) == len(O.count_solid(b2, o2, k, 1)) // O.kwords(k)
+    one = capi.kmer_solid(*O.reads_to_arrays([b"G" * k]), k, 1)                      # a single k-mer, all G: counted as all C
+    assert O.kmers_to_ints(one, k) == [int("01" * k, 2)]
+
+
 def test_very_long_read_three_byte_numerics():
     # one read longer than 65535 bases: read size / anchor-relative positions need three-byte numerics (numeric models [0..3])
     import synth
