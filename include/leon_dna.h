@@ -204,6 +204,13 @@ int leon_qual_smooth_batch_device(leon_dna_ctx* ctx, const uint8_t* d_bases, con
  * on n_threads threads; blocks go to the sink in increasing id starting at first_block_id.  zlib_level: -1 = zlib default. */
 int leon_host_qual_encode_blocks(const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads, uint32_t reads_per_block,
                                  int zlib_level, uint32_t n_threads, leon_block_sink sink, void* user, uint64_t first_block_id);
+/* The same blocks written on the device: d_quals = the qualities in device memory (d_quals[j] is the byte at offsets[0] + j of the
+ * concatenation, as leon_qual_smooth_batch_device leaves them), offsets in HOST memory.  Each block is a zlib stream that inflates
+ * to the block's quality lines, each followed by '\n' -- what leon_host_qual_decode_blocks (or upstream's inflate) reads -- but
+ * not the bytes zlib's default strategy would write: deflate with matches at distance 1 only (zlib's Z_RLE) and dynamic Huffman
+ * codes per 32 KB of text (deflate_kernels.hip).  Errors: leon_last_error(NULL). */
+int leon_qual_deflate_blocks_device(int device_id, const uint8_t* d_quals, const uint64_t* offsets, uint64_t n_reads,
+                                    uint32_t reads_per_block, leon_block_sink sink, void* user, uint64_t first_block_id);
 /* inverse: block_n_bytes = quality bytes per block without the newlines; out_off[total reads + 1] */
 int leon_host_qual_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
                                  const uint64_t* block_n_bytes, uint64_t n_blocks, uint8_t* out, uint64_t out_cap,

@@ -99,6 +99,7 @@ _EXPORTS = {
     "leon_device_download": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "leon_host_qual_encode_blocks": (C.c_int, [C.c_char_p, _u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, SINK, C.c_void_p,
                                                 C.c_uint64]),
+    "leon_qual_deflate_blocks_device": (C.c_int, [C.c_int, C.c_void_p, _u64p, C.c_uint64, C.c_uint32, SINK, C.c_void_p, C.c_uint64]),
     "leon_host_qual_decode_blocks": (C.c_int, [_u8p, _u64p, _u32p, _u64p, C.c_uint64, _u8p, C.c_uint64, _u64p, C.c_uint32]),
 }
 EXPORTED_SYMBOLS = tuple(_EXPORTS)
@@ -206,6 +207,23 @@ def host_qual_encode_blocks(quals, offsets, reads_per_block, zlib_level=-1, n_th
     return blocks
 
 
+def qual_deflate_blocks_device(d_quals_ptr, offsets, reads_per_block, device_id=0, first_block_id=0):
+    """the lossless quality blocks written by the device (RLE deflate + dynamic Huffman): [(id, zlib payload, n_reads)];
+    d_quals_ptr = device pointer to the concatenated qualities, offsets on the host"""
+    lib = load_library()
+    blocks = []
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+
+    def cb(user, block_id, payload, size, n_reads):
+        blocks.append((block_id, C.string_at(payload, size), n_reads))
+        return 0
+    rc = lib.leon_qual_deflate_blocks_device(device_id, C.c_void_p(int(d_quals_ptr)), _ptr(offsets, _u64p), len(offsets) - 1, reads_per_block,
+                                             SINK(cb), None, first_block_id)
+    if rc:
+        raise LeonDnaError(rc, (lib.leon_last_error(None) or b"").decode())
+    return blocks
+
+
 def host_qual_decode_blocks(blocks, block_n_bytes, n_threads=0):
     lib = load_library()
     if not blocks:
@@ -268,6 +286,19 @@ def kmer_solid_device(d_bases_ptr, d_offsets_ptr, n_reads, k, min_abundance, dev
 def device_free(ptr):
     if ptr:
         load_library().leon_device_free(C.c_void_p(int(ptr)))
+
+
+def device_upload_bytes(data, device_id=0):
+    """a new device buffer holding `data` (bytes-like); the caller frees it with device_free"""
+    lib = load_library()
+    data = bytes(data)
+    p = C.c_void_p()
+    rc = lib.leon_device_alloc(device_id, len(data) + 64, C.byref(p))
+    if rc == 0 and data:
+        rc = lib.leon_device_upload(device_id, p, C.c_char_p(data), len(data))
+    if rc:
+        raise LeonDnaError(rc, (lib.leon_last_error(None) or b"").decode())
+    return p.value
 
 
 class DnaEncodeContext:

@@ -148,6 +148,38 @@ int device_for(int gpu_index) {
     return gpu_index % n_dev;
 }
 
+
+// Which encoder writes the quality blocks.  The device's deflate (leon_qual_deflate_blocks_device) looks for runs only -- zlib's
+// Z_RLE strategy -- which is what quality strings usually reward, and is tens of times faster than zlib's default strategy on
+// all the host's cores; but where the lines resemble one another (old instruments' staircases, a file of identical lines) the
+// default strategy's matches against earlier lines win.  So a sample decides (LEON_QUAL_DEFLATE=device|host overrides): the first
+// reads' lines, up to 256 KB, through zlib both ways; the device takes the stream unless that would cost more than 2 %.
+enum class QualEncoder { Auto, Device, Host };
+QualEncoder qual_encoder_from_env() {
+    const char* e = getenv("LEON_QUAL_DEFLATE");
+    if (!e || !*e || !strcmp(e, "auto")) return QualEncoder::Auto;
+    if (!strcmp(e, "device")) return QualEncoder::Device;
+    if (!strcmp(e, "host")) return QualEncoder::Host;
+    throw Exception(std::string("LEON_QUAL_DEFLATE=") + e + ": expected auto, device or host");
+}
+size_t deflated_size(const std::string& text, int strategy) {
+    z_stream z{};
+    if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15, 8, strategy) != Z_OK) return 0;
+    std::vector<uint8_t> out(deflateBound(&z, (uLong)text.size()));
+    z.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(text.data())); z.avail_in = (uInt)text.size();
+    z.next_out = out.data(); z.avail_out = (uInt)out.size();
+    const int rc = deflate(&z, Z_FINISH);
+    const size_t n = rc == Z_STREAM_END ? (size_t)z.total_out : 0;
+    deflateEnd(&z);
+    return n;
+}
+bool runs_are_enough(const char* quals, const uint64_t* off, uint64_t n_reads) {
+    std::string text;
+    for (uint64_t r = 0; r < n_reads && text.size() < (256u << 10); r++) { text.append(quals + (off[r] - off[0]), off[r + 1] - off[r]); text.push_back('\n'); }
+    if (text.size() < 1024) return true;
+    const size_t d = deflated_size(text, Z_DEFAULT_STRATEGY), r = deflated_size(text, Z_RLE);
+    return d && r && (double)r <= 1.02 * (double)d;
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ Leon
@@ -232,7 +264,11 @@ void Leon::executeCompression() {
     std::vector<uint64_t> hdr_text;                              // bytes of header text per read block: the decoder sizes its buffers from it
     const uint64_t batch_reads = 64ull * rpb;
     ReadBatch batch;
-    std::future<void> qual_job;
+    const QualEncoder qual_enc = qual_encoder_from_env();
+    bool qual_on_device = false;
+    void* d_qbuf = nullptr; uint64_t d_qbuf_cap = 0;             // the batch's qualities on the device, for its deflate (one job at a time uses it)
+    struct QBufGuard { void** p; ~QBufGuard() { leon_device_free(*p); } } qbuf_guard{&d_qbuf};
+    std::future<void> qual_job;                                  // (declared after the buffer it uses: joined before that is freed)
     // Lossy qualities need the bloom, which needs the whole file: they stay resident on device 0 (one byte per base, indexed
     // like the bases) until then, unless the file is too large for that (LEON_QUAL_RESIDENT_MB, default 64 GB): then a
     // second pass over the file feeds them through.
@@ -260,13 +296,28 @@ void Leon::executeCompression() {
             for (uint64_t r = 0; r < got; r += rpb) hdr_text.push_back(batch.header_off[std::min<uint64_t>(got, r + rpb)] - batch.header_off[r]);   // (batches are whole blocks but the last)
         }
         qual_bytes += batch.quals.size();
-        if (keep_qual && _lossless) {                            // deflated on the host threads while the next batch is being parsed
+        if (keep_qual && _lossless) {                            // deflated while the next batch is being parsed: on the device, or on the host threads
             if (qual_job.valid()) qual_job.get();
+            if (n_reads == 0) qual_on_device = qual_enc == QualEncoder::Device || (qual_enc == QualEncoder::Auto && runs_are_enough(batch.quals.data(), batch.qual_off.data(), got));
             auto quals = std::make_shared<std::string>(std::move(batch.quals));
             auto qoff = std::make_shared<std::vector<uint64_t>>(batch.qual_off);
             const uint64_t first_block = n_reads / rpb;
             const uint32_t cores = (uint32_t)_nbCores;
-            qual_job = std::async(std::launch::async, [quals, qoff, got, first_block, cores, &wq] {
+            const int qdev = store[0]->device;
+            const bool on_device = qual_on_device;
+            qual_job = std::async(std::launch::async, [quals, qoff, got, first_block, cores, qdev, on_device, &wq, &d_qbuf, &d_qbuf_cap] {
+                if (on_device) {
+                    if (quals->size() > d_qbuf_cap) {
+                        leon_device_free(d_qbuf); d_qbuf = nullptr; d_qbuf_cap = 0;
+                        const uint64_t want = quals->size() + quals->size() / 8 + 64;
+                        check(nullptr, leon_device_alloc(qdev, want, &d_qbuf), "leon_device_alloc");
+                        d_qbuf_cap = want;
+                    }
+                    if (!quals->empty()) check(nullptr, leon_device_upload(qdev, d_qbuf, quals->data(), quals->size()), "leon_device_upload");
+                    int rc = leon_qual_deflate_blocks_device(qdev, static_cast<const uint8_t*>(d_qbuf), qoff->data(), got, READ_PER_BLOCK, StreamWriter::sink, &wq, first_block);
+                    check_sink(nullptr, rc, wq, "leon_qual_deflate_blocks_device");
+                    return;
+                }
                 int rc = leon_host_qual_encode_blocks(reinterpret_cast<const uint8_t*>(quals->data()), qoff->data(), got, READ_PER_BLOCK, -1, cores, StreamWriter::sink, &wq,
                                                       first_block);
                 check_sink(nullptr, rc, wq, "leon_host_qual_encode_blocks");
@@ -357,16 +408,28 @@ void Leon::executeCompression() {
         // ONE call over the whole file: the library smooths the reads in the order of their minimizers, so that reads of the same
         // locus follow one another and share their bloom probes in cache -- which needs them all in one call
         check(ctx[0].get(), leon_qual_smooth_batch_device(ctx[0].get(), store[0]->d_bases, store[0]->d_off, n_reads, qstore->d_bases), "leon_qual_smooth_batch_device");
+        {   // the sample that picks the encoder: the first reads' smoothed lines
+            const uint64_t ns = std::min<uint64_t>(n_reads, 4000);
+            std::string sample(offsets[ns] - offsets[0], '\0');
+            if (!sample.empty()) check(nullptr, leon_device_download(store[0]->device, &sample[0], qstore->d_bases, sample.size()), "leon_device_download");
+            qual_on_device = qual_enc == QualEncoder::Device || (qual_enc == QualEncoder::Auto && runs_are_enough(sample.data(), offsets.data(), ns));
+        }
         for (uint64_t r = 0; r < n_reads;) {
             const uint64_t got = std::min<uint64_t>(batch_reads, n_reads - r);
             const uint64_t nb = offsets[r + got] - offsets[r];
+            const uint64_t first_block = r / rpb;
+            if (qual_on_device) {                                // deflated where they lie
+                int rc = leon_qual_deflate_blocks_device(store[0]->device, qstore->d_bases + offsets[r], offsets.data() + r, got, READ_PER_BLOCK, StreamWriter::sink, &wq, first_block);
+                check_sink(nullptr, rc, wq, "leon_qual_deflate_blocks_device");
+                r += got;
+                continue;
+            }
             auto quals = std::make_shared<std::string>();
             quals->resize(nb);
             if (nb) check(nullptr, leon_device_download(store[0]->device, &(*quals)[0], qstore->d_bases + offsets[r], nb), "leon_device_download");
             auto qoff = std::make_shared<std::vector<uint64_t>>(got + 1);
             for (uint64_t i = 0; i <= got; i++) (*qoff)[i] = offsets[r + i] - offsets[r];
             if (qual_job.valid()) qual_job.get();
-            const uint64_t first_block = r / rpb;
             const uint32_t cores = (uint32_t)_nbCores;
             qual_job = std::async(std::launch::async, [quals, qoff, got, first_block, cores, &wq] {
                 int rc = leon_host_qual_encode_blocks(reinterpret_cast<const uint8_t*>(quals->data()), qoff->data(), got, READ_PER_BLOCK, -1, cores, StreamWriter::sink, &wq,
@@ -395,10 +458,21 @@ void Leon::executeCompression() {
             check(nullptr, leon_device_upload(store[0]->device, d_q, batch.quals.data(), batch.quals.size()), "leon_device_upload");
             check(ctx[0].get(), leon_qual_smooth_batch_device(ctx[0].get(), store[0]->d_bases, store[0]->d_off + r, got, static_cast<uint8_t*>(d_q)),
                   "leon_qual_smooth_batch_device");
-            check(nullptr, leon_device_download(store[0]->device, &batch.quals[0], d_q, batch.quals.size()), "leon_device_download");
-            int rc = leon_host_qual_encode_blocks(reinterpret_cast<const uint8_t*>(batch.quals.data()), batch.qual_off.data(), got, rpb, -1, (uint32_t)_nbCores,
-                                                  StreamWriter::sink, &wq, r / rpb);
-            check_sink(nullptr, rc, wq, "leon_host_qual_encode_blocks");
+            if (r == 0) {                                        // the sample that picks the encoder: the first reads' smoothed lines
+                const uint64_t ns = std::min<uint64_t>(got, 4000);
+                std::string sample(batch.qual_off[ns] - batch.qual_off[0], '\0');
+                if (!sample.empty()) check(nullptr, leon_device_download(store[0]->device, &sample[0], d_q, sample.size()), "leon_device_download");
+                qual_on_device = qual_enc == QualEncoder::Device || (qual_enc == QualEncoder::Auto && runs_are_enough(sample.data(), batch.qual_off.data(), ns));
+            }
+            if (qual_on_device) {
+                int rc = leon_qual_deflate_blocks_device(store[0]->device, static_cast<const uint8_t*>(d_q), batch.qual_off.data(), got, rpb, StreamWriter::sink, &wq, r / rpb);
+                check_sink(nullptr, rc, wq, "leon_qual_deflate_blocks_device");
+            } else {
+                check(nullptr, leon_device_download(store[0]->device, &batch.quals[0], d_q, batch.quals.size()), "leon_device_download");
+                int rc = leon_host_qual_encode_blocks(reinterpret_cast<const uint8_t*>(batch.quals.data()), batch.qual_off.data(), got, rpb, -1, (uint32_t)_nbCores,
+                                                      StreamWriter::sink, &wq, r / rpb);
+                check_sink(nullptr, rc, wq, "leon_host_qual_encode_blocks");
+            }
             r += got;
             if (got < batch_reads) break;
         }
@@ -451,7 +525,8 @@ void Leon::executeCompression() {
     std::cout << "DNA stream: " << n_reads << " reads, " << n_bases << " bases -> " << dna_bytes << " bytes (" << n_anchors << " anchors, "
               << n_blocks << " blocks, abundance threshold " << abundance << (_abundance ? "" : " (automatic)") << ", " << n_solid << " solid k-mers)\n";
     if (keep_header) std::cout << "header stream: " << header_bytes << " bytes -> " << wh.bytes << " bytes\n";
-    if (keep_qual) std::cout << "quality stream (" << (_lossless ? "lossless" : "lossy") << "): " << qual_bytes << " bytes -> " << wq.bytes << " bytes\n";
+    if (keep_qual) std::cout << "quality stream (" << (_lossless ? "lossless" : "lossy") << "): " << qual_bytes << " bytes -> " << wq.bytes << " bytes"
+                             << (qual_on_device ? " (deflated on the device: runs + dynamic Huffman codes)" : " (zlib on the host threads)") << "\n";
     std::cout << "written to " << _outputFilename << std::endl;
     if (_verbose)
         std::cout << "time: parse + headers" << (keep_qual && _lossless ? " + qualities " : " ") << t_parse << " s, k-mer counting " << t_kmers << " s, contexts + bloom "

@@ -31,6 +31,8 @@ with open(fq, "wb") as f:
         quals = np.frombuffer(b"#5:?ABCDEFGHIJ", dtype=np.uint8)[np.minimum(rng.integers(0, 14, (n, L)), rng.integers(4, 14, (n, 1)))]
         rec = [h + r.tobytes() + b"\n+\n" + q.tobytes() + b"\n" for h, r, q in zip(head.tolist(), reads, quals)]
         f.write(b"".join(rec))
+        if c0 % 10 == 9:
+            print("generated %d M reads, %.0f s" % (c0 + 1, time.time() - t0), file=sys.stderr, flush=True)
 gen_s = time.time() - t0
 del genome
 torch.cuda.empty_cache()

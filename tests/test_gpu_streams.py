@@ -194,3 +194,58 @@ def test_header_stream_fuzz(seed):
     assert capi.host_header_decode_blocks(blocks, first, n_threads=3) == hs
     assert ctx.header_decode_blocks(blocks, first, n_threads=3) == hs
     ctx.close()
+
+
+def _quality_sets():
+    import random
+    rnd = random.Random(11)
+    sets = {}
+    sets["uniform19"] = H.fastq_quals(6000, 150, seed=5)                                   # near-incompressible: 19 symbols, no runs
+    binned = []                                                                            # four levels with long runs (modern instruments)
+    for _ in range(5000):
+        q, cur = bytearray(), 70
+        for _ in range(150):
+            if rnd.random() < 0.08:
+                cur = rnd.choice(b"#,:F")
+            q.append(cur)
+        binned.append(bytes(q))
+    sets["binned_runs"] = binned
+    sets["constant"] = [b"I" * 151] * 3000                                                 # runs far longer than 258, across chunks and threads
+    sets["ragged"] = [bytes(rnd.choice(b"ABCDEFGH!~") for _ in range(rnd.choice((0, 1, 2, 3, 40, 257, 258, 259, 260, 700)))) for _ in range(2500)]
+    sets["all_bytes"] = [bytes((i * 7 + j) % 256 if (i * 7 + j) % 256 != 10 else 11 for j in range(300)) for i in range(400)]   # 255 literal symbols in use
+    sets["empty_lines"] = [b""] * 1000
+    sets["one_read"] = [b"#"]
+    sets["skewed"] = [b"F" * 140 + bytes(rnd.choice(b"#,:") for _ in range(10)) for _ in range(4000)]
+    return sets
+
+
+@pytest.mark.parametrize("name", ["uniform19", "binned_runs", "constant", "ragged", "all_bytes", "empty_lines", "one_read", "skewed"])
+def test_device_deflate_of_quality_blocks(name):
+    """leon_qual_deflate_blocks_device: every block is a zlib stream that inflates to the block's quality lines (any inflate reads
+    it: Python's here, the product's own decoder below), about as small as zlib's own RLE strategy makes it, and the Adler-32
+    the host combines from the chunks' is the text's"""
+    import zlib
+    from leon_amd import capi
+    qs = _quality_sets()[name]
+    rpb = 1000 if len(qs) > 1 else 50
+    blob, off = O.reads_to_arrays(qs)
+    d = capi.device_upload_bytes(blob)
+    try:
+        blocks = capi.qual_deflate_blocks_device(d, off, rpb, first_block_id=7)
+    finally:
+        capi.device_free(d)
+    assert [b[0] for b in blocks] == [7 + i for i in range((len(qs) + rpb - 1) // rpb)]
+    tot_dev = tot_rle = tot_def = 0
+    for i, (bid, pay, nr) in enumerate(blocks):
+        text = b"".join(q + b"\n" for q in qs[i * rpb:(i + 1) * rpb])
+        assert nr == len(qs[i * rpb:(i + 1) * rpb])
+        assert zlib.decompress(pay) == text, (name, i)            # (checks the Adler-32 too)
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_RLE)
+        tot_rle += len(c.compress(text) + c.flush())
+        tot_def += len(zlib.compress(text, 6))
+        tot_dev += len(pay)
+    # 32 KB deflate blocks against zlib's ~100+ KB ones: a few per cent of headers, never more than 5 % + a few bytes per chunk
+    assert tot_dev <= 1.05 * tot_rle + 64 * len(blocks) + 12 * (len(blob) // 32768 + len(blocks)), (name, tot_dev, tot_rle, tot_def)
+    nbytes = [sum(len(q) for q in qs[b * rpb:(b + 1) * rpb]) for b in range(len(blocks))]
+    assert capi.host_qual_decode_blocks([(b[0] - 7, b[1], b[2]) for b in blocks], nbytes, n_threads=2) == qs
+    print("%s: device %d, zlib RLE %d, zlib default %d bytes" % (name, tot_dev, tot_rle, tot_def))
