@@ -18,6 +18,10 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -341,14 +345,118 @@ __global__ void k_deflate_gather(const uint8_t* chunks, const uint32_t* sizes, c
     }
 }
 
-struct DBuf {
-    void* p = nullptr;
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    ~DBuf() { if (p) (void)hipFree(p); }
+// Device buffers kept from call to call (one set per process, taken under a lock): a call per batch of a file would otherwise
+// allocate and free ~1.5 GB each time, and memory this process has freed comes back from hipMalloc at the driver's wiping
+// rate (~43 GB/s), for this call and for whoever allocates next.  Large calls go through in slices, so the set stays small.
+struct Grow {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 4 + 256;
+        const hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
     template <typename T> T* as() { return (T*)p; }
 };
+struct DeflateScratch {
+    std::mutex mu;
+    int device = -1;
+    Grow off, text, cb, cl, out, sizes, adler, cdst, fin;
+    std::vector<uint8_t> h;
+    void drop() { for (Grow* g : {&off, &text, &cb, &cl, &out, &sizes, &adler, &cdst, &fin}) { if (g->p) (void)hipFree(g->p); g->p = nullptr; g->cap = 0; } }
+};
+DeflateScratch& scratch() { static DeflateScratch* s = new DeflateScratch(); return *s; }     // (never destroyed: the HIP runtime may be gone by then)
+
+constexpr uint64_t DF_SLICE_TEXT = 512ull << 20;                // text bytes per slice of a large call
 
 #define DCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_create_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LEON_E_HIP; } } while (0)
+
+// blocks [b0, b1) of the call: reads [r0, r1), whose qualities start at d_quals + (offsets[r0] - offsets[0])
+int deflate_slice(DeflateScratch& S, int device_id, const uint8_t* d_quals, const uint64_t* offsets, uint64_t r0, uint64_t r1, uint32_t reads_per_block,
+                  leon_block_sink sink, void* user, uint64_t first_block_id) {
+    hipStream_t s = nullptr;
+    static const bool trace = getenv("LEON_TRACE_DEFLATE") != nullptr;           // measurement aid: a slice's stages on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    double ms_tables = 0, ms_kernels = 0, ms_d2h = 0;
+    const uint64_t n_reads = r1 - r0, n_blocks = (n_reads + reads_per_block - 1) / reads_per_block;
+    const uint64_t* off = offsets + r0;
+    const uint64_t q0 = off[0], n_q = off[n_reads] - q0, n_text = n_q + n_reads;
+    const uint8_t* dq = d_quals + (q0 - offsets[0]);
+    // chunk table: block b's text is [blk_text[b], blk_text[b + 1]) of the slice's text, cut in DF_CHUNK pieces
+    std::vector<uint64_t> blk_text(n_blocks + 1), chunk_begin, blk_chunk0(n_blocks + 1);
+    std::vector<uint32_t> chunk_len;
+    for (uint64_t b = 0; b <= n_blocks; b++) {
+        const uint64_t r = std::min<uint64_t>(n_reads, b * reads_per_block);
+        blk_text[b] = off[r] - q0 + r;
+    }
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        blk_chunk0[b] = chunk_begin.size();
+        for (uint64_t p = blk_text[b]; p < blk_text[b + 1]; p += DF_CHUNK) {
+            chunk_begin.push_back(p);
+            chunk_len.push_back((uint32_t)std::min<uint64_t>(DF_CHUNK, blk_text[b + 1] - p));
+        }
+    }
+    blk_chunk0[n_blocks] = chunk_begin.size();
+    const uint64_t n_chunks = chunk_begin.size();
+    ms_tables = ms_since(t_start);
+    const auto t_k = std::chrono::steady_clock::now();
+    DCHK(S.off.ensure((n_reads + 1) * 8)); DCHK(S.text.ensure(n_text + 64));
+    DCHK(staged_h2d(device_id, S.off.p, off, (n_reads + 1) * 8));
+    hipLaunchKernelGGL(k_qual_text, dim3((uint32_t)std::min<uint64_t>((n_reads + 3) / 4, 1u << 16)), dim3(256), 0, s, dq, S.off.as<uint64_t>(), n_reads, q0,
+                       S.text.as<uint8_t>());
+    std::vector<uint32_t> sizes(n_chunks), adl(n_chunks);
+    if (n_chunks) {
+        DCHK(S.cb.ensure(n_chunks * 8)); DCHK(S.cl.ensure(n_chunks * 4)); DCHK(S.out.ensure(n_chunks * (uint64_t)DF_OUT_STRIDE));
+        DCHK(S.sizes.ensure(n_chunks * 4)); DCHK(S.adler.ensure(n_chunks * 4)); DCHK(S.cdst.ensure(n_chunks * 8));
+        DCHK(hipMemcpyAsync(S.cb.p, chunk_begin.data(), n_chunks * 8, hipMemcpyHostToDevice, s));
+        DCHK(hipMemcpyAsync(S.cl.p, chunk_len.data(), n_chunks * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_deflate_chunks, dim3((uint32_t)std::min<uint64_t>(n_chunks, 1u << 20)), dim3(DF_T), 0, s, S.text.as<uint8_t>(), S.cb.as<uint64_t>(),
+                           S.cl.as<uint32_t>(), n_chunks, S.out.as<uint8_t>(), S.sizes.as<uint32_t>(), S.adler.as<uint32_t>());
+        DCHK(hipGetLastError());
+        DCHK(hipMemcpy(sizes.data(), S.sizes.p, n_chunks * 4, hipMemcpyDeviceToHost));
+        DCHK(hipMemcpy(adl.data(), S.adler.p, n_chunks * 4, hipMemcpyDeviceToHost));
+    }
+    // layout of the final streams: per block 2 bytes of zlib header, its chunks, 5 bytes of final stored block, 4 of Adler-32
+    std::vector<uint64_t> blk_dst(n_blocks + 1, 0), chunk_dst(n_chunks);
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        uint64_t at = blk_dst[b] + 2;
+        for (uint64_t c = blk_chunk0[b]; c < blk_chunk0[b + 1]; c++) { chunk_dst[c] = at; at += sizes[c]; }
+        blk_dst[b + 1] = at + 5 + 4;
+    }
+    const uint64_t total = blk_dst[n_blocks];
+    if (S.h.size() < total) S.h.resize(total + total / 4);
+    uint8_t* h = S.h.data();
+    if (n_chunks) {
+        DCHK(S.fin.ensure(total + 16));
+        DCHK(hipMemcpyAsync(S.cdst.p, chunk_dst.data(), n_chunks * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_deflate_gather, dim3((uint32_t)std::min<uint64_t>(n_chunks, 1u << 20)), dim3(256), 0, s, S.out.as<uint8_t>(), S.sizes.as<uint32_t>(),
+                           S.cdst.as<uint64_t>(), n_chunks, S.fin.as<uint8_t>());
+        DCHK(hipGetLastError());
+        DCHK(hipStreamSynchronize(s));
+        ms_kernels = ms_since(t_k);
+        const auto t_d = std::chrono::steady_clock::now();
+        DCHK(staged_d2h(device_id, h, S.fin.p, total));
+        ms_d2h = ms_since(t_d);
+    }
+    const auto t_sink = std::chrono::steady_clock::now();
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        uint8_t* p = h + blk_dst[b];
+        p[0] = 0x78; p[1] = 0x01;
+        uLong ad = adler32(0L, Z_NULL, 0);
+        for (uint64_t c = blk_chunk0[b]; c < blk_chunk0[b + 1]; c++) ad = adler32_combine(ad, adl[c], (z_off_t)chunk_len[c]);
+        uint8_t* e = h + blk_dst[b + 1] - 9;
+        e[0] = 1; e[1] = 0; e[2] = 0; e[3] = 0xFF; e[4] = 0xFF;                  // BFINAL 1, stored, empty
+        e[5] = (uint8_t)(ad >> 24); e[6] = (uint8_t)(ad >> 16); e[7] = (uint8_t)(ad >> 8); e[8] = (uint8_t)ad;
+        const uint32_t nr = (uint32_t)std::min<uint64_t>(reads_per_block, n_reads - b * reads_per_block);
+        if (sink(user, first_block_id + b, p, blk_dst[b + 1] - blk_dst[b], nr)) { set_create_error("qual_deflate: block sink returned non-zero"); return LEON_E_SINK; }
+    }
+    if (trace) fprintf(stderr, "[leon deflate] %llu blocks, %.1f MB of text -> %.1f MB: tables %.1f ms, offsets + kernels %.1f, D2H %.1f, sink %.1f\n",
+                       (unsigned long long)n_blocks, n_text / 1e6, total / 1e6, ms_tables, ms_kernels, ms_d2h, ms_since(t_sink));
+    return LEON_OK;
+}
 
 }  // namespace
 }  // namespace leon
@@ -364,70 +472,18 @@ extern "C" int leon_qual_deflate_blocks_device(int device_id, const uint8_t* d_q
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) { set_create_error("qual_deflate: no such HIP device"); return LEON_E_NO_DEVICE; }
     DCHK(hipSetDevice(device_id));
-    hipStream_t s = nullptr;
+    DeflateScratch& S = scratch();
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (S.device != device_id) { if (S.device >= 0 && hipSetDevice(S.device) == hipSuccess) S.drop(); DCHK(hipSetDevice(device_id)); S.device = device_id; }
     const uint64_t n_blocks = (n_reads + reads_per_block - 1) / reads_per_block;
-    const uint64_t q0 = offsets[0], n_q = offsets[n_reads] - q0, n_text = n_q + n_reads;
-    // chunk table: block b's text is [tb[b], tb[b + 1]) of the batch's text, cut in DF_CHUNK pieces
-    std::vector<uint64_t> blk_text(n_blocks + 1), chunk_begin, blk_chunk0(n_blocks + 1);
-    std::vector<uint32_t> chunk_len;
-    for (uint64_t b = 0; b <= n_blocks; b++) {
-        const uint64_t r = std::min<uint64_t>(n_reads, b * reads_per_block);
-        blk_text[b] = offsets[r] - q0 + r;
-    }
-    for (uint64_t b = 0; b < n_blocks; b++) {
-        blk_chunk0[b] = chunk_begin.size();
-        for (uint64_t p = blk_text[b]; p < blk_text[b + 1]; p += DF_CHUNK) {
-            chunk_begin.push_back(p);
-            chunk_len.push_back((uint32_t)std::min<uint64_t>(DF_CHUNK, blk_text[b + 1] - p));
-        }
-    }
-    blk_chunk0[n_blocks] = chunk_begin.size();
-    const uint64_t n_chunks = chunk_begin.size();
-    DBuf d_off, d_text, d_cb, d_cl, d_out, d_sizes, d_adler, d_cdst, d_final;
-    DCHK(d_off.alloc((n_reads + 1) * 8)); DCHK(d_text.alloc(n_text + 64));
-    DCHK(staged_h2d(device_id, d_off.p, offsets, (n_reads + 1) * 8));
-    hipLaunchKernelGGL(k_qual_text, dim3((uint32_t)std::min<uint64_t>((n_reads + 3) / 4, 1u << 16)), dim3(256), 0, s, d_quals, d_off.as<uint64_t>(), n_reads, q0,
-                       d_text.as<uint8_t>());
-    std::vector<uint32_t> sizes(n_chunks), adl(n_chunks);
-    if (n_chunks) {
-        DCHK(d_cb.alloc(n_chunks * 8)); DCHK(d_cl.alloc(n_chunks * 4)); DCHK(d_out.alloc(n_chunks * (uint64_t)DF_OUT_STRIDE));
-        DCHK(d_sizes.alloc(n_chunks * 4)); DCHK(d_adler.alloc(n_chunks * 4)); DCHK(d_cdst.alloc(n_chunks * 8));
-        DCHK(hipMemcpyAsync(d_cb.p, chunk_begin.data(), n_chunks * 8, hipMemcpyHostToDevice, s));
-        DCHK(hipMemcpyAsync(d_cl.p, chunk_len.data(), n_chunks * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_deflate_chunks, dim3((uint32_t)std::min<uint64_t>(n_chunks, 1u << 20)), dim3(DF_T), 0, s, d_text.as<uint8_t>(), d_cb.as<uint64_t>(),
-                           d_cl.as<uint32_t>(), n_chunks, d_out.as<uint8_t>(), d_sizes.as<uint32_t>(), d_adler.as<uint32_t>());
-        DCHK(hipGetLastError());
-        DCHK(hipMemcpy(sizes.data(), d_sizes.p, n_chunks * 4, hipMemcpyDeviceToHost));
-        DCHK(hipMemcpy(adl.data(), d_adler.p, n_chunks * 4, hipMemcpyDeviceToHost));
-    }
-    // layout of the final streams: per block 2 bytes of zlib header, its chunks, 5 bytes of final stored block, 4 of Adler-32
-    std::vector<uint64_t> blk_dst(n_blocks + 1, 0), chunk_dst(n_chunks);
-    for (uint64_t b = 0; b < n_blocks; b++) {
-        uint64_t at = blk_dst[b] + 2;
-        for (uint64_t c = blk_chunk0[b]; c < blk_chunk0[b + 1]; c++) { chunk_dst[c] = at; at += sizes[c]; }
-        blk_dst[b + 1] = at + 5 + 4;
-    }
-    const uint64_t total = blk_dst[n_blocks];
-    std::vector<uint8_t> h(total);
-    if (n_chunks) {
-        DCHK(d_final.alloc(total + 16));
-        DCHK(hipMemcpyAsync(d_cdst.p, chunk_dst.data(), n_chunks * 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_deflate_gather, dim3((uint32_t)std::min<uint64_t>(n_chunks, 1u << 20)), dim3(256), 0, s, d_out.as<uint8_t>(), d_sizes.as<uint32_t>(),
-                           d_cdst.as<uint64_t>(), n_chunks, d_final.as<uint8_t>());
-        DCHK(hipGetLastError());
-        DCHK(hipStreamSynchronize(s));
-        DCHK(staged_d2h(device_id, h.data(), d_final.p, total));
-    }
-    for (uint64_t b = 0; b < n_blocks; b++) {
-        uint8_t* p = h.data() + blk_dst[b];
-        p[0] = 0x78; p[1] = 0x01;
-        uLong ad = adler32(0L, Z_NULL, 0);
-        for (uint64_t c = blk_chunk0[b]; c < blk_chunk0[b + 1]; c++) ad = adler32_combine(ad, adl[c], (z_off_t)chunk_len[c]);
-        uint8_t* e = h.data() + blk_dst[b + 1] - 9;
-        e[0] = 1; e[1] = 0; e[2] = 0; e[3] = 0xFF; e[4] = 0xFF;                  // BFINAL 1, stored, empty
-        e[5] = (uint8_t)(ad >> 24); e[6] = (uint8_t)(ad >> 16); e[7] = (uint8_t)(ad >> 8); e[8] = (uint8_t)ad;
-        const uint32_t nr = (uint32_t)std::min<uint64_t>(reads_per_block, n_reads - b * reads_per_block);
-        if (sink(user, first_block_id + b, p, blk_dst[b + 1] - blk_dst[b], nr)) { set_create_error("qual_deflate: block sink returned non-zero"); return LEON_E_SINK; }
+    for (uint64_t b0 = 0; b0 < n_blocks;) {                      // slices of whole blocks, ~DF_SLICE_TEXT of text each
+        uint64_t b1 = b0 + 1;
+        const uint64_t r0 = b0 * reads_per_block;
+        while (b1 < n_blocks && offsets[std::min<uint64_t>(n_reads, (b1 + 1) * reads_per_block)] - offsets[r0] <= DF_SLICE_TEXT) b1++;
+        const uint64_t r1 = std::min<uint64_t>(n_reads, b1 * reads_per_block);
+        const int rc = deflate_slice(S, device_id, d_quals, offsets, r0, r1, reads_per_block, sink, user, first_block_id + b0);
+        if (rc) return rc;
+        b0 = b1;
     }
     return LEON_OK;
 }

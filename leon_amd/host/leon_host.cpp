@@ -268,7 +268,6 @@ void Leon::executeCompression() {
     bool qual_on_device = false;
     void* d_qbuf = nullptr; uint64_t d_qbuf_cap = 0;             // the batch's qualities on the device, for its deflate (one job at a time uses it)
     struct QBufGuard { void** p; ~QBufGuard() { leon_device_free(*p); } } qbuf_guard{&d_qbuf};
-    std::future<void> qual_job;                                  // (declared after the buffer it uses: joined before that is freed)
     // Lossy qualities need the bloom, which needs the whole file: they stay resident on device 0 (one byte per base, indexed
     // like the bases) until then, unless the file is too large for that (LEON_QUAL_RESIDENT_MB, default 64 GB): then a
     // second pass over the file feeds them through.
@@ -276,18 +275,29 @@ void Leon::executeCompression() {
     uint64_t qual_resident_max = 64ull << 30;
     if (const char* e = getenv("LEON_QUAL_RESIDENT_MB")) qual_resident_max = (uint64_t)std::max<long long>(0, atoll(e)) << 20;
     if (fastq && !_noQual && !_lossless && qual_resident_max) { qstore.reset(new DeviceReads()); qstore->device = store[0]->device; }
+    const bool qstore_used = qstore != nullptr;
     // the reader runs one batch ahead on its own thread: batch i + 1 is parsed while batch i's headers are coded on the device
     // and its bases (and qualities) cross to it
     ReadBatch buffers[2];
+    std::future<void> qual_job;                                  // (declared after what it reads -- these buffers, d_qbuf -- so that it is joined before they go)
     auto parse_next = [&bank, batch_reads](ReadBatch* b) -> uint64_t { b->clear(); return bank.next(*b, batch_reads); };
     std::future<uint64_t> parsing = std::async(std::launch::async, parse_next, &buffers[0]);
     struct ParseJoin { std::future<uint64_t>& f; ~ParseJoin() { if (f.valid()) { try { f.get(); } catch (...) {} } } } parse_join{parsing};   // (never left running over dead buffers)
+    double w_reader = 0, w_headers = 0, w_quals = 0, w_uploads = 0;   // where the pass's own thread spent its time (-verbose)
     for (uint32_t cur = 0;; cur ^= 1) {
+        auto t_w = std::chrono::steady_clock::now();
         const uint64_t got = parsing.get();                      // (the reader's exceptions surface here)
+        w_reader += seconds_since(t_w);
         if (!got) break;
         ReadBatch& batch = buffers[cur];
+        // the quality blocks of the batch before read this buffer's twin in place: they are done (they started a whole batch ago)
+        // before the reader is allowed to fill it again
+        t_w = std::chrono::steady_clock::now();
+        if (qual_job.valid()) qual_job.get();
+        w_quals += seconds_since(t_w);
         if (got == batch_reads) parsing = std::async(std::launch::async, parse_next, &buffers[cur ^ 1]);
         if (n_reads == 0) first_header.assign(batch.headers, 0, batch.header_off[1]);
+        t_w = std::chrono::steady_clock::now();
         if (keep_header) {
             check_sink(hdr_ctx.get(), leon_header_encode_batch(hdr_ctx.get(), reinterpret_cast<const uint8_t*>(batch.headers.data()), batch.header_off.data(), got, n_reads,
                                                                reinterpret_cast<const uint8_t*>(first_header.data()), first_header.size(), StreamWriter::sink, &wh),
@@ -295,12 +305,15 @@ void Leon::executeCompression() {
             header_bytes += batch.headers.size();
             for (uint64_t r = 0; r < got; r += rpb) hdr_text.push_back(batch.header_off[std::min<uint64_t>(got, r + rpb)] - batch.header_off[r]);   // (batches are whole blocks but the last)
         }
+        w_headers += seconds_since(t_w);
         qual_bytes += batch.quals.size();
+        t_w = std::chrono::steady_clock::now();
         if (keep_qual && _lossless) {                            // deflated while the next batch is being parsed: on the device, or on the host threads
-            if (qual_job.valid()) qual_job.get();
             if (n_reads == 0) qual_on_device = qual_enc == QualEncoder::Device || (qual_enc == QualEncoder::Auto && runs_are_enough(batch.quals.data(), batch.qual_off.data(), got));
-            auto quals = std::make_shared<std::string>(std::move(batch.quals));
-            auto qoff = std::make_shared<std::vector<uint64_t>>(batch.qual_off);
+            // (read in place: moving the strings out would make the reader allocate and fault in half a gigabyte per batch -- 0.23 s
+            // of every batch at 100 M reads when this path did)
+            const std::string* quals = &batch.quals;
+            const std::vector<uint64_t>* qoff = &batch.qual_off;
             const uint64_t first_block = n_reads / rpb;
             const uint32_t cores = (uint32_t)_nbCores;
             const int qdev = store[0]->device;
@@ -323,6 +336,8 @@ void Leon::executeCompression() {
                 check_sink(nullptr, rc, wq, "leon_host_qual_encode_blocks");
             });
         }
+        w_quals += seconds_since(t_w);
+        t_w = std::chrono::steady_clock::now();
         for (auto& st : store) st->append(batch.bases);
         if (qstore) {                                            // lossy mode: the qualities wait in HBM, beside the bases, for the bloom
             try { qstore->append(batch.quals); }
@@ -330,6 +345,7 @@ void Leon::executeCompression() {
             if (qstore && qstore->n_bases > qual_resident_max) qstore.reset();
         }
         for (uint64_t i = 1; i <= got; i++) offsets.push_back(offsets[n_reads] + batch.base_off[i]);
+        w_uploads += seconds_since(t_w);
         n_reads += got;
         if (got < batch_reads) break;                            // the partial batch is the last one
     }
@@ -530,7 +546,9 @@ void Leon::executeCompression() {
     std::cout << "written to " << _outputFilename << std::endl;
     if (_verbose)
         std::cout << "time: parse + headers" << (keep_qual && _lossless ? " + qualities " : " ") << t_parse << " s, k-mer counting " << t_kmers << " s, contexts + bloom "
-                  << t_bloom - t_kmers << " s, DNA encode " << t_encode << " s, total " << seconds_since(t_start) << " s" << std::endl;
+                  << t_bloom - t_kmers << " s, DNA encode " << t_encode << " s, total " << seconds_since(t_start) << " s\n"
+                  << "the pass over the file: waited for the reader " << w_reader << " s, header blocks " << w_headers << " s, waited for the previous batch's quality blocks "
+                  << w_quals << " s, bases" << (qstore_used ? " + qualities" : "") << " to the device " << w_uploads << " s" << std::endl;
 }
 
 // ------------------------------------------------------------------------------------------------ -d

@@ -46,6 +46,9 @@ def timed(name, *args):
     out[name + "_s"] = round(time.time() - t, 2)
     out[name + "_rc"] = r.returncode
     out[name + "_stdout"] = r.stdout.strip().splitlines()
+    trace = [l for l in r.stderr.splitlines() if l.startswith("[leon ")]
+    if trace:
+        out[name + "_trace"] = trace[:12] + (["... %d more" % (len(trace) - 12)] if len(trace) > 12 else [])
     if r.returncode:
         out[name + "_stderr"] = r.stderr[-500:]
 
