@@ -529,6 +529,38 @@ def bench_streams(ctx, capi, reads, offsets, n_total, device):
     streams["qual_smooth"] = {"ms": round(dt * 1e3, 1), "MBps": round(n_total * L / 1e6 / dt, 1), "fraction_smoothed": round(smoothed, 4),
                               "what": "leon_qual_smooth_batch_device over the workload's reads: pack + one wave per read, L-k+1 bloom look-ups per read"}
     del quals
+    # lossless qualities: the read blocks' zlib streams written by the device (runs + dynamic Huffman codes per 32 KB), qualities of
+    # the end-to-end FASTQ's kind resident in HBM, the streams back in host memory; beside it zlib's default strategy on a sample
+    import zlib
+    nq = min(10_000_000, n_total)
+    g = torch.Generator(device=device); g.manual_seed(11)
+    qalpha = torch.tensor(list(b"#5:?ABCDEFGHIJ"), dtype=torch.uint8, device=device)
+    qd = qalpha[torch.minimum(torch.randint(0, 14, (nq, L), device=device, generator=g), torch.randint(4, 14, (nq, 1), device=device, generator=g))].contiguous()
+    qoff = (np.arange(nq + 1, dtype=np.uint64) * L)
+    torch.cuda.synchronize()
+    got = {}
+    qsink = capi.SINK(lambda user, bid, ptr, size, nreads: (got.__setitem__(int(bid), ctypes.string_at(ptr, size) if int(bid) in (0, 7) else size), 0)[1])
+    best = None
+    for _ in range(2):
+        got.clear()
+        t0 = time.perf_counter()
+        rc = ctx.lib.leon_qual_deflate_blocks_device(device.index or 0, ctypes.c_void_p(qd.data_ptr()), capi._ptr(qoff, capi._u64p), nq, RPB, qsink, None, 0)
+        dt = time.perf_counter() - t0
+        assert rc == 0, rc
+        best = dt if best is None else min(best, dt)
+    out_bytes = sum(len(v) if isinstance(v, bytes) else v for v in got.values())
+    h = qd[:8 * RPB].cpu().numpy()
+    text = lambda b: b"".join(r.tobytes() + b"\n" for r in h[b * RPB:(b + 1) * RPB])
+    inflates = all(zlib.decompress(got[b]) == text(b) for b in (0, 7) if b in got and (b + 1) * RPB <= nq)
+    t0 = time.perf_counter()
+    zl = len(zlib.compress(text(0)))
+    z_dt = time.perf_counter() - t0
+    streams["qual_deflate"] = {"reads": nq, "bytes_in": nq * (L + 1), "bytes_out": out_bytes, "ms": round(best * 1e3, 1), "MBps": round(nq * (L + 1) / 1e6 / best, 1),
+                               "ratio": round(out_bytes / (nq * (L + 1)), 4), "inflates_to_input": bool(inflates),
+                               "zlib_default_one_core": {"MBps": round(len(text(0)) / 1e6 / z_dt, 1), "ratio": round(zl / len(text(0)), 4)},
+                               "what": "leon_qual_deflate_blocks_device: qualities resident in HBM -> one zlib stream per read block in host memory (text with "
+                                       "newlines, one workgroup per 32 KB deflate block, gather, D2H), best of 2; sampled blocks through Python's zlib.decompress"}
+    del qd
     # header stream: 10 M SRA-style headers resident in HBM -> records (one lane per header) -> k_rc_encode
     nh = min(10_000_000, n_total)
     blob, hoff = sra_headers(nh, seed=7)

@@ -81,6 +81,7 @@ def test_default_bench_line_fills_every_key():
     assert line["end_to_end"]["identical"] is True and line["end_to_end"]["compress_lossless_rc"] == 0
     assert line["verify"]["n_blocks"] == 20
     assert line["streams"]["header_decode"]["equal_input"] is True and line["streams"]["qual_smooth"]["MBps"] > 0
+    assert line["streams"]["qual_deflate"]["inflates_to_input"] is True and 0 < line["streams"]["qual_deflate"]["ratio"] < 0.6
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
     assert "UNPINNED" in line["parity"]
     assert line["host"]["cpus_allowed"] >= 1 and line["host"]["chain_ns_per_symbol"] > 0

@@ -338,6 +338,37 @@ def test_cli_stream_selection_flags_and_lossy_qualities(leon_bin, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_quality_encoder_choice(leon_bin, tmp_path):
+    """the quality blocks come from the device's deflate (runs + dynamic Huffman codes) or from zlib on the host threads: a sample of
+    the file's first lines decides, LEON_QUAL_DEFLATE overrides; whichever wrote them, `leon -d` gives the file back"""
+    import random
+    import synth
+    rnd = random.Random(3)
+    g = synth.make_genome(30000, seed=21)
+    bases, off = synth.make_reads(g, 2600, 120, seed=22, err=0.01)
+    reads = [bytes(bases[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    noisy = [bytes(rnd.choice(b"#,-5:<>?@ABCDEFGHIJ") for _ in r) for r in reads]             # nothing to match: runs are enough
+    stair = [bytes(74 - min(41, (j * 41) // len(r)) for j in range(len(r))) for r in reads]     # every line the same staircase: earlier lines match
+    for name, quals, want in (("noisy", noisy, "deflated on the device"), ("stair", stair, "zlib on the host threads")):
+        fq = str(tmp_path / (name + ".fastq"))
+        text = b"".join(b"@r%d\n" % i + r + b"\n+\n" + q + b"\n" for i, (r, q) in enumerate(zip(reads, quals)))
+        open(fq, "wb").write(text)
+        sizes = {}
+        for mode in ("auto", "device", "host"):
+            r = run(leon_bin, "-file", fq, "-c", "-lossless", "-kmer-size", "21", "-abundance", "2", env=dict(os.environ, LEON_QUAL_DEFLATE=mode))
+            assert r.returncode == 0, r.stderr
+            line = next(l for l in r.stdout.splitlines() if l.startswith("quality stream"))
+            assert ("deflated on the device" in line) == (mode == "device" or (mode == "auto" and want == "deflated on the device")), (name, mode, line)
+            sizes[mode] = int(line.split("->")[1].split()[0])
+            r = run(leon_bin, "-file", fq + ".leon", "-d")
+            assert r.returncode == 0, r.stderr
+            assert open(fq + ".d", "rb").read() == text, (name, mode)
+        assert sizes["auto"] <= 1.02 * min(sizes["device"], sizes["host"]) + 64, (name, sizes)       # the sample picked the smaller one
+    r = run(leon_bin, "-file", fq, "-c", "-lossless", env=dict(os.environ, LEON_QUAL_DEFLATE="gpu"))
+    assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: ") and "LEON_QUAL_DEFLATE" in r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_failures_leave_no_container(leon_bin, tmp_path):
     """a failed compression ends with EXCEPTION: and a non-zero status, and leaves no .leon behind (a swallowed
     encode error used to produce a container with missing blocks and exit 0)"""
