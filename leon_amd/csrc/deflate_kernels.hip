@@ -62,56 +62,77 @@ __device__ inline uint32_t df_len_code(uint32_t len) {        // 3..258 -> 0..28
 }
 __device__ inline uint32_t df_rev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32 - len); }
 
-// Huffman code lengths of `n` symbols from their frequencies, none above `limit`: Moffat & Katajainen's in-place algorithm on the
-// used symbols sorted by frequency; when the depth exceeds the limit the frequencies are halved (rounded up) and it runs again
-// (zlib moves the overflowing leaves instead; either gives a complete code).  One lane's work; scratch A[n], order[n] in LDS.
-__device__ void df_code_lengths(const uint32_t* freq, uint32_t n, uint32_t limit, uint8_t* len, uint32_t* A, uint16_t* order, uint32_t* fr2) {
-    uint32_t used = 0;
-    for (uint32_t i = 0; i < n; i++) { fr2[i] = freq[i]; len[i] = 0; if (freq[i]) used++; }
-    if (used == 0) return;
-    if (used == 1) {                                          // one symbol: give it and a neighbour one bit each (inflate wants a complete code)
-        for (uint32_t i = 0; i < n; i++) if (freq[i]) { len[i] = 1; len[i ? i - 1 : 1] = 1; }
-        return;
-    }
+// Huffman code lengths of `n` symbols from their frequencies, none above `limit`, by the whole workgroup: the used symbols are
+// ranked by (frequency, symbol) -- every thread counts the symbols before its own, broadcast reads, no sort -- then one lane runs
+// Moffat & Katajainen's in-place algorithm over the ranked frequencies; when the depth exceeds the limit the frequencies are
+// halved (rounded up) and it runs again (zlib moves the overflowing leaves instead; either gives a complete code).
+// Scratch in LDS: A[n], order[n], fr2[n], ctl[2].
+__device__ void df_code_lengths(const uint32_t* freq, uint32_t n, uint32_t limit, uint8_t* len, uint32_t* A, uint16_t* order, uint32_t* fr2, uint32_t* ctl) {
+    const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < n; i += DF_T) { fr2[i] = freq[i]; len[i] = 0; }
+    __syncthreads();
     for (;;) {
-        // insertion sort of the used symbols by (frequency, symbol): a few dozen of them
-        uint32_t m = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            if (!fr2[i]) continue;
-            uint32_t j = m++;
-            while (j > 0 && fr2[order[j - 1]] > fr2[i]) { order[j] = order[j - 1]; j--; }
-            order[j] = (uint16_t)i;
+        if (t == 0) ctl[0] = 0;
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += DF_T) {
+            const uint32_t f = fr2[i];
+            if (!f) continue;
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < n; j++) { const uint32_t g = fr2[j]; r += (g && (g < f || (g == f && j < i))) ? 1u : 0u; }
+            order[r] = (uint16_t)i; A[r] = f;
+            atomicAdd(&ctl[0], 1u);
         }
-        for (uint32_t i = 0; i < m; i++) A[i] = fr2[order[i]];
-        A[0] += A[1];
-        uint32_t root = 0, leaf = 2;
-        for (uint32_t next = 1; next + 1 < m; next++) {
-            if (leaf >= m || A[root] < A[leaf]) { A[next] = A[root]; A[root++] = next; } else A[next] = A[leaf++];
-            if (leaf >= m || (root < next && A[root] < A[leaf])) { A[next] += A[root]; A[root++] = next; } else A[next] += A[leaf++];
+        __syncthreads();
+        if (t == 0) {
+            const uint32_t m = ctl[0];
+            uint32_t done = 1;
+            if (m == 1) { const uint32_t i = order[0]; len[i] = 1; len[i ? i - 1 : 1] = 1; }   // one symbol: it and a neighbour get one bit each (inflate wants a complete code)
+            else if (m >= 2) {
+                A[0] += A[1];
+                uint32_t root = 0, leaf = 2;
+                for (uint32_t next = 1; next + 1 < m; next++) {
+                    if (leaf >= m || A[root] < A[leaf]) { A[next] = A[root]; A[root++] = next; } else A[next] = A[leaf++];
+                    if (leaf >= m || (root < next && A[root] < A[leaf])) { A[next] += A[root]; A[root++] = next; } else A[next] += A[leaf++];
+                }
+                A[m - 2] = 0;
+                for (int next = (int)m - 3; next >= 0; next--) A[next] = A[A[next]] + 1;
+                int avbl = 1, usedn = 0, dpth = 0, rt = (int)m - 2, nx = (int)m - 1;
+                while (avbl > 0) {
+                    while (rt >= 0 && (int)A[rt] == dpth) { usedn++; rt--; }
+                    while (avbl > usedn) { A[nx--] = (uint32_t)dpth; avbl--; }
+                    avbl = 2 * usedn; dpth++; usedn = 0;
+                }
+                done = A[0] <= limit ? 1u : 0u;               // A[0]: the rarest symbol's length, the longest
+            }
+            ctl[1] = done | (m << 1);
         }
-        A[m - 2] = 0;
-        for (int next = (int)m - 3; next >= 0; next--) A[next] = A[A[next]] + 1;
-        int avbl = 1, usedn = 0, dpth = 0, rt = (int)m - 2, nx = (int)m - 1;
-        while (avbl > 0) {
-            while (rt >= 0 && (int)A[rt] == dpth) { usedn++; rt--; }
-            while (avbl > usedn) { A[nx--] = (uint32_t)dpth; avbl--; }
-            avbl = 2 * usedn; dpth++; usedn = 0;
-        }
-        if (A[0] <= limit) {                                  // A[0]: the rarest symbol's length, the longest
-            for (uint32_t i = 0; i < m; i++) len[order[i]] = (uint8_t)A[i];
+        __syncthreads();
+        const uint32_t m = ctl[1] >> 1;
+        if (ctl[1] & 1u) {
+            if (m >= 2) for (uint32_t i = t; i < m; i += DF_T) len[order[i]] = (uint8_t)A[i];
+            __syncthreads();
             return;
         }
-        for (uint32_t i = 0; i < n; i++) if (fr2[i]) fr2[i] = (fr2[i] + 1) >> 1;
+        for (uint32_t i = t; i < n; i += DF_T) if (fr2[i]) fr2[i] = (fr2[i] + 1) >> 1;
+        __syncthreads();
     }
 }
-// canonical codes (RFC 1951 3.2.2), bit-reversed for the LSB-first stream
-__device__ void df_codes(const uint8_t* len, uint32_t n, uint16_t* code) {
-    uint32_t cnt[16] = {0}, nxt[16];
-    for (uint32_t i = 0; i < n; i++) cnt[len[i]]++;
-    cnt[0] = 0;
-    uint32_t c = 0;
-    for (uint32_t b = 1; b < 16; b++) { c = (c + cnt[b - 1]) << 1; nxt[b] = c; }
-    for (uint32_t i = 0; i < n; i++) code[i] = len[i] ? (uint16_t)df_rev(nxt[len[i]]++, len[i]) : (uint16_t)0;
+// canonical codes (RFC 1951 3.2.2), bit-reversed for the LSB-first stream; cnt[16], nxt[16] in LDS
+__device__ void df_codes(const uint8_t* len, uint32_t n, uint16_t* code, uint32_t* cnt, uint32_t* nxt) {
+    const uint32_t t = threadIdx.x;
+    if (t < 16) cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += DF_T) if (len[i]) atomicAdd(&cnt[len[i]], 1u);
+    __syncthreads();
+    if (t == 0) { uint32_t c = 0; nxt[0] = 0; for (uint32_t b = 1; b < 16; b++) { c = (c + cnt[b - 1]) << 1; nxt[b] = c; } }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += DF_T) {
+        const uint32_t l = len[i];
+        uint32_t r = 0;
+        if (l) for (uint32_t j = 0; j < i; j++) r += len[j] == l ? 1u : 0u;
+        code[i] = l ? (uint16_t)df_rev(nxt[l] + r, l) : (uint16_t)0;
+    }
+    __syncthreads();
 }
 
 struct BitW {                                                  // one lane's writer into a zeroed word buffer
@@ -154,7 +175,7 @@ __global__ void __launch_bounds__(DF_T) k_deflate_chunks(const uint8_t* text, co
     __shared__ uint8_t len[DF_MAXSYM], cllen[DF_NCL], hdr_extra[DF_MAXSYM + 8];
     __shared__ uint8_t tfirst[DF_T], tlast[DF_T];
     __shared__ uint16_t tlead[DF_T], ttrail[DF_T], tn[DF_T];
-    __shared__ uint32_t sh_misc[8];                               // 0 header bits, 1 total bits, 2 n header symbols, 3 hlit, 4 hclen
+    __shared__ uint32_t sh_misc[8], ctl[2], cnt16[16], nxt16[16];                               // 0 header bits, 1 total bits, 2 n header symbols, 3 hlit, 4 hclen
     uint8_t* const tb = (uint8_t*)textw;
     const uint32_t t = threadIdx.x;
     for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -219,10 +240,10 @@ __global__ void __launch_bounds__(DF_T) k_deflate_chunks(const uint8_t* text, co
         });
         if (t == 0) atomicAdd(&freq[256], 1u);
         __syncthreads();
-        // ---- the codes and the block header (one lane) ----
+        // ---- the codes (the whole workgroup) and the block header (one lane) ----
+        df_code_lengths(freq, DF_NLIT, 15, len, A, order, fr2, ctl);
+        df_codes(len, DF_NLIT, code, cnt16, nxt16);
         if (t == 0) {
-            df_code_lengths(freq, DF_NLIT, 15, len, A, order, fr2);
-            df_codes(len, DF_NLIT, code);
             uint32_t hlit = DF_NLIT;
             while (hlit > 257 && len[hlit - 1] == 0) hlit--;
             // lengths of the hlit literal/length codes, then two distance codes of one bit each (only code 0, distance 1, is ever used;
@@ -253,8 +274,13 @@ __global__ void __launch_bounds__(DF_T) k_deflate_chunks(const uint8_t* text, co
                 i += r;
             }
             for (uint32_t i = 0; i < nh; i++) clfreq[hdr_sym[i]]++;
-            df_code_lengths(clfreq, DF_NCL, 7, cllen, A, order, fr2);
-            df_codes(cllen, DF_NCL, clcode);
+            sh_misc[2] = nh; sh_misc[3] = hlit;
+        }
+        __syncthreads();
+        df_code_lengths(clfreq, DF_NCL, 7, cllen, A, order, fr2, ctl);
+        df_codes(cllen, DF_NCL, clcode, cnt16, nxt16);
+        if (t == 0) {
+            const uint32_t nh = sh_misc[2], hlit = sh_misc[3];
             uint32_t hclen = DF_NCL;
             while (hclen > 4 && cllen[df_cl_order[hclen - 1]] == 0) hclen--;
             BitW bw{outw, 0};
