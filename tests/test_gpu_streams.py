@@ -249,3 +249,75 @@ def test_device_deflate_of_quality_blocks(name):
     nbytes = [sum(len(q) for q in qs[b * rpb:(b + 1) * rpb]) for b in range(len(blocks))]
     assert capi.host_qual_decode_blocks([(b[0] - 7, b[1], b[2]) for b in blocks], nbytes, n_threads=2) == qs
     print("%s: device %d, zlib RLE %d, zlib default %d bytes" % (name, tot_dev, tot_rle, tot_def))
+
+
+def test_device_deflate_fuzz():
+    """random shapes through leon_qual_deflate_blocks_device: alphabets of 1 to 200 symbols, run lengths from none to thousands, lines
+    from empty to longer than a deflate block, block texts that end exactly on, one before and one after a 32 KB boundary"""
+    import random
+    import zlib
+    from leon_amd import capi
+    rnd = random.Random(2026)
+    for case in range(40):
+        nsym = rnd.choice((1, 2, 3, 5, 16, 41, 94, 200))
+        alphabet = bytes(rnd.sample([c for c in range(1, 256) if c != 10], nsym))
+        p_run = rnd.choice((0.0, 0.3, 0.9, 0.99, 0.999))
+        rpb = rnd.choice((1, 7, 100, 1000))
+        n = rnd.choice((1, 3, 50, 800))
+        qs = []
+        for _ in range(n):
+            L = rnd.choice((0, 1, 2, 150, 151, 5000)) if case % 5 else rnd.choice((32767 - 1, 32768 - 1, 32769 - 1, 70000))
+            q, cur = bytearray(), alphabet[0]
+            for _ in range(L):
+                if rnd.random() >= p_run:
+                    cur = rnd.choice(alphabet)
+                q.append(cur)
+            qs.append(bytes(q))
+            if sum(len(x) for x in qs) > 3_000_000:
+                break
+        blob, off = O.reads_to_arrays(qs)
+        d = capi.device_upload_bytes(blob)
+        try:
+            blocks = capi.qual_deflate_blocks_device(d, off, rpb)
+        finally:
+            capi.device_free(d)
+        assert len(blocks) == (len(qs) + rpb - 1) // rpb
+        for i, (bid, pay, nr) in enumerate(blocks):
+            assert zlib.decompress(pay) == b"".join(q + b"\n" for q in qs[i * rpb:(i + 1) * rpb]), (case, i)
+
+
+def test_device_deflate_code_length_limit():
+    """Fibonacci frequencies in one 32 KB deflate block would give Huffman codes of 19 bits: the encoder must stay within deflate's 15
+    (it halves the frequencies and builds again), and within 7 for the code-length alphabet"""
+    import heapq
+    import zlib
+    from leon_amd import capi
+    fib = [1, 1]
+    while sum(fib) + fib[-1] + fib[-2] < 32000:
+        fib.append(fib[-1] + fib[-2])
+    syms = [c for c in range(33, 33 + len(fib))]
+    heap = [(-f, s) for f, s in zip(fib, syms)]
+    heapq.heapify(heap)
+    out, prev = bytearray(), None
+    while heap:                                                   # never two equal neighbours: no runs, every byte a literal
+        f, s = heapq.heappop(heap)
+        if s == prev and heap:
+            f2, s2 = heapq.heappop(heap)
+            out.append(s2); prev = s2
+            if f2 + 1 < 0:
+                heapq.heappush(heap, (f2 + 1, s2))
+            heapq.heappush(heap, (f, s))
+            continue
+        out.append(s); prev = s
+        if f + 1 < 0:
+            heapq.heappush(heap, (f + 1, s))
+    line = bytes(out)
+    assert len(line) < 32767 and len(set(line)) == len(fib) >= 20
+    for qs in ([line], [line] * 3, [line[:20000], line[20000:]]):
+        blob, off = O.reads_to_arrays(qs)
+        d = capi.device_upload_bytes(blob)
+        try:
+            blocks = capi.qual_deflate_blocks_device(d, off, 50)
+        finally:
+            capi.device_free(d)
+        assert zlib.decompress(blocks[0][1]) == b"".join(q + b"\n" for q in qs)
