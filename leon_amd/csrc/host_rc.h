@@ -9,7 +9,10 @@
 #include <emmintrin.h>
 #define LEON_HOST_CHAIN_X86 1
 #endif
+#include <pthread.h>
+#include <sched.h>
 #include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <new>
@@ -101,6 +104,43 @@ private:
 // The next quotient so needs ONE multiply of the carried quotient and does not wait for the new range: the loop-carried
 // path is multiply, add, xor, compare, select (~7 cycles; the renormalisation test low ^ (low + range) < TOP is what bounds
 // it), with three multiplies per symbol, where carrying the range costs multiply-high, shift, select, multiply (~9) and four.
+// LEON_CHAIN_PIN=1 (measurement: DESIGN.md 4.4): the chain and its helpers run on the CPUs that share one L3 -- the one the thread
+// that starts them happens to be on -- so that the helpers' records reach the chain through that cache instead of across the fabric.
+struct ChainCpus {
+    bool use = false;
+    cpu_set_t set;
+    void pick() {
+        const char* e = getenv("LEON_CHAIN_PIN");
+        if (!e || e[0] != '1') return;
+        const int cpu = sched_getcpu();
+        if (cpu < 0) return;
+        char path[128];
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+        FILE* f = fopen(path, "r");
+        if (!f) return;
+        char line[1024];
+        const bool ok = fgets(line, sizeof line, f) != nullptr;
+        fclose(f);
+        if (!ok) return;
+        cpu_set_t l3, allowed;
+        CPU_ZERO(&l3);
+        for (char* p = line; *p && *p != '\n';) {               // "0-7,128-135"
+            char* q = nullptr;
+            const long a = strtol(p, &q, 10);
+            if (q == p) break;
+            long b = a;
+            if (*q == '-') { p = q + 1; b = strtol(p, &q, 10); }
+            for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0) CPU_SET((int)c, &l3);
+            p = *q == ',' ? q + 1 : q;
+            if (*q != ',') break;
+        }
+        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+        CPU_AND(&set, &l3, &allowed);
+        use = CPU_COUNT(&set) >= 7;                              // room for the chain and its helpers
+    }
+    void apply() const { if (use) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set); }
+};
+
 struct ChainRec16 { uint64_t c; uint32_t lo, fr; };          // streams below 2^32 symbols (every count fits 32 bits)
 struct ChainRec24 { uint64_t c, lo, fr; };
 
@@ -122,6 +162,7 @@ public:
         n_threads_ = n;
     }
     ~ChainFeed() { stop(); }
+    ChainCpus cpus_;                                           // (set by the owner before start())
     void start() {
         if (running_) return;
         quit_ = false;
@@ -186,6 +227,7 @@ private:
         n[1] += (uint64_t)__builtin_popcountll(lo & ~hi); n[2] += (uint64_t)__builtin_popcountll(hi & ~lo); n[3] += (uint64_t)__builtin_popcountll(lo & hi);
     }
     void run() {
+        cpus_.apply();
         for (;;) {
             uint64_t s; Seg sg;
             {
@@ -512,7 +554,7 @@ public:
         const uint32_t W = k_ >= 32 ? 2u : 1u;
         {
             std::lock_guard<std::mutex> g(mu_);
-            if (!running_) { running_ = true; quit_ = false; feed_.start(); th_ = std::thread([this] { run(); }); }   // (threads only for contexts that code a dictionary)
+            if (!running_) { running_ = true; quit_ = false; feed_.cpus_.pick(); feed_.start(); th_ = std::thread([this] { feed_.cpus_.apply(); run(); }); }   // (threads only for contexts that code a dictionary)
             q_.emplace_back(std::move(kmers), 0u);
             // the helpers start on the batch's records at once (the vector's storage does not move with the deque's entry)
             q_.back().second = feed_.push(q_.back().first.data(), q_.back().first.size() / W);
