@@ -325,15 +325,28 @@ def main():
 
     for _ in range(a.warmup):
         timed_step()
-    times, walk_ms, walk_n, dev_ms, stage = [], [], [], [], None
+    # the K timed steps, bracketed ONCE on both sides (barrier + synchronize), back to back in between: a step ends with
+    # leon_dna_finish, which has every block delivered and the dictionary stream complete, so nothing of it is still in flight.
+    # (Bracketing every step cost up to two scheduler ticks per step: torch.cuda.synchronize() on an idle device returns on a
+    # 10 ms boundary here -- steps of exactly 820.0 / 830.0 ms around a chain of 800.)
+    times, walk_ms, walk_n, dev_ms, chain_ms, stage = [], [], [], [], [], None
+    sync()
+    t_begin = t_prev = time.perf_counter()
     for _ in range(a.steps):
-        (dict_bytes, n_anchors, acc), dt = timed_step()
-        times.append(dt)
+        dict_bytes, n_anchors, acc = step()
+        now = time.perf_counter()
+        times.append(now - t_prev)
+        t_prev = now
+        chain_ms.append(acc["ms_chain_busy"])
         walk_ms.append(acc["ms_walk"]); walk_n.append(max(acc["walk_launches"], 1))
         dev_ms.append(acc["ms_total"])
         stage = acc
+    sync()
+    wall_s = time.perf_counter() - t_begin
+    if cold_ms[0] is None:                                       # (no warm-up: the first timed step was the process's first)
+        cold_ms[0] = times[0] * 1e3
     # max over ranks: whole step, device stages alone (HIP events on each rank's stream), cold first step
-    red = torch.tensor([sum(times), float(np.mean(dev_ms)), cold_ms[0]], dtype=torch.float64, device=device)
+    red = torch.tensor([wall_s, float(np.mean(dev_ms)), cold_ms[0]], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
     total_s, device_ms_max, cold_first_step_ms = float(red[0].item()), float(red[1].item()), float(red[2].item())
@@ -486,6 +499,8 @@ def main():
             "end_to_end": e2e,
             "streams": streams,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
+            # every timed step on rank 0 (ms_per_step is their mean, max over ranks): the whole step, and the dictionary chain inside it
+            "step_ms_rank0": [round(t * 1e3, 1) for t in times], "chain_ms_rank0": [round(c, 1) for c in chain_ms],
             # `value` is the host chain's (one core of rank 0): which CPU that was, and what a dictionary symbol cost on it
             "host": host_info(stage["ms_chain_busy"], n_anchors * K),
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
