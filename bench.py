@@ -286,19 +286,24 @@ def main():
 
     def encode_stream(the_sink):
         """one file: every batch in order through leon_dna_encode_batch_device; returns the stage times summed over the batches"""
+        t0 = time.perf_counter()
         ctx.reset_stream()
+        t1 = time.perf_counter()
         acc = {k: 0.0 for k in STAGES + COUNTS}
         for lo, hi in batches:
             ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr() + 8 * lo, hi - lo, sink=the_sink)
             st = ctx.stats()
             for k in STAGES + COUNTS:
                 acc[k] += st[k]
+        acc["host_reset_ms"], acc["host_encode_calls_ms"] = (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
         return acc
 
     def step():
         payload[0] = payload[1] = 0
         acc = encode_stream(cb)
+        t0 = time.perf_counter()
         d_size, na = ctx.finish(copy=False)                  # the stream stays in the context, as for a C caller
+        acc["host_finish_ms"] = (time.perf_counter() - t0) * 1e3
         st = ctx.stats()
         acc["ms_anchor_wait"], acc["ms_chain_busy"] = st["ms_anchor_wait"], st["ms_chain_busy"]
         return d_size, na, acc
@@ -501,6 +506,8 @@ def main():
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
             # every timed step on rank 0 (ms_per_step is their mean, max over ranks): the whole step, and the dictionary chain inside it
             "step_ms_rank0": [round(t * 1e3, 1) for t in times], "chain_ms_rank0": [round(c, 1) for c in chain_ms],
+            # the last step's host view: leon_dna_reset_stream, the encode calls (they return when the blocks are delivered), leon_dna_finish (waits for the chain)
+            "step_parts_ms_rank0": {k: round(stage[k], 1) for k in ("host_reset_ms", "host_encode_calls_ms", "host_finish_ms")},
             # `value` is the host chain's (one core of rank 0): which CPU that was, and what a dictionary symbol cost on it
             "host": host_info(stage["ms_chain_busy"], n_anchors * K),
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
