@@ -211,6 +211,8 @@ int leon_host_qual_encode_blocks(const uint8_t* quals, const uint64_t* offsets, 
  * codes per 32 KB of text (deflate_kernels.hip).  Errors: leon_last_error(NULL). */
 int leon_qual_deflate_blocks_device(int device_id, const uint8_t* d_quals, const uint64_t* offsets, uint64_t n_reads,
                                     uint32_t reads_per_block, leon_block_sink sink, void* user, uint64_t first_block_id);
+/* It keeps its device buffers (about 1.5 GB after a large call) for the next call: this returns them. */
+void leon_qual_deflate_release(void);
 /* inverse: block_n_bytes = quality bytes per block without the newlines; out_off[total reads + 1] */
 int leon_host_qual_decode_blocks(const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
                                  const uint64_t* block_n_bytes, uint64_t n_blocks, uint8_t* out, uint64_t out_cap,

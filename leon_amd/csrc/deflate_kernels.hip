@@ -513,3 +513,12 @@ extern "C" int leon_qual_deflate_blocks_device(int device_id, const uint8_t* d_q
     }
     return LEON_OK;
 }
+
+/* the device buffers leon_qual_deflate_blocks_device keeps from call to call (about 1.5 GB after a large call) */
+extern "C" void leon_qual_deflate_release(void) {
+    DeflateScratch& S = scratch();
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (S.device >= 0 && hipSetDevice(S.device) == hipSuccess) S.drop();
+    S.device = -1;
+    std::vector<uint8_t>().swap(S.h);
+}
