@@ -132,6 +132,10 @@ int leon_kmer_solid(int device_id, const uint8_t* bases, const uint64_t* offsets
                     uint32_t min_abundance, uint64_t max_keys_per_pass, uint64_t* out, uint64_t out_cap, uint64_t* n_solid,
                     uint64_t* histogram);
 void leon_device_free(void* d_ptr);
+/* leon_kmer_solid_device keeps its large work buffers for its next call instead of freeing them (freed device memory is wiped by the
+ * driver before it is handed out again, at the expense of whoever allocates next); leon_dna_reserve returns them once the context's
+ * own buffers exist, and so does this. */
+void leon_device_trim(void);
 /* min_abundance = 0 in the two calls above means "automatic" (Leon's default, /root/reference/README.md:54): the threshold
  * this function derives from the abundance spectrum (first local minimum, never below 2; 2 when there is no valley).
  * histogram: 256 entries as returned above.  Host-only. */

@@ -101,6 +101,7 @@ _EXPORTS = {
                                                 C.c_uint64]),
     "leon_qual_deflate_blocks_device": (C.c_int, [C.c_int, C.c_void_p, _u64p, C.c_uint64, C.c_uint32, SINK, C.c_void_p, C.c_uint64]),
     "leon_qual_deflate_release": (None, []),
+    "leon_device_trim": (None, []),
     "leon_host_qual_decode_blocks": (C.c_int, [_u8p, _u64p, _u32p, _u64p, C.c_uint64, _u8p, C.c_uint64, _u64p, C.c_uint32]),
 }
 EXPORTED_SYMBOLS = tuple(_EXPORTS)

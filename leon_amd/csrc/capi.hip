@@ -38,6 +38,7 @@ struct DevBuf {
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); leon_device_trim(); e = hipMalloc(&p, want); }   // (the k-mer counter's parked buffers: kmer_kernels.hip)
         if (e == hipSuccess) cap = want;
         if (g_trace_alloc) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -859,6 +860,7 @@ int leon_dna_reserve(leon_dna_ctx* c, uint64_t max_reads, uint64_t max_bases) {
     if (int rc = dict_reserve(c, c->n_keys + n / 6 + 1024)) return rc;
     if ((n / 6) * 8 * kmer_words(c->cfg.kmer_size) > c->anchor_kmers.cap && c->n_anchors == 0) HIPCHK(c, c->anchor_kmers.ensure((n / 6) * 8 * kmer_words(c->cfg.kmer_size)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    leon_device_trim();                                          // (the k-mer counter's parked buffers go back now that this context's exist: kmer_kernels.hip)
     return LEON_OK;
 }
 

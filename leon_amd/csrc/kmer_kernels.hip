@@ -9,6 +9,7 @@
 #include "staging.h"
 
 #include <algorithm>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -197,20 +198,44 @@ __global__ void k_join_words(const uint64_t* lo, const uint64_t* hi, uint64_t n,
 }
 struct Pair128 { uint64_t lo, hi; };
 
+// The counter's large buffers are PARKED when it is done, not freed: memory this process has freed comes back from hipMalloc at
+// the driver's wiping rate (10-43 GB/s), and the first thing a caller does after counting is create its context and size its
+// per-batch buffers -- at 100 M reads one of those (16.9 GB) landed on the counter's 22 GB and took 1.6 s.  Parked buffers
+// are taken again by the next counter call (same device, large enough) and returned by leon_device_trim(), which
+// leon_dna_reserve calls once its own buffers exist and any allocation of the library calls before giving up.
+struct Parked { void* p; size_t bytes; int device; };
+std::mutex g_park_mu;
+std::vector<Parked> g_parked;
+
 struct Buf {
     void* p = nullptr;
+    size_t bytes_ = 0;
+    int park_device = -1;                                       // >= 0: park instead of free
     hipError_t alloc(size_t bytes) {
         static const bool trace = getenv("LEON_TRACE_ALLOC") != nullptr;       // (as in capi.hip: allocations of 1 ms or more on stderr)
+        bytes_ = bytes ? bytes : 16;
+        if (park_device >= 0) {                                 // a parked buffer of this device that is large enough (and not absurdly larger)?
+            std::lock_guard<std::mutex> g(g_park_mu);
+            for (size_t i = 0; i < g_parked.size(); i++)
+                if (g_parked[i].device == park_device && g_parked[i].bytes >= bytes_ && g_parked[i].bytes <= 2 * bytes_ + (64u << 20)) {
+                    p = g_parked[i].p; bytes_ = g_parked[i].bytes;
+                    g_parked.erase(g_parked.begin() + (long)i);
+                    return hipSuccess;
+                }
+        }
+        if (park_device >= 0) leon_device_trim();               // nothing parked fits: what is parked goes back first (the list never grows past one call's buffers)
         const auto t0 = std::chrono::steady_clock::now();
-        const hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        hipError_t e = hipMalloc(&p, bytes_);
+        if (e != hipSuccess) { (void)hipGetLastError(); leon_device_trim(); e = hipMalloc(&p, bytes_); }
         if (trace) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (ms >= 1.0) fprintf(stderr, "[leon alloc] kmer: %.1f MB in %.1f ms\n", bytes / 1e6, ms);
+            if (ms >= 1.0) fprintf(stderr, "[leon alloc] kmer: %.1f MB in %.1f ms\n", bytes_ / 1e6, ms);
         }
         return e;
     }
     ~Buf() {
         if (!p) return;
+        if (park_device >= 0) { std::lock_guard<std::mutex> g(g_park_mu); g_parked.push_back({p, bytes_, park_device}); return; }
         static const bool trace = getenv("LEON_TRACE_ALLOC") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         (void)hipFree(p);
@@ -233,6 +258,15 @@ using namespace leon;
 extern "C" {
 
 void leon_device_free(void* p) { if (p) (void)hipFree(p); }
+
+void leon_device_trim(void) {
+    std::vector<Parked> take;
+    { std::lock_guard<std::mutex> g(g_park_mu); take.swap(g_parked); }
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (const Parked& b : take) { if (hipSetDevice(b.device) == hipSuccess) (void)hipFree(b.p); }
+    if (cur >= 0) (void)hipSetDevice(cur);
+}
 
 int leon_device_count(int* n_devices) {
     if (!n_devices) return LEON_E_INVALID;
@@ -349,6 +383,7 @@ int leon_kmer_solid_device(int device_id, const uint8_t* d_bases, const uint64_t
     const uint64_t cap = (n_parts == 1 ? total : (uint64_t)(total / n_parts * 1.25) + (1u << 20)) + (uint64_t)part_grid * 4 * PART_CHUNK + total / n_parts / 8;
     // ---- per-partition buffers ----
     Buf keys, alt, alt2, alt3, flags, nsel, hist, sort_tmp, sel_tmp, runlen, runsel;
+    keys.park_device = alt.park_device = alt2.park_device = alt3.park_device = device_id;       // (the large ones: see Parked)
     KCHK(keys.alloc(cap * 8 * W)); KCHK(alt.alloc(cap * 8 * W)); KCHK(flags.alloc(cap));
     if (automatic) { KCHK(runlen.alloc(cap)); KCHK(runsel.alloc(cap)); }
     if (W == 2) { KCHK(alt2.alloc(cap * 8)); KCHK(alt3.alloc(cap * 8)); }

@@ -53,11 +53,13 @@ def timed(name, *args):
         out[name + "_stderr"] = r.stderr[-500:]
 
 
+only = os.environ.get("LEON_CLI_ONLY", "")                    # e.g. "lossless": just that command (measurement runs)
 timed("compress_lossless", "-file", fq, "-c", "-lossless", "-verbose", "1")
 out["leon_bytes_lossless"] = os.path.getsize(fq + ".leon") if os.path.exists(fq + ".leon") else None
-timed("decompress", "-file", fq + ".leon", "-d", "-test-file", "-verbose", "1")
-timed("compress_lossy", "-file", fq, "-c", "-verbose", "1")
-out["leon_bytes_lossy"] = os.path.getsize(fq + ".leon") if os.path.exists(fq + ".leon") else None
+if only != "lossless":
+    timed("decompress", "-file", fq + ".leon", "-d", "-test-file", "-verbose", "1")
+    timed("compress_lossy", "-file", fq, "-c", "-verbose", "1")
+    out["leon_bytes_lossy"] = os.path.getsize(fq + ".leon") if os.path.exists(fq + ".leon") else None
 for f in (fq, fq + ".leon", fq + ".d"):
     if os.path.exists(f):
         os.remove(f)
