@@ -745,10 +745,118 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
         if (rB != 0x100u) walk_apply<K>(rB, k, kmask_k, xB, yB, ntB, leftB, ev + posB);
     }
 }
+// ---- measurement only (LEON_WALK_TILE=1): the LDS-tile form of the probe.  The seven probes of a step all fall in the
+// 514 bytes that start at the k-mer's `racine`; here a wave stages that window in LDS once per DISTINCT racine among its lanes
+// (130 dwords, cooperative, coalesced) and the lanes that share it read their seven words from the tile.  Same events, byte for byte.
+template <typename K>
+__device__ inline uint32_t bloom_contains4_tile(const BloomDev& B, const uint16_t* rv16, uint32_t* tile, bool need, K kmer, K rc) {
+    const uint32_t k = B.k, lane = lane_id();
+    BloomKeys Kk;
+    uint32_t pv4 = 0;
+    Kk.racine = 0;
+    if (need) {                                                    // (the `right` form of bloom_contains4: every lane extends rightwards)
+        const K mkm2 = kmask<K>(k - 2);
+        const uint32_t p = (uint32_t)(uint64_t)(kmer >> (2 * (k - 2))) & 3u;
+        pv4 = cano2(p << 2) | (cano2((p << 2) | 1) << 4) | (cano2((p << 2) | 2) << 8) | (cano2((p << 2) | 3) << 12);
+        bloom_keys<K>(B, rv16, kmer & mkm2, rc >> 4, Kk);
+    }
+    uint32_t w = 0xFFFFFFFFu;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint64_t r = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(Kk.racine >> 32), (int)leader) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)Kk.racine, (int)leader);
+        const bool mine = need && Kk.racine == r;
+        const unsigned long long same = __ballot(mine);
+        const uint8_t* src = B.bits + (r >> 3);
+        uint32_t v0, v1;
+        __builtin_memcpy(&v0, src + 4 * lane, 4);
+        __builtin_memcpy(&v1, src + 256 + 4 * lane, 4);
+        tile[lane] = v0; tile[64 + lane] = v1;
+        if (lane < 3) { uint32_t v2; __builtin_memcpy(&v2, src + 512 + 4 * lane, 4); tile[128 + lane] = v2; }
+        __builtin_amdgcn_wave_barrier();
+        if (mine) {
+            const uint32_t sh0 = (uint32_t)(r & 7);
+#pragma unroll
+            for (uint32_t i = 0; i < 10; i++) {
+                if (i < B.n_hash) {
+                    const uint32_t bp = sh0 + Kk.key[i], d = bp >> 5, sft = bp & 31;
+                    const uint32_t lo = ((volatile uint32_t*)tile)[d], hi = ((volatile uint32_t*)tile)[d + 1];
+                    w &= sft ? ((lo >> sft) | (hi << (32 - sft))) : lo;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        todo &= ~same;
+    }
+    return ((w >> (pv4 & 15)) & 1u) | (((w >> ((pv4 >> 4) & 15)) & 1u) << 1) |
+           (((w >> ((pv4 >> 8) & 15)) & 1u) << 2) | (((w >> ((pv4 >> 12) & 15)) & 1u) << 3);
+}
+template <typename K>
+__global__ void __launch_bounds__(256) k_walk_tile(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
+                                                  const uint8_t* flags, const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
+    __shared__ uint16_t rv16[256];
+    __shared__ uint32_t tiles[4][132];
+    load_rv16(rv16, rv16g);
+    uint32_t* const tile = tiles[threadIdx.x >> 6];
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    // (every lane of a wave stays to the end: the staging is cooperative)
+    bool live = t < n_walk;
+    const uint32_t i = live ? perm[t] : 0u;
+    const int32_t a = live ? anchor_pos[i] : -1;
+    live = live && a >= 0;
+    const uint32_t k = R.k, len = live ? R.len[i] : k;
+    const K kmask_k = kmask<K>(k);
+    const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+    const uint32_t* nm = R.nmask + R.slot_off[i];
+    const bool hasN = live && R.n_count[i] != 0;
+    uint8_t* ev = events + (R.base_off[i] - R.base_off[R.ev_origin]);
+    const K anchor = live ? kmer_at<K>(pk, (uint32_t)a, k) : (K)0;
+    const K anchor_rc = revcomp(anchor, k);
+    const bool rev = live && (flags[i] & 1u) != 0;
+    const bool leftA = !rev, leftB = rev;
+    K xA = leftA ? anchor_rc : anchor, yA = leftA ? anchor : anchor_rc;
+    K xB = leftB ? anchor_rc : anchor, yB = leftB ? anchor : anchor_rc;
+    const uint32_t nL = live ? (uint32_t)a : 0u, nR = live ? len - k - (uint32_t)a : 0u;
+    const uint32_t nA = leftA ? nL : nR, nB = leftB ? nL : nR;
+    uint32_t nmax = nA > nB ? nA : nB;
+    for (uint32_t d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)nmax, (int)d); nmax = o > nmax ? o : nmax; }   // the wave's longest walk
+    uint32_t pwA = 0, pwA_idx = 0xFFFFFFFFu, nwA = 0, nwA_idx = 0xFFFFFFFFu;
+    uint32_t pwB = 0, pwB_idx = 0xFFFFFFFFu, nwB = 0, nwB_idx = 0xFFFFFFFFu;
+    // what k_walk's side_probe does before it probes: the position, the read's base, an N pushed into the k-mer; true = probe
+    auto side_prep = [&](bool on, bool left, uint32_t j, K& x, K& y, uint32_t& pw, uint32_t& pw_idx, uint32_t& nw, uint32_t& nw_idx,
+                         uint32_t& pos, uint32_t& nt) -> bool {
+        if (!on) return false;
+        pos = left ? (uint32_t)a - 1 - j : (uint32_t)a + k + j;
+        if ((pos >> 4) != pw_idx) { pw_idx = pos >> 4; pw = pk[pw_idx]; }
+        nt = (pw >> (30 - 2 * (pos & 15))) & 3u;
+        if (hasN) {
+            if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
+            if ((nw >> (pos & 31)) & 1u) {
+                const uint32_t f = left ? 2u : 0u;
+                x = ((x << 2) | (K)f) & kmask_k;
+                y = (y >> 2) | ((K)(f ^ 2u) << (2 * (k - 1)));
+                return false;
+            }
+        }
+        return true;
+    };
+    for (uint32_t j = 0; j < nmax; j++) {
+        uint32_t posA = 0, ntA = 0, posB = 0, ntB = 0;
+        const bool pA = side_prep(j < nA, leftA, j, xA, yA, pwA, pwA_idx, nwA, nwA_idx, posA, ntA);
+        const bool pB = side_prep(j < nB, leftB, j, xB, yB, pwB, pwB_idx, nwB, nwB_idx, posB, ntB);
+        const uint32_t rA = bloom_contains4_tile<K>(B, rv16, tile, pA, xA, yA);
+        const uint32_t rB = bloom_contains4_tile<K>(B, rv16, tile, pB, xB, yB);
+        if (pA) walk_apply<K>(rA, k, kmask_k, xA, yA, ntA, leftA, ev + posA);
+        if (pB) walk_apply<K>(rB, k, kmask_k, xB, yB, ntB, leftB, ev + posB);
+    }
+}
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos, const uint8_t* flags,
                  const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
     if (!n_walk) return;
     uint64_t g = (n_walk + 255) / 256;
+    static const bool tile = getenv("LEON_WALK_TILE") != nullptr && getenv("LEON_WALK_TILE")[0] == '1';       // measurement only
+    if (tile) { DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk_tile<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events)); return; }
     DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events));
 }
 
