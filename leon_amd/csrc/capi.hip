@@ -1117,6 +1117,8 @@ int leon_dna_finish(leon_dna_ctx* c, const uint8_t** payload, uint64_t* size, ui
     }
     c->anchor_worker->drain();
     c->anchor_wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("LEON_TRACE_STEP")) fprintf(stderr, "[leon step] dictionary chain busy %.1f ms, of which %.1f ms waiting for its helpers' records\n",
+                                           c->anchor_worker->busy_ms(), c->anchor_worker->starved_ms());
     if (!c->finished) {
         if (c->shard_rank == 0) c->anchor_worker->coder().flush();
         c->finished = true;

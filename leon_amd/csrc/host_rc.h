@@ -146,7 +146,7 @@ struct ChainRec24 { uint64_t c, lo, fr; };
 
 class ChainFeed {
 public:
-    static constexpr uint32_t kBufs = 16;
+    static constexpr uint32_t kMaxBufs = 1024;                  // the ring's size is n_bufs_ (LEON_CHAIN_RING, default 512), at most this
     static constexpr uint64_t kPlainBelow = 512;               // symbols coded in the plain form at the start of a stream (m needs a total above 256)
     struct View {
         const void* recs = nullptr; uint64_t n_syms = 0;       // produced records (null for a plain segment): ChainRec16, or ChainRec24 when `wide`
@@ -160,13 +160,18 @@ public:
                                                                // more only lower the clock the chain's core gets (8 helpers: +9 % on its time)
         if (const char* e = getenv("LEON_CHAIN_HELPERS")) { const int v = atoi(e); if (v >= 1 && v <= 32) n = (uint32_t)v; }
         n_threads_ = n;
+        // The ring: 512 segments of ~32 k symbols = ~30 ms of the chain's work ahead of it (12 MB of records per millisecond, touched
+        // only as far as the helpers get ahead).  With 16 segments -- one millisecond -- a helper that lost its core for a time slice to
+        // another tenant of the host stalled the chain, which takes its segments in order: 76-98 ms of a loaded host's 870-888 ms steps
+        // were the chain waiting for records (LEON_TRACE_STEP=1 prints it), 1.3-1.8 ms of a quiet host's 822.
+        if (const char* e = getenv("LEON_CHAIN_RING")) { const int v = atoi(e); if (v >= 4 && v <= (int)kMaxBufs) n_bufs_ = (uint32_t)v; }
     }
     ~ChainFeed() { stop(); }
     ChainCpus cpus_;                                           // (set by the owner before start())
     void start() {
         if (running_) return;
         quit_ = false;
-        for (auto& b : buf_) if (!b) b.reset(new ChainRec24[(size_t)seg_kmers_ * k_]);      // (12 MB, only for contexts that code a dictionary)
+        for (uint32_t b = 0; b < n_bufs_; b++) if (!buf_[b]) buf_[b].reset(new ChainRec24[(size_t)seg_kmers_ * k_]);      // (0.8 MB each, untouched until used; only for contexts that code a dictionary)
         for (uint32_t j = 0; j < n_threads_; j++) th_.emplace_back([this] { run(); });
         running_ = true;
     }
@@ -208,9 +213,9 @@ public:
     void take(View& v) {
         std::unique_lock<std::mutex> g(mu_);
         const uint64_t s = next_take_++;
-        cv_ready_.wait(g, [&] { return ready_[s % kBufs] == s + 1; });
+        cv_ready_.wait(g, [&] { return ready_[s % n_bufs_] == s + 1; });
         const Seg& sg = segs_[s - base_];
-        v.recs = sg.plain ? nullptr : buf_[s % kBufs].get();
+        v.recs = sg.plain ? nullptr : buf_[s % n_bufs_].get();
         v.wide = sg.wide;
         v.n_syms = (uint64_t)sg.n_kmers * k_; v.kmers = sg.kmers; v.n_kmers = sg.n_kmers; v.t0 = sg.t0;
         for (int i = 0; i < 4; i++) v.c_end[i] = sg.c_end[i];
@@ -232,7 +237,7 @@ private:
             uint64_t s; Seg sg;
             {
                 std::unique_lock<std::mutex> g(mu_);
-                cv_work_.wait(g, [&] { return quit_ || (next_claim_ < base_ + segs_.size() && next_claim_ < released_ + kBufs); });
+                cv_work_.wait(g, [&] { return quit_ || (next_claim_ < base_ + segs_.size() && next_claim_ < released_ + n_bufs_); });
                 if (quit_) return;
                 s = next_claim_++;
                 sg = segs_[s - base_];
@@ -251,8 +256,8 @@ private:
                 for (int i = 0; i < 4; i++) { d.c0[i] = c[i]; d.c_end[i] = prefix_c_[i]; }
             }
             cv_prefix_.notify_all();
-            if (!sg.plain) { if (sg.wide) fill(buf_[s % kBufs].get(), sg, c); else fill(reinterpret_cast<ChainRec16*>(buf_[s % kBufs].get()), sg, c); }
-            { std::lock_guard<std::mutex> g(mu_); ready_[s % kBufs] = s + 1; }
+            if (!sg.plain) { if (sg.wide) fill(buf_[s % n_bufs_].get(), sg, c); else fill(reinterpret_cast<ChainRec16*>(buf_[s % n_bufs_].get()), sg, c); }
+            { std::lock_guard<std::mutex> g(mu_); ready_[s % n_bufs_] = s + 1; }
             cv_ready_.notify_all();
         }
     }
@@ -286,8 +291,9 @@ private:
     }
     const uint32_t k_, W_, seg_kmers_;
     uint32_t n_threads_ = 5;
-    std::unique_ptr<ChainRec24[]> buf_[kBufs];             // (holds either record type)
-    uint64_t ready_[kBufs] = {};                               // segment index + 1 a buffer currently holds
+    std::unique_ptr<ChainRec24[]> buf_[kMaxBufs];          // (holds either record type)
+    uint64_t ready_[kMaxBufs] = {};                            // segment index + 1 a buffer currently holds
+    uint32_t n_bufs_ = 512;
     std::deque<Seg> segs_;                                     // segments pushed and not yet released; segs_[0] is segment base_
     uint64_t base_ = 0, next_claim_ = 0, next_take_ = 0, released_ = 0, prefix_upto_ = 0, t_pushed_ = 0;
     uint64_t prefix_c_[4] = {1, 1, 1, 1};                      // Order0Model::clear: every symbol starts with a count of 1
@@ -576,8 +582,9 @@ public:
         th_.join();
         running_ = false;
     }
-    void reset() { drain(); coder_.clear(); feed_.reset_stream(); busy_ms_ = 0; }
+    void reset() { drain(); coder_.clear(); feed_.reset_stream(); busy_ms_ = 0; starved_ms_ = 0; }
     double busy_ms() const { return busy_ms_; }              // time spent coding since the last reset (read after drain())
+    double starved_ms() const { return starved_ms_; }        // ... of which the chain waited for its helpers' records
     AnchorDictCoder& coder() { return coder_; }                // only after drain()
 private:
     void run() {
@@ -593,7 +600,9 @@ private:
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t sgm = 0; sgm < batch.second; sgm++) {
                 ChainFeed::View v;
+                const auto tw = std::chrono::steady_clock::now();
                 feed_.take(v);
+                starved_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
                 coder_.encode_segment(v, k_);
                 feed_.release();
             }
@@ -612,7 +621,7 @@ private:
     std::condition_variable cv_, cv_done_;
     std::deque<std::pair<std::vector<uint64_t>, uint32_t>> q_;
     uint64_t pending_ = 0;
-    double busy_ms_ = 0;
+    double busy_ms_ = 0, starved_ms_ = 0;
     bool running_ = false, quit_ = false;
     std::thread th_;
 };

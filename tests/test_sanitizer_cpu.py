@@ -42,9 +42,9 @@ def test_dictionary_chain_worker_under_sanitizers(tmp_path, san):
     exe = str(tmp_path / "chain_san")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-o", exe,
                            os.path.join(ROOT, "profiles", "scripts", "chain_ab", "ab_new.cpp"), "-lpthread"])
-    for n, k in ((60000, 31), (30000, 63)):                  # ~1.9 M symbols each: 58 segments through 16 buffers
+    for n, k, ring in ((60000, 31, "8"), (30000, 63, "8"), (60000, 31, "512")):   # ~1.9 M symbols each: 58 segments round a ring of 8 buffers several times, and inside the default 512
         r = subprocess.run([exe, str(n), str(k)], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
+                           env=dict(os.environ, LEON_CHAIN_RING=ring, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
         out = r.stdout + r.stderr
         assert r.returncode == 0 and "Sanitizer" not in out and "runtime error" not in out, out[-3000:]
         fnv = {l.split("fnv")[1].strip() for l in r.stdout.splitlines() if "fnv" in l}
