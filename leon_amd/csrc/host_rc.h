@@ -156,10 +156,14 @@ public:
         uint64_t c_end[4] = {};                                // the model's counts (1 + occurrences of A, C, T, G) after the segment
     };
     explicit ChainFeed(uint32_t k) : k_(k), W_(k >= 32 ? 2u : 1u), seg_kmers_(std::max<uint32_t>(1, (1u << 15) / k)) {
-        uint32_t n = 5;                                        // ~4.8 ns per record and helper inside the library: 3 just keep ahead of the chain, 5 leave a margin;
-                                                               // more only lower the clock the chain's core gets (8 helpers: +9 % on its time)
+        // ~4.8 ns per record and helper inside the library against the chain's ~1.8 per symbol: three helpers keep ahead of it, and
+        // every further busy core lowers the clock the chain's own gets (with the deep ring: 786-808 ms per step with 3 helpers,
+        // 795-817 with 4, 821-848 with 5, 840-859 with 7; profiles/r3_chain_helpers_ab.txt).  So three work all the time and
+        // three SPARES only while the look-ahead is thin (the start of a stream, a host whose other tenants slow the helpers down).
+        uint32_t n = 3, spares = 3;
         if (const char* e = getenv("LEON_CHAIN_HELPERS")) { const int v = atoi(e); if (v >= 1 && v <= 32) n = (uint32_t)v; }
-        n_threads_ = n;
+        if (const char* e = getenv("LEON_CHAIN_SPARES")) { const int v = atoi(e); if (v >= 0 && v <= 32) spares = (uint32_t)v; }
+        n_threads_ = n; n_spares_ = spares;
         // The ring: 512 segments of ~32 k symbols = ~30 ms of the chain's work ahead of it (12 MB of records per millisecond, touched
         // only as far as the helpers get ahead).  With 16 segments -- one millisecond -- a helper that lost its core for a time slice to
         // another tenant of the host stalled the chain, which takes its segments in order: 76-98 ms of a loaded host's 870-888 ms steps
@@ -172,13 +176,13 @@ public:
         if (running_) return;
         quit_ = false;
         for (uint32_t b = 0; b < n_bufs_; b++) if (!buf_[b]) buf_[b].reset(new ChainRec24[(size_t)seg_kmers_ * k_]);      // (0.8 MB each, untouched until used; only for contexts that code a dictionary)
-        for (uint32_t j = 0; j < n_threads_; j++) th_.emplace_back([this] { run(); });
+        for (uint32_t j = 0; j < n_threads_ + n_spares_; j++) th_.emplace_back([this, j] { run(j >= n_threads_); });
         running_ = true;
     }
     void stop() {
         if (!running_) return;
         { std::lock_guard<std::mutex> g(mu_); quit_ = true; }
-        cv_work_.notify_all(); cv_ready_.notify_all();
+        cv_work_.notify_all(); cv_spare_.notify_all(); cv_ready_.notify_all();
         for (auto& t : th_) t.join();
         th_.clear();
         running_ = false;
@@ -206,13 +210,14 @@ public:
                 kmers += take * W_; count -= take; t_pushed_ += take * k_; n++;
             }
         }
-        cv_work_.notify_all();
+        cv_work_.notify_all(); cv_spare_.notify_all();
         return n;
     }
     // the next segment, in order; blocks until its records are there
     void take(View& v) {
         std::unique_lock<std::mutex> g(mu_);
         const uint64_t s = next_take_++;
+        if (n_spares_ && (int64_t)(next_claim_ - next_take_) < (int64_t)low_water()) cv_spare_.notify_all();        // thin look-ahead: the spares join in
         cv_ready_.wait(g, [&] { return ready_[s % n_bufs_] == s + 1; });
         const Seg& sg = segs_[s - base_];
         v.recs = sg.plain ? nullptr : buf_[s % n_bufs_].get();
@@ -231,13 +236,16 @@ private:
         const uint64_t lo = x & 0x5555555555555555ull, hi = (x >> 1) & 0x5555555555555555ull;
         n[1] += (uint64_t)__builtin_popcountll(lo & ~hi); n[2] += (uint64_t)__builtin_popcountll(hi & ~lo); n[3] += (uint64_t)__builtin_popcountll(lo & hi);
     }
-    void run() {
+    uint64_t low_water() const { return n_bufs_ / 4; }          // segments of look-ahead below which the spare helpers work
+    void run(bool spare) {
         cpus_.apply();
         for (;;) {
             uint64_t s; Seg sg;
             {
                 std::unique_lock<std::mutex> g(mu_);
-                cv_work_.wait(g, [&] { return quit_ || (next_claim_ < base_ + segs_.size() && next_claim_ < released_ + n_bufs_); });
+                auto work = [&] { return next_claim_ < base_ + segs_.size() && next_claim_ < released_ + n_bufs_; };
+                if (spare) cv_spare_.wait(g, [&] { return quit_ || (work() && (int64_t)(next_claim_ - next_take_) < (int64_t)low_water()); });
+                else cv_work_.wait(g, [&] { return quit_ || work(); });
                 if (quit_) return;
                 s = next_claim_++;
                 sg = segs_[s - base_];
@@ -293,7 +301,8 @@ private:
     uint32_t n_threads_ = 5;
     std::unique_ptr<ChainRec24[]> buf_[kMaxBufs];          // (holds either record type)
     uint64_t ready_[kMaxBufs] = {};                            // segment index + 1 a buffer currently holds
-    uint32_t n_bufs_ = 512;
+    uint32_t n_bufs_ = 512, n_spares_ = 0;
+    std::condition_variable cv_spare_;
     std::deque<Seg> segs_;                                     // segments pushed and not yet released; segs_[0] is segment base_
     uint64_t base_ = 0, next_claim_ = 0, next_take_ = 0, released_ = 0, prefix_upto_ = 0, t_pushed_ = 0;
     uint64_t prefix_c_[4] = {1, 1, 1, 1};                      // Order0Model::clear: every symbol starts with a count of 1
