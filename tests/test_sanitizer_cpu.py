@@ -42,10 +42,16 @@ def test_dictionary_chain_worker_under_sanitizers(tmp_path, san):
     exe = str(tmp_path / "chain_san")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-o", exe,
                            os.path.join(ROOT, "profiles", "scripts", "chain_ab", "ab_new.cpp"), "-lpthread"])
-    for n, k, ring in ((60000, 31, "8"), (30000, 63, "8"), (60000, 31, "512")):   # ~1.9 M symbols each: 58 segments round a ring of 8 buffers several times, and inside the default 512
+    seen = {}
+    # ~1.9 M symbols each: 58 segments round a ring of 8 buffers several times, inside the default 512, and with one helper whose five
+    # spares do most of the work (the look-ahead never leaves the low-water zone of a ring of 64)
+    for n, k, ring, helpers, spares in ((60000, 31, "8", "3", "3"), (30000, 63, "8", "3", "3"), (60000, 31, "512", "3", "3"), (60000, 31, "64", "1", "5")):
         r = subprocess.run([exe, str(n), str(k)], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, LEON_CHAIN_RING=ring, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
+                           env=dict(os.environ, LEON_CHAIN_RING=ring, LEON_CHAIN_HELPERS=helpers, LEON_CHAIN_SPARES=spares,
+                                    TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
         out = r.stdout + r.stderr
         assert r.returncode == 0 and "Sanitizer" not in out and "runtime error" not in out, out[-3000:]
         fnv = {l.split("fnv")[1].strip() for l in r.stdout.splitlines() if "fnv" in l}
         assert len(fnv) == 1, "three runs of the same stream must give the same bytes: %s" % fnv
+        seen.setdefault((n, k), set()).update(fnv)
+    assert all(len(v) == 1 for v in seen.values()), "the same stream under another ring / helper configuration: other bytes %s" % seen
