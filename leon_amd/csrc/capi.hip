@@ -74,10 +74,28 @@ __global__ void k_iota(uint32_t* v, uint64_t n) {
 
 }  // namespace
 
+// The short waits of a batch -- a counter read back after a kernel of a millisecond, hundreds of them in the anchor resolution, and
+// the ones before the first anchors reach the dictionary chain -- POLL the stream instead of calling hipStreamSynchronize: a wait
+// that goes to sleep comes back on the host's 10 ms tick here (steps of chain + 30-40 ms, leon_dna_reset_stream taking 17 ms instead
+// of 0.4), and the read-backs land in pinned host words so that the copies themselves do not wait inside the runtime.  Long waits
+// (the walk, the range coder) keep sleeping: a spinning core would only take clock from the chain's.
+inline hipError_t spin_sync(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0;; i++) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        for (int k = 0; k < 32; k++) __builtin_ia32_pause();
+        if ((i & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    (void)hipGetLastError();
+    return hipStreamSynchronize(s);
+}
+
 struct leon_dna_ctx {
     leon_dna_cfg cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    uint64_t* h_rb = nullptr;                                    // pinned host words the short read-backs of a batch land in (spin_sync)
     std::string err;
     // bloom
     uint8_t* d_bloom = nullptr;
@@ -262,6 +280,7 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     } while (0)
     CREATE_CHK(hipSetDevice(c->device));
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipHostMalloc((void**)&c->h_rb, 256, hipHostMallocDefault));
     for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
     // BloomCacheCoherent / BloomContainer geometry
     uint64_t blk = 1ull << cfg->bloom_block_nbits;
@@ -314,6 +333,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
     if (c->d_rv16) (void)hipFree(c->d_rv16);
     if (c->d_nkeys) (void)hipFree(c->d_nkeys);
     if (c->h_payload) (void)hipHostFree(c->h_payload);
+    if (c->h_rb) (void)hipHostFree(c->h_rb);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pack_ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -471,8 +491,10 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
 
     // ---- sizes ----
     uint64_t off_first = 0, off_last = 0;
-    HIPCHK(c, hipMemcpy(&off_first, d_off, 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&off_last, d_off + n, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, d_off, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_rb + 1, d_off + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, spin_sync(s));
+    off_first = c->h_rb[0]; off_last = c->h_rb[1];
     if (off_last < off_first) return fail(c, LEON_E_INVALID, "offsets are not monotonic");
     const uint64_t n_bases = off_last - off_first;
     (void)n_bases;
@@ -489,9 +511,10 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, tmp_bytes, c->slot_off.as<uint64_t>(), c->slot_off.as<uint64_t>(), n + 1, s));
     uint64_t n_slots = 0;
     uint32_t bad_offsets = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_slots, c->slot_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&bad_offsets, c->counters.as<uint32_t>() + 4, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, c->slot_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_rb + 1, c->counters.as<uint32_t>() + 4, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, spin_sync(s));
+    n_slots = c->h_rb[0]; bad_offsets = (uint32_t)c->h_rb[1];
     if (bad_offsets) return fail(c, LEON_E_INVALID, "offsets are not monotonic (or a read is longer than 2^31 bases)");
     mark("offsets checked, slots scanned");
     HIPCHK(c, c->packed.ensure((n_slots * 2 + 16) * 4));     // wave loads reach 12 dwords past a pass start
@@ -560,9 +583,10 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters);
         uint32_t cnt = 0;
         int dict_err = 0;
-        HIPCHK(c, hipMemcpyAsync(&cnt, counters, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(&dict_err, c->D.err, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, counters, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_rb + 1, c->D.err, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, spin_sync(s));
+        cnt = (uint32_t)c->h_rb[0]; dict_err = (int)(uint32_t)c->h_rb[1];
         if (dict_err) {
             HIPCHK(c, hipMemsetAsync(c->D.err, 0, 4, s));
             return fail(c, LEON_E_STATE, "anchor dictionary: a two-word key stayed half-written (a stalled wave); batch abandoned");
@@ -574,8 +598,9 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             HIPCHK(c, hipMemsetAsync(counters + nxt, 0, 4, s));
             launch_check(s, R, c->D, V, first_read_index, lists[cur], counters + cur, cnt, lists[nxt], counters + nxt);
             uint32_t ncnt = 0;
-            HIPCHK(c, hipMemcpyAsync(&ncnt, counters + nxt, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, counters + nxt, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, spin_sync(s));
+            ncnt = (uint32_t)c->h_rb[0];
             if (ncnt >= cnt) return fail(c, LEON_E_STATE, "anchor resolution made no progress (internal error)");
             launch_reset_tent(s, c->D, V, lists[cur], counters + cur, cnt);
             launch_propose(s, c->D, V, first_read_index, lists[nxt], counters + nxt, ncnt);
@@ -587,10 +612,11 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             launch_ins_flags(s, V, w0, w1);
             HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), w1 - w0, s));
             uint32_t last_rank = 0, last_flag = 0;
-            HIPCHK(c, hipMemcpyAsync(&last_rank, c->rank.as<uint32_t>() + (w1 - w0 - 1), 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipMemcpyAsync(&last_flag, V.ins_flag + (w1 - w0 - 1), 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipMemcpyAsync(&c->n_keys, c->d_nkeys, 8, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, c->rank.as<uint32_t>() + (w1 - w0 - 1), 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_rb + 1, V.ins_flag + (w1 - w0 - 1), 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_rb + 2, c->d_nkeys, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, spin_sync(s));
+            last_rank = (uint32_t)c->h_rb[0]; last_flag = (uint32_t)c->h_rb[1]; c->n_keys = c->h_rb[2];
             uint64_t n_new = (uint64_t)last_rank + last_flag;
             if (c->n_anchors + n_new > 0xFFFFFFFFull) return fail(c, LEON_E_OVERFLOW, "more than 2^32 anchors");
             const uint64_t KW = kmer_words(k);                              // 64-bit words per anchor k-mer
@@ -606,7 +632,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             if (n_new && c->shard_rank == 0 && !(c->cfg.flags & LEON_F_DICT_ON_DEVICE)) {   // the window's new anchors go straight to the host thread coding the dictionary stream
                 std::vector<uint64_t> fresh(n_new * KW);
                 HIPCHK(c, hipMemcpyAsync(fresh.data(), c->anchor_kmers.as<uint64_t>() + c->n_anchors * KW, n_new * 8 * KW, hipMemcpyDeviceToHost, s));
-                HIPCHK(c, hipStreamSynchronize(s));
+                HIPCHK(c, spin_sync(s));
                 c->anchor_worker->push(std::move(fresh));
                 if (w0 == 0) mark("first window's anchors to the chain");
             }
@@ -1150,12 +1176,12 @@ int leon_dna_reset_stream(leon_dna_ctx* c) {
     struct Done { bool on; std::chrono::steady_clock::time_point t0; ~Done() { if (on) fprintf(stderr, "[leon step] %-34s %8.2f ms\n", "reset_stream", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } } done{trace_step, t_enter};
     c->anchor_worker->reset();
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     HIPCHK(c, hipMemsetAsync(c->fbits.p, 0, (1ull << c->fbits_log2) / 8, c->stream));
     if (c->dict_cap) {
         HIPCHK(c, hipMemsetAsync(c->d_nkeys, 0, 8, c->stream));
         launch_dict_init(c->stream, c->D, c->dict_cap, kmer_words(c->cfg.kmer_size));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, spin_sync(c->stream));
     }
     c->n_keys = 0; c->n_anchors = 0;
     c->next_read = 0; c->next_block = 0; c->partial_seen = false; c->finished = false; c->poisoned = false;
