@@ -1,8 +1,12 @@
 #include "bank.hpp"
 #include "leon_host.hpp"
 
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
+
+#include <cerrno>
 
 #include <algorithm>
 #include <cstring>
@@ -54,15 +58,23 @@ size_t PlusLines::lower(uint64_t read) const {
     return (size_t)(std::lower_bound(exc.begin(), exc.end(), read, [](const Exc& e, uint64_t r) { return e.read < r; }) - exc.begin());
 }
 
-Bank::Bank(const std::string& path) : path_(path), buf_(1 << 20) {
+Bank::Bank(const std::string& path) : path_(path), buf_(4 << 20) {
     struct stat st;
     if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) throw Exception("cannot open " + path);
     file_bytes_ = (uint64_t)st.st_size;
-    gz_ = gzopen(path.c_str(), "rb");
-    if (!gz_) throw Exception("cannot open " + path);
-    gzbuffer((gzFile)gz_, 1 << 20);
+    // gzip input (magic 1f 8b) goes through zlib; anything else is read as it is
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) throw Exception("cannot open " + path);
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = ::pread(fd_, magic, 2, 0);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        ::close(fd_); fd_ = -1;
+        gz_ = gzopen(path.c_str(), "rb");
+        if (!gz_) throw Exception("cannot open " + path);
+        gzbuffer((gzFile)gz_, 1 << 20);
+    }
 }
-Bank::~Bank() { if (gz_) gzclose((gzFile)gz_); }
+Bank::~Bank() { if (gz_) gzclose((gzFile)gz_); if (fd_ >= 0) ::close(fd_); }
 
 // one line without its terminator ("\n" or "\r\n"); false at the end of the file
 bool Bank::getline(std::string& line) {
@@ -70,15 +82,22 @@ bool Bank::getline(std::string& line) {
     bool any = false;
     for (;;) {
         if (buf_pos_ == buf_len_) {
-            const int got = gzread((gzFile)gz_, buf_.data(), (unsigned)buf_.size());
-            if (got < 0) { int e = 0; throw Exception(std::string("read error in ") + path_ + ": " + gzerror((gzFile)gz_, &e)); }
-            if (got == 0) {
-                // end of the data -- or of a TRUNCATED .gz, which zlib reports as 0 bytes + Z_BUF_ERROR after handing out
-                // what it could inflate: compressing that part and calling it success would lose the rest silently
-                int e = 0;
-                const char* msg = gzerror((gzFile)gz_, &e);
-                if (e != Z_OK && e != Z_STREAM_END) throw Exception(path_ + " is truncated or corrupt (" + (msg && *msg ? msg : "unexpected end of file") + ")");
-                break;
+            long got;
+            if (fd_ >= 0) {
+                do { got = (long)::read(fd_, buf_.data(), buf_.size()); } while (got < 0 && errno == EINTR);
+                if (got < 0) throw Exception(std::string("read error in ") + path_ + ": " + strerror(errno));
+                if (got == 0) break;
+            } else {
+                got = gzread((gzFile)gz_, buf_.data(), (unsigned)buf_.size());
+                if (got < 0) { int e = 0; throw Exception(std::string("read error in ") + path_ + ": " + gzerror((gzFile)gz_, &e)); }
+                if (got == 0) {
+                    // end of the data -- or of a TRUNCATED .gz, which zlib reports as 0 bytes + Z_BUF_ERROR after handing out
+                    // what it could inflate: compressing that part and calling it success would lose the rest silently
+                    int e = 0;
+                    const char* msg = gzerror((gzFile)gz_, &e);
+                    if (e != Z_OK && e != Z_STREAM_END) throw Exception(path_ + " is truncated or corrupt (" + (msg && *msg ? msg : "unexpected end of file") + ")");
+                    break;
+                }
             }
             buf_pos_ = 0; buf_len_ = (size_t)got;
         }

@@ -36,7 +36,8 @@ public:
 private:
     bool getline(std::string& line);
     bool view(const char*& p, size_t& n);         // the next line where it lies (in the read buffer when it ends there), else assembled in spill_
-    void* gz_ = nullptr;                          // gzFile: reads plain files transparently as well
+    void* gz_ = nullptr;                          // gzFile (gzip input)
+    int fd_ = -1;                                 // plain input: read(2) straight into buf_ (zlib's transparent mode copies every byte once more)
     std::string path_, pending_, spill_;
     bool have_pending_ = false, decided_ = false, fastq_ = false;
     std::vector<char> buf_;
