@@ -76,7 +76,7 @@ def test_host_anchor_dict_stream_matches_oracle(lib):
     from leon_amd import capi
     rng = np.random.default_rng(3)
     sizes = [2, 5, 5, 2, 3, 3, 3, 2] + [256] * 72
-    for k, n in [(31, 0), (31, 1), (31, 700), (21, 3000), (5, 10), (32, 50), (33, 4000), (47, 2500), (63, 900), (31, 30000), (63, 20000)]:   # the last two: 29 and 39 segments of records through the feed's 16 buffers
+    for k, n in [(31, 0), (31, 1), (31, 700), (21, 3000), (5, 10), (32, 50), (33, 4000), (47, 2500), (63, 900), (31, 30000), (63, 20000)]:   # the last two: 29 and 39 segments of records through the feed (its ring of 512; smaller rings below)
         ints = [(int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 1 << 62)) << 62)) & ((1 << (2 * k)) - 1) for _ in range(n)]
         w = O.kwords(k)
         kmers = np.array([[x & 0xFFFFFFFFFFFFFFFF, x >> 64][:w] for x in ints], dtype=np.uint64).reshape(-1)
@@ -84,6 +84,27 @@ def test_host_anchor_dict_stream_matches_oracle(lib):
         exp = O.rc_encode_stream(np.ones(len(syms), dtype=np.uint8), syms, sizes)   # model 1: alphabet 5
         assert capi.host_anchor_dict_encode(kmers, k) == exp
         assert O.kmers_to_ints(O.decode_anchor_dict(exp, n, k), k) == ints
+
+
+@pytest.mark.parametrize("ring,helpers,spares", [("8", "3", "3"), ("8", "1", "0"), ("64", "1", "5"), ("4", "2", "6")])
+def test_host_anchor_dict_stream_under_other_feed_shapes(lib, monkeypatch, ring, helpers, spares):
+    """the feed between the helpers and the chain -- ring size, helpers at work all the time, spares that join while the look-ahead
+    is thin -- decides who makes which record when, never the bytes: 29 and 39 segments several times round small rings, one helper with
+    five spares, == the oracle's stream"""
+    import numpy as np
+    import oracle_lib as O
+    from leon_amd import capi
+    monkeypatch.setenv("LEON_CHAIN_RING", ring)
+    monkeypatch.setenv("LEON_CHAIN_HELPERS", helpers)
+    monkeypatch.setenv("LEON_CHAIN_SPARES", spares)
+    rng = np.random.default_rng(17)
+    sizes = [2, 5, 5, 2, 3, 3, 3, 2] + [256] * 72
+    for k, n in [(31, 30000), (63, 20000)]:
+        ints = [(int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 1 << 62)) << 62)) & ((1 << (2 * k)) - 1) for _ in range(n)]
+        w = O.kwords(k)
+        kmers = np.array([[x & 0xFFFFFFFFFFFFFFFF, x >> 64][:w] for x in ints], dtype=np.uint64).reshape(-1)
+        syms = np.array([(x >> (2 * (k - 1 - i))) & 3 for x in ints for i in range(k)], dtype=np.uint8)
+        assert capi.host_anchor_dict_encode(kmers, k) == O.rc_encode_stream(np.ones(len(syms), dtype=np.uint8), syms, sizes)
 
 
 @pytest.mark.parametrize("kind", ["polyA", "skewed", "two_letter", "uniform_long"])
