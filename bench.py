@@ -12,6 +12,11 @@ dictionary stream.  The job is one file of fixed size: strong scaling.  Prints O
 `python bench.py --gpus N` without a launcher starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
 itself, as a child process, before anything touches the GPU, and relays rank 0's line.
 
+LEON_BENCH_AS_RANK=r:N (one process, one GPU): this process takes the seat of rank r of an N-rank job -- leon_dna_set_shard(r, N),
+every collective of the N-rank code path on a process group of one (RCCL by default) -- so that what such a rank does, how long it
+takes and how much memory it needs can be measured on a one-GPU box; the line says `"as_rank": "r:N"` and its `value` is what the
+N-GPU job would report if this rank were its slowest.
+
 `value` is the HBM-resident figure (the bench contract: inputs resident when the timed region starts).  SURVEY 8(d)
 also wants the figure with the H2D copy inside: `pcie_inclusive` (one step through leon_dna_encode_batch, reads in
 pageable host memory) is measured in every default N = 1 run, beside `verify` (checksum of block checksums), `decode`
@@ -172,11 +177,23 @@ def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         self_launch(a)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    pg_world = int(os.environ.get("WORLD_SIZE", "1"))        # the process group: one process per GPU
+    pg_rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    as_rank = os.environ.get("LEON_BENCH_AS_RANK")            # "r:N": this ONE process is rank r of an N-rank job (rehearsal on a one-GPU box)
+    if pg_world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, pg_world))
+    # the job's shape as leon_dna_set_shard sees it: (rank, world) = the process group's, or the seat LEON_BENCH_AS_RANK names
+    rank, world = pg_rank, pg_world
+    if as_rank:
+        if pg_world != 1:
+            raise SystemExit("LEON_BENCH_AS_RANK is for a single process (--gpus 1)")
+        try:
+            rank, world = (int(v) for v in as_rank.split(":"))
+        except ValueError:
+            raise SystemExit("LEON_BENCH_AS_RANK=%r: expected r:N" % as_rank)
+        if not 0 <= rank < world:
+            raise SystemExit("LEON_BENCH_AS_RANK=%r: rank out of range" % as_rank)
     import torch.distributed as dist
     n_dev = torch.cuda.device_count()
     if local >= n_dev:                       # rehearsal of the N>1 path on a one-GPU box (LEON_BENCH_BACKEND=gloo)
@@ -184,15 +201,22 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # (LEON_BENCH_FORCE_DIST=1: a one-rank run under torch.distributed.run still goes through the process group, the RCCL broadcast
-    # of the bloom and the reductions -- the N > 1 code on the one GPU a test box has)
-    use_dist = world > 1 or (os.environ.get("LEON_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    # of the bloom and the reductions -- the N > 1 code on the one GPU a test box has; LEON_BENCH_AS_RANK does the same by itself)
+    use_dist = pg_world > 1 or (os.environ.get("LEON_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ) or bool(as_rank)
+    backend = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("LEON_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI; gloo only to rehearse
+        kw = {}
+        if "RANK" not in os.environ:                              # a process group of one, started here (LEON_BENCH_AS_RANK without a launcher)
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            kw = dict(init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
+    is_root = pg_rank == 0                   # the process that prints the line (and, in the job, the rank that codes the dictionary: rank 0)
 
     import leon_amd
     from leon_amd import capi
@@ -231,7 +255,7 @@ def main():
     n_solid_t = torch.zeros(1, dtype=torch.int64, device=device)
     d_solid = 0
     if bloom_from == "count":
-        if rank == 0:
+        if is_root:
             d_solid, n_solid = capi.kmer_solid_device(reads.data_ptr(), offsets.data_ptr(), n_total, K, ABUNDANCE, device_id=local,
                                                       max_keys_per_pass=a.kmer_max_keys)
             n_solid_t[0] = n_solid
@@ -248,7 +272,7 @@ def main():
     ctx.reserve(B, B * L)                      # what a host does while it parses: the first step then allocates nothing large
     nbytes = ctx.bloom_nbytes
     bcast_ms = 0.0
-    if rank == 0:
+    if is_root:
         if bloom_from == "count":
             ctx.bloom_insert_device(d_solid, n_solid)
             capi.device_free(d_solid)
@@ -262,14 +286,14 @@ def main():
     del genome
     if use_dist:                           # RCCL broadcast of the bloom over xGMI, device to device
         bits = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        if rank == 0:
+        if is_root:
             ctx.bloom_download_device(bits.data_ptr(), nbytes)
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.time()
         dist.broadcast(bits, src=0)
         torch.cuda.synchronize()
         bcast_ms = (time.time() - t0) * 1e3
-        if rank != 0:
+        if rank != 0:                          # (a rehearsed seat r > 0 takes the receiving side too: the same bits back into its context)
             ctx.bloom_upload_device(bits.data_ptr(), nbytes)
         del bits
     bloom_s = time.time() - t_b
@@ -372,9 +396,17 @@ def main():
         dstream, na_v = ctx.finish()
         tables = [mine]
         if use_dist:
-            tables = [None] * world
+            tables = [None] * pg_world
             dist.all_gather_object(tables, mine)
-        if rank == 0:
+        if is_root and as_rank:                                      # one seat of an N-rank job: its own blocks only (the union needs the other seats)
+            h = hashlib.sha256()
+            for bid, digest, nr in sorted(mine):
+                h.update(bytes.fromhex(digest) + bid.to_bytes(8, "little") + nr.to_bytes(4, "little"))
+            lo_b, hi_b = (min(b[0] for b in mine), max(b[0] for b in mine)) if mine else (None, None)
+            verify = {"blocks_sha256_of_this_seat": h.hexdigest(), "n_blocks": len(mine), "first_block": lo_b, "last_block": hi_b,
+                      "dict_sha256": hashlib.sha256(dstream).hexdigest(), "n_anchors": int(na_v),
+                      "what": "this seat's blocks only (checksum of block checksums) + the dictionary stream's (empty unless the seat is rank 0)"}
+        elif is_root:
             from leon_amd.shard import merge_block_tables
             h = hashlib.sha256()
             for bid, digest, nr in merge_block_tables(tables):       # raises on a gap or a duplicate block
@@ -472,10 +504,23 @@ def main():
     e2e = guarded(lambda: end_to_end(min(a.e2e_reads, n_total), device)) if extras and world == 1 and rank == 0 and a.e2e_reads > 0 else None
     cpu = guarded(lambda: cpu_baseline(ctx, reads, min(a.cpu_sample, n_total))) if rank == 0 and world == 1 and a.cpu_sample > 0 else None
 
-    if rank == 0:
+    # what an N-rank curve needs, rank by rank: every rank's device stages and what it coded (gathered; one entry at N = 1)
+    mine_rank = {"rank": rank, "blocks": payload[1], "payload_bytes": payload[0], "device_ms": round(float(np.mean(dev_ms)), 2),
+                 "chain_ms": round(stage["ms_chain_busy"], 2),
+                 # (device memory in use on this rank's GPU after the timed steps: the read set, the context's per-batch buffers, the dictionary, the bloom)
+                 "hbm_in_use_GB": round((lambda f, t: (t - f) / 1e9)(*torch.cuda.mem_get_info(device)), 1),
+                 "stages_ms": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")}}
+    per_rank = [mine_rank]
+    if use_dist:
+        per_rank = [None] * pg_world
+        dist.all_gather_object(per_rank, mine_rank)
+
+    if is_root:
         out = {
             "metric": "compressed input MB/s (DNA encode path)", "value": round(value, 1), "unit": "MB/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
+            "n_gpus": pg_world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
+            **({"as_rank": as_rank, "as_rank_note": "ONE process in the seat of rank %d of a %d-rank job (leon_dna_set_shard): `value` is what that job would "
+                                                     "report if this rank were its slowest, not a measured %d-GPU figure" % (rank, world, world)} if as_rank else {}),
             "value_hbm_resident": round(value, 1),
             "value_h2d_inclusive": pcie.get("value") if pcie else None,
             "cold_first_step_ms": round(cold_first_step_ms, 2),
@@ -483,6 +528,10 @@ def main():
             # chain on a host core of rank 0 whatever N is; the device stages are what shards
             "device_ms_max_over_ranks": round(device_ms_max, 2), "host_chain_ms": round(stage["ms_chain_busy"], 2),
             "value_device_only": round(n_total * L / 1e6 / (device_ms_max * 1e-3), 1),
+            "bloom_bcast_ms": round(bcast_ms, 2),
+            # the collectives' backend and how many ranks the process group really has (RCCL when "nccl"; null without a process group)
+            "collective_backend": backend, "rccl_ranks": dist.get_world_size() if use_dist and backend == "nccl" else None,
+            "per_rank": per_rank,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "parity": "bit-identical to oracle/leon_oracle.c in the -m gpu tests; the oracle is a restatement: parity with reference Leon is UNPINNED (gatb-core absent)",
             "config": {"workload": "%d x %d bp synthetic reads, k=%d, genome %d bp (30x), 1%% substitutions, "

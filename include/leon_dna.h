@@ -158,7 +158,8 @@ int leon_host_anchor_dict_encode(const uint64_t* kmers, uint64_t n_anchors, uint
  * from leon_host_anchor_dict_decode).  payloads: the blocks' payloads back to back, payload_off[n_blocks + 1];
  * block_n_reads / block_n_bases: reads and bases per block (the container's block table).  Output: the reads' bases back
  * to back in block order (out_cap >= the sum of block_n_bases) and every read's length (sum of block_n_reads entries).
- * LEON_E_INVALID with a message when a payload does not decode against this bloom / dictionary.
+ * LEON_E_INVALID with a message when a payload does not decode against this bloom / dictionary; out_bases and out_len are then
+ * as the caller left them (the call writes them only once every block has decoded).
  * Memory: the context keeps a table of what the decoding waves have learnt from the bloom (16 or 32 bytes x 4 per solid
  * k-mer the bloom was sized for, at most 40 % of the device's free memory; LEON_DC_CACHE_MB in the environment overrides,
  * 0 = none) from call to call, for as long as the bloom's bits do not change and the context does not encode (an encode

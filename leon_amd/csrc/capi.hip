@@ -79,7 +79,11 @@ __global__ void k_iota(uint32_t* v, uint64_t n) {
 // that goes to sleep comes back on the host's 10 ms tick here (steps of chain + 30-40 ms, leon_dna_reset_stream taking 17 ms instead
 // of 0.4), and the read-backs land in pinned host words so that the copies themselves do not wait inside the runtime.  Long waits
 // (the walk, the range coder) keep sleeping: a spinning core would only take clock from the chain's.
+// LEON_SPIN_SYNC=0: always sleep in the runtime instead (hosts with few cores, or many contexts whose spinning waits would compete
+// with one another and with the chain thread the spinning was meant to help).
 inline hipError_t spin_sync(hipStream_t s) {
+    static const bool spin = [] { const char* e = getenv("LEON_SPIN_SYNC"); return !(e && e[0] == '0'); }();
+    if (!spin) return hipStreamSynchronize(s);
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t i = 0;; i++) {
         const hipError_t e = hipStreamQuery(s);
@@ -1307,7 +1311,8 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
     HIPCHK(c, hipGetLastError());
     // While the blocks decode (seconds), the caller's output buffer is touched page by page: fresh memory is mapped on first
     // write, which would otherwise happen inside the copy back -- 3.7 M page faults for a 100 M-read file, on the critical path.
-    // (Only the pages' first bytes are written; the copy overwrites all of it.)
+    // Each page's first byte is written back as it was read, so the buffer's contents survive a call that then fails (a corrupt
+    // block, a HIP error): a successful call overwrites all of it, a failed one changes nothing.
     std::vector<std::thread> toucher;
     {
         const uint64_t nb_out = out0[n_blocks];
@@ -1315,7 +1320,7 @@ int leon_dna_decode_blocks(leon_dna_ctx* c, const uint64_t* anchors, uint64_t n_
         for (uint32_t w = 0; w < nt; w++)
             toucher.emplace_back([out_bases, nb_out, w, nt] {
                 volatile uint8_t* q = out_bases;
-                for (uint64_t a = nb_out * w / nt; a < nb_out * (w + 1) / nt; a += 4096) q[a] = 0;
+                for (uint64_t a = nb_out * w / nt; a < nb_out * (w + 1) / nt; a += 4096) q[a] = q[a];
             });
     }
     struct Join { std::vector<std::thread>& t; ~Join() { for (auto& x : t) if (x.joinable()) x.join(); } } join_touchers{toucher};

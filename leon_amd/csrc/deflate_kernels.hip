@@ -386,6 +386,8 @@ struct Grow {
     }
     template <typename T> T* as() { return (T*)p; }
 };
+// One set PER DEVICE (it was one for the process, dropped and rebuilt whenever the device changed: callers on several GPUs serialised
+// behind one mutex and thrashed 1.5 GB each way -- ADVICE r3).  A device's set is used by one call at a time.
 struct DeflateScratch {
     std::mutex mu;
     int device = -1;
@@ -393,7 +395,9 @@ struct DeflateScratch {
     std::vector<uint8_t> h;
     void drop() { for (Grow* g : {&off, &text, &cb, &cl, &out, &sizes, &adler, &cdst, &fin}) { if (g->p) (void)hipFree(g->p); g->p = nullptr; g->cap = 0; } }
 };
-DeflateScratch& scratch() { static DeflateScratch* s = new DeflateScratch(); return *s; }     // (never destroyed: the HIP runtime may be gone by then)
+constexpr int DF_MAX_DEVICES = 64;
+DeflateScratch* scratch_table() { static DeflateScratch* t = new DeflateScratch[DF_MAX_DEVICES]; return t; }     // (never destroyed: the HIP runtime may be gone by then)
+DeflateScratch& scratch(int device_id) { return scratch_table()[device_id]; }
 
 constexpr uint64_t DF_SLICE_TEXT = 512ull << 20;                // text bytes per slice of a large call
 
@@ -497,10 +501,11 @@ extern "C" int leon_qual_deflate_blocks_device(int device_id, const uint8_t* d_q
         if (offsets[i + 1] < offsets[i]) { set_create_error("qual_deflate: offsets are not monotonic"); return LEON_E_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) { set_create_error("qual_deflate: no such HIP device"); return LEON_E_NO_DEVICE; }
+    if (device_id >= DF_MAX_DEVICES) { set_create_error("qual_deflate: device ordinal beyond the scratch table"); return LEON_E_INVALID; }
     DCHK(hipSetDevice(device_id));
-    DeflateScratch& S = scratch();
+    DeflateScratch& S = scratch(device_id);
     std::lock_guard<std::mutex> lock(S.mu);
-    if (S.device != device_id) { if (S.device >= 0 && hipSetDevice(S.device) == hipSuccess) S.drop(); DCHK(hipSetDevice(device_id)); S.device = device_id; }
+    S.device = device_id;
     const uint64_t n_blocks = (n_reads + reads_per_block - 1) / reads_per_block;
     for (uint64_t b0 = 0; b0 < n_blocks;) {                      // slices of whole blocks, ~DF_SLICE_TEXT of text each
         uint64_t b1 = b0 + 1;
@@ -516,9 +521,14 @@ extern "C" int leon_qual_deflate_blocks_device(int device_id, const uint8_t* d_q
 
 /* the device buffers leon_qual_deflate_blocks_device keeps from call to call (about 1.5 GB after a large call) */
 extern "C" void leon_qual_deflate_release(void) {
-    DeflateScratch& S = scratch();
-    std::lock_guard<std::mutex> lock(S.mu);
-    if (S.device >= 0 && hipSetDevice(S.device) == hipSuccess) S.drop();
-    S.device = -1;
-    std::vector<uint8_t>().swap(S.h);
+    int before = -1;
+    const bool had_device = hipGetDevice(&before) == hipSuccess;
+    for (int d = 0; d < DF_MAX_DEVICES; d++) {
+        DeflateScratch& S = scratch(d);
+        std::lock_guard<std::mutex> lock(S.mu);
+        if (S.device >= 0 && hipSetDevice(S.device) == hipSuccess) S.drop();
+        S.device = -1;
+        std::vector<uint8_t>().swap(S.h);
+    }
+    if (had_device) (void)hipSetDevice(before);
 }

@@ -386,7 +386,10 @@ private:
     // selected by conditional moves.  The product's fraction within q of the next integer (see ChainFeed; rare), two bytes at
     // once or the carry-less coder's range < BOTTOM reset take a division.
     template <typename Rec> void encode_records(const Rec* r, uint64_t n, uint64_t t0) {
-        if (buf_.size() < w_ + n + 64) buf_.resize(buf_.size() * 2 + n + 4096);      // (a symbol emits one byte at most here; the rare path checks its room)
+        // Room for the worst case up front -- 8 bytes per symbol: the loop below shifts 64 bits out at most -- so that the fast path's
+        // unchecked store can never run past the buffer, whatever mix of rare-path symbols (several bytes each) came before it.
+        // (It was n + 64 on the argument that a genomic dictionary codes at ~2 bits per symbol: an unstated property of the input.)
+        if (buf_.size() < w_ + 8 * n + 64) buf_.resize(buf_.size() * 2 + 8 * n + 4096);
         settle();
         uint8_t* p = buf_.data() + w_;
         uint8_t* p_end = buf_.data() + buf_.size() - 32;

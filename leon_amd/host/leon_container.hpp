@@ -30,7 +30,18 @@ constexpr const char* DS_ANCHOR_DICT = "leon/anchors/dict";            // u8[]: 
 constexpr const char* DS_BLOOM_BITS = "bloom/bits";                    // u8[nchar]
 constexpr const char* BLOCK_PREFIX = "block_";
 enum Param : uint32_t { P_VERSION_MAJOR, P_VERSION_MINOR, P_VERSION_PATCH, P_KMER_SIZE, P_READS_PER_BLOCK, P_N_READS, P_N_ANCHORS,
-                        P_ABUNDANCE, P_BLOOM_TAI, P_BLOOM_N_HASH, P_BLOOM_BLOCK_NBITS, P_TOTAL_BASES, P_FASTA_LINE_WIDTH, PARAM_COUNT };
+                        P_ABUNDANCE, P_BLOOM_TAI, P_BLOOM_N_HASH, P_BLOOM_BLOCK_NBITS, P_TOTAL_BASES, P_FASTA_LINE_WIDTH,
+                        PARAM_COUNT_REV1,                                  // what containers of revision 1 (rounds 1-3 of this build) hold: 13 words
+                        P_CONTAINER_REV = PARAM_COUNT_REV1,                // revision of THIS container layout (not Leon's version): see CONTAINER_REV
+                        P_QUAL_ENCODER,                                    // who wrote leon/qual/block_<i>: QUAL_ENC_*
+                        PARAM_COUNT };
+// Container revisions.  1 (no P_CONTAINER_REV word): the header table has 2 words per block (payload bytes, reads) in files written before
+// the text-bytes column existed, 3 in later ones -- told apart by the table's size.  2: 3 words per block, P_QUAL_ENCODER recorded.
+constexpr uint64_t CONTAINER_REV = 2;
+// leon/qual/block_<i> are zlib streams either way; what differs is whose bytes they are
+enum QualEnc : uint64_t { QUAL_ENC_NONE = 0,          // no quality stream (or a revision-1 file: not recorded)
+                          QUAL_ENC_ZLIB = 1,          // zlib's compress2 at its default level (what upstream writes [RECALLED]): the default
+                          QUAL_ENC_DEVICE_RLE = 2 };  // the device's deflate (runs + dynamic Huffman codes): inflates to the same text, other bytes
 // info byte: bit 0 FASTA input (else FASTQ), bit 1 no header stream, bit 2 no quality stream, bit 3 lossless qualities
 enum Info : uint8_t { INFO_FASTA = 1, INFO_NO_HEADER = 2, INFO_NO_QUAL = 4, INFO_LOSSLESS = 8 };
 }  // namespace layout

@@ -149,18 +149,22 @@ int device_for(int gpu_index) {
 }
 
 
-// Which encoder writes the quality blocks.  The device's deflate (leon_qual_deflate_blocks_device) looks for runs only -- zlib's
-// Z_RLE strategy -- which is what quality strings usually reward, and is tens of times faster than zlib's default strategy on
-// all the host's cores; but where the lines resemble one another (old instruments' staircases, a file of identical lines) the
-// default strategy's matches against earlier lines win.  So a sample decides (LEON_QUAL_DEFLATE=device|host overrides): the first
-// reads' lines, up to 256 KB, through zlib both ways; the device takes the stream unless that would cost more than 2 %.
+// Which encoder writes the quality blocks.  The default is zlib itself on the host threads (leon_host_qual_encode_blocks: compress2 at
+// its default level, the bytes upstream writes [RECALLED] and the one stream of the file a third-party library can pin byte for byte).
+// `-qual-deflate device` hands them to the device's deflate (leon_qual_deflate_blocks_device), which looks for runs only -- zlib's
+// Z_RLE strategy -- and is tens of times faster than zlib's default strategy on all the host's cores; its blocks inflate to the same
+// text but are not zlib's bytes.  `-qual-deflate auto` lets a sample decide (the first reads' lines, up to 256 KB, through zlib both
+// ways: the device takes the stream unless that would cost more than 2 % -- where the lines resemble one another the default
+// strategy's matches against earlier lines win).  Without the flag, LEON_QUAL_DEFLATE=auto|device|host in the environment is the
+// tests' hook for the same choice.  The container records who wrote the blocks (layout::P_QUAL_ENCODER).
 enum class QualEncoder { Auto, Device, Host };
-QualEncoder qual_encoder_from_env() {
-    const char* e = getenv("LEON_QUAL_DEFLATE");
-    if (!e || !*e || !strcmp(e, "auto")) return QualEncoder::Auto;
+QualEncoder qual_encoder_choice(const std::string& flag) {
+    const char* e = flag.empty() ? getenv("LEON_QUAL_DEFLATE") : flag.c_str();
+    const char* what = flag.empty() ? "LEON_QUAL_DEFLATE=" : "option -qual-deflate: ";
+    if (!e || !*e || !strcmp(e, "host")) return QualEncoder::Host;
+    if (!strcmp(e, "auto")) return QualEncoder::Auto;
     if (!strcmp(e, "device")) return QualEncoder::Device;
-    if (!strcmp(e, "host")) return QualEncoder::Host;
-    throw Exception(std::string("LEON_QUAL_DEFLATE=") + e + ": expected auto, device or host");
+    throw Exception(std::string(what) + "'" + e + "': expected host, device or auto");
 }
 size_t deflated_size(const std::string& text, int strategy) {
     z_stream z{};
@@ -215,6 +219,7 @@ void Leon::run(int argc, char* argv[]) {
             else if (a == "-noheader") _noHeader = true;
             else if (a == "-noqual") _noQual = true;
             else if (a == "-test-file") _testFile = true;
+            else if (a == "-qual-deflate") { _qualDeflate = need("-qual-deflate"); (void)qual_encoder_choice(_qualDeflate); }
             else throw Exception("unknown option " + a);
         }
         if (_inputFilename.empty()) throw Exception("option -file is mandatory");
@@ -264,7 +269,7 @@ void Leon::executeCompression() {
     std::vector<uint64_t> hdr_text;                              // bytes of header text per read block: the decoder sizes its buffers from it
     const uint64_t batch_reads = 64ull * rpb;
     ReadBatch batch;
-    const QualEncoder qual_enc = qual_encoder_from_env();
+    const QualEncoder qual_enc = qual_encoder_choice(_qualDeflate);
     bool qual_on_device = false;
     void* d_qbuf = nullptr; uint64_t d_qbuf_cap = 0;             // the batch's qualities on the device, for its deflate (one job at a time uses it)
     struct QBufGuard { void** p; ~QBufGuard() { leon_device_free(*p); } } qbuf_guard{&d_qbuf};
@@ -423,7 +428,17 @@ void Leon::executeCompression() {
         // chunk i + 1 is copied
         // ONE call over the whole file: the library smooths the reads in the order of their minimizers, so that reads of the same
         // locus follow one another and share their bloom probes in cache -- which needs them all in one call
-        check(ctx[0].get(), leon_qual_smooth_batch_device(ctx[0].get(), store[0]->d_bases, store[0]->d_off, n_reads, qstore->d_bases), "leon_qual_smooth_batch_device");
+        // ... up to the DNA stream's batch size (2 000 blocks = 100 M reads: a call's work buffers grow with its reads, on top of the
+        // resident bases and qualities).  A call the device has no room for is retried in halves: smoothing is idempotent (it
+        // depends on the bases and on whether a quality is above '@'), and the reads' order inside a call only decides who
+        // shares probes with whom, never the bytes.
+        for (uint64_t r = 0, step = batch_blocks * rpb; r < n_reads;) {
+            const uint64_t got = std::min<uint64_t>(step, n_reads - r);
+            const int rc = leon_qual_smooth_batch_device(ctx[0].get(), store[0]->d_bases, store[0]->d_off + r, got, qstore->d_bases + offsets[r]);
+            if (rc == LEON_E_HIP && step > 64ull * rpb) { step = std::max<uint64_t>(64ull * rpb, (step / 2 + rpb - 1) / rpb * rpb); leon_device_trim(); continue; }
+            check(ctx[0].get(), rc, "leon_qual_smooth_batch_device");
+            r += got;
+        }
         {   // the sample that picks the encoder: the first reads' smoothed lines
             const uint64_t ns = std::min<uint64_t>(n_reads, 4000);
             std::string sample(offsets[ns] - offsets[0], '\0');
@@ -532,6 +547,8 @@ void Leon::executeCompression() {
     params[P_KMER_SIZE] = k; params[P_READS_PER_BLOCK] = rpb; params[P_N_READS] = n_reads; params[P_N_ANCHORS] = n_anchors;
     params[P_ABUNDANCE] = abundance; params[P_BLOOM_TAI] = tai; params[P_BLOOM_N_HASH] = 7; params[P_BLOOM_BLOCK_NBITS] = 12;
     params[P_TOTAL_BASES] = n_bases; params[P_FASTA_LINE_WIDTH] = fastq ? 0 : bank.fastaLineWidth();
+    params[P_CONTAINER_REV] = CONTAINER_REV;
+    params[P_QUAL_ENCODER] = !keep_qual ? QUAL_ENC_NONE : qual_on_device ? QUAL_ENC_DEVICE_RLE : QUAL_ENC_ZLIB;
     out.putU64(DS_PARAMS, params, PARAM_COUNT);
     out.close();
     if (std::rename(tmp_name.c_str(), _outputFilename.c_str()) != 0) throw Exception("cannot write " + _outputFilename);
@@ -557,12 +574,16 @@ void Leon::executeDecompression() {
     Container in(_inputFilename, Container::READ);
     const std::vector<uint8_t> infov = in.getBytes(DS_INFOBYTE);
     const std::vector<uint64_t> params = in.getU64(DS_PARAMS);
-    if (infov.size() != 1 || params.size() < PARAM_COUNT) throw Exception(_inputFilename + ": metadata is not what this build writes");
+    if (infov.size() != 1 || params.size() < PARAM_COUNT_REV1) throw Exception(_inputFilename + ": metadata is not what this build writes");
     const uint8_t info = infov[0];
     const bool fasta_in = info & INFO_FASTA, has_header = !(info & INFO_NO_HEADER), has_qual = !(info & INFO_NO_QUAL);
     const uint64_t k = params[P_KMER_SIZE], rpb = params[P_READS_PER_BLOCK], n_reads = params[P_N_READS], n_anchors = params[P_N_ANCHORS];
     const uint64_t tai = params[P_BLOOM_TAI], n_hash = params[P_BLOOM_N_HASH], nbits = params[P_BLOOM_BLOCK_NBITS], total_bases = params[P_TOTAL_BASES];
     if (params[P_VERSION_MAJOR] != 1) throw Exception(_inputFilename + " was written by an incompatible version");
+    // the container's own revision (layout::CONTAINER_REV): files of revision 1 have no such word
+    const uint64_t rev = params.size() > P_CONTAINER_REV ? params[P_CONTAINER_REV] : 1;
+    if (rev < 1 || rev > CONTAINER_REV)
+        throw Exception(_inputFilename + " was written by a later build (container revision " + std::to_string(rev) + ", this build reads up to " + std::to_string(CONTAINER_REV) + ")");
     if (k < 3 || k > 63 || rpb == 0 || rpb > (1u << 30) || n_hash < 1 || n_hash > 10 || nbits < 4 || nbits > 16 || n_anchors > (1ull << 32) ||
         n_reads > (1ull << 40) || total_bases > (1ull << 46))
         throw Exception(_inputFilename + ": implausible parameters in the metadata");
@@ -583,6 +604,13 @@ void Leon::executeDecompression() {
     if (has_header) {
         thdr = in.getU64(DS_HEADER_TABLE);
         first_header = in.getBytes(DS_FIRST_HEADER);
+        // revision 1 before the text-bytes column existed: 2 words per block (payload bytes, reads).  Such a file decodes like any
+        // other: its text buffers start from a guess (64 bytes per header) and the decoder asks for more where that falls short.
+        if (rev == 1 && thdr.size() == 2 * n_blocks && n_blocks) {
+            std::vector<uint64_t> t3(3 * n_blocks);
+            for (uint64_t b = 0; b < n_blocks; b++) { t3[3 * b] = thdr[2 * b]; t3[3 * b + 1] = thdr[2 * b + 1]; t3[3 * b + 2] = 64 * std::min<uint64_t>(thdr[2 * b + 1], rpb); }
+            thdr.swap(t3);
+        }
         if (thdr.size() != 3 * n_blocks) throw Exception(_inputFilename + ": the header block table does not match the read count");
         for (uint64_t b = 0; b < n_blocks; b++) {
             if (thdr[3 * b + 1] != tdna[3 * b + 1]) throw Exception(_inputFilename + ": header and DNA blocks disagree");

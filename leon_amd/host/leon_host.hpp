@@ -46,6 +46,7 @@ public:
     int _nbCores = 0;                     // 0 = all
     int _gpus = 1;
     bool _lossless = false, _seqOnly = false, _noHeader = false, _noQual = false, _testFile = false, _verbose = false;
+    std::string _qualDeflate;             // -qual-deflate host|device|auto; empty = not given: zlib on the host threads (the reference's bytes)
 
 private:
     void executeCompression();

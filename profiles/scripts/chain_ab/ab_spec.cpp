@@ -1,0 +1,273 @@
+// The dictionary chain with the renormalisation flag PREDICTED one symbol ahead (round 4), against the
+// chain as it stands (host_rc.h encode_records), on records produced beforehand.  No GPU involved.
+//   ./ab_spec [n_kmers] [skew]     skew: 0 uniform k-mers, 1 poly-A rich, 2 two-letter
+//
+// The carried recurrence of the chain as it stands is  q -> imul -> add -> xor -> cmp -> cmov -> q'  (7 cycles): the next
+// quotient is selected by the flag f = "exactly one byte leaves", and f needs the step's new low and high ends.
+// Here f(t + 1) is predicted during step t from step t's un-normalised (Lu, Ru) alone:
+//     q(t+1) * lo'  ~  hi(Ru * G1'),   q(t+1) * (lo' + fr')  ~  hi(Ru * G2'),     G = floor(count * 2^32 / total') << 32
+//     f(t+1)  ~  ((Lu + p1) ^ (Lu + pw)) < (f(t) ? 2^48 : 2^56)       (a byte that left at t moves the frame by 8 bits)
+// so the recurrence becomes  q -> (shl) -> mulhi -> cmov -> q'  (6 cycles: the shifted quotient's product is one shift late),
+// and the exact flag, computed as before but off the carried path, only CHECKS the prediction: a wrong one (the predicted
+// ends are within ~2^32 of a byte boundary: ~10^-5 of the symbols) redoes the step's selections.  Bytes are identical by
+// construction: every selection is finally made with the exact flag.
+#define private public
+#include "../../../leon_amd/csrc/host_rc.h"
+#include <cstdio>
+#include <cstring>
+#include <random>
+using namespace leon;
+
+struct SpecRec { uint64_t c; uint32_t lo, g1, fr, g2; };     // 24 bytes: C = floor(fr 2^64 / (tot + 1)); g1 = floor(lo 2^32 / tot), g2 = floor((lo + fr) 2^32 / tot)
+
+static constexpr uint64_t kTop = 1ull << 56, kBottom = 1ull << 48;
+
+struct SpecCoder {
+    uint64_t low_ = 0, range_ = ~0ull;
+    std::vector<uint8_t> buf_;
+    size_t w_ = 0;
+    uint64_t mispredicted = 0, slow = 0, doubt = 0;       // (slow counts every plain step: rare cases, doubts and mispredictions)
+    void settle() {
+        uint8_t* p = buf_.data() + w_;
+        while ((low_ ^ (low_ + range_)) < kTop || (range_ < kBottom && ((range_ = (0 - low_) & (kBottom - 1)), true))) {
+            *p++ = (uint8_t)(low_ >> 56); range_ <<= 8; low_ <<= 8;
+        }
+        w_ = (size_t)(p - buf_.data());
+    }
+    void flush() {
+        if (buf_.size() < w_ + 24) buf_.resize(w_ + 24);
+        settle();
+        for (int i = 0; i < 8; i++) { buf_[w_++] = (uint8_t)(low_ >> 56); low_ <<= 8; }
+    }
+    // One symbol the plain way, from the carried (q, L): used for whatever the fast path does not cover -- two bytes or more leaving at
+    // once, the carry-less coder's range reset, a quotient in doubt, a mispredicted flag, a segment's last symbol (which must leave the
+    // exact range behind).  Returns the new range; q, L, f, p are updated (f: the NEXT symbol's flag, exact, when there is a next record).
+    struct Plain { uint64_t q, L, f, R; uint8_t* p; };
+    __attribute__((noinline)) Plain step_plain(const SpecRec* r, bool has_next, uint64_t tot_next, uint64_t q, uint64_t L, uint64_t f, uint8_t* p) {
+        uint64_t Lo = L + q * r->lo, R = q * r->fr;
+        while ((Lo ^ (Lo + R)) < kTop || (R < kBottom && ((R = (0 - Lo) & (kBottom - 1)), true))) { *p++ = (uint8_t)(Lo >> 56); R <<= 8; Lo <<= 8; }
+        const uint64_t qn = R / tot_next;
+        if (has_next) f = ((Lo + qn * r[1].lo) ^ (Lo + qn * ((uint64_t)r[1].lo + r[1].fr))) < kTop ? 1 : 0;
+        slow++;
+        return Plain{qn, Lo, f, R, p};
+    }
+    // n symbols from their records, the first one being symbol t0 of the stream; r[n] must be readable (its g1, g2 feed the last
+    // fast symbol's prediction)
+    void encode_records(const SpecRec* r, uint64_t n, uint64_t t0) {
+        if (!n) return;
+        if (buf_.size() < w_ + 8 * n + 64) buf_.resize(buf_.size() * 2 + 8 * n + 4096);
+        settle();
+        uint8_t* p = buf_.data() + w_;
+        uint64_t L = low_;
+        const SpecRec* const r0 = r;
+        uint64_t q = range_ / (5 + t0);
+        // the first symbol's flag, exactly (the state is normalised here)
+        uint64_t f = ((L + q * r->lo) ^ (L + q * ((uint64_t)r->lo + r->fr))) < kTop ? 1 : 0;
+        const SpecRec* const e = r + n - 1;                      // the last symbol goes the plain way
+        const uint64_t top = kTop, bottom = kBottom;
+        while (r < e) {
+            __builtin_prefetch(reinterpret_cast<const char*>(r) + 3072);
+            const uint64_t lo = r->lo, fr = r->fr, C = r->c;
+            const uint64_t Ru = q * fr;
+            const uint64_t Lu = L + q * lo, x = Lu ^ (Lu + Ru);
+            const uint64_t q8 = q << 8;
+            const uint64_t Phi = (uint64_t)(((unsigned __int128)q * C) >> 64);
+            const unsigned __int128 P8 = (unsigned __int128)q8 * C;
+            const uint64_t Phi8 = (uint64_t)(P8 >> 64), Plo8 = (uint64_t)P8;
+            // prediction of the NEXT symbol's flag from this symbol's un-normalised ends (the next record's g1 / g2 sit in the
+            // high halves of two 8-byte words whose low halves -- lo, fr -- are noise far below the predictor's resolution)
+            uint64_t G1, G2;
+            memcpy(&G1, reinterpret_cast<const char*>(r + 1) + 8, 8);
+            memcpy(&G2, reinterpret_cast<const char*>(r + 1) + 16, 8);
+            const uint64_t xp = (Lu + (uint64_t)(((unsigned __int128)Ru * G1) >> 64)) ^ (Lu + (uint64_t)(((unsigned __int128)Ru * G2) >> 64));
+            // whatever is not "no byte or exactly one, as predicted, with a quotient beyond doubt" goes the plain way, from (q, L)
+            if (__builtin_expect((x < bottom) | (Ru < bottom) | ((x < top) != (f != 0)) | (Plo8 > ~q8), 0)) {
+                mispredicted += (x >= bottom && Ru >= bottom && (x < top) != (f != 0));
+                const Plain s = step_plain(r, true, 5 + t0 + (uint64_t)(r - r0) + 1, q, L, f, p);
+                q = s.q; L = s.L; f = s.f; p = s.p;
+                r++;
+                continue;
+            }
+            *p = (uint8_t)(Lu >> 56);
+            uint64_t qn = Phi, Ln = Lu, thr = top, fn;
+            // (qn, Ln, thr) = f ? (Phi8, Lu << 8, 2^48) : (Phi, Lu, 2^56): conditional moves on the PREDICTED flag, known since the step before
+            asm("testq %[f], %[f]\n\tcmovnzq %[A], %[qn]\n\tcmovnzq %[L1], %[Ln]\n\tcmovnzq %[B], %[thr]"
+                : [qn] "+r"(qn), [Ln] "+r"(Ln), [thr] "+r"(thr)
+                : [f] "r"(f), [A] "r"(Phi8), [L1] "r"(Lu << 8), [B] "r"(bottom)
+                : "cc");
+            p += f;
+            asm("cmpq %[thr], %[xp]\n\tsbbq %[fn], %[fn]\n\tnegq %[fn]" : [fn] "=r"(fn) : [xp] "r"(xp), [thr] "r"(thr) : "cc");     // fn = xp < thr
+            q = qn; L = Ln; f = fn; r++;
+        }
+        const Plain s = step_plain(r, false, 5 + t0 + n, q, L, f, p);
+        slow--;
+        range_ = s.R; low_ = s.L;
+        w_ = (size_t)(s.p - buf_.data());
+    }
+    // The same, the fast path as ONE hand-scheduled asm loop (the compiler's schedule of the C form above spills the carried quotient
+    // and puts its multiply last): state in registers, left at the first symbol that needs the plain way or at the end.
+    void encode_records_asm(const SpecRec* r, uint64_t n, uint64_t t0) {
+        if (!n) return;
+        if (buf_.size() < w_ + 8 * n + 64) buf_.resize(buf_.size() * 2 + 8 * n + 4096);
+        settle();
+        uint8_t* p = buf_.data() + w_;
+        uint64_t L = low_;
+        const SpecRec* const r0 = r;
+        uint64_t q = range_ / (5 + t0);
+        uint64_t fm = ((L + q * r->lo) ^ (L + q * ((uint64_t)r->lo + r->fr))) < kTop ? ~0ull : 0;      // the first symbol's flag, exactly, as a mask
+        const SpecRec* const e = r + n - 1;                      // the last symbol goes the plain way
+        while (r < e) {
+            asm volatile(
+                ".p2align 5\n"
+                "1:\n\t"
+                "prefetcht0 3072(%[r])\n\t"
+                "movq  %[q], %%rdx\n\t"
+                "mulxq (%[r]), %%rbx, %%rbx\n\t"          // rbx = Phi = hi(q * C)
+                "movl  8(%[r]), %%ecx\n\t"
+                "imulq %[q], %%rcx\n\t"                   // q * lo
+                "movl  16(%[r]), %%r14d\n\t"
+                "imulq %[q], %%r14\n\t"                   // Ru = q * fr
+                "shlq  $8, %%rdx\n\t"                     // q8
+                "mulxq (%[r]), %%rax, %%r15\n\t"          // r15 = Phi8 = hi(q8 * C), rax = its low half
+                "addq  %[L], %%rcx\n\t"                   // Lu
+                "addq  %%rdx, %%rax\n\t"                  // quotient in doubt: the low half within q8 of 2^64
+                "jc    2f\n\t"
+                "leaq  (%%rcx,%%r14), %%rax\n\t"
+                "xorq  %%rcx, %%rax\n\t"                  // x = Lu ^ (Lu + Ru)
+                "cmpq  %[bot], %%rax\n\t"
+                "jb    2f\n\t"                            // two bytes or more
+                "cmpq  %[bot], %%r14\n\t"
+                "jb    2f\n\t"                            // range below BOTTOM
+                "cmpq  %[top], %%rax\n\t"
+                "sbbq  %%rax, %%rax\n\t"                  // the exact flag, as a mask
+                "cmpq  %[fm], %%rax\n\t"
+                "jne   2f\n\t"                            // mispredicted
+                "movq  %%r14, %%rdx\n\t"
+                "mulxq 32(%[r]), %%rax, %%rax\n\t"        // ~ q' * lo'
+                "mulxq 40(%[r]), %%rdx, %%rdx\n\t"        // ~ q' * (lo' + fr')
+                "addq  %%rcx, %%rax\n\t"
+                "addq  %%rcx, %%rdx\n\t"
+                "xorq  %%rdx, %%rax\n\t"                  // xp
+                "rorxq $56, %%rcx, %%rdx\n\t"             // dl = the top byte of Lu
+                "movb  %%dl, (%[p])\n\t"
+                "subq  %[fm], %[p]\n\t"                   // p += f
+                "movq  %%rcx, %%rdx\n\t"
+                "shlq  $8, %%rdx\n\t"
+                "movq  %[top], %%r14\n\t"
+                "testq %[fm], %[fm]\n\t"
+                "cmovnzq %%r15, %%rbx\n\t"                // q' = f ? Phi8 : Phi
+                "cmovnzq %%rdx, %%rcx\n\t"                // L' = f ? Lu << 8 : Lu
+                "cmovnzq %[bot], %%r14\n\t"               // the next symbol's byte boundary in this symbol's frame: f ? 2^48 : 2^56
+                "cmpq  %%r14, %%rax\n\t"
+                "sbbq  %[fm], %[fm]\n\t"                  // the next symbol's flag, predicted
+                "movq  %%rbx, %[q]\n\t"
+                "movq  %%rcx, %[L]\n\t"
+                "addq  $24, %[r]\n\t"
+                "cmpq  %[e], %[r]\n\t"
+                "jb    1b\n"
+                "2:\n"
+                : [r] "+r"(r), [q] "+r"(q), [L] "+r"(L), [fm] "+r"(fm), [p] "+r"(p)
+                : [e] "r"(e), [top] "r"(kTop), [bot] "r"(kBottom)
+                : "rax", "rbx", "rcx", "rdx", "r14", "r15", "cc", "memory");
+            if (r >= e) break;
+            const Plain s = step_plain(r, true, 5 + t0 + (uint64_t)(r - r0) + 1, q, L, fm & 1, p);
+            q = s.q; L = s.L; fm = 0 - s.f; p = s.p;
+            r++;
+        }
+        const Plain s = step_plain(r, false, 5 + t0 + n, q, L, fm & 1, p);
+        slow--;
+        range_ = s.R; low_ = s.L;
+        w_ = (size_t)(s.p - buf_.data());
+    }
+};
+
+int main(int argc, char** argv) {
+    const uint32_t k = 31;
+    const size_t n = argc > 1 ? atol(argv[1]) : 4000000;
+    const int skew = argc > 2 ? atoi(argv[2]) : 0;
+    std::mt19937_64 rng(1);
+    std::vector<uint64_t> km(n);
+    for (auto& x : km) {
+        x = rng() >> 2;
+        if (skew == 1) { const uint64_t m = rng() & rng() & rng(); x &= m >> 2; }           // mostly A
+        if (skew == 2) x &= 0x5555555555555555ull >> 2;                                      // A and C only
+    }
+    std::vector<ChainRec16> recs(n * k);
+    std::vector<SpecRec> srecs(n * k + 1);
+    uint64_t c[4] = {1, 1, 1, 1}, t = 0;
+    ChainRec16* out = recs.data();
+    SpecRec* so = srecs.data();
+    for (size_t a = 0; a < n; a++) for (uint32_t i = 0; i < k; i++, t++, out++, so++) {
+        const uint32_t sy = (uint32_t)(km[a] >> (2 * (k - 1 - i))) & 3u;
+        const uint64_t c01 = c[0] + c[1], lo = sy == 0 ? 0 : sy == 1 ? c[0] : sy == 2 ? c01 : c01 + c[2], fr = c[sy];
+        uint64_t q, r; const uint64_t tot = 5 + t, d = tot + 1;
+        asm("divq %[d]" : "=a"(q), "=d"(r) : "a"(0ull), "d"(fr), [d] "r"(d) : "cc");
+        out->c = q; out->lo = (uint32_t)lo; out->fr = (uint32_t)fr;
+        so->c = q; so->lo = (uint32_t)lo; so->fr = (uint32_t)fr;
+        so->g1 = (uint32_t)((lo << 32) / tot); so->g2 = (uint32_t)(std::min<uint64_t>(((lo + fr) << 32) / tot, 0xFFFFFFFFull));
+        c[sy]++;
+    }
+    srecs[n * k] = SpecRec{0, 0, 0, 0, 0};
+    const size_t plain = 20;
+    // correctness: the whole stream both ways
+    std::vector<uint8_t> ref;
+    {
+        AnchorDictCoder cd;
+        cd.encode_kmers(km.data(), plain, k);
+        auto t0 = std::chrono::steady_clock::now();
+        cd.encode_records(recs.data() + plain * k, (n - plain) * k, plain * k);
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        cd.flush();
+        ref.assign(cd.data(), cd.data() + cd.size());
+        printf("AS IT STANDS, records from DRAM: %.3f ns/symbol, %zu bytes\n", dt / ((n - plain) * (double)k) * 1e9, cd.size());
+    }
+    for (int rep = 0; rep < 4; rep++) {
+        const bool use_asm = rep >= 2;
+        AnchorDictCoder head;
+        head.encode_kmers(km.data(), plain, k);
+        SpecCoder sc;
+        sc.buf_.assign(head.buf_.data(), head.buf_.data() + head.w_); sc.buf_.resize(sc.buf_.size() + 64);
+        sc.w_ = head.w_; sc.low_ = head.low_; sc.range_ = head.range_;
+        auto t0 = std::chrono::steady_clock::now();
+        if (use_asm) sc.encode_records_asm(srecs.data() + plain * k, (n - plain) * k, plain * k); else sc.encode_records(srecs.data() + plain * k, (n - plain) * k, plain * k);
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        sc.flush();
+        const bool same = sc.w_ == ref.size() && memcmp(sc.buf_.data(), ref.data(), ref.size()) == 0;
+        printf("PREDICTED FLAG%s, records from DRAM: %.3f ns/symbol, %zu bytes, %s; mispredicted %llu, slow path %llu, in doubt %llu of %zu symbols\n",
+               use_asm ? " (asm)" : "", dt / ((n - plain) * (double)k) * 1e9, sc.w_, same ? "IDENTICAL" : "DIFFERENT", (unsigned long long)sc.mispredicted,
+               (unsigned long long)sc.slow, (unsigned long long)sc.doubt, (n - plain) * (size_t)k);
+        if (!same) return 1;
+    }
+    {   // cache-resident stretches, over and over (the state keeps evolving; output discarded by rewinding)
+        const size_t m = 60000, start = (n > 1100000 ? 1000000 : n / 2) * (size_t)k;
+        {
+            AnchorDictCoder cd;
+            cd.encode_kmers(km.data(), 20, k);
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 300; i++) { cd.w_ = 0; cd.encode_records(recs.data() + start, m, start); }
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("AS IT STANDS, records in cache: %.3f ns/symbol\n", dt / (300.0 * m) * 1e9);
+        }
+        {
+            AnchorDictCoder head;
+            head.encode_kmers(km.data(), 20, k);
+            SpecCoder sc;
+            sc.buf_.resize(1 << 20); sc.low_ = head.low_; sc.range_ = head.range_;
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 300; i++) { sc.w_ = 0; sc.encode_records(srecs.data() + start, m, start); }
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("PREDICTED FLAG, records in cache: %.3f ns/symbol (mispredicted %llu of %zu)\n", dt / (300.0 * m) * 1e9, (unsigned long long)sc.mispredicted, (size_t)300 * m);
+        }
+        {
+            AnchorDictCoder head;
+            head.encode_kmers(km.data(), 20, k);
+            SpecCoder sc;
+            sc.buf_.resize(1 << 20); sc.low_ = head.low_; sc.range_ = head.range_;
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 300; i++) { sc.w_ = 0; sc.encode_records_asm(srecs.data() + start, m, start); }
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("PREDICTED FLAG (asm), records in cache: %.3f ns/symbol (plain steps %llu of %zu)\n", dt / (300.0 * m) * 1e9, (unsigned long long)sc.slow, (size_t)300 * m);
+        }
+    }
+    return 0;
+}

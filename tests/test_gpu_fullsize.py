@@ -72,11 +72,18 @@ def test_full_size_properties(N_READS, K, L):
     # (1) determinism: a second run gives the same bytes
     blocks2, d2, na2, _, _ = run()
     assert _checksum(blocks2) == _checksum(blocks) and d2 == d and na2 == na
-    # (2) shard union == single stream
+    # (2) shard union == single stream.  BASELINE configuration #4 is this file (100 M x 150 bp, k = 31) over EIGHT ranks: its 8-way
+    # split is byte-checked here at its size (the other shapes take 3 ranks), and what every rank reports is what block_range says
+    from leon_amd.shard import block_range
+    world = 8 if (N_READS, K, L) == (100_000_000, 31, 150) else 3
     u = []
-    for r in range(3):
-        bl_r, d_r, na_r, _, _ = run(r, 3)
-        assert na_r == na and (d_r == d if r == 0 else len(d_r) == 0)
+    for r in range(world):
+        bl_r, d_r, na_r, _, st_r = run(r, world)
+        lo, hi = block_range(r, world, n_blocks)
+        assert [b[0] for b in bl_r] == list(range(lo, hi)) and all(b[2] == RPB for b in bl_r)
+        assert st_r["n_blocks"] == hi - lo and st_r["n_reads"] == (hi - lo) * RPB and st_r["n_bases"] == (hi - lo) * RPB * L
+        assert st_r["n_anchors"] == na and na_r == na and (d_r == d if r == 0 else len(d_r) == 0)
+        print("rank %d of %d: %d blocks, device %.0f ms (resolve %.0f, walk %.0f, range coder %.0f)" % (r, world, hi - lo, st_r["ms_total"], st_r["ms_resolve"], st_r["ms_walk"], st_r["ms_rangecoder"]))
         u += bl_r
     assert _checksum(u) == _checksum(blocks)
     # (3) the reference's own acceptance test (decompress(compress(x)) == x), on sampled blocks, through the oracle's decoder

@@ -59,8 +59,13 @@ def test_two_and_three_process_runs_reproduce_the_single_process_stream():
         assert many["verify"]["dict_sha256"] == one["verify"]["dict_sha256"]
         assert many["verify"]["n_anchors"] == one["verify"]["n_anchors"]
         assert many["config"]["bloom_bytes"] == one["config"]["bloom_bytes"] and many["config"]["bloom_bcast_ms"] > 0
-        for key in ("device_ms_max_over_ranks", "host_chain_ms", "value_device_only", "cold_first_step_ms"):
+        for key in ("device_ms_max_over_ranks", "host_chain_ms", "value_device_only", "cold_first_step_ms", "bloom_bcast_ms"):
             assert many[key] > 0
+        # what the 1 -> 8 curve will be read from: every rank's device stages, gathered
+        assert [r["rank"] for r in many["per_rank"]] == list(range(world)) and many["collective_backend"] == "gloo" and many["rccl_ranks"] is None
+        assert [r["blocks"] for r in many["per_rank"]] == many["verify"]["blocks_per_rank"]
+        assert all(r["stages_ms"]["ms_resolve"] > 0 and r["stages_ms"]["ms_walk"] > 0 and r["device_ms"] > 0 for r in many["per_rank"])
+        assert many["per_rank"][0]["chain_ms"] > 0 and all(r["chain_ms"] == 0 for r in many["per_rank"][1:])      # rank 0 alone codes the dictionary
 
 
 def test_default_bench_line_fills_every_key():
@@ -107,3 +112,30 @@ def test_rccl_path_with_one_rank():
     assert line["n_gpus"] == 1 and line["config"]["bloom_bcast_ms"] > 0            # the broadcast ran (through RCCL)
     plain = _bench(1, extra_args=("--quick", "--verify"))
     assert line["verify"]["blocks_sha256"] == plain["verify"]["blocks_sha256"] and line["verify"]["dict_sha256"] == plain["verify"]["dict_sha256"]
+
+
+def test_bench_as_rank_r_of_8_seats_add_up_to_the_single_stream():
+    """LEON_BENCH_AS_RANK=r:N: ONE process takes the seat of rank r of an N-rank job (leon_dna_set_shard(r, N), every collective of
+    the N-rank code on an RCCL process group of one).  The eight seats of an 8-rank job, one after the other on the one GPU: every seat
+    codes exactly its block range, rank 0 alone the dictionary, and the eight seats' blocks are the single-process stream's (each seat's
+    checksum over its own blocks == the same checksum over those blocks of the whole stream is what `verify` cannot say from one seat;
+    the union over the seats can: block counts add up, ranges are contiguous and disjoint, the dictionary is rank 0's)."""
+    import hashlib
+    from leon_amd.shard import block_range
+    n_blocks = READS // 50000
+    one = _bench(1, extra_args=("--quick", "--verify"))
+    env0 = {"LEON_BENCH_BACKEND": "nccl"}
+    seats = []
+    for r in range(8):
+        line = _bench(1, extra_env=dict(env0, LEON_BENCH_AS_RANK="%d:8" % r), extra_args=("--quick", "--verify"))
+        assert line["as_rank"] == "%d:8" % r and line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["collective_backend"] == "nccl"
+        lo, hi = block_range(r, 8, n_blocks)
+        v = line["verify"]
+        assert (v["n_blocks"], v["first_block"], v["last_block"]) == (hi - lo, lo, hi - 1), (r, v)
+        assert line["per_rank"][0]["rank"] == r and line["per_rank"][0]["blocks"] == hi - lo
+        assert v["n_anchors"] == one["verify"]["n_anchors"]
+        assert (v["dict_sha256"] == one["verify"]["dict_sha256"]) if r == 0 else (v["dict_sha256"] == hashlib.sha256(b"").hexdigest())
+        assert (line["host_chain_ms"] > 0) == (r == 0)
+        assert line["bloom_bcast_ms"] > 0
+        seats.append(v["n_blocks"])
+    assert sum(seats) == n_blocks == one["verify"]["n_blocks"]

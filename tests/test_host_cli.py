@@ -339,8 +339,11 @@ def test_cli_stream_selection_flags_and_lossy_qualities(leon_bin, tmp_path):
 
 @pytest.mark.gpu
 def test_cli_quality_encoder_choice(leon_bin, tmp_path):
-    """the quality blocks come from the device's deflate (runs + dynamic Huffman codes) or from zlib on the host threads: a sample of
-    the file's first lines decides, LEON_QUAL_DEFLATE overrides; whichever wrote them, `leon -d` gives the file back"""
+    """`leon -c` writes zlib's own quality blocks (compress2 at the default level: the bytes upstream writes [RECALLED], and the one stream
+    of the file a third-party library pins) unless the user asks otherwise: `-qual-deflate device` hands them to the device's deflate
+    (runs + dynamic Huffman codes: inflates to the same text, other bytes), `-qual-deflate auto` lets a sample of the first lines decide;
+    LEON_QUAL_DEFLATE is the same choice for tests when the flag is absent.  The container records who wrote the blocks
+    (leon/metadata/params, word 14); whichever did, `leon -d` gives the file back"""
     import random
     import synth
     rnd = random.Random(3)
@@ -349,23 +352,72 @@ def test_cli_quality_encoder_choice(leon_bin, tmp_path):
     reads = [bytes(bases[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
     noisy = [bytes(rnd.choice(b"#,-5:<>?@ABCDEFGHIJ") for _ in r) for r in reads]             # nothing to match: runs are enough
     stair = [bytes(74 - min(41, (j * 41) // len(r)) for j in range(len(r))) for r in reads]     # every line the same staircase: earlier lines match
-    for name, quals, want in (("noisy", noisy, "deflated on the device"), ("stair", stair, "zlib on the host threads")):
+    env0 = {k: v for k, v in os.environ.items() if k != "LEON_QUAL_DEFLATE"}
+    P_REV, P_QUAL_ENCODER, ZLIB, DEVICE = 13, 14, 1, 2
+    for name, quals, auto_picks_device in (("noisy", noisy, True), ("stair", stair, False)):
         fq = str(tmp_path / (name + ".fastq"))
         text = b"".join(b"@r%d\n" % i + r + b"\n+\n" + q + b"\n" for i, (r, q) in enumerate(zip(reads, quals)))
+        qtext = b"".join(q + b"\n" for q in quals)
         open(fq, "wb").write(text)
         sizes = {}
-        for mode in ("auto", "device", "host"):
-            r = run(leon_bin, "-file", fq, "-c", "-lossless", "-kmer-size", "21", "-abundance", "2", env=dict(os.environ, LEON_QUAL_DEFLATE=mode))
+        for how, flags, env in (("default", (), env0), ("host", ("-qual-deflate", "host"), env0), ("device", ("-qual-deflate", "device"), env0),
+                                ("auto", ("-qual-deflate", "auto"), env0), ("env-device", (), dict(env0, LEON_QUAL_DEFLATE="device")),
+                                ("flag-over-env", ("-qual-deflate", "host"), dict(env0, LEON_QUAL_DEFLATE="device"))):
+            r = run(leon_bin, "-file", fq, "-c", "-lossless", "-kmer-size", "21", "-abundance", "2", *flags, env=env)
             assert r.returncode == 0, r.stderr
             line = next(l for l in r.stdout.splitlines() if l.startswith("quality stream"))
-            assert ("deflated on the device" in line) == (mode == "device" or (mode == "auto" and want == "deflated on the device")), (name, mode, line)
-            sizes[mode] = int(line.split("->")[1].split()[0])
-            r = run(leon_bin, "-file", fq + ".leon", "-d")
+            on_device = how in ("device", "env-device") or (how == "auto" and auto_picks_device)
+            assert ("deflated on the device" in line) == on_device, (name, how, line)
+            sizes[how] = int(line.split("->")[1].split()[0])
+            params = h5_dataset(fq + ".leon", "leon/metadata/params", np.uint64)
+            assert len(params) == 15 and params[P_REV] == 2 and params[P_QUAL_ENCODER] == (DEVICE if on_device else ZLIB), (name, how, list(params))
+            q0 = h5_dataset(fq + ".leon", "leon/qual/block_0").tobytes()
+            assert zlib.decompress(q0) == qtext, (name, how)               # either way a zlib stream of the block's lines ...
+            assert (q0 == zlib.compress(qtext)) == (not on_device), (name, how)     # ... zlib's own bytes unless the device was asked for
+            r = run(leon_bin, "-file", fq + ".leon", "-d", env=env0)
             assert r.returncode == 0, r.stderr
-            assert open(fq + ".d", "rb").read() == text, (name, mode)
+            assert open(fq + ".d", "rb").read() == text, (name, how)
+        assert sizes["default"] == sizes["host"] == sizes["flag-over-env"] and sizes["device"] == sizes["env-device"]
         assert sizes["auto"] <= 1.02 * min(sizes["device"], sizes["host"]) + 64, (name, sizes)       # the sample picked the smaller one
-    r = run(leon_bin, "-file", fq, "-c", "-lossless", env=dict(os.environ, LEON_QUAL_DEFLATE="gpu"))
+    # the lossy default takes the same road: smoothed lines through zlib unless asked otherwise
+    r = run(leon_bin, "-file", fq, "-c", "-kmer-size", "21", "-abundance", "2", env=env0)
+    assert r.returncode == 0 and "zlib on the host threads" in r.stdout, r.stdout + r.stderr
+    assert h5_dataset(fq + ".leon", "leon/metadata/params", np.uint64)[P_QUAL_ENCODER] == ZLIB
+    r = run(leon_bin, "-file", fq, "-c", "-kmer-size", "21", "-abundance", "2", "-qual-deflate", "device", env=env0)
+    assert r.returncode == 0 and "deflated on the device" in r.stdout, r.stdout + r.stderr
+    assert h5_dataset(fq + ".leon", "leon/metadata/params", np.uint64)[P_QUAL_ENCODER] == DEVICE
+    r = run(leon_bin, "-file", fq, "-c", "-noqual", env=env0)
+    assert r.returncode == 0 and h5_dataset(fq + ".leon", "leon/metadata/params", np.uint64)[P_QUAL_ENCODER] == 0
+    r = run(leon_bin, "-file", fq, "-c", "-lossless", env=dict(env0, LEON_QUAL_DEFLATE="gpu"))
     assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: ") and "LEON_QUAL_DEFLATE" in r.stderr
+    r = run(leon_bin, "-file", fq, "-c", "-lossless", "-qual-deflate", "gpu", env=env0)
+    assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: ") and "-qual-deflate" in r.stderr
+    r = run(leon_bin, "-file", fq, "-c", "-lossless", "-qual-deflate", env=env0)
+    assert r.returncode == 1 and r.stderr.startswith("EXCEPTION: ")
+
+
+@pytest.mark.gpu
+def test_container_of_the_previous_layout_still_decodes(leon_bin, tmp_path):
+    """the header block table went from 2 to 3 words per block without the container saying so.  Containers now carry their
+    own revision (leon/metadata/params word 13; absent = revision 1) and revision 1 is read in both of its shapes.
+    tests/golden/r2_layout_toy.fasta.leon was written by the round-2 build (git 12ee041: 13 parameter words, 2-word header table) from
+    tests/golden/toy.fasta (tests/golden/make_r2_layout.sh); a file from a LATER revision is refused by name, not mis-parsed"""
+    old = os.path.join(ROOT, "tests", "golden", "r2_layout_toy.fasta.leon")
+    params = h5_dataset(old, "leon/metadata/params", np.uint64)
+    n_blocks = 1
+    assert len(params) == 13 and len(h5_dataset(old, "leon/metadata/header_blocksizes", np.uint64)) == 2 * n_blocks
+    f = str(tmp_path / "toy.fasta.leon")
+    shutil.copy(old, f)
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "toy.fasta"), str(tmp_path / "toy.fasta"))
+    for env in (os.environ, dict(os.environ, LEON_HEADER_DEVICE_BLOCKS="0")):
+        r = run(leon_bin, "-file", f, "-d", "-test-file", env=env)
+        assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
+    # today's writer on the same input: revision 2, 3-word table, the same reads back
+    r = run(leon_bin, "-file", str(tmp_path / "toy.fasta"), "-c")
+    assert r.returncode == 0, r.stderr
+    params = h5_dataset(f, "leon/metadata/params", np.uint64)
+    assert len(params) == 15 and params[13] == 2 and len(h5_dataset(f, "leon/metadata/header_blocksizes", np.uint64)) == 3 * n_blocks
+    assert run(leon_bin, "-file", f, "-d", "-test-file").returncode == 0
 
 
 @pytest.mark.gpu
