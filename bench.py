@@ -64,6 +64,10 @@ def parse():
                     help="reads timed through the CPU restatement on rank 0 at N=1 (0 = skip)")
     ap.add_argument("--err", type=float, default=0.01)
     ap.add_argument("--kmer-max-keys", type=int, default=0, help="k-mers sorted per pass by the solid k-mer counter (0 = sized by the library)")
+    ap.add_argument("--walk-by", choices=("auto", "block", "anchor"), default=os.environ.get("LEON_BENCH_WALK_BY", "auto"),
+                    help="N > 1: how a batch's walk is divided among the ranks -- `block`: every rank walks the reads of its own block range (no exchange); "
+                         "`anchor`: rank r walks the r-th slice of the batch's reads sorted by anchor address and the walk events reach the rank that codes the "
+                         "read's block through one all-to-all per batch (leon_dna_set_exchange); auto = anchor")
     ap.add_argument("--quick", action="store_true",
                     help="only the timed steps, roofline and cpu_baseline: skip pcie_inclusive / verify / decode / streams / end_to_end")
     ap.add_argument("--decode", action="store_true", help="(always on at N = 1 unless --quick) decode the whole file on the device and compare it with the input")
@@ -269,6 +273,13 @@ def main():
     ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local,
                                     resolve_window=int(os.environ.get("LEON_RESOLVE_WINDOW", 0)))
     ctx.set_shard(rank, world)
+    walk_by = "block" if world == 1 else ("anchor" if a.walk_by == "auto" else a.walk_by)
+    if walk_by == "anchor":
+        # a seat of an N-rank job on its own (LEON_BENCH_AS_RANK) plays the other ranks' slices itself; real ranks exchange
+        if as_rank:
+            ctx.set_exchange(capi.XCH_EMULATE)
+        else:
+            ctx.set_exchange(capi.XCH_BY_ANCHOR, make_exchange(dist, device, backend, pg_rank, pg_world, capi))
     ctx.reserve(B, B * L)                      # what a host does while it parses: the first step then allocates nothing large
     nbytes = ctx.bloom_nbytes
     bcast_ms = 0.0
@@ -305,8 +316,8 @@ def main():
         payload[1] += 1
         return 0
     cb = capi.SINK(sink)
-    STAGES = ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder", "ms_d2h", "ms_total")
-    COUNTS = ("n_symbols", "resolve_rounds", "resolve_windows", "walk_launches")
+    STAGES = ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder", "ms_d2h", "ms_total", "ms_exchange", "ms_exchange_call", "ms_emulated")
+    COUNTS = ("n_symbols", "resolve_rounds", "resolve_windows", "walk_launches", "xch_words_sent", "xch_words_received", "walk_reads")
 
     def encode_stream(the_sink):
         """one file: every batch in order through leon_dna_encode_batch_device; returns the stage times summed over the batches"""
@@ -368,7 +379,7 @@ def main():
         t_prev = now
         chain_ms.append(acc["ms_chain_busy"])
         walk_ms.append(acc["ms_walk"]); walk_n.append(max(acc["walk_launches"], 1))
-        dev_ms.append(acc["ms_total"])
+        dev_ms.append(acc["ms_total"] - acc["ms_emulated"])      # (a rehearsed seat's own work: not the other ranks' slices it walked in their stead)
         stage = acc
     sync()
     wall_s = time.perf_counter() - t_begin
@@ -540,9 +551,11 @@ def main():
                                       "the reads' k-mers of abundance >= %d, device counter" % ABUNDANCE if bloom_from == "count" else "the genome's k-mers"),
                        "reads": n_total, "read_len": L, "kmer_size": K, "reads_per_block": RPB,
                        "batches": len(batches), "batch_reads": B,
-                       "sharding": "bloom broadcast over RCCL; anchor resolution replicated on every rank (file-order "
-                                   "dictionary, no exchange); walk + range coder on contiguous block ranges of every batch; "
-                                   "dictionary stream on rank 0" if world > 1 else "single GPU",
+                       "sharding": ("bloom broadcast over RCCL; anchor resolution replicated on every rank (file-order dictionary, no exchange); "
+                                    + ("walk divided by anchor (rank r walks the r-th slice of the reads sorted by anchor address), its events sent to the "
+                                       "rank that codes the read's block in one all-to-all per batch; " if walk_by == "anchor" else "walk on the rank's own block range; ")
+                                    + "range coder on contiguous block ranges of every batch; dictionary stream on rank 0") if world > 1 else "single GPU",
+                       "walk_by": walk_by,
                        "bloom_bytes": nbytes, "bloom_bcast_ms": round(bcast_ms, 2), "bloom_build_s": round(bloom_s, 2),
                        "kmer_count_s": round(count_s, 2), "solid_kmers": n_solid},
             "roofline": roofline,
@@ -568,6 +581,47 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def make_exchange(dist, device, backend, pg_rank, pg_world, capi):
+    """the all-to-all of leon_dna_set_exchange: 64-bit words in device memory, send_counts[d] of them for rank d, over the process
+    group -- RCCL's all_to_all_single between GPUs (the words never touch the host); over gloo (rehearsals on one device) every rank
+    gathers everybody's words through host memory and keeps its own pieces"""
+    keep = {}
+
+    def fn(d_send, counts):
+        n_send = sum(counts)
+        send = torch.empty(max(n_send, 1), dtype=torch.int64, device=device)
+        if n_send:
+            capi.device_copy(send.data_ptr(), d_send, n_send * 8, device_id=device.index or 0)
+        mine = torch.tensor(counts, dtype=torch.int64)
+        if backend == "nccl":
+            mat = torch.empty(pg_world * pg_world, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(mat, mine.to(device))
+            mat = mat.cpu().view(pg_world, pg_world)                 # mat[src][dst]
+            recv_counts = [int(mat[src][pg_rank]) for src in range(pg_world)]
+            recv = torch.empty(max(sum(recv_counts), 1), dtype=torch.int64, device=device)
+            dist.all_to_all_single(recv[:sum(recv_counts)], send[:n_send], output_split_sizes=recv_counts, input_split_sizes=list(counts))
+            torch.cuda.synchronize()
+        else:
+            rows = [torch.empty(pg_world, dtype=torch.int64) for _ in range(pg_world)]
+            dist.all_gather(rows, mine)
+            width = max(int(r.sum()) for r in rows)
+            padded = torch.zeros(max(width, 1), dtype=torch.int64)
+            padded[:n_send] = send[:n_send].cpu()
+            bufs = [torch.empty_like(padded) for _ in range(pg_world)]
+            dist.all_gather(bufs, padded)
+            pieces = []
+            for src in range(pg_world):
+                at = int(rows[src][:pg_rank].sum())
+                pieces.append(bufs[src][at:at + int(rows[src][pg_rank])])
+            got = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.int64)
+            recv = got.to(device) if got.numel() else torch.empty(1, dtype=torch.int64, device=device)
+            recv_counts = [int(rows[src][pg_rank]) for src in range(pg_world)]
+            torch.cuda.synchronize()
+        keep["recv"] = recv                                          # stays alive until the next exchange
+        return recv.data_ptr(), sum(recv_counts)
+    return fn
 
 
 def host_info(chain_ms, chain_symbols):

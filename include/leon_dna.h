@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LEON_DNA_ABI_VERSION 2
+#define LEON_DNA_ABI_VERSION 3
 
 enum {
     LEON_OK = 0,
@@ -73,6 +73,11 @@ typedef struct leon_dna_stats {
     float ms_pack, ms_resolve, ms_sort, ms_walk, ms_symbols, ms_rangecoder, ms_d2h, ms_total;
     uint32_t walk_launches, reserved;
     float ms_anchor_wait, ms_chain_busy;   /* host ms leon_dna_finish waited for the dictionary-stream thread; ms that thread spent coding */
+    /* the walk divided by anchor (leon_dna_set_exchange), last batch: ms_walk above is then this rank's SLICE; ms_exchange = forming the
+       words + the caller's exchange + scattering what came back (host wall-clock, the call waits for the device around it);
+       ms_emulated = LEON_XCH_EMULATE only: the other ranks' slices walked here in their stead (not part of a real rank's time) */
+    float ms_exchange, ms_exchange_call, ms_emulated, reserved2;
+    uint64_t xch_words_sent, xch_words_received, walk_reads;
 } leon_dna_stats;
 
 /* -- lifecycle (DnaEncoder ctor / dtor bracket one thread's work upstream) -- */
@@ -116,6 +121,27 @@ int leon_dna_reserve(leon_dna_ctx* ctx, uint64_t max_reads, uint64_t max_bases);
  * without any exchange), then walks and codes only its contiguous share of each batch's blocks, which its sink
  * receives with their global block ids.  Rank 0 alone produces the dictionary stream.  Default: rank 0 of 1. */
 int leon_dna_set_shard(leon_dna_ctx* ctx, uint32_t rank, uint32_t world);
+
+/* How a batch's WALK is divided among the ranks of leon_dna_set_shard(rank, world > 1).
+ * LEON_XCH_OFF (default): every rank walks the reads of its own block range.  The reads of one anchor are spread over all block
+ * ranges, so every rank fetches nearly every anchor group's bloom sectors: the eight ranks' walks of a 100 M-read file add up to
+ * 2.8 x the one-GPU walk.
+ * LEON_XCH_BY_ANCHOR: the batch's reads, sorted by anchor address, are cut into `world` contiguous slices and rank r walks slice r --
+ * whole anchor groups, the sharing that makes the one-GPU walk cheap -- whatever block the reads belong to; what the walk found then
+ * travels to the rank that codes each read's block in ONE exchange per batch, which the CALLER performs (the library stays free of
+ * RCCL): `fn` is called once per batch, on the calling thread, with this rank's 64-bit words in DEVICE memory grouped by
+ * destination rank (send_counts[d] words for rank d, in rank order) and must return, in device memory that stays valid until the
+ * next call on this context, the words the other ranks (and this one) hold for this rank, concatenated in any order, with their
+ * total in *recv_total -- an all-to-all (ncclAllToAllv / all_to_all_single).  Every rank must call it for every batch, also a rank
+ * that codes no block of the batch.  Non-zero return = the batch fails (LEON_E_SINK-like: LEON_E_STATE, stream poisoned).
+ * LEON_XCH_EMULATE: the same division with NO other rank present: the context walks every slice itself, one after the other, and
+ * keeps the words meant for its own rank -- the bytes of a real run (one-process tests of an N-rank job, timing one seat of it:
+ * stats.ms_walk is the own slice, stats.ms_emulated the rest).  fn is ignored.
+ * The blocks' bytes are the same in all three modes. */
+enum { LEON_XCH_OFF = 0, LEON_XCH_BY_ANCHOR = 1, LEON_XCH_EMULATE = 2 };
+typedef int (*leon_exchange_fn)(void* user, const uint64_t* d_send, const uint64_t* send_counts, uint32_t world,
+                                const uint64_t** d_recv, uint64_t* recv_total);
+int leon_dna_set_exchange(leon_dna_ctx* ctx, uint32_t mode, leon_exchange_fn fn, void* user);
 
 /* Leon::endDnaCompression: flush the anchor-dictionary range coder (Leon::encodeInsertedAnchor stream).
  * payload stays owned by ctx until destroy. */

@@ -33,13 +33,18 @@ class Stats(C.Structure):
                [(n, C.c_float) for n in ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder",
                                          "ms_d2h", "ms_total")] + \
                [("walk_launches", C.c_uint32), ("reserved", C.c_uint32), ("ms_anchor_wait", C.c_float),
-                ("ms_chain_busy", C.c_float)]
+                ("ms_chain_busy", C.c_float)] + \
+               [(n, C.c_float) for n in ("ms_exchange", "ms_exchange_call", "ms_emulated", "reserved2")] + \
+               [(n, C.c_uint64) for n in ("xch_words_sent", "xch_words_received", "walk_reads")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
 
 
 SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32)
+# leon_exchange_fn: (user, d_send, send_counts[world], world, &d_recv, &recv_total) -> 0 on success
+EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64))
+XCH_OFF, XCH_BY_ANCHOR, XCH_EMULATE = 0, 1, 2
 
 _u8p, _u32p, _i32p, _u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_int32, C.c_uint64))
 
@@ -69,6 +74,7 @@ _EXPORTS = {
     "leon_dna_reset_stream": (C.c_int, [C.c_void_p]),
     "leon_dna_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "leon_dna_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "leon_dna_set_exchange": (C.c_int, [C.c_void_p, C.c_uint32, EXCHANGE, C.c_void_p]),
     "leon_dna_debug_walk_order": (C.c_int, [C.c_void_p, C.c_void_p]),
     "leon_kmer_solid_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                           C.POINTER(C.c_void_p), _u64p, _u64p]),
@@ -290,6 +296,13 @@ def device_free(ptr):
         load_library().leon_device_free(C.c_void_p(int(ptr)))
 
 
+def device_copy(d_dst, d_src, n_bytes, device_id=0):
+    """device to device, n_bytes from d_src to d_dst (raw device pointers)"""
+    rc = load_library().leon_device_copy(device_id, C.c_void_p(int(d_dst)), C.c_void_p(int(d_src)), int(n_bytes))
+    if rc:
+        raise LeonDnaError(rc, (load_library().leon_last_error(None) or b"").decode())
+
+
 def device_upload_bytes(data, device_id=0):
     """a new device buffer holding `data` (bytes-like); the caller frees it with device_free"""
     lib = load_library()
@@ -507,6 +520,24 @@ class DnaEncodeContext:
 
     def set_shard(self, rank, world):
         self._chk(self.lib.leon_dna_set_shard(self.h, rank, world))
+
+    def set_exchange(self, mode, fn=None):
+        """how the walk is divided among the ranks of set_shard: XCH_OFF (by block range), XCH_BY_ANCHOR with `fn(d_send, send_counts) ->
+        (d_recv, recv_total)` doing the all-to-all of the 64-bit words in device memory, XCH_EMULATE (this context plays every rank's slice)"""
+        if fn is None:
+            self._xch_cb = C.cast(None, EXCHANGE)
+        else:
+            def thunk(user, d_send, counts, world, d_recv, recv_total):
+                try:
+                    ptr, total = fn(int(d_send or 0), [int(counts[i]) for i in range(world)])
+                    d_recv[0] = C.c_void_p(ptr)
+                    recv_total[0] = int(total)
+                    return 0
+                except Exception as e:                 # noqa: BLE001 -- nothing may cross the C boundary
+                    self._xch_error = e
+                    return 1
+            self._xch_cb = EXCHANGE(thunk)
+        self._chk(self.lib.leon_dna_set_exchange(self.h, mode, self._xch_cb, None))
 
     def reset_stream(self):
         self._hdr_next = 0

@@ -119,6 +119,11 @@ struct leon_dna_ctx {
     // stream state
     uint64_t next_read = 0, next_block = 0;
     uint32_t shard_rank = 0, shard_world = 1;    // leon_dna_set_shard
+    uint32_t xch_mode = LEON_XCH_OFF;            // leon_dna_set_exchange: how the walk is divided among the ranks
+    leon_exchange_fn xch_fn = nullptr; void* xch_user = nullptr;
+    DevBuf xch_slot, xch_off, xch_evoff, xch_events, xch_send, xch_split;
+    DevBuf round_hist;                           // the counts of a window's fixpoint rounds, read back together
+    uint64_t* h_anchor[2] = {nullptr, nullptr}; size_t h_anchor_cap = 0;   // pinned: a window's new anchors on their way to the dictionary chain
     bool partial_seen = false, finished = false;
     uint64_t hdr_next_read = 0, hdr_next_block = 0;   // the header stream's own counters (leon_header_encode_batch)
     bool hdr_partial_seen = false;
@@ -284,7 +289,7 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     } while (0)
     CREATE_CHK(hipSetDevice(c->device));
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CREATE_CHK(hipHostMalloc((void**)&c->h_rb, 256, hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void**)&c->h_rb, 4096, hipHostMallocDefault));
     for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
     // BloomCacheCoherent / BloomContainer geometry
     uint64_t blk = 1ull << cfg->bloom_block_nbits;
@@ -331,13 +336,15 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
                        &c->status, &c->hit_pos, &c->hit_slot, &c->cand_pos, &c->cand_slot, &c->anchor_pos, &c->anchor_addr,
                        &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
                        &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
-                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->fbits, &c->pbits, &c->hdr_first, &c->dc_cache, &c->dc_out, &c->dc_pay, &c->dc_len, &c->dc_pool, &c->dc_scr };
+                       &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->fbits, &c->pbits, &c->hdr_first, &c->dc_cache, &c->dc_out, &c->dc_pay, &c->dc_len, &c->dc_pool, &c->dc_scr,
+                       &c->xch_slot, &c->xch_off, &c->xch_evoff, &c->xch_events, &c->xch_send, &c->xch_split, &c->round_hist };
     for (DevBuf* b : bufs) b->release();
     if (c->d_bloom) (void)hipFree(c->d_bloom);
     if (c->d_rv16) (void)hipFree(c->d_rv16);
     if (c->d_nkeys) (void)hipFree(c->d_nkeys);
     if (c->h_payload) (void)hipHostFree(c->h_payload);
     if (c->h_rb) (void)hipHostFree(c->h_rb);
+    for (auto& b : c->h_anchor) if (b) (void)hipHostFree(b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pack_ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -578,6 +585,31 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, prim::ExclusiveSum(nullptr, scan_tmp, V.ins_flag, c->rank.as<uint32_t>(), W, s));
     if (int rc = ensure_cub(c, scan_tmp)) return rc;
     c->poisoned = true;             // from here on the dictionary and the dictionary stream change: cleared on success
+    // Host round trips: a wait costs 20-40 us and the stage used to make ~6 per window (580 per 100 M reads: the window's first count,
+    // one per fixpoint round, the insert count, the new anchors' copy).  Now two: the rounds are launched AHEAD of their counts -- the
+    // kernels take the list lengths from device memory, an empty list costs a launch that finds nothing to do -- three at once, then two
+    // at a time for the few windows that need more, with every round's count copied to a small history that comes back with the
+    // next wait; and a window's new anchors travel to pinned memory behind the kernels and are handed to the dictionary chain at
+    // the NEXT window's first wait (the first window's at once: the chain, the longest piece of a step, starts with them).
+    const uint64_t KW = kmer_words(k);                              // 64-bit words per anchor k-mer
+    constexpr uint32_t kRoundsAhead = 3, kRoundsMore = 2, kHist = 64;
+    HIPCHK(c, c->round_hist.ensure(kHist * 4));
+    uint32_t* d_hist = c->round_hist.as<uint32_t>();
+    if (c->h_anchor_cap < W * 8 * KW) {
+        for (auto& b : c->h_anchor) { if (b) HIPCHK(c, hipHostFree(b)); b = nullptr; }
+        c->h_anchor_cap = 0;
+        for (auto& b : c->h_anchor) HIPCHK(c, hipHostMalloc((void**)&b, W * 8 * KW + 64, hipHostMallocDefault));
+        c->h_anchor_cap = W * 8 * KW;
+    }
+    struct Pending { int buf = -1; uint64_t n = 0; } pending;      // a window's new anchors on their way to pinned memory
+    auto hand_over = [&]() {                                       // (called right after a wait: the copy has landed)
+        if (pending.buf < 0) return;
+        std::vector<uint64_t> fresh(c->h_anchor[pending.buf], c->h_anchor[pending.buf] + pending.n * KW);
+        c->anchor_worker->push(std::move(fresh));
+        pending.buf = -1;
+    };
+    int anchor_buf = 0;
+    uint32_t hint = (uint32_t)std::min<uint64_t>(W, 1u << 20);      // grid-size hint of a window's first round (any size is correct: grid-stride loops)
     for (uint64_t w0 = 0, w1 = 0; w0 < n; w0 = w1) {
         w1 = std::min(n, w0 + (w0 == 0 ? first_window(W) : W));
         if (int rc = dict_reserve(c, c->n_keys + (w1 - w0))) return rc;
@@ -585,32 +617,41 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         HIPCHK(c, hipMemsetAsync(c->wbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
         HIPCHK(c, hipMemsetAsync(c->pbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
         launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters);
-        uint32_t cnt = 0;
-        int dict_err = 0;
-        HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, counters, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_rb + 1, c->D.err, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, spin_sync(s));
-        cnt = (uint32_t)c->h_rb[0]; dict_err = (int)(uint32_t)c->h_rb[1];
-        if (dict_err) {
-            HIPCHK(c, hipMemsetAsync(c->D.err, 0, 4, s));
-            return fail(c, LEON_E_STATE, "anchor dictionary: a two-word key stayed half-written (a stalled wave); batch abandoned");
-        }
-        const uint32_t cnt0 = cnt;
+        HIPCHK(c, hipMemcpyAsync(d_hist, counters, 4, hipMemcpyDeviceToDevice, s));         // hist[0]: the window's unresolved reads
         int cur = 0;
-        while (cnt > 0) {
-            int nxt = cur ^ 1;
-            HIPCHK(c, hipMemsetAsync(counters + nxt, 0, 4, s));
-            launch_check(s, R, c->D, V, first_read_index, lists[cur], counters + cur, cnt, lists[nxt], counters + nxt);
-            uint32_t ncnt = 0;
-            HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, counters + nxt, 4, hipMemcpyDeviceToHost, s));
+        uint32_t n_hist = 1, cnt = 0, cnt0 = 0;
+        bool first_wait = true;
+        for (uint32_t ahead = kRoundsAhead;; ahead = kRoundsMore) {
+            for (uint32_t r = 0; r < ahead && n_hist < kHist; r++) {
+                const int nxt = cur ^ 1;
+                const uint32_t h = std::max<uint32_t>(hint >> (2 * (n_hist - 1) < 31 ? 2 * (n_hist - 1) : 31), 4096);
+                HIPCHK(c, hipMemsetAsync(counters + nxt, 0, 4, s));
+                launch_check(s, R, c->D, V, first_read_index, lists[cur], counters + cur, h, lists[nxt], counters + nxt);
+                HIPCHK(c, hipMemcpyAsync(d_hist + n_hist, counters + nxt, 4, hipMemcpyDeviceToDevice, s));
+                launch_reset_tent(s, c->D, V, lists[cur], counters + cur, h);
+                launch_propose(s, c->D, V, first_read_index, lists[nxt], counters + nxt, h);
+                cur = nxt; n_hist++;
+            }
+            HIPCHK(c, hipMemcpyAsync(c->h_rb + 8, d_hist, n_hist * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_rb + 1, c->D.err, 4, hipMemcpyDeviceToHost, s));
             HIPCHK(c, spin_sync(s));
-            ncnt = (uint32_t)c->h_rb[0];
-            if (ncnt >= cnt) return fail(c, LEON_E_STATE, "anchor resolution made no progress (internal error)");
-            launch_reset_tent(s, c->D, V, lists[cur], counters + cur, cnt);
-            launch_propose(s, c->D, V, first_read_index, lists[nxt], counters + nxt, ncnt);
-            cur = nxt; cnt = ncnt;
-            c->stats.resolve_rounds++;
+            if (first_wait) { hand_over(); first_wait = false; }
+            if ((int)(uint32_t)c->h_rb[1]) {
+                HIPCHK(c, hipMemsetAsync(c->D.err, 0, 4, s));
+                return fail(c, LEON_E_STATE, "anchor dictionary: a two-word key stayed half-written (a stalled wave); batch abandoned");
+            }
+            const uint32_t* hist = reinterpret_cast<const uint32_t*>(c->h_rb + 8);
+            cnt0 = hist[0];
+            for (uint32_t r = 1; r < n_hist; r++)
+                if (hist[r - 1] > 0 && hist[r] >= hist[r - 1]) return fail(c, LEON_E_STATE, "anchor resolution made no progress (internal error)");
+            cnt = hist[n_hist - 1];
+            if (cnt == 0) {
+                for (uint32_t r = 1; r < n_hist; r++) if (hist[r - 1] > 0) c->stats.resolve_rounds++;
+                break;
+            }
+            if (n_hist >= kHist) return fail(c, LEON_E_STATE, "anchor resolution did not settle in its rounds (internal error)");
         }
+        hint = std::max<uint32_t>(2 * cnt0, 4096);
         if (cnt0 > 0) {
             launch_final_pos(s, R, c->D, V, w0, w1, first_read_index);
             launch_ins_flags(s, V, w0, w1);
@@ -623,7 +664,6 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             last_rank = (uint32_t)c->h_rb[0]; last_flag = (uint32_t)c->h_rb[1]; c->n_keys = c->h_rb[2];
             uint64_t n_new = (uint64_t)last_rank + last_flag;
             if (c->n_anchors + n_new > 0xFFFFFFFFull) return fail(c, LEON_E_OVERFLOW, "more than 2^32 anchors");
-            const uint64_t KW = kmer_words(k);                              // 64-bit words per anchor k-mer
             if ((c->n_anchors + n_new) * 8 * KW > c->anchor_kmers.cap) {      // grow, keeping what is there
                 TmpBuf nb;
                 HIPCHK(c, nb.ensure(std::max<uint64_t>((c->n_anchors + n_new) * 2, 1024) * 8 * KW));
@@ -633,12 +673,15 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
                 std::swap(static_cast<DevBuf&>(nb).cap, c->anchor_kmers.cap);
             }
             launch_assign_addr(s, c->D, V, w0, w1, c->rank.as<uint32_t>(), c->n_anchors, c->anchor_kmers.as<uint64_t>(), k);
-            if (n_new && c->shard_rank == 0 && !(c->cfg.flags & LEON_F_DICT_ON_DEVICE)) {   // the window's new anchors go straight to the host thread coding the dictionary stream
-                std::vector<uint64_t> fresh(n_new * KW);
-                HIPCHK(c, hipMemcpyAsync(fresh.data(), c->anchor_kmers.as<uint64_t>() + c->n_anchors * KW, n_new * 8 * KW, hipMemcpyDeviceToHost, s));
-                HIPCHK(c, spin_sync(s));
-                c->anchor_worker->push(std::move(fresh));
-                if (w0 == 0) mark("first window's anchors to the chain");
+            if (n_new && c->shard_rank == 0 && !(c->cfg.flags & LEON_F_DICT_ON_DEVICE)) {   // the window's new anchors, for the host thread coding the dictionary stream
+                HIPCHK(c, hipMemcpyAsync(c->h_anchor[anchor_buf], c->anchor_kmers.as<uint64_t>() + c->n_anchors * KW, n_new * 8 * KW, hipMemcpyDeviceToHost, s));
+                pending.buf = anchor_buf; pending.n = n_new;
+                anchor_buf ^= 1;
+                if (w0 == 0) {
+                    HIPCHK(c, spin_sync(s));
+                    hand_over();
+                    mark("first window's anchors to the chain");
+                }
             }
             c->n_anchors += n_new;
         }
@@ -646,6 +689,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         if (w1 < n && packed_upto < std::min(n, w1 + W)) { if (int rc = pack_group()) return rc; }   // the next window's reads
         c->stats.resolve_windows++;
     }
+    if (pending.buf >= 0) { HIPCHK(c, spin_sync(s)); hand_over(); }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     mark("resolution launched to its end");
@@ -669,7 +713,8 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     c->stats.n_reads = nl; c->stats.n_bases = nl_bases; c->stats.n_blocks = nbl; c->stats.n_anchors = c->n_anchors;
     c->last_n = n; c->last_bases = nl_bases;
     c->last_d_bases = d_bases; c->last_d_off = d_off;
-    if (nl == 0) {                                            // nothing of this batch is ours to encode
+    const bool by_anchor = c->shard_world > 1 && c->xch_mode != LEON_XCH_OFF;
+    if (nl == 0 && !(by_anchor && c->xch_mode == LEON_XCH_BY_ANCHOR)) {   // nothing of this batch is ours to encode (and nobody waits for our slice)
         HIPCHK(c, hipStreamSynchronize(s));
         float pack2 = 0; for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
         c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_total = ms(0, 2);
@@ -678,29 +723,144 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         c->poisoned = false;
         return LEON_OK;
     }
-
-    // ---- sort the share's reads by (anchor address, strand) ----
-    HIPCHK(c, c->sort_key2.ensure(nl * 8)); HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(nl * 4));
-    hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
-    size_t sort_tmp = 0;
-    // (measurement hook: another order of the reads in the walk changes which lanes share bloom sectors, never the bytes --
-    // events are indexed by read position)
-    const uint64_t* walk_key = walk_keys ? walk_keys + r0 : V.sort_key + r0;
-    const unsigned key_bits = walk_keys ? 48u : 33u;
-    HIPCHK(c, prim::SortPairs(nullptr, sort_tmp, walk_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
-                                                 c->perm2.as<uint32_t>(), nl, 0, key_bits, s));
-    if (int rc = ensure_cub(c, sort_tmp)) return rc;
-    HIPCHK(c, prim::SortPairs(c->cub_tmp.p, sort_tmp, walk_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
-                                                 c->perm2.as<uint32_t>(), nl, 0, key_bits, s));
-    HIPCHK(c, hipEventRecord(c->ev[3], s));
-
-    // ---- walk ----
     HIPCHK(c, c->events.ensure(nl_bases + 16));
     HIPCHK(c, hipMemsetAsync(c->events.p, 0, nl_bases + 16, s));
-    HIPCHK(c, hipEventRecord(c->ev[4], s));
-    launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, V.flags, c->perm2.as<uint32_t>(), nl, c->events.as<uint8_t>());
-    HIPCHK(c, hipEventRecord(c->ev[5], s));
-    c->stats.walk_launches = 1;
+    HIPCHK(c, c->perm.ensure(n * 4));
+    hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
+    size_t sort_tmp = 0;
+    if (!by_anchor) {
+        // ---- sort the share's reads by (anchor address, strand) ----
+        HIPCHK(c, c->sort_key2.ensure(nl * 8)); HIPCHK(c, c->perm2.ensure(nl * 4));
+        // (measurement hook: another order of the reads in the walk changes which lanes share bloom sectors, never the bytes --
+        // events are indexed by read position)
+        const uint64_t* walk_key = walk_keys ? walk_keys + r0 : V.sort_key + r0;
+        const unsigned key_bits = walk_keys ? 48u : 33u;
+        HIPCHK(c, prim::SortPairs(nullptr, sort_tmp, walk_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
+                                                     c->perm2.as<uint32_t>(), nl, 0, key_bits, s));
+        if (int rc = ensure_cub(c, sort_tmp)) return rc;
+        HIPCHK(c, prim::SortPairs(c->cub_tmp.p, sort_tmp, walk_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>() + r0,
+                                                     c->perm2.as<uint32_t>(), nl, 0, key_bits, s));
+        HIPCHK(c, hipEventRecord(c->ev[3], s));
+        // ---- walk ----
+        HIPCHK(c, hipEventRecord(c->ev[4], s));
+        launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, V.flags, c->perm2.as<uint32_t>(), nl, c->events.as<uint8_t>());
+        HIPCHK(c, hipEventRecord(c->ev[5], s));
+        c->stats.walk_launches = 1; c->stats.walk_reads = nl;
+    } else {
+        // ---- the walk divided by anchor (leon_dna_set_exchange): ALL of the batch's reads sorted by anchor address, cut into `world`
+        // slices of equal size; this rank walks its slice into a buffer of its own and what it found goes to the ranks that code
+        // the reads' blocks, as (place in that rank's event buffer, byte) words grouped by destination ----
+        const uint32_t Wd = c->shard_world, me = c->shard_rank;
+        if (Wd + 2 > 4096 / 8) return fail(c, LEON_E_INVALID, "set_exchange: world too large");
+        HIPCHK(c, c->sort_key2.ensure(n * 8)); HIPCHK(c, c->perm2.ensure(n * 4));
+        HIPCHK(c, prim::SortPairs(nullptr, sort_tmp, V.sort_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>(), c->perm2.as<uint32_t>(), n, 0, 33, s));
+        if (int rc = ensure_cub(c, sort_tmp)) return rc;
+        HIPCHK(c, prim::SortPairs(c->cub_tmp.p, sort_tmp, V.sort_key, c->sort_key2.as<uint64_t>(), c->perm.as<uint32_t>(), c->perm2.as<uint32_t>(), n, 0, 33, s));
+        unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(c->counters.as<uint32_t>() + 10);
+        launch_lower_bound(s, c->sort_key2.as<uint64_t>(), n, 1ull << 32, d_cnt);            // reads without an anchor sort last: nothing to walk
+        HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, d_cnt, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, spin_sync(s));
+        const uint64_t n_anch = c->h_rb[0];
+        // the slices: equal WEIGHT (a read 1, an anchor group's first read SLICE_GROUP_WEIGHT more), the same cuts on every rank
+        HIPCHK(c, c->xch_slot.ensure(n * 4)); HIPCHK(c, c->xch_off.ensure((n + 1) * 8));
+        size_t scan_n = 0;
+        HIPCHK(c, prim::ExclusiveSum(nullptr, scan_n, c->xch_off.as<uint64_t>(), c->xch_off.as<uint64_t>(), n + 1, s));
+        if (int rc = ensure_cub(c, scan_n)) return rc;
+        HIPCHK(c, c->xch_split.ensure((Wd + 1) * 8));
+        launch_slice_weights(s, c->sort_key2.as<uint64_t>(), n_anch, c->xch_off.as<uint64_t>());
+        HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, scan_n, c->xch_off.as<uint64_t>(), c->xch_off.as<uint64_t>(), n_anch + 1, s));
+        launch_slice_splits(s, c->xch_off.as<uint64_t>(), n_anch, Wd, c->xch_split.as<unsigned long long>());
+        HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, c->xch_split.p, (Wd + 1) * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->ev[3], s));
+        HIPCHK(c, spin_sync(s));
+        std::vector<uint64_t> slice_at(c->h_rb, c->h_rb + Wd + 1);
+        // where each rank's reads begin in file order (block_range of every rank), for the words' grouping
+        std::vector<uint64_t> rank_r0(Wd + 1);
+        for (uint32_t d = 0; d <= Wd; d++) {
+            const uint64_t q = n_blocks / Wd, rm = n_blocks % Wd;
+            rank_r0[d] = std::min<uint64_t>(n, (d * q + std::min<uint64_t>(d, rm)) * rpb);
+        }
+        std::vector<uint64_t> send_counts(Wd, 0), send_at(Wd + 1, 0);
+        // one slice: walked into xch_events, its words formed in xch_send (grouped by destination; send_at[d] = where rank d's begin)
+        auto do_slice = [&](uint32_t sl, bool timed) -> int {
+            const uint64_t s0 = slice_at[sl], s1 = slice_at[sl + 1], ns = s1 - s0;
+            const uint32_t* slice = c->perm2.as<uint32_t>() + s0;
+            HIPCHK(c, c->xch_evoff.ensure((ns + 1) * 8));
+            HIPCHK(c, hipMemsetAsync(c->xch_slot.p, 0xFF, n * 4, s));
+            launch_slice_reads(s, R, slice, ns, c->xch_evoff.as<uint64_t>(), c->xch_slot.as<uint32_t>());
+            size_t tb = 0;
+            HIPCHK(c, prim::ExclusiveSum(nullptr, tb, c->xch_evoff.as<uint64_t>(), c->xch_evoff.as<uint64_t>(), ns + 1, s));
+            if (int rc = ensure_cub(c, std::max(tb, scan_n))) return rc;
+            HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, tb, c->xch_evoff.as<uint64_t>(), c->xch_evoff.as<uint64_t>(), ns + 1, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, c->xch_evoff.as<uint64_t>() + ns, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, spin_sync(s));
+            const uint64_t slice_bases = c->h_rb[0];
+            HIPCHK(c, c->xch_events.ensure(slice_bases + 16));
+            HIPCHK(c, hipMemsetAsync(c->xch_events.p, 0, slice_bases + 16, s));
+            if (timed) HIPCHK(c, hipEventRecord(c->ev[4], s));
+            launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, V.flags, slice, ns, c->xch_events.as<uint8_t>(), c->xch_evoff.as<uint64_t>());
+            if (timed) { HIPCHK(c, hipEventRecord(c->ev[5], s)); c->stats.walk_launches = 1; c->stats.walk_reads = ns; }
+            launch_ev_words(s, R, c->xch_slot.as<uint32_t>(), c->xch_evoff.as<uint64_t>(), c->xch_events.as<uint8_t>(), n, rpb, n_blocks, Wd,
+                            c->xch_off.as<uint64_t>(), nullptr);
+            HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, scan_n, c->xch_off.as<uint64_t>(), c->xch_off.as<uint64_t>(), n + 1, s));
+            for (uint32_t d = 0; d <= Wd; d++) HIPCHK(c, hipMemcpyAsync(c->h_rb + 1 + d, c->xch_off.as<uint64_t>() + rank_r0[d], 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, spin_sync(s));
+            for (uint32_t d = 0; d <= Wd; d++) send_at[d] = c->h_rb[1 + d];
+            for (uint32_t d = 0; d < Wd; d++) send_counts[d] = send_at[d + 1] - send_at[d];
+            HIPCHK(c, c->xch_send.ensure(send_at[Wd] * 8 + 64));
+            launch_ev_words(s, R, c->xch_slot.as<uint32_t>(), c->xch_evoff.as<uint64_t>(), c->xch_events.as<uint8_t>(), n, rpb, n_blocks, Wd,
+                            c->xch_off.as<uint64_t>(), c->xch_send.as<uint64_t>());
+            HIPCHK(c, hipGetLastError());
+            return LEON_OK;
+        };
+        HIPCHK(c, hipMemsetAsync(c->errflag.as<int>() + 1, 0, 4, s));
+        const auto t_x0 = std::chrono::steady_clock::now();     // (ms_exchange: everything of the division that is not the slice's walk itself)
+        if (int rc = do_slice(me, true)) return rc;
+        HIPCHK(c, hipStreamSynchronize(s));
+        float walk_own = 0; (void)hipEventElapsedTime(&walk_own, c->ev[4], c->ev[5]);
+        auto since = [](std::chrono::steady_clock::time_point t) { return (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+        c->stats.xch_words_sent = send_at[Wd];
+        if (c->xch_mode == LEON_XCH_BY_ANCHOR) {
+            const uint64_t* d_recv = nullptr; uint64_t recv_total = 0;
+            const auto t_call = std::chrono::steady_clock::now();
+            if (c->xch_fn(c->xch_user, c->xch_send.as<uint64_t>(), send_counts.data(), Wd, &d_recv, &recv_total))
+                return fail(c, LEON_E_STATE, "the exchange callback returned non-zero");
+            c->stats.ms_exchange_call = since(t_call);
+            if (recv_total && !d_recv) return fail(c, LEON_E_STATE, "the exchange callback returned no buffer");
+            c->stats.xch_words_received = recv_total;
+            HIPCHK(c, hipSetDevice(c->device));                   // (the callback may have changed the thread's device)
+            launch_ev_scatter(s, d_recv, recv_total, c->events.as<uint8_t>(), nl_bases, c->errflag.as<int>() + 1);
+            HIPCHK(c, hipStreamSynchronize(s));                   // the caller's buffer is free again when this call returns
+            c->stats.ms_exchange = since(t_x0) - walk_own;
+        } else {
+            // no other rank present: this context plays them all, one slice after the other, and keeps what is meant for its own rank
+            launch_ev_scatter(s, c->xch_send.as<uint64_t>() + send_at[me], send_counts[me], c->events.as<uint8_t>(), nl_bases, c->errflag.as<int>() + 1);
+            c->stats.xch_words_received = send_counts[me];
+            HIPCHK(c, hipStreamSynchronize(s));
+            c->stats.ms_exchange = since(t_x0) - walk_own;
+            const auto t_e0 = std::chrono::steady_clock::now();
+            for (uint32_t sl = 0; sl < Wd; sl++) {
+                if (sl == me) continue;
+                if (int rc = do_slice(sl, false)) return rc;
+                launch_ev_scatter(s, c->xch_send.as<uint64_t>() + send_at[me], send_counts[me], c->events.as<uint8_t>(), nl_bases, c->errflag.as<int>() + 1);
+                c->stats.xch_words_received += send_counts[me];
+            }
+            HIPCHK(c, hipStreamSynchronize(s));
+            c->stats.ms_emulated = since(t_e0);
+        }
+        HIPCHK(c, hipEventRecord(c->ev[9], s));                  // the symbols stage begins here
+        int xerr = 0;
+        HIPCHK(c, hipMemcpy(&xerr, c->errflag.as<int>() + 1, 4, hipMemcpyDeviceToHost));
+        if (xerr) return fail(c, LEON_E_STATE, "the exchange delivered a word that lies outside this rank's blocks");
+        if (nl == 0) {                                           // our slice is delivered; no block of the batch is ours to code
+            float pack2 = 0; for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
+            c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5); c->stats.ms_total = ms(0, 5);
+            c->next_read += n; c->next_block += n_blocks;
+            if (n % rpb) c->partial_seen = true;
+            c->poisoned = false;
+            return LEON_OK;
+        }
+    }
 
     // ---- symbols ----
     HIPCHK(c, c->prev.ensure(n * 8));
@@ -768,7 +928,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     float pack2 = 0;                                                   // the part of the pack stage that ran inside the resolution loop
     for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
     c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5);
-    c->stats.ms_symbols = ms(5, 6); c->stats.ms_rangecoder = ms(6, 7); c->stats.ms_d2h = ms(7, 8); c->stats.ms_total = ms(0, 8);
+    c->stats.ms_symbols = by_anchor ? ms(9, 6) : ms(5, 6); c->stats.ms_rangecoder = ms(6, 7); c->stats.ms_d2h = ms(7, 8); c->stats.ms_total = ms(0, 8);
 
     // ---- Leon::writeBlock, in block order ----
     const uint8_t* hp = (const uint8_t*)c->h_payload;
@@ -1170,6 +1330,15 @@ int leon_dna_set_shard(leon_dna_ctx* c, uint32_t rank, uint32_t world) {
     if (world == 0 || rank >= world) return fail(c, LEON_E_INVALID, "set_shard: need rank < world");
     if (c->next_read) return fail(c, LEON_E_STATE, "set_shard must precede the first batch of a stream");
     c->shard_rank = rank; c->shard_world = world;
+    return LEON_OK;
+}
+
+int leon_dna_set_exchange(leon_dna_ctx* c, uint32_t mode, leon_exchange_fn fn, void* user) {
+    if (!c) return LEON_E_INVALID;
+    if (mode > LEON_XCH_EMULATE) return fail(c, LEON_E_INVALID, "set_exchange: unknown mode");
+    if (mode == LEON_XCH_BY_ANCHOR && !fn) return fail(c, LEON_E_INVALID, "set_exchange: LEON_XCH_BY_ANCHOR needs the exchange callback");
+    if (c->next_read) return fail(c, LEON_E_STATE, "set_exchange must precede the first batch of a stream");
+    c->xch_mode = mode; c->xch_fn = fn; c->xch_user = user;
     return LEON_OK;
 }
 

@@ -680,7 +680,7 @@ __device__ inline void walk_apply(uint32_t res4, uint32_t k, K kmask_k, K& x, K&
 
 template <typename K>
 __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
-                                             const uint8_t* flags, const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
+                                             const uint8_t* flags, const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off) {
     __shared__ uint16_t rv16[256];
     load_rv16(rv16, rv16g);
     // (measured, round 3: giving every XCD one contiguous eighth of the order -- workgroup b takes chunk (b % 8) * n/8 + b / 8 --
@@ -695,7 +695,9 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
     const uint32_t* pk = R.packed + 2 * R.slot_off[i];
     const uint32_t* nm = R.nmask + R.slot_off[i];
     bool hasN = R.n_count[i] != 0;
-    uint8_t* ev = events + (R.base_off[i] - R.base_off[R.ev_origin]);
+    // where this read's event bytes go: at its bases' place in the rank's block range, or -- the walk divided by anchor (k_ev_* below) --
+    // at the t-th read's place in the slice's own buffer
+    uint8_t* ev = events + (ev_off ? ev_off[t] : R.base_off[i] - R.base_off[R.ev_origin]);
     const K anchor = kmer_at<K>(pk, (uint32_t)a, k);
     const K anchor_rc = revcomp(anchor, k);
 
@@ -852,12 +854,131 @@ __global__ void __launch_bounds__(256) k_walk_tile(ReadsDev R, BloomDev B, const
     }
 }
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos, const uint8_t* flags,
-                 const uint32_t* perm, uint64_t n_walk, uint8_t* events) {
+                 const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off) {
     if (!n_walk) return;
     uint64_t g = (n_walk + 255) / 256;
     static const bool tile = getenv("LEON_WALK_TILE") != nullptr && getenv("LEON_WALK_TILE")[0] == '1';       // measurement only
-    if (tile) { DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk_tile<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events)); return; }
-    DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events));
+    if (tile && !ev_off) { DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk_tile<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events)); return; }
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events, ev_off));
+}
+
+// ================================================================================================
+// The walk divided by ANCHOR among the ranks of one job (leon_dna_set_exchange): the batch's reads, sorted by anchor address, are cut
+// into `world` contiguous slices; rank r walks slice r -- whole anchor groups, the sharing that makes the one-GPU walk cheap --
+// into a buffer of its own (k_walk with ev_off), and what the walk found travels to the rank that codes the read's block as a list of
+// (place in that rank's event buffer, event byte) pairs, one 64-bit word each, grouped by destination: reads in file order are
+// in block order, so a scan over the reads' event counts gives every destination a contiguous piece.
+// ================================================================================================
+// first index of `sorted` (ascending) whose key is >= bound: the number of anchored reads (unanchored ones carry the key 2^32)
+__global__ void k_lower_bound(const uint64_t* sorted, uint64_t n, uint64_t bound, unsigned long long* out) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (sorted[mid] < bound) lo = mid + 1; else hi = mid; }
+    *out = lo;
+}
+void launch_lower_bound(hipStream_t s, const uint64_t* sorted, uint64_t n, uint64_t bound, unsigned long long* out) {
+    hipLaunchKernelGGL(k_lower_bound, dim3(1), dim3(64), 0, s, sorted, n, bound, out);
+}
+// Where the slices begin.  A slice's walk costs about 2 ns per read plus 9 ns per anchor GROUP (the group's bloom sectors are fetched
+// once and shared by its reads): equal numbers of reads would give the rank with the late, thinly covered anchors twice the work
+// of the rank with the early ones (64 against 32 ms at 100 M reads over 8 ranks).  Reads are weighted 1, plus SLICE_GROUP_WEIGHT
+// for the first read of every anchor; the slices are cut at equal weight.
+constexpr uint64_t SLICE_GROUP_WEIGHT = 4;
+__global__ void k_slice_weights(const uint64_t* sorted_keys, uint64_t n, uint64_t* w) {
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t <= n; t += (uint64_t)gridDim.x * blockDim.x)
+        w[t] = t == n ? 0 : 1 + ((t == 0 || sorted_keys[t] != sorted_keys[t - 1]) ? SLICE_GROUP_WEIGHT : 0);
+}
+// cum = exclusive sums of the weights (n + 1 entries): split[d] = first t whose cum >= total * d / world
+__global__ void k_slice_splits(const uint64_t* cum, uint64_t n, uint32_t world, unsigned long long* split) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > world) return;
+    const uint64_t total = cum[n];
+    const uint64_t target = d == world ? total : (uint64_t)(((unsigned __int128)total * d) / world);
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (cum[mid] < target) lo = mid + 1; else hi = mid; }
+    split[d] = d == world ? n : lo;
+}
+void launch_slice_weights(hipStream_t s, const uint64_t* sorted_keys, uint64_t n, uint64_t* w) {
+    hipLaunchKernelGGL(k_slice_weights, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, sorted_keys, n, w);
+}
+void launch_slice_splits(hipStream_t s, const uint64_t* cum, uint64_t n, uint32_t world, unsigned long long* split) {
+    hipLaunchKernelGGL(k_slice_splits, dim3((world + 1 + 63) / 64), dim3(64), 0, s, cum, n, world, split);
+}
+// the slice's reads in walk order: their lengths (scanned by the caller into their places in the slice's event buffer) and, per
+// read of the batch, its index in the slice (0xFFFFFFFF: not in it; the caller fills that first)
+__global__ void k_slice_reads(ReadsDev R, const uint32_t* perm, uint64_t n_slice, uint64_t* len_out, uint32_t* slot_of) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j <= n_slice; j += (uint64_t)gridDim.x * blockDim.x) {
+        if (j == n_slice) { len_out[j] = 0; continue; }
+        const uint32_t i = perm[j];
+        len_out[j] = R.len[i];
+        slot_of[i] = (uint32_t)j;
+    }
+}
+void launch_slice_reads(hipStream_t s, ReadsDev R, const uint32_t* perm, uint64_t n_slice, uint64_t* len_out, uint32_t* slot_of) {
+    hipLaunchKernelGGL(k_slice_reads, dim3(grid_for(n_slice + 1, 256)), dim3(256), 0, s, R, perm, n_slice, len_out, slot_of);
+}
+__device__ inline uint32_t block_owner(uint64_t b, uint64_t q, uint64_t rm) {     // leon_amd/shard.py block_range, inverted
+    const uint64_t cut = (q + 1) * rm;
+    return (uint32_t)(b < cut ? b / (q + 1) : rm + (q ? (b - cut) / q : 0));
+}
+// EMIT = false: cnt[i] = number of non-zero event bytes of read i (0 for reads outside the slice); EMIT = true: the words, at
+// send + off[i]: (place of the byte in the owner rank's event buffer << 8) | byte.  One lane per read of the BATCH, in file order.
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_ev_words(ReadsDev R, const uint32_t* slot_of, const uint64_t* ev_off, const uint8_t* events, uint64_t n,
+                                                 uint32_t rpb, uint64_t n_blocks, uint32_t world, uint64_t* cnt_or_off, uint64_t* send) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { if (!EMIT) cnt_or_off[n] = 0; return; }
+    const uint32_t j = slot_of[i];
+    if (j == 0xFFFFFFFFu) { if (!EMIT) cnt_or_off[i] = 0; return; }
+    const uint32_t len = R.len[i];
+    const uint8_t* ev = events + ev_off[j];
+    uint64_t w_at = 0, origin = 0;
+    if (EMIT) {
+        const uint64_t q = n_blocks / world, rm = n_blocks % world;
+        const uint32_t owner = block_owner(i / rpb, q, rm);
+        const uint64_t lb0 = (uint64_t)owner * q + (owner < rm ? owner : rm);
+        origin = R.base_off[i] - R.base_off[lb0 * rpb];          // the read's first byte in its owner's event buffer
+        w_at = cnt_or_off[i];
+    }
+    uint32_t c = 0;
+    for (uint32_t p0 = 0; p0 < len; p0 += 16) {                   // (the slice's buffer is padded by 16 bytes; bytes past the read are another read's: masked)
+        uint32_t w[4];
+        __builtin_memcpy(w, ev + p0, 16);
+        if (!(w[0] | w[1] | w[2] | w[3])) continue;
+#pragma unroll
+        for (uint32_t d = 0; d < 4; d++) {
+            uint32_t w4 = w[d];
+            const uint32_t q0 = p0 + 4 * d;
+            if (q0 >= len) w4 = 0; else if (q0 + 4 > len) w4 &= 0xFFFFFFFFu >> (8 * (q0 + 4 - len));
+            while (w4) {
+                const uint32_t byte = (uint32_t)__builtin_ctz(w4) >> 3;
+                if (EMIT) send[w_at + c] = ((origin + q0 + byte) << 8) | ((w4 >> (8 * byte)) & 0xFFu);
+                c++;
+                w4 &= ~(0xFFu << (8 * byte));
+            }
+        }
+    }
+    if (!EMIT) cnt_or_off[i] = c;
+}
+void launch_ev_words(hipStream_t s, ReadsDev R, const uint32_t* slot_of, const uint64_t* ev_off, const uint8_t* events, uint64_t n, uint32_t rpb,
+                     uint64_t n_blocks, uint32_t world, uint64_t* cnt_or_off, uint64_t* send) {
+    const uint32_t g = (uint32_t)((n + 1 + 255) / 256);
+    if (send) hipLaunchKernelGGL(k_ev_words<true>, dim3(g), dim3(256), 0, s, R, slot_of, ev_off, events, n, rpb, n_blocks, world, cnt_or_off, send);
+    else hipLaunchKernelGGL(k_ev_words<false>, dim3(g), dim3(256), 0, s, R, slot_of, ev_off, events, n, rpb, n_blocks, world, cnt_or_off, send);
+}
+// the receiving side: the words of every slice for this rank's blocks, into its (zeroed) event buffer; a place beyond the buffer
+// (words from another rank are input, not trusted) raises the flag
+__global__ void k_ev_scatter(const uint64_t* words, uint64_t n_words, uint8_t* events, uint64_t n_bytes, int* err) {
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_words; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = words[e], at = w >> 8;
+        if (at >= n_bytes) { atomicExch(err, 3); continue; }
+        events[at] = (uint8_t)w;
+    }
+}
+void launch_ev_scatter(hipStream_t s, const uint64_t* words, uint64_t n_words, uint8_t* events, uint64_t n_bytes, int* err) {
+    if (!n_words) return;
+    hipLaunchKernelGGL(k_ev_scatter, dim3(grid_for(n_words, 256)), dim3(256), 0, s, words, n_words, events, n_bytes, err);
 }
 
 // ================================================================================================

@@ -83,7 +83,16 @@ void launch_anchor_symbols(hipStream_t s, const uint64_t* kmers, uint64_t n_anch
 void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1);
 // ---- walk ----
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos, const uint8_t* flags,
-                 const uint32_t* perm, uint64_t n_walk, uint8_t* events);
+                 const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off = nullptr /* per walked read: its place in `events` */);
+// ---- the walk divided by anchor among the ranks of a job (leon_dna_set_exchange) ----
+void launch_lower_bound(hipStream_t s, const uint64_t* sorted, uint64_t n, uint64_t bound, unsigned long long* out);
+void launch_slice_weights(hipStream_t s, const uint64_t* sorted_keys, uint64_t n, uint64_t* w /* n + 1 */);
+void launch_slice_splits(hipStream_t s, const uint64_t* cum /* exclusive sums of the weights, n + 1 */, uint64_t n, uint32_t world, unsigned long long* split /* world + 1 */);
+void launch_slice_reads(hipStream_t s, ReadsDev R, const uint32_t* perm /* the slice */, uint64_t n_slice, uint64_t* len_out /* n_slice + 1 */,
+                        uint32_t* slot_of /* n, filled with 0xFF by the caller */);
+void launch_ev_words(hipStream_t s, ReadsDev R, const uint32_t* slot_of, const uint64_t* ev_off, const uint8_t* events, uint64_t n, uint32_t rpb,
+                     uint64_t n_blocks, uint32_t world, uint64_t* cnt_or_off /* n + 1 */, uint64_t* send /* nullptr = count pass */);
+void launch_ev_scatter(hipStream_t s, const uint64_t* words, uint64_t n_words, uint8_t* events, uint64_t n_bytes, int* err);
 // ---- symbols ----
 void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, uint32_t rpb, uint64_t first_block,
                           uint64_t n_blocks, int64_t* prev);

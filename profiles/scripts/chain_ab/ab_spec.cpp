@@ -106,6 +106,8 @@ struct SpecCoder {
     }
     // The same, the fast path as ONE hand-scheduled asm loop (the compiler's schedule of the C form above spills the carried quotient
     // and puts its multiply last): state in registers, left at the first symbol that needs the plain way or at the end.
+    // The predicted flag never lives in a register on the carried path: the compare that forms it (xp against thr, both carried from the
+    // step before) sits right in front of the conditional moves that use it, so the path is  Ru -> mulhi -> add -> xor | cmp -> cmov.
     void encode_records_asm(const SpecRec* r, uint64_t n, uint64_t t0) {
         if (!n) return;
         if (buf_.size() < w_ + 8 * n + 64) buf_.resize(buf_.size() * 2 + 8 * n + 4096);
@@ -114,9 +116,10 @@ struct SpecCoder {
         uint64_t L = low_;
         const SpecRec* const r0 = r;
         uint64_t q = range_ / (5 + t0);
-        uint64_t fm = ((L + q * r->lo) ^ (L + q * ((uint64_t)r->lo + r->fr))) < kTop ? ~0ull : 0;      // the first symbol's flag, exactly, as a mask
+        uint64_t f = ((L + q * r->lo) ^ (L + q * ((uint64_t)r->lo + r->fr))) < kTop ? 1 : 0;      // the first symbol's flag, exactly
         const SpecRec* const e = r + n - 1;                      // the last symbol goes the plain way
         while (r < e) {
+            uint64_t xp = f ? 0 : 1, thr = 1;                    // (xp < thr) == f: the exact flag, in the form the loop carries its prediction
             asm volatile(
                 ".p2align 5\n"
                 "1:\n\t"
@@ -125,56 +128,275 @@ struct SpecCoder {
                 "mulxq (%[r]), %%rbx, %%rbx\n\t"          // rbx = Phi = hi(q * C)
                 "movl  8(%[r]), %%ecx\n\t"
                 "imulq %[q], %%rcx\n\t"                   // q * lo
-                "movl  16(%[r]), %%r14d\n\t"
-                "imulq %[q], %%r14\n\t"                   // Ru = q * fr
+                "movl  16(%[r]), %%r13d\n\t"
+                "imulq %[q], %%r13\n\t"                   // Ru = q * fr
                 "shlq  $8, %%rdx\n\t"                     // q8
                 "mulxq (%[r]), %%rax, %%r15\n\t"          // r15 = Phi8 = hi(q8 * C), rax = its low half
                 "addq  %[L], %%rcx\n\t"                   // Lu
                 "addq  %%rdx, %%rax\n\t"                  // quotient in doubt: the low half within q8 of 2^64
                 "jc    2f\n\t"
-                "leaq  (%%rcx,%%r14), %%rax\n\t"
-                "xorq  %%rcx, %%rax\n\t"                  // x = Lu ^ (Lu + Ru)
-                "cmpq  %[bot], %%rax\n\t"
+                "rorxq $56, %%rcx, %%rdx\n\t"             // Lu rotated left by 8: dl = its top byte
+                "movb  %%dl, (%[p])\n\t"
+                "andq  $-256, %%rdx\n\t"                  // Lu << 8
+                "cmpq  %[thr], %[xp]\n\t"                 // CF = this symbol's flag as the step before predicted it
+                "cmovcq %%r15, %%rbx\n\t"                 // q' = f ? Phi8 : Phi
+                "cmovncq %%rcx, %%rdx\n\t"                // L' = f ? Lu << 8 : Lu
+                "movq  %[top], %[thr]\n\t"
+                "cmovcq %[bot], %[thr]\n\t"               // the next symbol's byte boundary in this symbol's frame: f ? 2^48 : 2^56
+                "sbbq  %%rax, %%rax\n\t"                  // the predicted flag as a mask
+                "leaq  (%%rcx,%%r13), %%r15\n\t"
+                "xorq  %%rcx, %%r15\n\t"                  // x = Lu ^ (Lu + Ru)
+                "cmpq  %[bot], %%r15\n\t"
                 "jb    2f\n\t"                            // two bytes or more
-                "cmpq  %[bot], %%r14\n\t"
+                "cmpq  %[bot], %%r13\n\t"
                 "jb    2f\n\t"                            // range below BOTTOM
-                "cmpq  %[top], %%rax\n\t"
-                "sbbq  %%rax, %%rax\n\t"                  // the exact flag, as a mask
-                "cmpq  %[fm], %%rax\n\t"
+                "cmpq  %[top], %%r15\n\t"
+                "sbbq  %%r15, %%r15\n\t"                  // the exact flag, as a mask
+                "cmpq  %%rax, %%r15\n\t"
                 "jne   2f\n\t"                            // mispredicted
-                "movq  %%r14, %%rdx\n\t"
+                "subq  %%rax, %[p]\n\t"                   // p += f
+                "movq  %%rbx, %[q]\n\t"
+                "movq  %%rdx, %[L]\n\t"
+                "movq  %%r13, %%rdx\n\t"
                 "mulxq 32(%[r]), %%rax, %%rax\n\t"        // ~ q' * lo'
                 "mulxq 40(%[r]), %%rdx, %%rdx\n\t"        // ~ q' * (lo' + fr')
                 "addq  %%rcx, %%rax\n\t"
                 "addq  %%rcx, %%rdx\n\t"
-                "xorq  %%rdx, %%rax\n\t"                  // xp
-                "rorxq $56, %%rcx, %%rdx\n\t"             // dl = the top byte of Lu
-                "movb  %%dl, (%[p])\n\t"
-                "subq  %[fm], %[p]\n\t"                   // p += f
-                "movq  %%rcx, %%rdx\n\t"
+                "xorq  %%rdx, %%rax\n\t"
+                "movq  %%rax, %[xp]\n\t"                  // the next symbol's predictor
+                "addq  $24, %[r]\n\t"
+                "cmpq  %[e], %[r]\n\t"
+                "jb    1b\n\t"
+                "movq  $-1, %%rax\n"                       // (left at the end: nothing to undo)
+                "2:\n"
+                : [r] "+r"(r), [q] "+r"(q), [L] "+r"(L), [p] "+r"(p), [xp] "+r"(xp), [thr] "+r"(thr)
+                : [e] "m"(e), [top] "r"(kTop), [bot] "r"(kBottom)
+                : "rax", "rbx", "rcx", "rdx", "r13", "r15", "cc", "memory");
+            if (r >= e) { f = xp < thr ? 1 : 0; break; }
+            // (left before anything of the symbol was committed: q, L, p are the step's inputs; its flag, whatever was predicted, is not needed)
+            const Plain s = step_plain(r, true, 5 + t0 + (uint64_t)(r - r0) + 1, q, L, 0, p);
+            q = s.q; L = s.L; f = s.f; p = s.p;
+            r++;
+        }
+        const Plain s = step_plain(r, false, 5 + t0 + n, q, L, f, p);
+        slow--;
+        range_ = s.R; low_ = s.L;
+        w_ = (size_t)(s.p - buf_.data());
+    }
+    // No prediction, as few micro-operations as the exact step allows (~31): for a core that sustains ~5 of them per cycle the step's
+    // instruction count, not its carried latency, may be what bounds it.  Record: C, lo, lf = lo + fr (both ends' products start
+    // together: q -> imul -> add -> xor -> cmp -> cmov, 7 cycles); Phi8 by a second multiply of the shifted quotient, whose low half
+    // is the doubt test's operand as it comes.  `q8max` >= any q << 8 of the segment: doubt = low half > ~q8max (conservative).
+    void encode_records_lean(const SpecRec* r, uint64_t n, uint64_t t0) {
+        if (!n) return;
+        if (buf_.size() < w_ + 8 * n + 64) buf_.resize(buf_.size() * 2 + 8 * n + 4096);
+        settle();
+        uint8_t* p = buf_.data() + w_;
+        uint64_t L = low_;
+        const SpecRec* const r0 = r;
+        uint64_t q = range_ / (5 + t0);
+        const SpecRec* const e = r + n - 1;
+        // q <= (2^64 - 1) / total, total >= 5 + t0 > 256: q << 8 < 2^72 / (5 + t0)
+        const uint64_t doubt_above = ~(uint64_t)((((unsigned __int128)1) << 72) / (5 + t0));
+        while (r < e) {
+            asm volatile(
+                ".p2align 5\n"
+                "1:\n\t"
+                "prefetcht0 3072(%[r])\n\t"
+                "movq  %[q], %%rdx\n\t"
+                "mulxq (%[r]), %%rbx, %%rbx\n\t"          // rbx = Phi
+                "movl  8(%[r]), %%ecx\n\t"
+                "imulq %[q], %%rcx\n\t"                   // q * lo
+                "movl  12(%[r]), %%r13d\n\t"
+                "imulq %[q], %%r13\n\t"                   // q * lf
                 "shlq  $8, %%rdx\n\t"
-                "movq  %[top], %%r14\n\t"
-                "testq %[fm], %[fm]\n\t"
-                "cmovnzq %%r15, %%rbx\n\t"                // q' = f ? Phi8 : Phi
-                "cmovnzq %%rdx, %%rcx\n\t"                // L' = f ? Lu << 8 : Lu
-                "cmovnzq %[bot], %%r14\n\t"               // the next symbol's byte boundary in this symbol's frame: f ? 2^48 : 2^56
-                "cmpq  %%r14, %%rax\n\t"
-                "sbbq  %[fm], %[fm]\n\t"                  // the next symbol's flag, predicted
+                "mulxq (%[r]), %%rax, %%r15\n\t"          // r15 = Phi8, rax = the low half of q8 * C
+                "addq  %[L], %%rcx\n\t"                   // Lu
+                "addq  %[L], %%r13\n\t"                   // Tu
+                "cmpq  %[dbt], %%rax\n\t"
+                "ja    2f\n\t"                            // quotient in doubt
+                "movq  %%r13, %%rax\n\t"
+                "xorq  %%rcx, %%rax\n\t"                  // x
+                "subq  %%rcx, %%r13\n\t"                  // Ru
+                "cmpq  %[bot], %%rax\n\t"
+                "jb    2f\n\t"
+                "cmpq  %[bot], %%r13\n\t"
+                "jb    2f\n\t"
+                "rorxq $56, %%rcx, %%rdx\n\t"
+                "movb  %%dl, (%[p])\n\t"
+                "andq  $-256, %%rdx\n\t"                  // Lu << 8
+                "cmpq  %[top], %%rax\n\t"                 // CF = exactly one byte leaves
+                "cmovcq %%r15, %%rbx\n\t"
+                "cmovcq %%rdx, %%rcx\n\t"
+                "adcq  $0, %[p]\n\t"
                 "movq  %%rbx, %[q]\n\t"
                 "movq  %%rcx, %[L]\n\t"
                 "addq  $24, %[r]\n\t"
                 "cmpq  %[e], %[r]\n\t"
                 "jb    1b\n"
                 "2:\n"
-                : [r] "+r"(r), [q] "+r"(q), [L] "+r"(L), [fm] "+r"(fm), [p] "+r"(p)
-                : [e] "r"(e), [top] "r"(kTop), [bot] "r"(kBottom)
-                : "rax", "rbx", "rcx", "rdx", "r14", "r15", "cc", "memory");
+                : [r] "+r"(r), [q] "+r"(q), [L] "+r"(L), [p] "+r"(p)
+                : [e] "m"(e), [top] "r"(kTop), [bot] "r"(kBottom), [dbt] "r"(doubt_above)
+                : "rax", "rbx", "rcx", "rdx", "r13", "r15", "cc", "memory");
             if (r >= e) break;
-            const Plain s = step_plain(r, true, 5 + t0 + (uint64_t)(r - r0) + 1, q, L, fm & 1, p);
-            q = s.q; L = s.L; fm = 0 - s.f; p = s.p;
+            const Plain s = step_plain(r, false, 5 + t0 + (uint64_t)(r - r0) + 1, q, L, 0, p);
+            q = s.q; L = s.L; p = s.p;
             r++;
         }
-        const Plain s = step_plain(r, false, 5 + t0 + n, q, L, fm & 1, p);
+        const Plain s = step_plain(r, false, 5 + t0 + n, q, L, 0, p);
+        slow--;
+        range_ = s.R; low_ = s.L;
+        w_ = (size_t)(s.p - buf_.data());
+    }
+    // LEAN without the redundant test and the prefetch, and unrolled by two so that nothing is moved between steps.
+    // (x < 2^48 implies Ru < 2^48: adding Ru flips a bit of Lu at or above Ru's highest one, so x >= 2^floor(log2 Ru): the range test covers both.)
+#define LEAN_STEP(OFF, QIN, LIN, QOUT, LOUT, LOUT32, EXIT)                                                            \
+                "movq  " QIN ", %%rdx\n\t"                                                                             \
+                "mulxq " OFF "(%[r]), " QOUT ", " QOUT "\n\t"                                                          \
+                "movl  " OFF "+8(%[r]), " LOUT32 "\n\t"                                                                \
+                "imulq " QIN ", " LOUT "\n\t"                                                                          \
+                "movl  " OFF "+12(%[r]), %%r13d\n\t"                                                                   \
+                "imulq " QIN ", %%r13\n\t"                                                                             \
+                "shlq  $8, %%rdx\n\t"                                                                                  \
+                "mulxq " OFF "(%[r]), %%rax, %%r15\n\t"                                                                \
+                "addq  " LIN ", " LOUT "\n\t"                                                                          \
+                "addq  " LIN ", %%r13\n\t"                                                                             \
+                "cmpq  %[dbt], %%rax\n\t"                                                                              \
+                "ja    " EXIT "\n\t"                                                                                   \
+                "movq  %%r13, %%rax\n\t"                                                                               \
+                "xorq  " LOUT ", %%rax\n\t"                                                                            \
+                "subq  " LOUT ", %%r13\n\t"                                                                            \
+                "cmpq  %[bot], %%r13\n\t"                                                                              \
+                "jb    " EXIT "\n\t"                                                                                   \
+                "rorxq $56, " LOUT ", %%rdx\n\t"                                                                       \
+                "movb  %%dl, (%[p])\n\t"                                                                               \
+                "andq  $-256, %%rdx\n\t"                                                                               \
+                "cmpq  %[top], %%rax\n\t"                                                                              \
+                "cmovcq %%r15, " QOUT "\n\t"                                                                           \
+                "cmovcq %%rdx, " LOUT "\n\t"                                                                           \
+                "adcq  $0, %[p]\n\t"
+    void encode_records_lean2(const SpecRec* r, uint64_t n, uint64_t t0, bool unroll) {
+        if (!n) return;
+        if (buf_.size() < w_ + 8 * n + 64) buf_.resize(buf_.size() * 2 + 8 * n + 4096);
+        settle();
+        uint8_t* p = buf_.data() + w_;
+        uint64_t L = low_;
+        const SpecRec* const r0 = r;
+        uint64_t q = range_ / (5 + t0);
+        const SpecRec* const e = r + n - 1;
+        const SpecRec* const e2 = e - 1;                          // the unrolled loop needs two records
+        const uint64_t doubt_above = ~(uint64_t)((((unsigned __int128)1) << 72) / (5 + t0));
+        while (r < e) {
+            if (unroll && r < e2) {
+                asm volatile(
+                    ".p2align 5\n"
+                    "1:\n\t"
+                    LEAN_STEP("0", "%[q]", "%[L]", "%%rbx", "%%rcx", "%%ecx", "2f")
+                    LEAN_STEP("24", "%%rbx", "%%rcx", "%[q]", "%[L]", "%k[L]", "3f")
+                    "addq  $48, %[r]\n\t"
+                    "cmpq  %[e], %[r]\n\t"
+                    "jb    1b\n\t"
+                    "jmp   2f\n"
+                    "3:\n\t"                                   // left in the second half: the first half's results are the state, one record on
+                    "movq  %%rbx, %[q]\n\t"
+                    "movq  %%rcx, %[L]\n\t"
+                    "addq  $24, %[r]\n"
+                    "2:\n"
+                    : [r] "+r"(r), [q] "+r"(q), [L] "+r"(L), [p] "+r"(p)
+                    : [e] "m"(e2), [top] "r"(kTop), [bot] "r"(kBottom), [dbt] "r"(doubt_above)
+                    : "rax", "rbx", "rcx", "rdx", "r13", "r15", "cc", "memory");
+            } else if (!unroll) {
+                asm volatile(
+                    ".p2align 5\n"
+                    "1:\n\t"
+                    LEAN_STEP("0", "%[q]", "%[L]", "%%rbx", "%%rcx", "%%ecx", "2f")
+                    "movq  %%rbx, %[q]\n\t"
+                    "movq  %%rcx, %[L]\n\t"
+                    "addq  $24, %[r]\n\t"
+                    "cmpq  %[e], %[r]\n\t"
+                    "jb    1b\n"
+                    "2:\n"
+                    : [r] "+r"(r), [q] "+r"(q), [L] "+r"(L), [p] "+r"(p)
+                    : [e] "m"(e), [top] "r"(kTop), [bot] "r"(kBottom), [dbt] "r"(doubt_above)
+                    : "rax", "rbx", "rcx", "rdx", "r13", "r15", "cc", "memory");
+            }
+            if (r >= e) break;
+            // the record the loop stopped at (a rare case, or the odd record before the last): the plain way
+            const Plain s = step_plain(r, false, 5 + t0 + (uint64_t)(r - r0) + 1, q, L, 0, p);
+            q = s.q; L = s.L; p = s.p;
+            r++;
+        }
+        const Plain s = step_plain(r, false, 5 + t0 + n, q, L, 0, p);
+        slow--;
+        range_ = s.R; low_ = s.L;
+        w_ = (size_t)(s.p - buf_.data());
+    }
+    // LEAN2 x2 with NO register move on a carried path: the quotient lives in rdx (mulx's implicit operand), the shifted quotient is
+    // formed by shlx into rax for a legacy mul whose high half lands in rdx -- where the next quotient belongs -- and the exclusive-or
+    // is done in place.  (A mov that the renamer does not eliminate costs its cycle on the quotient's and on the flag's path.)
+#define NOMOV_STEP(OFF, LIN, LOUT, LOUT32, EXIT)                                                                      \
+                "movq  %%rdx, %%r14\n\t"                       /* the step's quotient, kept for a rare exit */           \
+                "mulxq " OFF "(%[r]), %%rbx, %%rbx\n\t"        /* Phi */                                                 \
+                "movl  " OFF "+8(%[r]), " LOUT32 "\n\t"                                                                \
+                "imulq %%rdx, " LOUT "\n\t"                                                                            \
+                "movl  " OFF "+12(%[r]), %%r13d\n\t"                                                                   \
+                "imulq %%rdx, %%r13\n\t"                                                                               \
+                "shlxq %[eight], %%rdx, %%rax\n\t"             /* q8 */                                                  \
+                "mulq  " OFF "(%[r])\n\t"                      /* rdx = Phi8, rax = the low half */                      \
+                "addq  " LIN ", " LOUT "\n\t"                  /* Lu */                                                  \
+                "addq  " LIN ", %%r13\n\t"                     /* Tu */                                                  \
+                "cmpq  %[dbt], %%rax\n\t"                                                                              \
+                "ja    " EXIT "\n\t"                                                                                   \
+                "movq  %%r13, %%rax\n\t"                                                                               \
+                "subq  " LOUT ", %%rax\n\t"                    /* Ru */                                                  \
+                "cmpq  %[bot], %%rax\n\t"                                                                              \
+                "jb    " EXIT "\n\t"                                                                                   \
+                "xorq  " LOUT ", %%r13\n\t"                    /* x, in place */                                         \
+                "rorxq $56, " LOUT ", %%r15\n\t"                                                                       \
+                "movb  %%r15b, (%[p])\n\t"                                                                             \
+                "andq  $-256, %%r15\n\t"                       /* Lu << 8 */                                             \
+                "cmpq  %[top], %%r13\n\t"                      /* CF = exactly one byte leaves */                        \
+                "cmovncq %%rbx, %%rdx\n\t"                     /* q' = f ? Phi8 : Phi, in rdx */                         \
+                "cmovcq %%r15, " LOUT "\n\t"                                                                           \
+                "adcq  $0, %[p]\n\t"
+    void encode_records_nomov(const SpecRec* r, uint64_t n, uint64_t t0) {
+        if (!n) return;
+        if (buf_.size() < w_ + 8 * n + 64) buf_.resize(buf_.size() * 2 + 8 * n + 4096);
+        settle();
+        uint8_t* p = buf_.data() + w_;
+        uint64_t L = low_;
+        const SpecRec* const r0 = r;
+        uint64_t q = range_ / (5 + t0);
+        const SpecRec* const e = r + n - 1;
+        const SpecRec* const e2 = e - 1;
+        const uint64_t doubt_above = ~(uint64_t)((((unsigned __int128)1) << 72) / (5 + t0));
+        while (r < e) {
+            if (r < e2) {
+                asm volatile(
+                    ".p2align 5\n"
+                    "1:\n\t"
+                    NOMOV_STEP("0", "%[L]", "%%rcx", "%%ecx", "2f")
+                    NOMOV_STEP("24", "%%rcx", "%[L]", "%k[L]", "3f")
+                    "addq  $48, %[r]\n\t"
+                    "cmpq  %[e], %[r]\n\t"
+                    "jb    1b\n\t"
+                    "jmp   4f\n"
+                    "3:\n\t"                                   // left in the second half: the first half's low end is the state, one record on
+                    "movq  %%rcx, %[L]\n\t"
+                    "addq  $24, %[r]\n"
+                    "2:\n\t"
+                    "movq  %%r14, %%rdx\n"                      // the quotient the step that was left began with
+                    "4:\n"
+                    : [r] "+r"(r), [q] "+d"(q), [L] "+r"(L), [p] "+r"(p)
+                    : [e] "m"(e2), [top] "r"(kTop), [bot] "r"(kBottom), [dbt] "r"(doubt_above), [eight] "r"((uint64_t)8)
+                    : "rax", "rbx", "rcx", "r13", "r14", "r15", "cc", "memory");
+            }
+            if (r >= e) break;
+            const Plain s = step_plain(r, false, 5 + t0 + (uint64_t)(r - r0) + 1, q, L, 0, p);
+            q = s.q; L = s.L; p = s.p;
+            r++;
+        }
+        const Plain s = step_plain(r, false, 5 + t0 + n, q, L, 0, p);
         slow--;
         range_ = s.R; low_ = s.L;
         w_ = (size_t)(s.p - buf_.data());
@@ -208,6 +430,8 @@ int main(int argc, char** argv) {
         c[sy]++;
     }
     srecs[n * k] = SpecRec{0, 0, 0, 0, 0};
+    std::vector<SpecRec> lrecs(srecs);                              // the lean variant's records: {C, lo, lf = lo + fr, -, -} in the same 24 bytes
+    for (auto& x : lrecs) x.g1 = x.lo + x.fr;
     const size_t plain = 20;
     // correctness: the whole stream both ways
     std::vector<uint8_t> ref;
@@ -221,20 +445,28 @@ int main(int argc, char** argv) {
         ref.assign(cd.data(), cd.data() + cd.size());
         printf("AS IT STANDS, records from DRAM: %.3f ns/symbol, %zu bytes\n", dt / ((n - plain) * (double)k) * 1e9, cd.size());
     }
-    for (int rep = 0; rep < 4; rep++) {
-        const bool use_asm = rep >= 2;
+    for (int rep = 0; rep < 12; rep++) {
+        const bool use_asm = rep >= 2 && rep < 4, use_lean = rep >= 4 && rep < 6, use_lean2 = rep >= 6 && rep < 8, use_lean2x2 = rep >= 8 && rep < 10, use_nomov = rep >= 10;
         AnchorDictCoder head;
         head.encode_kmers(km.data(), plain, k);
         SpecCoder sc;
         sc.buf_.assign(head.buf_.data(), head.buf_.data() + head.w_); sc.buf_.resize(sc.buf_.size() + 64);
         sc.w_ = head.w_; sc.low_ = head.low_; sc.range_ = head.range_;
+        sc.buf_.resize(sc.buf_.size() + 8 * n * k + 4096);               // (room made and touched outside the timed region)
         auto t0 = std::chrono::steady_clock::now();
-        if (use_asm) sc.encode_records_asm(srecs.data() + plain * k, (n - plain) * k, plain * k); else sc.encode_records(srecs.data() + plain * k, (n - plain) * k, plain * k);
+        for (uint64_t at = plain * k, end = n * k; at < end;) {         // segments of ~32 k symbols, as the library's feed hands them over
+            const uint64_t m = std::min<uint64_t>(32767, end - at);
+            if (use_nomov) sc.encode_records_nomov(lrecs.data() + at, m, at);
+            else if (use_lean2 || use_lean2x2) sc.encode_records_lean2(lrecs.data() + at, m, at, use_lean2x2);
+            else if (use_lean) sc.encode_records_lean(lrecs.data() + at, m, at);
+            else if (use_asm) sc.encode_records_asm(srecs.data() + at, m, at); else sc.encode_records(srecs.data() + at, m, at);
+            at += m;
+        }
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         sc.flush();
         const bool same = sc.w_ == ref.size() && memcmp(sc.buf_.data(), ref.data(), ref.size()) == 0;
         printf("PREDICTED FLAG%s, records from DRAM: %.3f ns/symbol, %zu bytes, %s; mispredicted %llu, slow path %llu, in doubt %llu of %zu symbols\n",
-               use_asm ? " (asm)" : "", dt / ((n - plain) * (double)k) * 1e9, sc.w_, same ? "IDENTICAL" : "DIFFERENT", (unsigned long long)sc.mispredicted,
+               use_nomov ? " -- none: NO-MOV x2 (asm)" : use_lean2x2 ? " -- none: LEAN2 x2 (asm)" : use_lean2 ? " -- none: LEAN2 (asm)" : use_lean ? " -- none: LEAN (asm)" : use_asm ? " (asm)" : "", dt / ((n - plain) * (double)k) * 1e9, sc.w_, same ? "IDENTICAL" : "DIFFERENT", (unsigned long long)sc.mispredicted,
                (unsigned long long)sc.slow, (unsigned long long)sc.doubt, (n - plain) * (size_t)k);
         if (!same) return 1;
     }
@@ -267,6 +499,26 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 300; i++) { sc.w_ = 0; sc.encode_records_asm(srecs.data() + start, m, start); }
             double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             printf("PREDICTED FLAG (asm), records in cache: %.3f ns/symbol (plain steps %llu of %zu)\n", dt / (300.0 * m) * 1e9, (unsigned long long)sc.slow, (size_t)300 * m);
+        }
+        {
+            AnchorDictCoder head;
+            head.encode_kmers(km.data(), 20, k);
+            SpecCoder sc;
+            sc.buf_.resize(1 << 20); sc.low_ = head.low_; sc.range_ = head.range_;
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 300; i++) { sc.w_ = 0; sc.encode_records_lean(lrecs.data() + start, m, start); }
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("NO PREDICTION, LEAN (asm), records in cache: %.3f ns/symbol (plain steps %llu of %zu)\n", dt / (300.0 * m) * 1e9, (unsigned long long)sc.slow, (size_t)300 * m);
+        }
+        for (int u = 0; u < 3; u++) {
+            AnchorDictCoder head;
+            head.encode_kmers(km.data(), 20, k);
+            SpecCoder sc;
+            sc.buf_.resize(1 << 20); sc.low_ = head.low_; sc.range_ = head.range_;
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 300; i++) { sc.w_ = 0; if (u == 2) sc.encode_records_nomov(lrecs.data() + start, m, start); else sc.encode_records_lean2(lrecs.data() + start, m, start, u == 1); }
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("NO PREDICTION, %s%s (asm), records in cache: %.3f ns/symbol (plain steps %llu of %zu)\n", u == 2 ? "NO-MOV" : "LEAN2", u ? " x2" : "", dt / (300.0 * m) * 1e9, (unsigned long long)sc.slow, (size_t)300 * m);
         }
     }
     return 0;

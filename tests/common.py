@@ -16,9 +16,16 @@ def toy_reads():
     return bases, off
 
 
-def synthetic(n_reads, read_len, genome_len, seed=1, **kw):
+def synthetic(n_reads, read_len, genome_len, seed=1, junk_reads=0, **kw):
+    """junk_reads: that many reads, spread over the set, are random bases (no solid k-mer: reads without an anchor)"""
     g = synth.make_genome(genome_len, seed=seed)
     b, off = synth.make_reads(g, n_reads, read_len, seed=seed + 1, **kw)
+    if junk_reads:
+        rng = np.random.default_rng(seed + 2)
+        b = b.copy()
+        for r in rng.choice(n_reads, size=junk_reads, replace=False):
+            s, e = int(off[r]), int(off[r + 1])
+            b[s:e] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=e - s)]
     return b.tobytes(), off
 
 

@@ -1,5 +1,7 @@
 """-m gpu: the HIP path, called through the C-ABI, against the CPU oracle on the same seeded inputs.
 Bit-exact everywhere (integer / byte work)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -300,6 +302,112 @@ def test_sharded_contexts_reproduce_the_single_stream():
         assert [g[0] for g in got] == list(range(len(ref.blocks)))
         assert [g[1] for g in got] == ref.blocks and [g[2] for g in got] == ref.block_nreads
         assert dicts[0] == ref.anchor_dict and all(len(d) == 0 for d in dicts[1:])
+
+
+def test_walk_divided_by_anchor_reproduces_the_single_stream():
+    """leon_dna_set_exchange: the walk of an N-rank job divided by ANCHOR (rank r walks the r-th slice of the batch's reads sorted
+    by anchor address, whatever block they belong to; what it finds travels to the rank that codes the read's block) instead of by
+    block range.  LEON_XCH_EMULATE: one context plays every rank's slice and keeps the words meant for its own rank -- the bytes of a
+    real run.  The union of the ranks' blocks must be the one-context stream (= the oracle's), for worlds that leave ranks without a
+    block, with N / errors / ragged reads / reads without an anchor, two batches, one- and two-word k-mers."""
+    from leon_amd import capi
+    for k in (31, 41):
+        rpb = 300
+        bases, off = common.synthetic(4000, 150, 15000, seed=51 + k, n_rate=0.002, ragged=True, junk_reads=40)
+        bl, solid, tai = common.make_bloom(bases, off, k)
+        ref = O.encode(bases, off, k, rpb, bl, trace=False)
+        for world in (2, 3, 8):
+            got = []
+            for rank in range(world):
+                ctx = _ctx(k, rpb, tai, resolve_window=1000)
+                ctx.set_shard(rank, world)
+                ctx.set_exchange(capi.XCH_EMULATE)
+                ctx.bloom_upload(bl.bits)
+                cut = 6 * rpb
+                b1 = ctx.encode_batch(bases, off[:cut + 1])
+                st1 = ctx.stats()
+                b2 = ctx.encode_batch(bases, off[cut:])
+                d, na = ctx.finish()
+                assert na == ref.n_anchors and (d == ref.anchor_dict if rank == 0 else len(d) == 0)
+                # a rank walks about a world-th of the batch's anchored reads, and receives exactly what its blocks hold
+                if st1["n_blocks"]:                       # (a rank without a block of the batch has nothing to receive: it walks nothing here)
+                    assert st1["walk_launches"] == 1 and st1["walk_reads"] <= cut and st1["xch_words_received"] > 0
+                got += b1 + b2
+                ctx.close()
+            got.sort()
+            assert [g[0] for g in got] == list(range(len(ref.blocks)))
+            assert [g[1] for g in got] == ref.blocks and [g[2] for g in got] == ref.block_nreads, (k, world)
+
+
+def test_walk_divided_by_anchor_with_a_real_exchange_between_contexts():
+    """the same with LEON_XCH_BY_ANCHOR and a real exchange: `world` contexts on the one device, one thread each, their callbacks
+    meeting at a barrier and handing one another the words (device to device, leon_device_copy) -- what an all-to-all does between
+    GPUs.  Every rank calls the exchange for every batch, also a rank that codes no block of it (world 8: the first batch's 6 blocks)."""
+    import threading
+    from leon_amd import capi
+    k, rpb = 31, 300
+    bases, off = common.synthetic(4000, 150, 15000, seed=77, n_rate=0.001, junk_reads=25)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ref = O.encode(bases, off, k, rpb, bl, trace=False)
+    for world in (2, 8):
+        barrier = threading.Barrier(world)
+        posted = [None] * world                      # rank -> (d_send, counts)
+        recv_bufs = [None] * world                   # rank -> device pointer it owns (freed at the next call)
+        import leon_amd
+        lib = leon_amd.load_library()
+        results, errors = [None] * world, []
+
+        def exchange(rank):
+            def fn(d_send, counts):
+                posted[rank] = (d_send, counts)
+                barrier.wait()
+                total = sum(posted[src][1][rank] for src in range(world))
+                if recv_bufs[rank]:
+                    lib.leon_device_free(C.c_void_p(recv_bufs[rank]))
+                    recv_bufs[rank] = None
+                ptr = C.c_void_p()
+                assert lib.leon_device_alloc(0, max(total, 1) * 8, C.byref(ptr)) == 0
+                recv_bufs[rank] = ptr.value
+                at = 0
+                for src in range(world):
+                    d, cnt = posted[src]
+                    skip = sum(cnt[:rank])
+                    if cnt[rank]:
+                        assert lib.leon_device_copy(0, C.c_void_p(ptr.value + 8 * at), C.c_void_p(d + 8 * skip), cnt[rank] * 8) == 0
+                    at += cnt[rank]
+                barrier.wait()                       # nobody's send buffer is reused before everybody has copied from it
+                return ptr.value, total
+            return fn
+
+        def run(rank):
+            try:
+                ctx = _ctx(k, rpb, tai, resolve_window=1000)
+                ctx.set_shard(rank, world)
+                ctx.set_exchange(capi.XCH_BY_ANCHOR, exchange(rank))
+                ctx.bloom_upload(bl.bits)
+                cut = 6 * rpb
+                blocks = ctx.encode_batch(bases, off[:cut + 1]) + ctx.encode_batch(bases, off[cut:])
+                d, na = ctx.finish()
+                st = ctx.stats()
+                ctx.close()
+                results[rank] = (blocks, d, na, st)
+            except Exception as e:                   # noqa: BLE001
+                errors.append((rank, e))
+                barrier.abort()
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        for p_ in recv_bufs:
+            if p_:
+                lib.leon_device_free(C.c_void_p(p_))
+        got = sorted(b for r in results for b in r[0])
+        assert [g[0] for g in got] == list(range(len(ref.blocks)))
+        assert [g[1] for g in got] == ref.blocks and [g[2] for g in got] == ref.block_nreads, world
+        assert results[0][1] == ref.anchor_dict and all(len(r[1]) == 0 for r in results[1:])
+        assert sum(r[3]["xch_words_sent"] for r in results) == sum(r[3]["xch_words_received"] for r in results)
 
 
 def test_dictionary_stream_on_device_equals_host_thread():
