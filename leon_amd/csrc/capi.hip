@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include "host_rc.h"
 #include "staging.h"
+#include "host_blocks.h"
 
 #include "prim.h"
 
@@ -122,7 +123,14 @@ struct leon_dna_ctx {
     uint32_t xch_mode = LEON_XCH_OFF;            // leon_dna_set_exchange: how the walk is divided among the ranks
     leon_exchange_fn xch_fn = nullptr; void* xch_user = nullptr;
     DevBuf xch_slot, xch_off, xch_evoff, xch_events, xch_send, xch_split;
+    DevBuf resolve_trace;
     DevBuf round_hist;                           // the counts of a window's fixpoint rounds, read back together
+    // small launches: the blocks' chains on host cores (host_blocks.h), fed by the device's modelers chunk by chunk
+    DevBuf hb_recs[2], hb_recoff, hb_state;
+    uint64_t* h_recs = nullptr; size_t h_recs_cap = 0;          // pinned: the records of a launch
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> hb_ev;                              // per chunk: modelled, copied
+    std::vector<HostBlockCoder> hb_coders;
     uint64_t* h_anchor[2] = {nullptr, nullptr}; size_t h_anchor_cap = 0;   // pinned: a window's new anchors on their way to the dictionary chain
     bool partial_seen = false, finished = false;
     uint64_t hdr_next_read = 0, hdr_next_block = 0;   // the header stream's own counters (leon_header_encode_batch)
@@ -246,6 +254,139 @@ int ensure_cub(leon_dna_ctx* c, size_t bytes) { HIPCHK(c, c->cub_tmp.ensure(byte
 
 }  // namespace
 
+
+namespace leon { uint32_t usable_cpus(); }
+
+namespace {
+// Launches of at most this many blocks have their chains coded on host cores (0 = never): LEON_RC_HOST_BLOCKS, default 400.
+// With 2 000 blocks (8 per CU) the device's chains all run at once and win: 126 ms for 2.3 G symbols is 18 G symbols/s, 16 host cores at ~2.3 ns do 7.
+uint64_t rc_host_blocks() {
+    if (const char* e = getenv("LEON_RC_HOST_BLOCKS")) return (uint64_t)std::max<long long>(0, atoll(e));
+    return 400;
+}
+uint32_t rc_host_threads(uint64_t n_blocks) {
+    uint32_t n_thr = std::max<uint32_t>(2, std::min<uint32_t>(16, usable_cpus() > 5 ? usable_cpus() - 4 : 2));   // (the dictionary chain and its helpers keep four)
+    if (const char* e = getenv("LEON_RC_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_thr = (uint32_t)v; }
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_thr, n_blocks));
+}
+// Who codes a launch's chains.  The device's coder waves take about as long as the LONGEST block's chain whatever the number of
+// blocks (~100 ns per symbol of it, up to 8 blocks per CU); the host's threads take the modelers' pass over the longest block
+// (~30 ns per symbol), then what is slower of the records' way over PCIe (8 bytes per symbol) and the chains themselves
+// (~2.4 ns per symbol and thread).  10 M reads of 150 bp in 200 blocks: 116 against ~80 ms, the host; 20 M reads of 250 bp in 400
+// blocks of 1.9 M symbols: 190 against ~210, the device (measured: 181 and 230).
+bool rc_on_host(uint64_t n_blocks, uint64_t n_syms, uint64_t max_block_syms) {
+    if (!n_blocks || n_blocks > rc_host_blocks() || max_block_syms + 1024 >= (1ull << HB_COUNT_BITS) || n_syms * 8 > (12ull << 30)) return false;
+    if (getenv("LEON_RC_HOST_BLOCKS")) return true;              // (asked for by name: the tests, measurements)
+    const double device_ns = 100.0 * (double)max_block_syms * (double)((n_blocks + 2047) / 2048);
+    const double host_ns = 30.0 * (double)max_block_syms + std::max(0.16 * (double)n_syms, 2.4 * (double)n_syms / rc_host_threads(n_blocks));
+    return host_ns < device_ns;
+}
+
+// The range coder stage of a small launch: the device's modeler waves turn the symbols of every block into records, chunk of tiles
+// by chunk; a chunk crosses PCIe while the next is modelled, and host threads -- each owning every n-th block -- code it while the
+// one after that crosses.  On return c->hb_coders[b] holds block b's payload.  Bytes: exactly k_rc_encode's (the tests run both).
+int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_blk_begin, uint64_t nbl, uint64_t n_syms, uint32_t small_sizes,
+                      uint32_t n_small) {
+    hipStream_t s = c->stream;
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    std::vector<uint64_t> bb(nbl + 1);
+    HIPCHK(c, hipMemcpyAsync(bb.data(), d_blk_begin, (nbl + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    uint64_t max_tiles = 0;
+    for (uint64_t b = 0; b < nbl; b++) max_tiles = std::max<uint64_t>(max_tiles, (bb[b + 1] - bb[b] + 63) / 64);
+    uint32_t n_chunks = 4;
+    if (const char* e = getenv("LEON_RC_HOST_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_chunks = (uint32_t)v; }
+    n_chunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_chunks, max_tiles));
+    const uint64_t Tc = (max_tiles + n_chunks - 1) / std::max<uint32_t>(n_chunks, 1);
+    // where block b's records of chunk ch lie inside the chunk, and the chunks inside the pinned buffer
+    std::vector<uint64_t> rec_off((size_t)n_chunks * nbl), rec_cnt((size_t)n_chunks * nbl), chunk_base(n_chunks + 1, 0);
+    uint64_t chunk_max = 0;
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        uint64_t at = 0;
+        for (uint64_t b = 0; b < nbl; b++) {
+            const uint64_t len = bb[b + 1] - bb[b], a0 = std::min<uint64_t>(len, ch * Tc * 64), a1 = std::min<uint64_t>(len, (ch + 1) * Tc * 64);
+            rec_off[(size_t)ch * nbl + b] = at; rec_cnt[(size_t)ch * nbl + b] = a1 - a0;
+            at += a1 - a0;
+        }
+        chunk_base[ch + 1] = chunk_base[ch] + at;
+        chunk_max = std::max(chunk_max, at);
+    }
+    if (chunk_base[n_chunks] != n_syms) return fail(c, LEON_E_STATE, "block symbol ranges do not add up (internal error)");
+    for (auto& b : c->hb_recs) HIPCHK(c, b.ensure(chunk_max * 8 + 64));
+    HIPCHK(c, c->hb_recoff.ensure((size_t)n_chunks * nbl * 8));
+    HIPCHK(c, c->hb_state.ensure(rc_records_state_bytes(nbl)));
+    HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
+    if (n_syms * 8 + 64 > c->h_recs_cap) {
+        if (c->h_recs) HIPCHK(c, hipHostFree(c->h_recs));
+        c->h_recs = nullptr; c->h_recs_cap = 0;
+        const size_t want = n_syms * 8 + n_syms + 4096;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_recs, want, hipHostMallocDefault));
+        c->h_recs_cap = want;
+    }
+    while (c->hb_ev.size() < 2 * (size_t)n_chunks) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->hb_ev.push_back(e); }
+    HIPCHK(c, hipMemcpyAsync(c->hb_recoff.p, rec_off.data(), rec_off.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
+    if (c->hb_coders.size() < nbl) c->hb_coders.resize(nbl);
+    // the host threads
+    const uint32_t n_thr = rc_host_threads(nbl);
+    static const bool trace = getenv("LEON_TRACE_RC_HOST") != nullptr;     // measurement aid: when each chunk was modelled / had crossed / was coded, on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    std::vector<double> t_coded(n_chunks, 0.0), t_copied(n_chunks, 0.0);
+    std::mutex trace_mu;
+    (void)hb_recip_table();                                      // (built before the threads ask for it)
+    std::atomic<uint32_t> chunks_ready{0};
+    std::atomic<int> abort_flag{0};
+    std::vector<std::thread> workers;
+    const uint64_t* const h_recs = c->h_recs;
+    HostBlockCoder* const coders = c->hb_coders.data();
+    for (uint32_t w = 0; w < n_thr; w++)
+        workers.emplace_back([&, w] {
+            for (uint64_t b = w; b < nbl; b += n_thr) coders[b].start(small_sizes, n_small);
+            for (uint32_t ch = 0; ch < n_chunks; ch++) {
+                for (uint32_t spin = 0; chunks_ready.load(std::memory_order_acquire) <= ch; spin++) {
+                    if (abort_flag.load()) return;
+                    if (spin < 2000) __builtin_ia32_pause(); else std::this_thread::yield();
+                }
+                for (uint64_t b = w; b < nbl; b += n_thr)
+                    coders[b].code(h_recs + chunk_base[ch] + rec_off[(size_t)ch * nbl + b], rec_cnt[(size_t)ch * nbl + b]);
+                if (trace) { const double t = ms_now(); std::lock_guard<std::mutex> g(trace_mu); t_coded[ch] = std::max(t_coded[ch], t); }
+            }
+            for (uint64_t b = w; b < nbl; b += n_thr) coders[b].flush();
+        });
+    struct Join { std::vector<std::thread>& t; std::atomic<int>& a; bool ok = false; ~Join() { if (!ok) a.store(1); for (auto& x : t) if (x.joinable()) x.join(); } } join{workers, abort_flag};
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        if (ch >= 2) HIPCHK(c, hipStreamWaitEvent(s, c->hb_ev[2 * (ch - 2) + 1], 0));            // the buffer's previous chunk has left it
+        launch_rc_records(s, d_syms, d_blk_begin, nbl, (uint32_t)(ch * Tc), (uint32_t)((ch + 1) * Tc), c->hb_recs[ch & 1].as<uint64_t>(),
+                          c->hb_recoff.as<uint64_t>() + (size_t)ch * nbl, c->hb_state.as<uint32_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>(), small_sizes);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->hb_ev[2 * ch], s));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->hb_ev[2 * ch], 0));
+        const uint64_t bytes = (chunk_base[ch + 1] - chunk_base[ch]) * 8;
+        if (bytes) HIPCHK(c, hipMemcpyAsync(c->h_recs + chunk_base[ch], c->hb_recs[ch & 1].p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->hb_ev[2 * ch + 1], c->copy_stream));
+    }
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        HIPCHK(c, hipEventSynchronize(c->hb_ev[2 * ch + 1]));
+        if (ch == 0) {                                           // (the modelers' one refusal comes with the first chunk)
+            int errflag = 0;
+            HIPCHK(c, hipMemcpy(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost));
+            if (errflag) return fail(c, LEON_E_OVERFLOW, "a block has more symbols than the host chains' records can count");
+        }
+        chunks_ready.store(ch + 1, std::memory_order_release);
+        t_copied[ch] = ms_now();
+    }
+    for (auto& t : workers) t.join();
+    join.ok = true;
+    if (trace) {
+        fprintf(stderr, "[leon rc host] %llu blocks, %llu symbols, %u chunks, %u threads:", (unsigned long long)nbl, (unsigned long long)n_syms, n_chunks, n_thr);
+        for (uint32_t ch = 0; ch < n_chunks; ch++) fprintf(stderr, " chunk %u in host memory at %.1f ms, coded at %.1f;", ch, t_copied[ch], t_coded[ch]);
+        fprintf(stderr, " done at %.1f ms\n", ms_now());
+    }
+    return LEON_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int leon_dna_abi_version(void) { return LEON_DNA_ABI_VERSION; }
@@ -337,7 +478,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
                        &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
                        &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
                        &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->fbits, &c->pbits, &c->hdr_first, &c->dc_cache, &c->dc_out, &c->dc_pay, &c->dc_len, &c->dc_pool, &c->dc_scr,
-                       &c->xch_slot, &c->xch_off, &c->xch_evoff, &c->xch_events, &c->xch_send, &c->xch_split, &c->round_hist };
+                       &c->xch_slot, &c->xch_off, &c->xch_evoff, &c->xch_events, &c->xch_send, &c->xch_split, &c->round_hist, &c->resolve_trace, &c->hb_recs[0], &c->hb_recs[1], &c->hb_recoff, &c->hb_state };
     for (DevBuf* b : bufs) b->release();
     if (c->d_bloom) (void)hipFree(c->d_bloom);
     if (c->d_rv16) (void)hipFree(c->d_rv16);
@@ -345,6 +486,9 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
     if (c->h_payload) (void)hipHostFree(c->h_payload);
     if (c->h_rb) (void)hipHostFree(c->h_rb);
     for (auto& b : c->h_anchor) if (b) (void)hipHostFree(b);
+    if (c->h_recs) (void)hipHostFree(c->h_recs);
+    for (auto& e : c->hb_ev) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pack_ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -608,6 +752,10 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         c->anchor_worker->push(std::move(fresh));
         pending.buf = -1;
     };
+    // LEON_TRACE_RESOLVE=1 (measurement aid): what a read costs k_lookup_cand by its outcome, on stderr at the end of the stage
+    static const bool trace_resolve = getenv("LEON_TRACE_RESOLVE") != nullptr;
+    unsigned long long* d_trace = nullptr;
+    if (trace_resolve) { HIPCHK(c, c->resolve_trace.ensure(12 * 8)); d_trace = c->resolve_trace.as<unsigned long long>(); HIPCHK(c, hipMemsetAsync(d_trace, 0, 12 * 8, s)); }
     int anchor_buf = 0;
     uint32_t hint = (uint32_t)std::min<uint64_t>(W, 1u << 20);      // grid-size hint of a window's first round (any size is correct: grid-stride loops)
     for (uint64_t w0 = 0, w1 = 0; w0 < n; w0 = w1) {
@@ -616,7 +764,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         HIPCHK(c, hipMemsetAsync(counters, 0, 8, s));
         HIPCHK(c, hipMemsetAsync(c->wbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
         HIPCHK(c, hipMemsetAsync(c->pbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
-        launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters);
+        launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters, d_trace);
         HIPCHK(c, hipMemcpyAsync(d_hist, counters, 4, hipMemcpyDeviceToDevice, s));         // hist[0]: the window's unresolved reads
         int cur = 0;
         uint32_t n_hist = 1, cnt = 0, cnt0 = 0;
@@ -690,6 +838,14 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         c->stats.resolve_windows++;
     }
     if (pending.buf >= 0) { HIPCHK(c, spin_sync(s)); hand_over(); }
+    if (trace_resolve) {
+        unsigned long long t[12];
+        HIPCHK(c, hipMemcpy(t, d_trace, sizeof t, hipMemcpyDeviceToHost));
+        const char* cls[3] = {"found an anchor of the dictionary", "went on to propose its own", "no anchor at all"};
+        for (int j = 0; j < 3; j++)
+            if (t[4 * j]) fprintf(stderr, "[leon resolve] k_lookup_cand, reads that %-34s: %10llu reads, per read %.1f filter probes, %.1f dictionary probes behind a filter maybe, %.1f k-mers through the bloom\n",
+                                  cls[j], t[4 * j], (double)t[4 * j + 1] / t[4 * j], (double)t[4 * j + 2] / t[4 * j], (double)t[4 * j + 3] / t[4 * j]);
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     mark("resolution launched to its end");
@@ -889,6 +1045,18 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipEventRecord(c->ev[6], s));
 
     // ---- range coder ----
+    const bool host_chains = rc_on_host(nbl, n_syms, max_block_syms);
+    std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
+    uint64_t payload_bytes = 0;
+    if (host_chains) {
+        // a small launch: the chains run on host cores, from the modelers' records (host_blocks.h)
+        if (int rc = rc_blocks_on_host(c, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, n_syms, SMALL_SIZES_DNA, N_SMALL_MODELS)) return rc;
+        HIPCHK(c, hipEventRecord(c->ev[7], s));
+        for (uint64_t b = 0; b < nbl; b++) { sizes[b] = c->hb_coders[b].size(); dst[b + 1] = dst[b] + sizes[b]; }
+        payload_bytes = dst[nbl];
+        HIPCHK(c, hipEventRecord(c->ev[8], s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    } else {
     const uint64_t rc_cap = 3 * n_syms + 72 * (nbl + 1);
     HIPCHK(c, c->rc_out.ensure(rc_cap));
     HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
@@ -899,7 +1067,6 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipEventRecord(c->ev[7], s));
 
     // ---- gather + D2H ----
-    std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
     int errflag = 0;
     HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, nbl * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost, s));
@@ -907,7 +1074,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     if (errflag) return fail(c, LEON_E_OVERFLOW, errflag == 2 ? "a read block has 2^32 symbols or more"
                                                               : "range coder output exceeded its 3 bytes/symbol bound");
     for (uint64_t b = 0; b < nbl; b++) dst[b + 1] = dst[b] + sizes[b];
-    const uint64_t payload_bytes = dst[nbl];
+    payload_bytes = dst[nbl];
     HIPCHK(c, c->payload.ensure(payload_bytes + 16));
     HIPCHK(c, hipMemcpyAsync(c->dst_off.p, dst.data(), (nbl + 1) * 8, hipMemcpyHostToDevice, s));
     launch_gather_payload(s, c->rc_out.as<uint8_t>(), c->out_off.as<uint64_t>(), c->dst_off.as<uint64_t>(), c->out_size.as<uint64_t>(),
@@ -922,6 +1089,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipMemcpyAsync(c->h_payload, c->payload.p, payload_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(c->ev[8], s));
     HIPCHK(c, hipStreamSynchronize(s));
+    }
 
     // ---- stats ----
     c->stats.n_symbols = n_syms; c->stats.payload_bytes = payload_bytes;
@@ -934,7 +1102,8 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     const uint8_t* hp = (const uint8_t*)c->h_payload;
     for (uint64_t b = 0; b < nbl; b++) {
         uint32_t nr = (uint32_t)std::min<uint64_t>(rpb, n - (lb0 + b) * rpb);
-        if (sink(user, c->next_block + lb0 + b, hp + dst[b], sizes[b], nr)) return fail(c, LEON_E_SINK, "block sink returned non-zero");
+        const uint8_t* pay = host_chains ? c->hb_coders[b].data() : hp + dst[b];
+        if (sink(user, c->next_block + lb0 + b, pay, sizes[b], nr)) return fail(c, LEON_E_SINK, "block sink returned non-zero");
     }
     c->next_read += n;
     c->next_block += n_blocks;
@@ -1110,13 +1279,18 @@ static int header_batch_impl(leon_dna_ctx* c, const uint8_t* d_hdr, const uint64
         HIPCHK(c, c->blk_begin.ensure((nbl + 1) * 8)); HIPCHK(c, c->out_off.ensure((nbl + 1) * 8));
         HIPCHK(c, c->out_size.ensure(nbl * 8)); HIPCHK(c, c->dst_off.ensure((nbl + 1) * 8));
         launch_block_ranges(s, c->sym_off.as<uint64_t>(), nl, rpb, nbl, c->blk_begin.as<uint64_t>(), c->out_off.as<uint64_t>());
+        const bool host_chains = rc_on_host(nbl, n_syms, max_block_syms);
+        std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
+        if (host_chains) {                                       // a small launch: the blocks' chains on host cores (host_blocks.h)
+            if (int rc = rc_blocks_on_host(c, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, n_syms, SMALL_SIZES_HEADER, N_SMALL_MODELS)) return rc;
+            for (uint64_t b = 0; b < nbl; b++) { sizes[b] = c->hb_coders[b].size(); dst[b + 1] = dst[b] + sizes[b]; }
+        } else {
         HIPCHK(c, c->rc_out.ensure(3 * n_syms + 72 * (nbl + 1)));
         HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
         HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
         launch_rc_encode(s, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, c->rc_out.as<uint8_t>(), c->out_off.as<uint64_t>(),
                          c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>(), max_block_syms, SMALL_SIZES_HEADER);
         HIPCHK(c, hipGetLastError());
-        std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
         int errflag = 0;
         HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, nbl * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost, s));
@@ -1138,10 +1312,11 @@ static int header_batch_impl(leon_dna_ctx* c, const uint8_t* d_hdr, const uint64
         }
         HIPCHK(c, hipMemcpyAsync(c->h_payload, c->payload.p, payload_bytes, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        }
         const uint8_t* hp = (const uint8_t*)c->h_payload;
         for (uint64_t b = 0; b < nbl; b++) {
             const uint32_t nr = (uint32_t)std::min<uint64_t>(rpb, n - (lb0 + b) * rpb);
-            if (sink(user, c->hdr_next_block + lb0 + b, hp + dst[b], sizes[b], nr)) {
+            if (sink(user, c->hdr_next_block + lb0 + b, host_chains ? c->hb_coders[b].data() : hp + dst[b], sizes[b], nr)) {
                 c->poisoned = true;                             // the caller holds part of the batch's blocks
                 return fail(c, LEON_E_SINK, "block sink returned non-zero (stream poisoned: leon_dna_reset_stream to go on)");
             }
@@ -1652,6 +1827,19 @@ int leon_rc_encode_streams(leon_dna_ctx* c, const uint8_t* syms, const uint64_t*
     HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
     uint64_t longest = 0;
     for (uint64_t b = 0; b < n_streams; b++) longest = std::max(longest, begin[b + 1] - begin[b]);
+    // (test hook, LEON_RC_STREAMS_ON_HOST=1: the same streams through the host chains fed by the device's modelers -- host_blocks.h --
+    // so that the tests hold the two coders against each other and against the oracle on the same symbols)
+    if (const char* e = getenv("LEON_RC_STREAMS_ON_HOST")) if (e[0] == '1' && longest + 1024 < (1ull << HB_COUNT_BITS)) {
+        if (int rc = rc_blocks_on_host(c, dsyms.as<uint8_t>(), dbegin.as<uint64_t>(), n_streams, n_syms, SMALL_SIZES_DNA, N_SMALL_MODELS)) return rc;
+        uint64_t w = 0;
+        for (uint64_t b = 0; b < n_streams; b++) {
+            sizes[b] = c->hb_coders[b].size();
+            if (w + sizes[b] > out_cap) return fail(c, LEON_E_OVERFLOW, "out_cap too small");
+            memcpy(out + w, c->hb_coders[b].data(), sizes[b]);
+            w += sizes[b];
+        }
+        return LEON_OK;
+    }
     launch_rc_encode(s, dsyms.as<uint8_t>(), dbegin.as<uint64_t>(), n_streams, dout.as<uint8_t>(), doff.as<uint64_t>(),
                      dsize.as<uint64_t>(), dscr.as<uint32_t>(), c->errflag.as<int>(), longest);
     HIPCHK(c, hipGetLastError());

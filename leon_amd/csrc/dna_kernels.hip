@@ -303,10 +303,13 @@ template <> __device__ inline u128 canon_from_words16<u128>(uint32_t words, uint
 // else the candidate Leon::findAndInsertAnchor would insert.  Four reads per wave, 16 k-mer positions per read and
 // step: the first anchor sits ~20 positions into a read, so quarter-waves look up ~1.7x fewer k-mers than whole
 // waves would, and a wave keeps four independent reads' memory requests in flight.
-template <typename K>
+// TRACE (LEON_TRACE_RESOLVE=1, a measurement aid): what a read costs by its outcome -- per class (found an anchor / goes on to insert / no
+// anchor at all) the reads, their filter probes, the dictionary probes behind a filter "maybe" and their bloom probes (k-mers
+// tested), summed per wave and added to trace[12] once per wave.
+template <typename K, bool TRACE>
 __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, const uint16_t* rv16g, DictDev D, ResolveDev V,
                                                     uint64_t w0, uint64_t w1, uint64_t first_global,
-                                                    uint32_t* ulist, uint32_t* ucount) {
+                                                    uint32_t* ulist, uint32_t* ucount, unsigned long long* trace) {
     __shared__ uint16_t rv16[256];
     load_rv16(rv16, rv16g);
     const uint32_t lane = lane_id(), k = R.k;
@@ -333,6 +336,9 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
     // with the current one: the kernel is bound by the number of wave-wide memory instructions (a read that inserts an anchor
     // needs ~40, one that finds an anchor ~10; with four reads in lockstep the wave paid for the slowest), so the other three
     // quarters must not idle while one read goes through all of its k-mers and the bloom scan.
+    uint32_t t_filter = 0, t_dict = 0, t_bloom = 0;               // (TRACE) this quarter-wave's current read: probes so far, counted on lane l == 0
+    unsigned long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto trace_done = [&](uint32_t cls) { if (TRACE && l == 0) { tr[cls * 4] += 1; tr[cls * 4 + 1] += t_filter; tr[cls * 4 + 2] += t_dict; tr[cls * 4 + 3] += t_bloom; } t_filter = t_dict = t_bloom = 0; };
     uint64_t i = w0 + 4 * wave + grp;
     bool have = false, started = false, exhausted = false;
     uint32_t len = 0, nk = 0, iMin = 0, iMax = 0, phase = PH_DONE, base = 0, limit = 0;
@@ -352,7 +358,7 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
                 // Leon::findAndInsertAnchor scan order: [n/2, n/2+10), [0, n/2), [n/2+10, n)
                 iMin = nk / 2; iMax = nk / 2 + 10 > nk ? nk : nk / 2 + 10;
                 base = 0; limit = nk;
-                if (nk) phase = PH_LOOKUP; else if (l == 0) V.status[i] = ST_NOANCHOR;      // (stays PH_DONE: the next round takes another read)
+                if (nk) phase = PH_LOOKUP; else { if (l == 0) V.status[i] = ST_NOANCHOR; trace_done(2); }      // (stays PH_DONE: the next round takes another read)
             }
         }
         if (!__any(have)) break;                                  // every quarter-wave has run out of reads
@@ -363,7 +369,7 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
                 if (phase == PH_LOOKUP) { phase = PH_SEG_A; base = iMin; limit = iMax; }
                 else if (phase == PH_SEG_A) { phase = PH_SEG_B; base = 0; limit = iMin; }
                 else if (phase == PH_SEG_B) { phase = PH_SEG_C; base = iMax; limit = nk; }
-                else { phase = PH_DONE; if (l == 0) V.status[i] = ST_NOANCHOR; }
+                else { phase = PH_DONE; if (l == 0) V.status[i] = ST_NOANCHOR; trace_done(2); }
             }
             const bool run = phase != PH_DONE && base < limit;
             const uint32_t p = base + l;
@@ -376,9 +382,14 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
                     // ~95 % of the look-ups miss (one k-mer in ~35 is an anchor): a 2 MiB bit filter of the final keys, resident
                     // in L2, answers most of them without a random sector from HBM
                     const uint32_t fb = final_bit(D, cn);
-                    if ((D.fbits[fb >> 5] >> (fb & 31)) & 1u) { uint64_t fin = IDX_INF; slot = dict_find(D, cn, fin); hit = slot != 0xFFFFFFFFu && fin < g; }
+                    const bool maybe = (D.fbits[fb >> 5] >> (fb & 31)) & 1u;
+                    if (maybe) { uint64_t fin = IDX_INF; slot = dict_find(D, cn, fin); hit = slot != 0xFFFFFFFFu && fin < g; }
+                    if (TRACE) {
+                        const uint32_t nf = (uint32_t)__popcll(__ballot(true) >> gbase & 0xFFFFull), nd = (uint32_t)__popcll(__ballot(maybe) >> gbase & 0xFFFFull);
+                        t_filter += nf; t_dict += nd;
+                    }
                 }
-                else hit = bloom_contains<K>(B, rv16, cn);
+                else { hit = bloom_contains<K>(B, rv16, cn); if (TRACE) t_bloom += (uint32_t)__popcll(__ballot(true) >> gbase & 0xFFFFull); }
             }
             const unsigned long long bal = __ballot(hit);
             const uint32_t gb = (uint32_t)(bal >> gbase) & 0xFFFFu;
@@ -387,8 +398,8 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
                 if (gb) {
                     const uint32_t f = (uint32_t)__builtin_ctz(gb);
                     const uint32_t hs = __shfl(slot, (int)(gbase + f));
-                    if (phase == PH_LOOKUP) { if (l == 0) { V.status[i] = ST_HIT; V.hit_pos[i] = base + f; V.hit_slot[i] = hs; } }
-                    else { want_insert = (l == 0); cpos = base + f; }
+                    if (phase == PH_LOOKUP) { if (l == 0) { V.status[i] = ST_HIT; V.hit_pos[i] = base + f; V.hit_slot[i] = hs; } trace_done(0); }
+                    else { want_insert = (l == 0); cpos = base + f; trace_done(1); }
                     phase = PH_DONE;
                 } else base += 16;
             }
@@ -419,14 +430,23 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
         }
     }
     flush_list();
+    if (TRACE) {
+        for (uint32_t j = 0; j < 12; j++) {
+            unsigned long long v = tr[j];
+            for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+            if (lane == 0 && v) atomicAdd(trace + j, v);
+        }
+    }
 }
 void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
-                        uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount) {
+                        uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount, unsigned long long* trace) {
     if (w1 <= w0) return;
+    if (trace) { DISPATCH_K(R.k, hipLaunchKernelGGL((k_lookup_cand<K, true>), dim3(grid_for(w1 - w0, 16, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
+                                                    first_global, ulist, ucount, trace)); return; }
     // 4 reads per wave, 64 waves launched per CU (32 resident).  Measured and no better (resolve stage, 100 M reads): 32 waves per
     // CU in a grid-stride loop 312 ms, 128 per CU 287, workgroups of 64 or 128 threads 310-330, against 290 for this geometry.
-    DISPATCH_K(R.k, hipLaunchKernelGGL(k_lookup_cand<K>, dim3(grid_for(w1 - w0, 16, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
-                                       first_global, ulist, ucount));
+    DISPATCH_K(R.k, hipLaunchKernelGGL((k_lookup_cand<K, false>), dim3(grid_for(w1 - w0, 16, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
+                                       first_global, ulist, ucount, trace));
 }
 
 // One resolution round over the unresolved reads: a read becomes a non-inserter as soon as one of its

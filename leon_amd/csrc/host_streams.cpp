@@ -40,6 +40,9 @@ uint32_t usable_cpus() {
     if (quota > 0 && period > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (quota + period - 1) / period));
     return n;
 }
+}  // namespace
+namespace leon { uint32_t usable_cpus() { return ::usable_cpus(); } }       // (capi.hip sizes its host-chain pool by it)
+namespace {
 
 template <typename F> void parallel_blocks(uint64_t n_blocks, uint32_t n_threads, F&& f) {
     if (n_threads == 0) n_threads = usable_cpus();

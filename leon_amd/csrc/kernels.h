@@ -69,7 +69,8 @@ void launch_pack(hipStream_t s, const uint8_t* bases, const uint64_t* base_off, 
 void launch_dict_init(hipStream_t s, DictDev D, uint64_t cap, uint32_t W);
 void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to, uint32_t k);
 void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
-                        uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount);
+                        uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount,
+                        unsigned long long* trace = nullptr /* 12 counters, zeroed by the caller: the traced instantiation (LEON_TRACE_RESOLVE) */);
 void launch_check(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global,
                   const uint32_t* ulist, const uint32_t* ucount, uint32_t max_count, uint32_t* next_list, uint32_t* next_count);
 void launch_reset_tent(hipStream_t s, DictDev D, ResolveDev V, const uint32_t* list, const uint32_t* count, uint32_t max_count);
@@ -110,6 +111,11 @@ void launch_max_block_syms(hipStream_t s, const uint64_t* sym_off /*offsets, n_r
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                       uint8_t* out, const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err,
                       uint64_t max_block_syms, uint32_t small_sizes = SMALL_SIZES_DNA);
+// the modelers alone, tiles [tile0, tile1) of every block: a 64-bit record per symbol (cumLow | freq << 22 | model << 44) at
+// recs + rec_off[block] (the launch's tiles of the block, in stream order); `state` carries a block's models from one launch to the next
+size_t rc_records_state_bytes(uint64_t n_blocks);
+void launch_rc_records(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint32_t tile0, uint32_t tile1, uint64_t* recs,
+                       const uint64_t* rec_off, uint32_t* state, uint32_t* model_scratch, int* err, uint32_t small_sizes);
 // ---- header stream (HeaderEncoder): records of every header against the previous one ----
 void launch_hdr_symbols(hipStream_t s, const uint8_t* hdr, const uint64_t* off, uint64_t n, uint32_t rpb, const uint8_t* first,
                         uint32_t first_len, uint64_t* sym_off /*count or offsets*/, uint8_t* syms /*nullptr = count pass*/);

@@ -23,6 +23,212 @@ size_t rc_model_scratch_bytes(uint64_t n_blocks) {
 // vector instruction; the other waves are the modelers.
 __host__ __device__ constexpr uint32_t rc_waves(uint32_t g) { return g + 1 + (g - 1) / 3; }
 
+// The modeler of ONE block, run by one wave (lane = symbol of the current tile of 64): the adaptive order-0 models of the block in
+// LDS (two-level cumulative counts, rc_model.h; numeric models beyond the LDS slots in a global overflow area), and per tile every
+// symbol's (cumLow, cumLow + freq, total) = the counts at the tile start + the earlier symbols of the tile, then
+// Order0Model::update for the whole tile.  Used by the block coder below (records into an LDS ring for the coder wave) and by
+// k_rc_records (records into global memory for host chains).
+template <uint32_t RC_NSLOT>
+struct RcModeler {
+    uint32_t* models; uint8_t* slotmap; uint32_t* gmodels; const uint16_t* sym16;
+    uint64_t s0, s1;
+    uint32_t nused, raw_next, small_sizes;
+    // per-lane constants of the branch-free Order0Model::update of the overflow area: lanes 0..15 own Lw of the symbol's 16-block,
+    // lanes 16..32 own H[0..16]
+    bool is_lw; uint32_t upd_lane, upd_base, upd_blkmask;
+
+    __device__ inline void init(uint32_t* models_, uint8_t* slotmap_, const uint16_t* sym16_, uint32_t small_sizes_, uint32_t lane) {
+        models = models_; slotmap = slotmap_; sym16 = sym16_; small_sizes = small_sizes_;
+        is_lw = lane < 16;
+        upd_lane = is_lw ? lane : (lane < 33 ? lane - 16 : 0);
+        upd_base = is_lw ? RC_LW + lane : upd_lane;
+        upd_blkmask = is_lw ? ~0u : 0u;
+        nused = 0; raw_next = 0xFFFFu; s0 = s1 = 0; gmodels = nullptr;
+    }
+    // AbstractDnaCoder::startBlock: the block's symbols are [s0_, s1_); the next tile's symbols are fetched one tile ahead
+    // (a global load costs ~2000 cycles)
+    __device__ inline void start_block(uint64_t s0_, uint64_t s1_, uint32_t* gmodels_, uint32_t lane) {
+        s0 = s0_; s1 = s1_; gmodels = gmodels_; nused = 0;
+        raw_next = lane < (uint32_t)((s1 - s0) < 64 ? (s1 - s0) : 64) ? sym16[s0 + lane] : 0xFFFFu;
+        for (uint32_t m = 0; m < N_SMALL_MODELS; m++) model_init(&models[m * RC_SSTRIDE], lane, true);
+        for (uint32_t i = lane; i < RC_NNUM; i += 64) slotmap[i] = 255;
+    }
+    // tile t of the block: this lane's record (lanes past the block's end: cumLow 0, freq = total = 1, which leaves a chain as it is)
+    __device__ inline void tile(uint32_t t, uint32_t lane, uint32_t& lo, uint32_t& hi, uint32_t& tot) {
+        const uint64_t base = s0 + (uint64_t)t * 64;
+        const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
+        const bool act = lane < cnt;
+        const uint32_t raw = raw_next;
+        {
+            const uint64_t nb = base + 64;
+            raw_next = (nb < s1 && lane < (uint32_t)((s1 - nb) < 64 ? (s1 - nb) : 64)) ? sym16[nb + lane] : 0xFFFFu;
+        }
+        const uint32_t m = raw & 0xff, c = raw >> 8;
+        const uint32_t key = (m << 8) | c;
+        const bool numeric = act && m >= N_SMALL_MODELS;
+        // slots for numeric models first seen in this tile
+        uint32_t slot = numeric ? slotmap[m - N_SMALL_MODELS] : 0;
+        unsigned long long need = __ballot(numeric && slot == 255);
+        while (need) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(need);
+            const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)l);
+            const uint32_t ns = nused++;
+            if (lane == 0) slotmap[mm - N_SMALL_MODELS] = (uint8_t)ns;
+            if (ns < RC_NSLOT) model_init(&models[RC_SMALL_WORDS + ns * RC_STRIDE], lane, false);
+            else { model_init(gmodels + (uint64_t)(ns - RC_NSLOT) * RC_STRIDE, lane, false); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (numeric && m == mm) slot = ns;
+            need &= ~__ballot(numeric && m == mm);
+        }
+        // word offset of this lane's model (RC_GLOBAL | offset for the overflow area)
+        uint32_t mb = 0;
+        if (act) mb = !numeric ? m * RC_SSTRIDE
+                               : (slot < RC_NSLOT ? RC_SMALL_WORDS + slot * RC_STRIDE : (RC_GLOBAL | ((slot - RC_NSLOT) * RC_STRIDE)));
+        const uint32_t tot_idx = numeric ? 16u : RC_LW + small_size_of(small_sizes, m);
+        __builtin_amdgcn_wave_barrier();
+        // counts at the tile start
+        lo = 0; hi = 1; tot = 1;
+        if (act) {
+            if (!(mb & RC_GLOBAL)) {
+                const uint32_t* s = &models[mb];
+                lo = s[c >> 4] + s[RC_LW + c]; hi = s[(c + 1) >> 4] + s[RC_LW + c + 1]; tot = s[tot_idx];
+            } else {
+                const uint32_t* s = gmodels + (mb & ~RC_GLOBAL);
+                lo = s[c >> 4] + s[RC_LW + c]; hi = s[(c + 1) >> 4] + s[RC_LW + c + 1]; tot = s[tot_idx];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // earlier symbols of the tile: lo += #(same model, smaller symbol), hi += #(same model, symbol <= mine),
+        // tot += #(same model) over the lanes before this one -- 64 steps of a broadcast and three
+        // compare/add-with-carry pairs; the lane mask "after lane i" is exec itself, shifted once per step
+        // (one asm block, exec restored inside it)
+        {
+            const uint32_t lowkey = m << 8;
+            uint32_t sk0, sk1, dd;
+            uint64_t m1, m2, sav;
+            asm volatile(
+                "s_mov_b64 %[sav], exec\n\t"
+                "v_readlane_b32 %[sk0], %[key], 0\n\t"
+                "s_mov_b64 exec, -2\n\t"
+                "s_nop 1\n\t"
+                ".set rc_i, 0\n\t"
+                ".rept 32\n\t"
+                "v_sub_u32 %[dd], %[sk0], %[lowkey]\n\t"
+                "v_readlane_b32 %[sk1], %[key], rc_i + 1\n\t"
+                "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
+                "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
+                "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
+                "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
+                "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
+                "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
+                "s_lshl_b64 exec, exec, 1\n\t"
+                "v_sub_u32 %[dd], %[sk1], %[lowkey]\n\t"
+                "v_readlane_b32 %[sk0], %[key], (rc_i + 2) & 63\n\t"
+                "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
+                "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
+                "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
+                "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
+                "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
+                "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
+                "s_lshl_b64 exec, exec, 1\n\t"
+                ".set rc_i, rc_i + 2\n\t"
+                ".endr\n\t"
+                "s_mov_b64 exec, %[sav]\n\t"
+                : [lo] "+v"(lo), [hi] "+v"(hi), [tot] "+v"(tot), [sk0] "=&s"(sk0), [sk1] "=&s"(sk1), [dd] "=&v"(dd),
+                  [m1] "=&s"(m1), [m2] "=&s"(m2), [sav] "=&s"(sav)
+                : [key] "v"(key), [lowkey] "v"(lowkey), [c] "v"(c), [k256] "s"(256u)
+                : "vcc");
+            if (!act) { lo = 0; hi = 1; tot = 1; }         // past the block's end: a record that leaves the chain as it is
+        }
+        // Order0Model::update for the whole tile, lane = symbol: F(x) += 1 for x > c, i.e. H[k] for k > c >> 4
+        // and Lw[x] for the x after c inside c's 16-block (adds of 0 where it does not apply: no exec juggling)
+        {
+            // (only the lanes an add applies to take part: same-address adds serialise in the LDS, and with 8
+            // modelers per CU its atomic unit is the busiest part of the kernel.  A small model's total is
+            // read from Lw[size], so its H[] is never touched)
+            const bool in_lds = act && !(mb & RC_GLOBAL);
+            uint32_t* mp = &models[in_lds ? mb : 0];
+            const uint32_t h4 = (in_lds && numeric) ? c >> 4 : 64u;
+            const uint32_t l4 = in_lds ? c & 15u : 64u, ymax = numeric ? 15u : small_size_of(small_sizes, m);
+            uint32_t* lp = mp + RC_LW + (in_lds ? (c & ~15u) : 0u);
+#pragma unroll
+            for (uint32_t k = 1; k <= 16; k++)
+                if (k > h4) (void)__hip_atomic_fetch_add(&mp[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+            for (uint32_t y = 1; y <= 15; y++)
+                if (y > l4 && y <= ymax) (void)__hip_atomic_fetch_add(&lp[y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            // symbols of models that live in the global overflow area: one at a time, lanes 0..32 own the entries
+            unsigned long long gl = __ballot(act && (mb & RC_GLOBAL));
+            while (gl) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(gl);
+                gl &= gl - 1;
+                const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)i);
+                const uint32_t mbi = (uint32_t)__builtin_amdgcn_readlane((int)mb, (int)i);
+                const uint32_t thr = is_lw ? (ci & 15u) : (ci >> 4);
+                const uint32_t idx = upd_base + ((ci & ~15u) & upd_blkmask);
+                if (upd_lane > thr)
+                    (void)__hip_atomic_fetch_add(gmodels + (mbi & ~RC_GLOBAL) + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+// The coder's 64 steps of one tile, lane = block: RangeEncoder::encode for every record of the tile.  EXACT: the quotient by a
+// 64-bit division (totals of 2^30 and more); else a truncated multiply-high by the total's reciprocal with a 32-bit fix-up.
+template <bool EXACT>
+__device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint64_t& low, uint64_t& range, uint32_t& nout, uint8_t* dst, uint32_t cap4) {
+    uint4 pa = ra[0];
+    uint2 pb = rb[0];
+#pragma clang loop unroll_count(EXACT ? 1 : 4)
+    for (uint32_t j = 0; j < 64; j++) {
+        const uint32_t s_lo = pa.x, s_fr = pa.y, s_tot = pa.z, s_hc = pa.w, b0 = pb.x, b1 = pb.y;
+        const uint32_t jn = j + 1;                                 // next step's record, fetched under this step
+        pa = ra[jn]; pb = rb[jn];
+        uint64_t q;
+        if (EXACT) q = range / (uint64_t)s_tot;
+        else {
+            // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since total < 2^30), fixed up on the low word
+            const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
+            q = (uint64_t)r1 * b1 + __umulhi(r1, b0);
+            q += __umulhi(r0, b1);
+            const uint32_t rem = r0 - (uint32_t)q * s_tot;          // true remainder < 4 * tot < 2^32
+            const uint32_t t2 = s_tot << 1, t3 = t2 + s_tot;
+            uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
+            asm volatile("" : "+v"(e));                             // (one 64-bit add, not three)
+            q += e;
+        }
+        const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
+        // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq)
+        uint64_t top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
+        low = (uint64_t)q0 * s_lo + low;            low += (uint64_t)(q1 * s_lo) << 32;
+        range = (uint64_t)q0 * s_fr;                range += (uint64_t)(q1 * s_fr) << 32;
+        // RangeEncoder::encode's while loop.  Usual case: low and low + range agree on their top 0..2
+        // bytes and the shifted range stays >= BOTTOM: those bytes leave at once -- one unaligned 4-byte
+        // store at the cursor (what lies past the cursor is overwritten by the stores that follow)
+        const uint32_t lh = (uint32_t)(low >> 32);
+        const uint32_t xh = lh ^ (uint32_t)(top >> 32);
+        const uint32_t sh = (uint32_t)__builtin_clz(xh | 1u) & 24u;
+        const uint64_t range_s = range << sh;
+        const bool rare = xh < 256u || (uint32_t)(range_s >> 32) < (1u << 16);
+        *(uint32_t*)(dst + (nout < cap4 ? nout : cap4)) = __builtin_bswap32(lh);
+        uint64_t low_n = low << sh, range_n = range_s;
+        uint32_t nout_n = nout + (sh >> 3);
+        if (__builtin_expect(rare, 0)) {
+            low_n = low; range_n = range; nout_n = nout;
+            while ((low_n ^ (low_n + range_n)) < (1ull << 56) ||
+                   (range_n < RC_BOTTOM && ((range_n = (0 - low_n) & (RC_BOTTOM - 1)), true))) {
+                dst[nout_n < cap4 ? nout_n : cap4] = (uint8_t)(low_n >> 56);
+                nout_n++;
+                range_n <<= 8;
+                low_n <<= 8;
+            }
+        }
+        low = low_n; range = range_n; nout = nout_n;
+    }
+}
+
 // One workgroup codes G blocks: G modeler waves, and one coder wave that runs the G serial chains
 // in its lanes 0..G-1 (lane = block).  A chain step costs the same issue slots whether one lane or eight are active, so
 // a CU that holds 8 blocks runs ONE chain instruction stream instead of eight; the step itself is branch-free in the
@@ -46,15 +252,8 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool is_coder = wave == 0, is_idle = wave != 0 && (wave & 3u) == 0;
     const uint32_t mi = is_coder || is_idle ? 0 : wave - 1 - (wave >> 2);     // the modeler's block inside the group
-    // per-lane constants of the branch-free Order0Model::update: lanes 0..15 own Lw of the symbol's 16-block,
-    // lanes 16..32 own H[0..16]
-    const bool is_lw = lane < 16;
-    const uint32_t upd_lane = is_lw ? lane : (lane < 33 ? lane - 16 : 0);
-    const uint32_t upd_base = is_lw ? RC_LW + lane : upd_lane;
-    const uint32_t upd_blkmask = is_lw ? ~0u : 0u;
-    uint32_t* models = models_all + mi * MW;
-    uint8_t* slotmap = slotmap_all[mi];
-    const uint16_t* sym16 = (const uint16_t*)syms;
+    RcModeler<RC_NSLOT> M;
+    M.init(models_all + mi * MW, slotmap_all[mi], (const uint16_t*)syms, small_sizes, lane);
 
     const uint64_t n_groups = (n_blocks + G - 1) / G;
     for (uint64_t bg = blockIdx.x; bg < n_groups; bg += gridDim.x) {
@@ -80,15 +279,8 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
             dst = out + out_off[b]; cap = out_off[b + 1] - out_off[b];
             cap4 = (uint32_t)(cap < 0xFFFFFFFFull ? cap : 0xFFFFFFFFull) - 4;
         }
-        // modeler state; the next tile's symbols are fetched one tile ahead (a global load costs ~2000 cycles)
-        uint32_t nused = 0;
-        uint32_t* gmodels = scratch + (valid ? b : 0) * (uint64_t)(RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE;
-        uint32_t raw_next = 0xFFFFu;
-        if (!is_coder && valid) {                                // AbstractDnaCoder::startBlock
-            raw_next = lane < (uint32_t)((s1 - s0) < 64 ? (s1 - s0) : 64) ? sym16[s0 + lane] : 0xFFFFu;
-            for (uint32_t m = 0; m < N_SMALL_MODELS; m++) model_init(&models[m * RC_SSTRIDE], lane, true);
-            for (uint32_t i = lane; i < RC_NNUM; i += 64) slotmap[i] = 255;
-        }
+        if (!is_coder && !is_idle && valid)                        // AbstractDnaCoder::startBlock
+            M.start_block(s0, s1, scratch + b * (uint64_t)(RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE, lane);
         __syncthreads();
         uint32_t T = 0;
         for (uint32_t w = 0; w < G; w++) T = ntiles_s[w] > T ? ntiles_s[w] : T;
@@ -98,123 +290,8 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
             } else if (!is_coder) {
                 if (t < ntiles) {
                     // =================== modeler: tile t -> ring[mi][t & 1] ===================
-                    const uint64_t base = s0 + (uint64_t)t * 64;
-                    const uint32_t cnt = (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64);
-                    const bool act = lane < cnt;
-                    const uint32_t raw = raw_next;
-                    {
-                        const uint64_t nb = base + 64;
-                        raw_next = (nb < s1 && lane < (uint32_t)((s1 - nb) < 64 ? (s1 - nb) : 64)) ? sym16[nb + lane] : 0xFFFFu;
-                    }
-                    const uint32_t m = raw & 0xff, c = raw >> 8;
-                    const uint32_t key = (m << 8) | c;
-                    const bool numeric = act && m >= N_SMALL_MODELS;
-                    // slots for numeric models first seen in this tile
-                    uint32_t slot = numeric ? slotmap[m - N_SMALL_MODELS] : 0;
-                    unsigned long long need = __ballot(numeric && slot == 255);
-                    while (need) {
-                        const uint32_t l = (uint32_t)__builtin_ctzll(need);
-                        const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)l);
-                        const uint32_t ns = nused++;
-                        if (lane == 0) slotmap[mm - N_SMALL_MODELS] = (uint8_t)ns;
-                        if (ns < RC_NSLOT) model_init(&models[RC_SMALL_WORDS + ns * RC_STRIDE], lane, false);
-                        else { model_init(gmodels + (uint64_t)(ns - RC_NSLOT) * RC_STRIDE, lane, false); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                        if (numeric && m == mm) slot = ns;
-                        need &= ~__ballot(numeric && m == mm);
-                    }
-                    // word offset of this lane's model (RC_GLOBAL | offset for the overflow area)
-                    uint32_t mb = 0;
-                    if (act) mb = !numeric ? m * RC_SSTRIDE
-                                           : (slot < RC_NSLOT ? RC_SMALL_WORDS + slot * RC_STRIDE : (RC_GLOBAL | ((slot - RC_NSLOT) * RC_STRIDE)));
-                    const uint32_t tot_idx = numeric ? 16u : RC_LW + small_size_of(small_sizes, m);
-                    __builtin_amdgcn_wave_barrier();
-                    // counts at the tile start
-                    uint32_t lo = 0, hi = 1, tot = 1;
-                    if (act) {
-                        if (!(mb & RC_GLOBAL)) {
-                            const uint32_t* s = &models[mb];
-                            lo = s[c >> 4] + s[RC_LW + c]; hi = s[(c + 1) >> 4] + s[RC_LW + c + 1]; tot = s[tot_idx];
-                        } else {
-                            const uint32_t* s = gmodels + (mb & ~RC_GLOBAL);
-                            lo = s[c >> 4] + s[RC_LW + c]; hi = s[(c + 1) >> 4] + s[RC_LW + c + 1]; tot = s[tot_idx];
-                        }
-                    }
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                    // earlier symbols of the tile: lo += #(same model, smaller symbol), hi += #(same model, symbol <= mine),
-                    // tot += #(same model) over the lanes before this one -- 64 steps of a broadcast and three
-                    // compare/add-with-carry pairs; the lane mask "after lane i" is exec itself, shifted once per step
-                    // (one asm block, exec restored inside it)
-                    {
-                        const uint32_t lowkey = m << 8;
-                        uint32_t sk0, sk1, dd;
-                        uint64_t m1, m2, sav;
-                        asm volatile(
-                            "s_mov_b64 %[sav], exec\n\t"
-                            "v_readlane_b32 %[sk0], %[key], 0\n\t"
-                            "s_mov_b64 exec, -2\n\t"
-                            "s_nop 1\n\t"
-                            ".set rc_i, 0\n\t"
-                            ".rept 32\n\t"
-                            "v_sub_u32 %[dd], %[sk0], %[lowkey]\n\t"
-                            "v_readlane_b32 %[sk1], %[key], rc_i + 1\n\t"
-                            "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
-                            "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
-                            "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
-                            "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
-                            "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
-                            "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
-                            "s_lshl_b64 exec, exec, 1\n\t"
-                            "v_sub_u32 %[dd], %[sk1], %[lowkey]\n\t"
-                            "v_readlane_b32 %[sk0], %[key], (rc_i + 2) & 63\n\t"
-                            "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
-                            "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
-                            "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
-                            "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
-                            "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
-                            "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
-                            "s_lshl_b64 exec, exec, 1\n\t"
-                            ".set rc_i, rc_i + 2\n\t"
-                            ".endr\n\t"
-                            "s_mov_b64 exec, %[sav]\n\t"
-                            : [lo] "+v"(lo), [hi] "+v"(hi), [tot] "+v"(tot), [sk0] "=&s"(sk0), [sk1] "=&s"(sk1), [dd] "=&v"(dd),
-                              [m1] "=&s"(m1), [m2] "=&s"(m2), [sav] "=&s"(sav)
-                            : [key] "v"(key), [lowkey] "v"(lowkey), [c] "v"(c), [k256] "s"(256u)
-                            : "vcc");
-                        if (!act) { lo = 0; hi = 1; tot = 1; }         // past the block's end: a record that leaves the chain as it is
-                    }
-                    // Order0Model::update for the whole tile, lane = symbol: F(x) += 1 for x > c, i.e. H[k] for k > c >> 4
-                    // and Lw[x] for the x after c inside c's 16-block (adds of 0 where it does not apply: no exec juggling)
-                    {
-                        // (only the lanes an add applies to take part: same-address adds serialise in the LDS, and with 8
-                        // modelers per CU its atomic unit is the busiest part of the kernel.  A small model's total is
-                        // read from Lw[size], so its H[] is never touched)
-                        const bool in_lds = act && !(mb & RC_GLOBAL);
-                        uint32_t* mp = &models[in_lds ? mb : 0];
-                        const uint32_t h4 = (in_lds && numeric) ? c >> 4 : 64u;
-                        const uint32_t l4 = in_lds ? c & 15u : 64u, ymax = numeric ? 15u : small_size_of(small_sizes, m);
-                        uint32_t* lp = mp + RC_LW + (in_lds ? (c & ~15u) : 0u);
-#pragma unroll
-                        for (uint32_t k = 1; k <= 16; k++)
-                            if (k > h4) (void)__hip_atomic_fetch_add(&mp[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#pragma unroll
-                        for (uint32_t y = 1; y <= 15; y++)
-                            if (y > l4 && y <= ymax) (void)__hip_atomic_fetch_add(&lp[y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        // symbols of models that live in the global overflow area: one at a time, lanes 0..32 own the entries
-                        unsigned long long gl = __ballot(act && (mb & RC_GLOBAL));
-                        while (gl) {
-                            const uint32_t i = (uint32_t)__builtin_ctzll(gl);
-                            gl &= gl - 1;
-                            const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)i);
-                            const uint32_t mbi = (uint32_t)__builtin_amdgcn_readlane((int)mb, (int)i);
-                            const uint32_t thr = is_lw ? (ci & 15u) : (ci >> 4);
-                            const uint32_t idx = upd_base + ((ci & ~15u) & upd_blkmask);
-                            if (upd_lane > thr)
-                                (void)__hip_atomic_fetch_add(gmodels + (mbi & ~RC_GLOBAL) + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                    uint32_t lo, hi, tot;
+                    M.tile(t, lane, lo, hi, tot);
                     const uint64_t inv = ~0ull / (uint64_t)tot;        // per lane, off the serial chains
                     ring_a[mi][t & 1][lane] = make_uint4(lo, hi - lo, tot, hi);
                     ring_b[mi][t & 1][lane] = make_uint2((uint32_t)inv, (uint32_t)(inv >> 32));
@@ -234,108 +311,11 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                 if (valid) {
                     const uint4* ra = &ring_a[lane][(t - 1) & 1][0];
                     const uint2* rb = &ring_b[lane][(t - 1) & 1][0];
-                    uint4 pa = ra[0];
-                    uint2 pb = rb[0];
                     // (a tile in which some block's total has reached fast_total takes the same steps with the exact division)
                     bool any_big = false;
                     if (BIGOK) any_big = __ballot(tile_big[lane < G ? lane : 0][(t - 1) & 1] != 0 && lane < G) != 0;
-                    if (!BIGOK || __builtin_expect(!any_big, 1)) {
-#pragma unroll 4
-                    for (uint32_t j = 0; j < 64; j++) {
-                        const uint32_t s_lo = pa.x, s_fr = pa.y, s_tot = pa.z, s_hc = pa.w, b0 = pb.x, b1 = pb.y;
-                        const uint32_t jn = j + 1;                                 // next step's record, fetched under this step
-                        pa = ra[jn]; pb = rb[jn];
-                        // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
-                        // total < 2^30), fixed up on the low word
-                        uint64_t q;
-                        if (false) q = range / (uint64_t)s_tot;                       // totals of 2^30 and more: the exact (slow) division
-                        else {
-                            const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
-                            q = (uint64_t)r1 * b1 + __umulhi(r1, b0);
-                            q += __umulhi(r0, b1);
-                            const uint32_t rem = r0 - (uint32_t)q * s_tot;          // true remainder < 4 * tot < 2^32
-                            const uint32_t t2 = s_tot << 1, t3 = t2 + s_tot;
-                            uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
-                            asm volatile("" : "+v"(e));                             // (one 64-bit add, not three)
-                            q += e;
-                        }
-                        const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
-                        // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq)
-                        uint64_t top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
-                        low = (uint64_t)q0 * s_lo + low;            low += (uint64_t)(q1 * s_lo) << 32;
-                        range = (uint64_t)q0 * s_fr;                range += (uint64_t)(q1 * s_fr) << 32;
-                        // RangeEncoder::encode's while loop.  Usual case: low and low + range agree on their top 0..2
-                        // bytes and the shifted range stays >= BOTTOM: those bytes leave at once -- one unaligned 4-byte
-                        // store at the cursor (what lies past the cursor is overwritten by the stores that follow)
-                        const uint32_t lh = (uint32_t)(low >> 32);
-                        const uint32_t xh = lh ^ (uint32_t)(top >> 32);
-                        const uint32_t sh = (uint32_t)__builtin_clz(xh | 1u) & 24u;
-                        const uint64_t range_s = range << sh;
-                        const bool rare = xh < 256u || (uint32_t)(range_s >> 32) < (1u << 16);
-                        *(uint32_t*)(dst + (nout < cap4 ? nout : cap4)) = __builtin_bswap32(lh);
-                        uint64_t low_n = low << sh, range_n = range_s;
-                        uint32_t nout_n = nout + (sh >> 3);
-                        if (__builtin_expect(rare, 0)) {
-                            low_n = low; range_n = range; nout_n = nout;
-                            while ((low_n ^ (low_n + range_n)) < (1ull << 56) ||
-                                   (range_n < RC_BOTTOM && ((range_n = (0 - low_n) & (RC_BOTTOM - 1)), true))) {
-                                dst[nout_n < cap4 ? nout_n : cap4] = (uint8_t)(low_n >> 56);
-                                nout_n++;
-                                range_n <<= 8;
-                                low_n <<= 8;
-                            }
-                        }
-                        low = low_n; range = range_n; nout = nout_n;
-                    }
-                    } else {
-#pragma unroll 1
-                    for (uint32_t j = 0; j < 64; j++) {
-                        const uint32_t s_lo = pa.x, s_fr = pa.y, s_tot = pa.z, s_hc = pa.w, b0 = pb.x, b1 = pb.y;
-                        const uint32_t jn = j + 1;                                 // next step's record, fetched under this step
-                        pa = ra[jn]; pb = rb[jn];
-                        // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since
-                        // total < 2^30), fixed up on the low word
-                        uint64_t q;
-                        if (true) q = range / (uint64_t)s_tot;                       // totals of 2^30 and more: the exact (slow) division
-                        else {
-                            const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
-                            q = (uint64_t)r1 * b1 + __umulhi(r1, b0);
-                            q += __umulhi(r0, b1);
-                            const uint32_t rem = r0 - (uint32_t)q * s_tot;          // true remainder < 4 * tot < 2^32
-                            const uint32_t t2 = s_tot << 1, t3 = t2 + s_tot;
-                            uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
-                            asm volatile("" : "+v"(e));                             // (one 64-bit add, not three)
-                            q += e;
-                        }
-                        const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
-                        // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq)
-                        uint64_t top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
-                        low = (uint64_t)q0 * s_lo + low;            low += (uint64_t)(q1 * s_lo) << 32;
-                        range = (uint64_t)q0 * s_fr;                range += (uint64_t)(q1 * s_fr) << 32;
-                        // RangeEncoder::encode's while loop.  Usual case: low and low + range agree on their top 0..2
-                        // bytes and the shifted range stays >= BOTTOM: those bytes leave at once -- one unaligned 4-byte
-                        // store at the cursor (what lies past the cursor is overwritten by the stores that follow)
-                        const uint32_t lh = (uint32_t)(low >> 32);
-                        const uint32_t xh = lh ^ (uint32_t)(top >> 32);
-                        const uint32_t sh = (uint32_t)__builtin_clz(xh | 1u) & 24u;
-                        const uint64_t range_s = range << sh;
-                        const bool rare = xh < 256u || (uint32_t)(range_s >> 32) < (1u << 16);
-                        *(uint32_t*)(dst + (nout < cap4 ? nout : cap4)) = __builtin_bswap32(lh);
-                        uint64_t low_n = low << sh, range_n = range_s;
-                        uint32_t nout_n = nout + (sh >> 3);
-                        if (__builtin_expect(rare, 0)) {
-                            low_n = low; range_n = range; nout_n = nout;
-                            while ((low_n ^ (low_n + range_n)) < (1ull << 56) ||
-                                   (range_n < RC_BOTTOM && ((range_n = (0 - low_n) & (RC_BOTTOM - 1)), true))) {
-                                dst[nout_n < cap4 ? nout_n : cap4] = (uint8_t)(low_n >> 56);
-                                nout_n++;
-                                range_n <<= 8;
-                                low_n <<= 8;
-                            }
-                        }
-                        low = low_n; range = range_n; nout = nout_n;
-                    }
-                    }
+                    if (!BIGOK || __builtin_expect(!any_big, 1)) rc_coder_tile<false>(ra, rb, low, range, nout, dst, cap4);
+                    else rc_coder_tile<true>(ra, rb, low, range, nout, dst, cap4);
                 }
             }
             __syncthreads();
@@ -351,6 +331,67 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
         }
         __syncthreads();
     }
+}
+
+// ---- the modelers alone: the records of every symbol, for chains that run on HOST cores -------------------------------------------
+// A launch of a few hundred blocks leaves most of the chip idle behind ONE block's serial chain per CU (126 ms for 1.16 M symbols:
+// ~280 cycles per symbol on a lone wave), and a host core runs such a chain ~50 times faster.  So for small launches the device
+// only does what it is good at -- the adaptive models' cumulative counts for every symbol, lane = symbol -- and writes a 64-bit
+// record per symbol: cumLow | freq << 22 | model << 44 (the host keeps the models' totals itself: they are the symbols counted).
+// The blocks go through in CHUNKS of tiles so that a chunk's records cross PCIe and are coded while the next chunk is modelled:
+// a block's model state (its LDS image) waits in global memory between two launches.
+constexpr uint32_t RCR_MW = RC_SMALL_WORDS + RC_NSLOT_BIG * RC_STRIDE;
+constexpr uint32_t RCR_STATE_WORDS = RCR_MW + RC_NNUM / 4 + 4;     // models, slot map, number of slots used
+size_t rc_records_state_bytes(uint64_t n_blocks) { return (size_t)n_blocks * RCR_STATE_WORDS * sizeof(uint32_t); }
+
+__global__ void __launch_bounds__(64) k_rc_records(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint32_t tile0, uint32_t tile1,
+                                                  uint64_t* recs, const uint64_t* rec_off, uint32_t* state, uint32_t* scratch, int* err, uint32_t small_sizes) {
+    __shared__ uint32_t models[RCR_MW];
+    __shared__ uint32_t slotmap_w[RC_NNUM / 4];
+    uint8_t* slotmap = (uint8_t*)slotmap_w;
+    const uint32_t lane = threadIdx.x;
+    RcModeler<RC_NSLOT_BIG> M;
+    M.init(models, slotmap, (const uint16_t*)syms, small_sizes, lane);
+    for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const uint64_t s0 = blk_begin[b], s1 = blk_begin[b + 1];
+        if (s1 - s0 >= (1ull << 22) - 512) { if (lane == 0) atomicExch(err, 2); continue; }     // (the host checks before it launches: 22-bit counts)
+        const uint32_t ntiles = (uint32_t)((s1 - s0 + 63) / 64);
+        const uint32_t ta = tile0 < ntiles ? tile0 : ntiles, tb = tile1 < ntiles ? tile1 : ntiles;
+        if (ta >= tb) continue;
+        uint32_t* st = state + b * (uint64_t)RCR_STATE_WORDS;
+        uint32_t* gm = scratch + b * (uint64_t)(RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE;
+        if (ta == 0) M.start_block(s0, s1, gm, lane);
+        else {                                                   // the block goes on where the launch before left it
+            for (uint32_t i = lane; i < RCR_MW; i += 64) models[i] = st[i];
+            for (uint32_t i = lane; i < RC_NNUM / 4; i += 64) slotmap_w[i] = st[RCR_MW + i];
+            M.s0 = s0; M.s1 = s1; M.gmodels = gm;
+            M.nused = st[RCR_MW + RC_NNUM / 4];
+            const uint64_t base = s0 + (uint64_t)ta * 64;
+            M.raw_next = lane < (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64) ? M.sym16[base + lane] : 0xFFFFu;
+        }
+        __syncthreads();
+        uint64_t* out = recs + rec_off[b];
+        for (uint32_t t = ta; t < tb; t++) {
+            uint32_t lo, hi, tot;
+            const uint32_t raw = M.raw_next;                     // (the tile's own symbols: tile() replaces them by the next tile's)
+            M.tile(t, lane, lo, hi, tot);
+            const uint64_t at = (uint64_t)(t - ta) * 64 + lane;
+            if (s0 + (uint64_t)t * 64 + lane < s1) out[at] = (uint64_t)lo | ((uint64_t)(hi - lo) << 22) | ((uint64_t)(raw & 0xFFu) << 44);
+        }
+        __syncthreads();
+        if (tb < ntiles) {                                       // to be continued
+            for (uint32_t i = lane; i < RCR_MW; i += 64) st[i] = models[i];
+            for (uint32_t i = lane; i < RC_NNUM / 4; i += 64) st[RCR_MW + i] = slotmap_w[i];
+            if (lane == 0) st[RCR_MW + RC_NNUM / 4] = M.nused;
+        }
+        __syncthreads();
+    }
+}
+void launch_rc_records(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint32_t tile0, uint32_t tile1, uint64_t* recs,
+                       const uint64_t* rec_off, uint32_t* state, uint32_t* model_scratch, int* err, uint32_t small_sizes) {
+    if (!n_blocks || tile0 >= tile1) return;
+    hipLaunchKernelGGL(k_rc_records, dim3((uint32_t)std::min<uint64_t>(n_blocks, 256 * 4)), dim3(64), 0, s, syms, blk_begin, n_blocks, tile0, tile1, recs, rec_off,
+                       state, model_scratch, err, small_sizes);
 }
 
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint8_t* out,

@@ -15,3 +15,13 @@ def pytest_configure(config):
 def oracle():
     import oracle_lib
     return oracle_lib
+
+
+@pytest.fixture(params=["host-chains", "device-chains"])
+def rc_chains(request, monkeypatch):
+    """Small launches (up to 400 blocks, when the library's estimate says so) have their range-coder chains coded on host cores from the device modelers' records (host_blocks.h);
+    larger ones by the device's coder waves (k_rc_encode).  Nearly every test launches a handful of blocks, so the tests that use this
+    fixture run twice: as they come, and with LEON_RC_HOST_BLOCKS=0 (the device coder for every launch).  Same bytes either way."""
+    # (named in the environment, the choice is taken as given; left alone, the library estimates both ways' times per launch)
+    monkeypatch.setenv("LEON_RC_HOST_BLOCKS", "0" if request.param == "device-chains" else "400")
+    return request.param

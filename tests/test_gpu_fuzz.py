@@ -8,7 +8,7 @@ import pytest
 import common
 import oracle_lib as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("rc_chains")]
 
 
 @pytest.mark.parametrize("chunk", range(4))

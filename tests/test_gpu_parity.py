@@ -8,7 +8,7 @@ import pytest
 import common
 import oracle_lib as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("rc_chains")]
 
 
 def _ctx(k, rpb, tai, **kw):
@@ -103,6 +103,28 @@ def test_range_coder_streams():
         a, b = int(begin[i]), int(begin[i + 1])
         exp = O.rc_encode_stream(syms[2 * a:2 * b:2], syms[2 * a + 1:2 * b:2], sizes)
         assert got[i] == exp, "stream %d differs" % i
+    ctx.close()
+
+
+def test_host_chains_equal_the_device_coder_and_the_oracle(monkeypatch):
+    """the same random symbol streams through the device's coder waves (k_rc_encode) and through the host chains fed by the device's
+    modelers (k_rc_records -> host_blocks.h), whose tiles go through in chunks with the models' state parked in global memory in
+    between: one chunk, three, more chunks than some streams have tiles; empty streams; streams of one symbol"""
+    rng = np.random.default_rng(19)
+    syms, begin, sizes = _random_symbol_streams(rng, 14, 7000)
+    extra_m = rng.choice(80, size=20000, p=_model_probs()).astype(np.uint8)         # one long stream on top: many tiles per chunk
+    extra_v = np.array([rng.integers(0, sizes[x]) for x in extra_m], dtype=np.uint8)
+    syms = np.concatenate([syms, np.stack([extra_m, extra_v], axis=1).reshape(-1), np.array([0, 1], dtype=np.uint8)])
+    begin = np.concatenate([begin, [begin[-1] + 20000, begin[-1] + 20000, begin[-1] + 20001]]).astype(np.uint64)   # + an empty stream, + a one-symbol stream
+    want = [O.rc_encode_stream(syms[2 * int(a):2 * int(b):2], syms[2 * int(a) + 1:2 * int(b):2], sizes) for a, b in zip(begin[:-1], begin[1:])]
+    ctx = _ctx(31, 1000, 1000)
+    assert ctx.rc_encode_streams(syms, begin) == want
+    monkeypatch.setenv("LEON_RC_STREAMS_ON_HOST", "1")
+    for chunks in ("1", "3", "64"):
+        monkeypatch.setenv("LEON_RC_HOST_CHUNKS", chunks)
+        for threads in ("1", "5"):
+            monkeypatch.setenv("LEON_RC_HOST_THREADS", threads)
+            assert ctx.rc_encode_streams(syms, begin) == want, (chunks, threads)
     ctx.close()
 
 

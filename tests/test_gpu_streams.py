@@ -7,7 +7,7 @@ import pytest
 import hdr_samples as H
 import oracle_lib as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("rc_chains")]
 
 
 def _ctx(rpb, **kw):
