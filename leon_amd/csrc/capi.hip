@@ -265,21 +265,24 @@ uint64_t rc_host_blocks() {
     return 400;
 }
 uint32_t rc_host_threads(uint64_t n_blocks) {
-    uint32_t n_thr = std::max<uint32_t>(2, std::min<uint32_t>(16, usable_cpus() > 5 ? usable_cpus() - 4 : 2));   // (the dictionary chain and its helpers keep four)
+    // (all but one of the process's CPUs: the dictionary chain and its helpers are busy for the first part of a small file's step only --
+    // configuration #2, 200 blocks: 88.9 ms with 12 threads and 4 chunks, 73.4 with 15 and 8, 63.9 with 15 and 16; profiles/r4_hostchains_sweep_config2.txt)
+    uint32_t n_thr = std::max<uint32_t>(2, std::min<uint32_t>(32, usable_cpus() > 2 ? usable_cpus() - 1 : 2));
     if (const char* e = getenv("LEON_RC_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_thr = (uint32_t)v; }
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_thr, n_blocks));
 }
 // Who codes a launch's chains.  The device's coder waves take about as long as the LONGEST block's chain whatever the number of
 // blocks (~100 ns per symbol of it, up to 8 blocks per CU); the host's threads take the modelers' pass over the longest block
-// (~30 ns per symbol), then what is slower of the records' way over PCIe (8 bytes per symbol) and the chains themselves
-// (~2.4 ns per symbol and thread).  10 M reads of 150 bp in 200 blocks: 116 against ~80 ms, the host; 20 M reads of 250 bp in 400
-// blocks of 1.9 M symbols: 190 against ~210, the device (measured: 181 and 230).
+// (~45 ns per symbol, the records crossing PCIe chunk by chunk beside it), with the chains (~3.5 ns per symbol and thread) running a
+// chunk behind and going on alone if they are the slower.  10 M reads of 150 bp in 200 blocks: 116 against ~60 ms, the host (measured
+// 134 and 64); 20 M reads of 250 bp in 400 blocks of 1.9 M symbols: 190 against ~190: the device (measured 181 and 230 with 12 threads).
 bool rc_on_host(uint64_t n_blocks, uint64_t n_syms, uint64_t max_block_syms) {
     if (!n_blocks || n_blocks > rc_host_blocks() || max_block_syms + 1024 >= (1ull << HB_COUNT_BITS) || n_syms * 8 > (12ull << 30)) return false;
     if (getenv("LEON_RC_HOST_BLOCKS")) return true;              // (asked for by name: the tests, measurements)
     const double device_ns = 100.0 * (double)max_block_syms * (double)((n_blocks + 2047) / 2048);
-    const double host_ns = 30.0 * (double)max_block_syms + std::max(0.16 * (double)n_syms, 2.4 * (double)n_syms / rc_host_threads(n_blocks));
-    return host_ns < device_ns;
+    const double host_ns = 45.0 * (double)max_block_syms + std::max(0.16 * (double)n_syms, 3.5 * (double)n_syms / rc_host_threads(n_blocks)) / 16.0
+                           + std::max(0.0, 3.5 * (double)n_syms / rc_host_threads(n_blocks) - 45.0 * (double)max_block_syms);
+    return host_ns < 0.9 * device_ns;                            // (a tie goes to the device: the host's cores have other work)
 }
 
 // The range coder stage of a small launch: the device's modeler waves turn the symbols of every block into records, chunk of tiles
@@ -294,7 +297,7 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
     HIPCHK(c, hipStreamSynchronize(s));
     uint64_t max_tiles = 0;
     for (uint64_t b = 0; b < nbl; b++) max_tiles = std::max<uint64_t>(max_tiles, (bb[b + 1] - bb[b] + 63) / 64);
-    uint32_t n_chunks = 4;
+    uint32_t n_chunks = 16;                                      // (a chunk = a pipeline stage: the first must be modelled and cross before a chain starts, the last is coded after everything)
     if (const char* e = getenv("LEON_RC_HOST_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_chunks = (uint32_t)v; }
     n_chunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_chunks, max_tiles));
     const uint64_t Tc = (max_tiles + n_chunks - 1) / std::max<uint32_t>(n_chunks, 1);
