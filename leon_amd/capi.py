@@ -296,6 +296,12 @@ def device_free(ptr):
         load_library().leon_device_free(C.c_void_p(int(ptr)))
 
 
+def device_trim():
+    """return the device memory the library parks between calls (the k-mer counter's ~22 GB of sort buffers after a large count) to the
+    driver: for hosts that go on allocating through torch or their own hipMalloc with no context's leon_dna_reserve in between"""
+    load_library().leon_device_trim()
+
+
 def device_copy(d_dst, d_src, n_bytes, device_id=0):
     """device to device, n_bytes from d_src to d_dst (raw device pointers)"""
     rc = load_library().leon_device_copy(device_id, C.c_void_p(int(d_dst)), C.c_void_p(int(d_src)), int(n_bytes))

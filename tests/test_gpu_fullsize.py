@@ -54,9 +54,11 @@ def test_full_size_properties(N_READS, K, L):
     d_solid, n_solid = capi.kmer_solid_device(reads.data_ptr(), offsets.data_ptr(), N_READS, K, 3)
     tai = n_solid * 12
 
-    def run(rank=0, world=1):
+    def run(rank=0, world=1, by_anchor=False):
         ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai)
         ctx.set_shard(rank, world)
+        if by_anchor:                                          # the walk divided by anchor, this context playing every rank's slice (leon_dna_set_exchange)
+            ctx.set_exchange(capi.XCH_EMULATE)
         ctx.bloom_insert_device(d_solid, n_solid)
         blocks = ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), N_READS)
         d, na = ctx.finish()
@@ -86,6 +88,19 @@ def test_full_size_properties(N_READS, K, L):
         print("rank %d of %d: %d blocks, device %.0f ms (resolve %.0f, walk %.0f, range coder %.0f)" % (r, world, hi - lo, st_r["ms_total"], st_r["ms_resolve"], st_r["ms_walk"], st_r["ms_rangecoder"]))
         u += bl_r
     assert _checksum(u) == _checksum(blocks)
+    if world == 8:
+        # ... and the same 8-way job with its walk divided by ANCHOR instead of by block range (what `bench.py --gpus 8` does): every seat's
+        # blocks again, each seat walking an eighth of the anchor-sorted reads and receiving the rest of its blocks' events
+        u = []
+        for r in range(world):
+            bl_r, d_r, na_r, _, st_r = run(r, world, by_anchor=True)
+            lo, hi = block_range(r, world, n_blocks)
+            assert [b[0] for b in bl_r] == list(range(lo, hi)) and na_r == na and (d_r == d if r == 0 else len(d_r) == 0)
+            assert 0 < st_r["walk_reads"] < N_READS // 4 and st_r["xch_words_received"] > 0
+            print("rank %d of %d, walk by anchor: slice of %d reads walked in %.0f ms, %d words sent, %d received, forming + exchange %.0f ms"
+                  % (r, world, st_r["walk_reads"], st_r["ms_walk"], st_r["xch_words_sent"], st_r["xch_words_received"], st_r["ms_exchange"]))
+            u += bl_r
+        assert _checksum(u) == _checksum(blocks)
     # (3) the reference's own acceptance test (decompress(compress(x)) == x), on sampled blocks, through the oracle's decoder
     bl = O.Bloom(tai, K)
     bl.set_bits(bits)

@@ -236,6 +236,16 @@ def test_reference_acceptance_test_lossless_fastq_gz(leon_bin, tmp_path):
     r = run(leon_bin, "-c", "-lossless", "-file", fq + ".gz", "-kmer-size", "25", env=dict(os.environ, LEON_BATCH_BLOCKS="1"))
     assert r.returncode == 0, r.stderr
     assert run(os.path.join(H5BIN, "h5diff"), fq + ".whole", fq + ".leon").returncode == 0
+    # the lossy default on the same file: its qualities smoothed in ONE call over the whole file, or in calls of one read block each (what a
+    # file beyond the DNA stream's batch size, or a device short of memory, takes -- ADVICE r3): the same container
+    shutil.copy(fq + ".leon", fq + ".lossless")
+    r = run(leon_bin, "-c", "-file", fq + ".gz", "-kmer-size", "25")
+    assert r.returncode == 0, r.stderr
+    shutil.move(fq + ".leon", fq + ".lossy_whole")
+    r = run(leon_bin, "-c", "-file", fq + ".gz", "-kmer-size", "25", env=dict(os.environ, LEON_BATCH_BLOCKS="1"))
+    assert r.returncode == 0, r.stderr
+    assert run(os.path.join(H5BIN, "h5diff"), fq + ".lossy_whole", fq + ".leon").returncode == 0
+    shutil.move(fq + ".lossless", fq + ".leon")
     # and decoded in rounds of one block (the path a host short of memory takes) it gives the same file
     r = run(leon_bin, "-d", "-file", fq + ".leon", env=dict(os.environ, LEON_DECODE_BLOCKS="1"))
     assert r.returncode == 0, r.stderr
