@@ -848,16 +848,23 @@ def end_to_end(n, device):
             if r.returncode:
                 out[name + "_stderr"] = r.stderr[-400:]
             return r
+        # the same file with the quality blocks written by the device's deflate (`-qual-deflate device`: inflates to the same text, not
+        # zlib's bytes), then -- what is kept and decoded back -- by zlib itself, the default and the reference's bytes
+        run("compress_lossless_qual_deflate_device", "-file", fq, "-c", "-lossless", "-qual-deflate", "device")
+        out["leon_bytes_qual_deflate_device"] = os.path.getsize(fq + ".leon") if os.path.exists(fq + ".leon") else None
         run("compress_lossless", "-file", fq, "-c", "-lossless")
         out["leon_bytes"] = os.path.getsize(fq + ".leon") if os.path.exists(fq + ".leon") else None
         r = run("decompress_test_file", "-file", fq + ".leon", "-d", "-test-file")
         out["identical"] = r.returncode == 0 and "is identical to" in r.stdout
         if out.get("compress_lossless_rc") == 0:
             out["compress_MBps_of_file"] = round(out["fastq_bytes"] / 1e6 / out["compress_lossless_s"], 1)
+        if out.get("compress_lossless_qual_deflate_device_rc") == 0:
+            out["compress_MBps_of_file_qual_deflate_device"] = round(out["fastq_bytes"] / 1e6 / out["compress_lossless_qual_deflate_device_s"], 1)
         if out["identical"]:
             out["decompress_MBps_of_file"] = round(out["fastq_bytes"] / 1e6 / out["decompress_test_file_s"], 1)
-        out["what"] = ("leon -file X.fastq -c -lossless, then leon -file X.fastq.leon -d -test-file (byte comparison with the original), "
-                       "whole commands timed from outside: parse, k-mer counting, bloom, the three streams, HDF5 container")
+        out["what"] = ("leon -file X.fastq -c -lossless (quality blocks: zlib's own bytes, the default; and once with -qual-deflate device), then "
+                       "leon -file X.fastq.leon -d -test-file (byte comparison with the original), whole commands timed from outside: parse, k-mer "
+                       "counting, bloom, the three streams, HDF5 container")
     finally:
         shutil.rmtree(work, ignore_errors=True)
     return out

@@ -223,6 +223,19 @@ int leon_host_header_decode_blocks(const uint8_t* payloads, const uint64_t* payl
 int leon_header_decode_blocks(leon_dna_ctx* ctx, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
                               uint64_t n_blocks, const uint8_t* first_header, uint64_t first_header_len, uint8_t* out,
                               uint64_t out_cap, uint64_t* out_off, uint64_t* out_size, uint32_t n_threads);
+/* leon_header_decode_blocks in its two halves, for callers that decode a file in rounds: the symbols of ALL header blocks in one device
+ * call (a block is one serial chain on one wave, ~1.5 s whether the call holds 200 blocks or 2 000: a call per round pays that every
+ * round), then the text of any run of blocks on host threads.  The set is the library's until leon_header_symbols_free.
+ * leon_header_text_from_symbols: blocks [first_block, first_block + n_blocks) of the set, block_n_reads = THOSE blocks' read counts; outputs
+ * and errors as leon_host_header_decode_blocks; LEON_E_STATE when the set's symbols did not fit the device buffer (free text in every
+ * header): the caller then decodes the payloads with leon_host_header_decode_blocks. */
+typedef struct leon_header_symbols leon_header_symbols;
+int leon_header_decode_symbols(leon_dna_ctx* ctx, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads,
+                               uint64_t n_blocks, leon_header_symbols** set);
+int leon_header_text_from_symbols(const leon_header_symbols* set, uint64_t first_block, uint64_t n_blocks, const uint32_t* block_n_reads,
+                                  const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
+                                  uint64_t* out_size, uint32_t n_threads);
+void leon_header_symbols_free(leon_header_symbols* set);
 /* Quality stream, lossy form (Leon's default, /root/reference/README.md:55): DnaEncoder::storeSolidCoverageInfo + smoothQuals
  * [RECALLED]: a quality becomes '@' where at least two of the read's solid k-mers (in the bloom of ctx) span the position, or
  * where it is above '@'; reads shorter than k are left alone.  quals: one byte per base, same offsets as the bases, rewritten

@@ -73,6 +73,9 @@ _EXPORTS = {
     "leon_dna_finish": (C.c_int, [C.c_void_p, C.POINTER(_u8p), _u64p, _u64p]),
     "leon_dna_reset_stream": (C.c_int, [C.c_void_p]),
     "leon_dna_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "leon_header_decode_symbols": (C.c_int, [C.c_void_p, _u8p, _u64p, _u32p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "leon_header_text_from_symbols": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _u32p, C.c_char_p, C.c_uint64, _u8p, C.c_uint64, _u64p, _u64p, C.c_uint32]),
+    "leon_header_symbols_free": (None, [C.c_void_p]),
     "leon_dna_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "leon_dna_set_exchange": (C.c_int, [C.c_void_p, C.c_uint32, EXCHANGE, C.c_void_p]),
     "leon_dna_debug_walk_order": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1703,18 +1703,24 @@ int header_blocks_from_symbols(const uint8_t* syms, const uint64_t* sym_begin, c
                                const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
                                uint64_t* out_size, uint32_t n_threads);
 } }
-int leon_header_decode_blocks(leon_dna_ctx* c, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads, uint64_t n_blocks,
-                              const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
-                              uint64_t* out_size, uint32_t n_threads) {
+struct leon_header_symbols {
+    std::unique_ptr<uint8_t[]> syms;                             // every block's symbols, one byte each, block after block
+    std::vector<uint64_t> begin, count;                          // block b: syms[begin[b] .. + count[b])
+    bool overflowed = false;                                     // some block had more symbols than its share of the device buffer: decode the payloads on the host
+};
+
+int leon_header_decode_symbols(leon_dna_ctx* c, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads, uint64_t n_blocks,
+                               leon_header_symbols** set) {
     if (!c) return LEON_E_INVALID;
-    if (!out_size || (n_blocks && (!payloads || !payload_off || !block_n_reads || !out_off)) || (!first_header && first_header_len))
-        return fail(c, LEON_E_INVALID, "null argument");
-    *out_size = 0;
-    if (!n_blocks) return LEON_OK;
+    if (!set || (n_blocks && (!payloads || !payload_off || !block_n_reads))) return fail(c, LEON_E_INVALID, "null argument");
+    *set = nullptr;
+    std::unique_ptr<leon_header_symbols> H(new leon_header_symbols());
+    H->begin.assign(n_blocks + 1, 0); H->count.assign(n_blocks, 0);
+    if (!n_blocks) { *set = H.release(); return LEON_OK; }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     // a block's share of the symbol buffer: enough for the headers sequencers write (a dozen symbols each); a block that
-    // needs more (free text in every header) sends the whole call to the host decoder -- same result, its speed
+    // needs more (free text in every header) marks the whole set for the host decoder -- same result, its speed
     std::vector<uint64_t> rel_off(n_blocks + 1), sym_begin(n_blocks + 1, 0);
     for (uint64_t b = 0; b < n_blocks; b++) {
         if (payload_off[b + 1] < payload_off[b]) return fail(c, LEON_E_INVALID, "payload offsets are not monotonic");
@@ -1740,22 +1746,48 @@ int leon_header_decode_blocks(leon_dna_ctx* c, const uint8_t* payloads, const ui
     HIPCHK(c, hipMemcpyAsync(err, d_err.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (err[0] == 2) return fail(c, LEON_E_INVALID, "header block " + std::to_string(err[1]) + " does not decode");
-    if (err[0] == 1) {                                           // more symbols than a block's share: the host decodes the payloads itself
-        int rc = leon_host_header_decode_blocks(payloads, payload_off, block_n_reads, n_blocks, first_header, first_header_len, out, out_cap, out_off, out_size, n_threads);
-        if (rc != LEON_OK) c->err = leon_last_error(nullptr);
-        return rc;
-    }
-    std::vector<uint64_t> sym_count(n_blocks);
-    HIPCHK(c, hipMemcpy(sym_count.data(), d_count.p, n_blocks * 8, hipMemcpyDeviceToHost));
+    if (err[0] == 1) { H->overflowed = true; *set = H.release(); return LEON_OK; }
+    HIPCHK(c, hipMemcpy(H->count.data(), d_count.p, n_blocks * 8, hipMemcpyDeviceToHost));
     // only the symbols that were written come back (a block's share is mostly empty)
-    std::vector<uint64_t> host_begin(n_blocks + 1, 0);
-    for (uint64_t b = 0; b < n_blocks; b++) host_begin[b + 1] = host_begin[b] + sym_count[b];
-    std::unique_ptr<uint8_t[]> syms(new uint8_t[host_begin[n_blocks] + 1]);
+    for (uint64_t b = 0; b < n_blocks; b++) H->begin[b + 1] = H->begin[b] + H->count[b];
+    H->syms.reset(new uint8_t[H->begin[n_blocks] + 1]);
     for (uint64_t b = 0; b < n_blocks; b++)
-        if (sym_count[b]) HIPCHK(c, hipMemcpyAsync(syms.get() + host_begin[b], d_syms.as<uint8_t>() + sym_begin[b], sym_count[b], hipMemcpyDeviceToHost, s));
+        if (H->count[b]) HIPCHK(c, hipMemcpyAsync(H->syms.get() + H->begin[b], d_syms.as<uint8_t>() + sym_begin[b], H->count[b], hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    int rc = leon::header_blocks_from_symbols(syms.get(), host_begin.data(), sym_count.data(), block_n_reads, n_blocks, first_header, first_header_len, out, out_cap,
-                                              out_off, out_size, n_threads);
+    *set = H.release();
+    return LEON_OK;
+}
+
+int leon_header_text_from_symbols(const leon_header_symbols* H, uint64_t first_block, uint64_t n_blocks, const uint32_t* block_n_reads,
+                                  const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
+                                  uint64_t* out_size, uint32_t n_threads) {
+    if (!H || !out_size || (n_blocks && (!block_n_reads || !out_off)) || (!first_header && first_header_len)) return fail(nullptr, LEON_E_INVALID, "null argument");
+    *out_size = 0;
+    if (first_block > H->count.size() || n_blocks > H->count.size() - first_block) return fail(nullptr, LEON_E_INVALID, "blocks beyond the symbol set");
+    if (H->overflowed) return fail(nullptr, LEON_E_STATE, "the set's symbols did not fit the device buffer: decode the payloads with leon_host_header_decode_blocks");
+    if (!n_blocks) return LEON_OK;
+    return leon::header_blocks_from_symbols(H->syms.get(), H->begin.data() + first_block, H->count.data() + first_block, block_n_reads, n_blocks, first_header,
+                                            first_header_len, out, out_cap, out_off, out_size, n_threads);
+}
+
+void leon_header_symbols_free(leon_header_symbols* H) { delete H; }
+
+int leon_header_decode_blocks(leon_dna_ctx* c, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* block_n_reads, uint64_t n_blocks,
+                              const uint8_t* first_header, uint64_t first_header_len, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
+                              uint64_t* out_size, uint32_t n_threads) {
+    if (!c) return LEON_E_INVALID;
+    if (!out_size || (n_blocks && (!payloads || !payload_off || !block_n_reads || !out_off)) || (!first_header && first_header_len))
+        return fail(c, LEON_E_INVALID, "null argument");
+    *out_size = 0;
+    if (!n_blocks) return LEON_OK;
+    leon_header_symbols* H = nullptr;
+    if (int rc = leon_header_decode_symbols(c, payloads, payload_off, block_n_reads, n_blocks, &H)) return rc;
+    std::unique_ptr<leon_header_symbols> own(H);
+    int rc;
+    if (H->overflowed)                                           // more symbols than a block's share: the host decodes the payloads itself
+        rc = leon_host_header_decode_blocks(payloads, payload_off, block_n_reads, n_blocks, first_header, first_header_len, out, out_cap, out_off, out_size, n_threads);
+    else
+        rc = leon_header_text_from_symbols(H, 0, n_blocks, block_n_reads, first_header, first_header_len, out, out_cap, out_off, out_size, n_threads);
     if (rc != LEON_OK) c->err = leon_last_error(nullptr);
     return rc;
 }

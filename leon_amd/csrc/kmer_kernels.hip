@@ -1,6 +1,6 @@
 // kmer_kernels.hip -- solid k-mer counting on the device: the step right before the DNA encode path (upstream: DSK,
 // kmer/impl/SortingCountAlgorithm [RECALLED], whose solid k-mers Leon::createBloom inserts).  Sort-based: the canonical
-// k-mers of the reads are emitted in hash partitions that fit the device, each partition is radix-sorted (hipCUB), runs
+// k-mers of the reads are emitted in hash partitions that fit the device, each partition is radix-sorted (rocPRIM, prim.h), runs
 // of at least min_abundance equal k-mers are kept.  k-mers containing an N are skipped, as DSK does.
 #include "../../include/leon_dna.h"
 #include "kernels.h"
