@@ -482,6 +482,37 @@ class DnaEncodeContext:
         raw = out.tobytes()
         return [raw[int(out_off[i]):int(out_off[i + 1])] for i in range(total)]
 
+    def header_symbol_set(self, blocks):
+        """the device half of header_decode_blocks alone: the symbols of ALL of `blocks` in one device call.  Returns an object whose
+        .text(first_block, n_blocks, first_header) gives those blocks' headers (host threads) and .close() frees the set"""
+        ctx = self
+        pay, off, nr = _join_blocks(blocks)
+        h = C.c_void_p()
+        self._chk(self.lib.leon_header_decode_symbols(self.h, _ptr(pay, _u8p), _ptr(off, _u64p), _ptr(nr, _u32p), len(blocks), C.byref(h)))
+
+        class Set:
+            def text(self, first_block, n_blocks, first_header, n_threads=0):
+                counts = np.ascontiguousarray(nr[first_block:first_block + n_blocks], dtype=np.uint32)
+                total = int(counts.sum())
+                out_off = np.zeros(total + 1, dtype=np.uint64)
+                need = C.c_uint64()
+                cap = max(64, 64 * total)
+                for _ in range(2):
+                    out = np.zeros(cap, dtype=np.uint8)
+                    rc = ctx.lib.leon_header_text_from_symbols(h, first_block, n_blocks, _ptr(counts, _u32p), first_header, len(first_header),
+                                                               _ptr(out, _u8p), cap, _ptr(out_off, _u64p), C.byref(need), n_threads)
+                    if rc != -5:
+                        break
+                    cap = need.value
+                if rc:
+                    raise LeonDnaError(rc, (ctx.lib.leon_last_error(None) or b"").decode())
+                raw = out.tobytes()
+                return [raw[int(out_off[i]):int(out_off[i + 1])] for i in range(total)]
+
+            def close(self):
+                ctx.lib.leon_header_symbols_free(h)
+        return Set()
+
     def qual_smooth_batch(self, bases, offsets, quals):
         """DnaEncoder::smoothQuals (lossy qualities) over a batch: returns the smoothed quality bytes (same offsets)"""
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)

@@ -702,7 +702,7 @@ void Leon::executeDecompression() {
     // what one round hands from the decoding stage to the writing stage
     struct DnaGroup { RawBytes bases; std::unique_ptr<uint32_t[]> lens; };   // the DNA blocks of one device call: the bases and lengths of its rounds
     struct Round {
-        uint64_t read_index = 0, file_off = 0, g_reads = 0, g_bases = 0, n_text = 0, nb = 0, hdr_text_bytes = 0;
+        uint64_t read_index = 0, file_off = 0, g_reads = 0, g_bases = 0, n_text = 0, nb = 0, hdr_text_bytes = 0, block0 = 0;
         std::shared_ptr<DnaGroup> dna; uint64_t base0 = 0, read0 = 0;   // this round's share of them
         const uint8_t* bases() const { return dna->bases.p.get() + base0; }
         const uint32_t* lens() const { return dna->lens.get() + read0; }
@@ -787,6 +787,11 @@ void Leon::executeDecompression() {
     // A never waits for B or C of its own rounds -- only for C of rounds further back (memory).
     uint64_t dna_rounds = n_blocks >= 800 ? 2 : 1;
     if (const char* e = getenv("LEON_DECODE_DNA_ROUNDS")) { const long v = atol(e); if (v > 0) dna_rounds = (uint64_t)v; }   // (tests)
+    // (what the header-symbol task and the rounds' tasks read: declared before `drain`, so destroyed after it has waited for them)
+    RawBytes all_pay_h; std::vector<uint64_t> all_off_h; std::vector<uint32_t> all_reads_h;
+    struct SymSet { leon_header_symbols* h = nullptr; ~SymSet() { leon_header_symbols_free(h); } };
+    auto hdr_set = std::make_shared<SymSet>();
+    std::shared_future<void> hdr_symbols;
     struct Drain {                                               // (no task outlives what it refers to, whatever way this function is left)
         std::vector<std::shared_future<void>> all;
         ~Drain() { for (auto& f : all) if (f.valid()) f.wait(); }
@@ -794,6 +799,27 @@ void Leon::executeDecompression() {
     std::shared_future<void> host_before, writer_before;
     std::deque<std::shared_future<void>> pending;               // stage C of the rounds in flight, oldest first
     uint64_t read_index = 0, bases_out = 0, next_file_off = 0;  // next_file_off: owned by stage C (one round at a time)
+    // Header blocks whose symbols the device decodes: ALL of the file's blocks in ONE device call, started here, beside everything else.
+    // A header block is one serial chain on one wave (~1.5 s for 50 000 headers) whether the call holds 200 blocks or 2 000, so a call
+    // per round paid that chain every round (4 x 2.7 s of configuration #3's 20 s); the rounds now only rebuild their blocks' text
+    // from the symbols, on the host threads.
+    const bool hdr_on_device = has_header && n_blocks > 0 && group >= header_blocks_on_device;
+    if (hdr_on_device) {
+        all_off_h.assign(n_blocks + 1, 0); all_reads_h.resize(n_blocks);
+        for (uint64_t b = 0; b < n_blocks; b++) { all_off_h[b + 1] = all_off_h[b] + thdr[3 * b]; all_reads_h[b] = (uint32_t)tdna[3 * b + 1]; }
+        all_pay_h.resize(all_off_h[n_blocks] + 1);
+        for (uint64_t b = 0; b < n_blocks; b++) {
+            const std::vector<uint8_t> blk = in.getBytes(Container::blockPath(GROUP_HEADER, b));
+            if (blk.size() != thdr[3 * b]) throw Exception(_inputFilename + ": block " + std::to_string(b) + " of " + GROUP_HEADER + " has not the size its table says");
+            if (!blk.empty()) memcpy(all_pay_h.data() + all_off_h[b], blk.data(), blk.size());
+        }
+        leon_dna_ctx* hc = hdr_ctx.get();
+        const uint8_t* pay = all_pay_h.data(); const uint64_t* off = all_off_h.data(); const uint32_t* nr = all_reads_h.data();
+        hdr_symbols = std::async(std::launch::async, [hc, pay, off, nr, n_blocks, hdr_set] {
+            if (leon_header_decode_symbols(hc, pay, off, nr, n_blocks, &hdr_set->h) != LEON_OK) throw Exception(std::string("header blocks: ") + leon_last_error(hc));
+        }).share();
+        drain.all.push_back(hdr_symbols);
+    }
     for (uint64_t a0 = 0; a0 < n_blocks; a0 += group * dna_rounds) {
         const uint64_t a1 = std::min(n_blocks, a0 + group * dna_rounds), na = a1 - a0;
         auto tl = std::chrono::steady_clock::now();
@@ -827,7 +853,8 @@ void Leon::executeDecompression() {
             for (uint64_t b = 0; b < nb; b++) { g_reads += R->blk_reads[b]; g_bases += R->blk_bases[b]; }
             R->read_index = read_index; R->g_reads = g_reads; R->g_bases = g_bases;
             R->dna = G; R->base0 = base0; R->read0 = read0;
-            if (has_header) gather(GROUP_HEADER, thdr, 3, g0, nb, R->pay_h, R->off_h);
+            if (has_header && !hdr_on_device) gather(GROUP_HEADER, thdr, 3, g0, nb, R->pay_h, R->off_h);
+            R->block0 = g0;
             if (fastq_out) gather(GROUP_QUAL, tqual, 3, g0, nb, R->pay_q, R->off_q);
             R->hdr_off.assign(g_reads + 1, 0); R->qual_off.assign(g_reads + 1, 0);
             R->hdr_text_bytes = 64;
@@ -837,32 +864,45 @@ void Leon::executeDecompression() {
                 if (host_before.valid()) host_before.wait();
                 auto th = std::chrono::steady_clock::now();
                 const uint64_t nb = R->nb, g_bases = R->g_bases;
-                const bool on_device = has_header && nb >= header_blocks_on_device;
+                const bool on_device = hdr_on_device;
                 auto decode_quals = [&] {
                     R->qual.resize(g_bases + 1);
                     if (leon_host_qual_decode_blocks(R->pay_q.data(), R->off_q.data(), R->blk_reads.data(), R->blk_bases.data(), nb, R->qual.data(), g_bases, R->qual_off.data(), cores) != LEON_OK)
                         throw Exception(std::string("leon_host_qual_decode_blocks: ") + leon_last_error(nullptr));
                 };
-                // while the device decodes the header symbols the host threads have nothing to do: the quality blocks go then
+                // while the first round waits for the device's header symbols the host threads have nothing to do: the quality blocks go then
                 std::future<void> quals_beside;
-                if (fastq_out && on_device) quals_beside = std::async(std::launch::async, decode_quals);
+                if (fastq_out && on_device && hdr_symbols.valid() && hdr_symbols.wait_for(std::chrono::seconds(0)) != std::future_status::ready)
+                    quals_beside = std::async(std::launch::async, decode_quals);
                 if (has_header) {
                     uint64_t need = 0;
                     R->hdr.resize(R->hdr_text_bytes);             // from the block table (a wrong entry only costs the second call below)
-                    // A round of many blocks: the stream's symbols on the device (its own context and stream, beside the DNA blocks: a
-                    // block is a serial chain there too, ~1.3 s for 50 000 headers, but all of them at once) and the text on the host
-                    // threads.  A few hundred blocks: the host threads alone are quicker (10 M headers in 200 blocks: 0.62 s against 1.27 s).
+                    // The symbols of every header block come from ONE device call over the whole file (above); a round rebuilds its
+                    // blocks' text from them.  Files of a few hundred blocks: the host threads alone are quicker (10 M headers in 200
+                    // blocks: 0.62 s against 1.27 s).  A set whose symbols did not fit the device buffer (free text in every header)
+                    // sends the rounds to the host decoder, from the same payloads.
+                    bool host_decoder = !on_device;
+                    if (on_device) {
+                        try { hdr_symbols.get(); }
+                        catch (...) { if (quals_beside.valid()) { try { quals_beside.get(); } catch (...) {} } throw; }
+                    }
                     auto decode = [&]() -> int {
+                        if (on_device && !host_decoder) {
+                            const int rc = leon_header_text_from_symbols(hdr_set->h, R->block0, nb, R->blk_reads.data(), first_header.data(), first_header.size(),
+                                                                         R->hdr.data(), R->hdr.size(), R->hdr_off.data(), &need, cores);
+                            if (rc != LEON_E_STATE) return rc;
+                            host_decoder = true;
+                        }
                         if (on_device)
-                            return leon_header_decode_blocks(hdr_ctx.get(), R->pay_h.data(), R->off_h.data(), R->blk_reads.data(), nb, first_header.data(), first_header.size(),
-                                                             R->hdr.data(), R->hdr.size(), R->hdr_off.data(), &need, cores);
+                            return leon_host_header_decode_blocks(all_pay_h.data(), all_off_h.data() + R->block0, R->blk_reads.data(), nb, first_header.data(), first_header.size(),
+                                                                  R->hdr.data(), R->hdr.size(), R->hdr_off.data(), &need, cores);
                         return leon_host_header_decode_blocks(R->pay_h.data(), R->off_h.data(), R->blk_reads.data(), nb, first_header.data(), first_header.size(), R->hdr.data(),
                                                               R->hdr.size(), R->hdr_off.data(), &need, cores);
                     };
                     int rc = decode();
                     if (rc == LEON_E_OVERFLOW) { R->hdr.resize(need + 1); rc = decode(); }
                     if (rc != LEON_OK) {
-                        const std::string msg = std::string("header blocks: ") + leon_last_error(on_device ? hdr_ctx.get() : nullptr);
+                        const std::string msg = std::string("header blocks: ") + leon_last_error(nullptr);
                         if (quals_beside.valid()) { try { quals_beside.get(); } catch (...) {} }
                         throw Exception(msg);
                     }

@@ -37,6 +37,19 @@ def test_header_blocks_bit_exact(name, make, n, rpb):
     assert ctx.header_decode_blocks(blocks, hs[0]) == hs
     assert ctx.header_decode_blocks(blocks, hs[0], n_threads=3) == hs
     assert ctx.header_decode_blocks([], b"") == []
+    # the same in its two halves, as `leon -d` uses them: the symbols of ALL blocks in one device call, then the text of any run of blocks
+    S = ctx.header_symbol_set(blocks)
+    try:
+        for b0, nb in ((0, len(blocks)), (len(blocks) - 1, 1), (1, max(len(blocks) - 2, 0)), (0, 0)):
+            if b0 > len(blocks):
+                continue
+            got = S.text(b0, nb, hs[0])
+            assert got == hs[b0 * rpb:(b0 + nb) * rpb], (name, b0, nb)
+    except capi.LeonDnaError as e:                                # "nasty": the set says its symbols did not fit -- the caller decodes the payloads on the host
+        assert name == "nasty" and e.code == -4, e
+    with pytest.raises(capi.LeonDnaError):
+        S.text(len(blocks), 1, hs[0])                             # beyond the set
+    S.close()
     if len(blocks) > 1:                                            # a payload that is not a header stream is reported, by both decoders
         bad = list(blocks)
         bad[1] = (bad[1][0], bytes(255 - x for x in bad[1][1]), bad[1][2])
