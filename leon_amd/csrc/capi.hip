@@ -315,15 +315,16 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
         chunk_max = std::max(chunk_max, at);
     }
     if (chunk_base[n_chunks] != n_syms) return fail(c, LEON_E_STATE, "block symbol ranges do not add up (internal error)");
-    for (auto& b : c->hb_recs) HIPCHK(c, b.ensure(chunk_max * 8 + 64));
-    HIPCHK(c, c->hb_recoff.ensure((size_t)n_chunks * nbl * 8));
-    HIPCHK(c, c->hb_state.ensure(rc_records_state_bytes(nbl)));
+    // (memory this way needs and the device's coder does not: when it is not to be had, the caller takes the device's coder -- return 1)
+    auto no_room = [&](hipError_t e) { if (e == hipSuccess) return false; (void)hipGetLastError(); return true; };
+    for (auto& b : c->hb_recs) if (no_room(b.ensure(chunk_max * 8 + 64))) return 1;
+    if (no_room(c->hb_recoff.ensure((size_t)n_chunks * nbl * 8)) || no_room(c->hb_state.ensure(rc_records_state_bytes(nbl)))) return 1;
     HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
     if (n_syms * 8 + 64 > c->h_recs_cap) {
         if (c->h_recs) HIPCHK(c, hipHostFree(c->h_recs));
         c->h_recs = nullptr; c->h_recs_cap = 0;
         const size_t want = n_syms * 8 + n_syms + 4096;
-        HIPCHK(c, hipHostMalloc((void**)&c->h_recs, want, hipHostMallocDefault));
+        if (no_room(hipHostMalloc((void**)&c->h_recs, want, hipHostMallocDefault))) { c->h_recs = nullptr; return 1; }
         c->h_recs_cap = want;
     }
     while (c->hb_ev.size() < 2 * (size_t)n_chunks) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->hb_ev.push_back(e); }
@@ -345,6 +346,7 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
     HostBlockCoder* const coders = c->hb_coders.data();
     for (uint32_t w = 0; w < n_thr; w++)
         workers.emplace_back([&, w] {
+            try {
             for (uint64_t b = w; b < nbl; b += n_thr) coders[b].start(small_sizes, n_small);
             for (uint32_t ch = 0; ch < n_chunks; ch++) {
                 for (uint32_t spin = 0; chunks_ready.load(std::memory_order_acquire) <= ch; spin++) {
@@ -356,6 +358,7 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
                 if (trace) { const double t = ms_now(); std::lock_guard<std::mutex> g(trace_mu); t_coded[ch] = std::max(t_coded[ch], t); }
             }
             for (uint64_t b = w; b < nbl; b += n_thr) coders[b].flush();
+            } catch (...) { abort_flag.store(2); }               // (an output buffer that could not grow: the call fails, nothing is thrown across threads)
         });
     struct Join { std::vector<std::thread>& t; std::atomic<int>& a; bool ok = false; ~Join() { if (!ok) a.store(1); for (auto& x : t) if (x.joinable()) x.join(); } } join{workers, abort_flag};
     for (uint32_t ch = 0; ch < n_chunks; ch++) {
@@ -381,6 +384,7 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
     }
     for (auto& t : workers) t.join();
     join.ok = true;
+    if (abort_flag.load() == 2) return fail(c, LEON_E_OVERFLOW, "a host chain ran out of memory for its output");
     if (trace) {
         fprintf(stderr, "[leon rc host] %llu blocks, %llu symbols, %u chunks, %u threads:", (unsigned long long)nbl, (unsigned long long)n_syms, n_chunks, n_thr);
         for (uint32_t ch = 0; ch < n_chunks; ch++) fprintf(stderr, " chunk %u in host memory at %.1f ms, coded at %.1f;", ch, t_copied[ch], t_coded[ch]);
@@ -1048,12 +1052,16 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipEventRecord(c->ev[6], s));
 
     // ---- range coder ----
-    const bool host_chains = rc_on_host(nbl, n_syms, max_block_syms);
+    bool host_chains = rc_on_host(nbl, n_syms, max_block_syms);
     std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
     uint64_t payload_bytes = 0;
     if (host_chains) {
         // a small launch: the chains run on host cores, from the modelers' records (host_blocks.h)
-        if (int rc = rc_blocks_on_host(c, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, n_syms, SMALL_SIZES_DNA, N_SMALL_MODELS)) return rc;
+        const int rc = rc_blocks_on_host(c, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, n_syms, SMALL_SIZES_DNA, N_SMALL_MODELS);
+        if (rc == 1) host_chains = false;                        // (no room for the records: the device's coder)
+        else if (rc) return rc;
+    }
+    if (host_chains) {
         HIPCHK(c, hipEventRecord(c->ev[7], s));
         for (uint64_t b = 0; b < nbl; b++) { sizes[b] = c->hb_coders[b].size(); dst[b + 1] = dst[b] + sizes[b]; }
         payload_bytes = dst[nbl];
@@ -1282,10 +1290,14 @@ static int header_batch_impl(leon_dna_ctx* c, const uint8_t* d_hdr, const uint64
         HIPCHK(c, c->blk_begin.ensure((nbl + 1) * 8)); HIPCHK(c, c->out_off.ensure((nbl + 1) * 8));
         HIPCHK(c, c->out_size.ensure(nbl * 8)); HIPCHK(c, c->dst_off.ensure((nbl + 1) * 8));
         launch_block_ranges(s, c->sym_off.as<uint64_t>(), nl, rpb, nbl, c->blk_begin.as<uint64_t>(), c->out_off.as<uint64_t>());
-        const bool host_chains = rc_on_host(nbl, n_syms, max_block_syms);
+        bool host_chains = rc_on_host(nbl, n_syms, max_block_syms);
         std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
         if (host_chains) {                                       // a small launch: the blocks' chains on host cores (host_blocks.h)
-            if (int rc = rc_blocks_on_host(c, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, n_syms, SMALL_SIZES_HEADER, N_SMALL_MODELS)) return rc;
+            const int rc = rc_blocks_on_host(c, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, n_syms, SMALL_SIZES_HEADER, N_SMALL_MODELS);
+            if (rc == 1) host_chains = false;
+            else if (rc) return rc;
+        }
+        if (host_chains) {
             for (uint64_t b = 0; b < nbl; b++) { sizes[b] = c->hb_coders[b].size(); dst[b + 1] = dst[b] + sizes[b]; }
         } else {
         HIPCHK(c, c->rc_out.ensure(3 * n_syms + 72 * (nbl + 1)));
@@ -1865,7 +1877,8 @@ int leon_rc_encode_streams(leon_dna_ctx* c, const uint8_t* syms, const uint64_t*
     // (test hook, LEON_RC_STREAMS_ON_HOST=1: the same streams through the host chains fed by the device's modelers -- host_blocks.h --
     // so that the tests hold the two coders against each other and against the oracle on the same symbols)
     if (const char* e = getenv("LEON_RC_STREAMS_ON_HOST")) if (e[0] == '1' && longest + 1024 < (1ull << HB_COUNT_BITS)) {
-        if (int rc = rc_blocks_on_host(c, dsyms.as<uint8_t>(), dbegin.as<uint64_t>(), n_streams, n_syms, SMALL_SIZES_DNA, N_SMALL_MODELS)) return rc;
+        if (int rc = rc_blocks_on_host(c, dsyms.as<uint8_t>(), dbegin.as<uint64_t>(), n_streams, n_syms, SMALL_SIZES_DNA, N_SMALL_MODELS))
+            return rc == 1 ? fail(c, LEON_E_HIP, "no memory for the host chains' records") : rc;
         uint64_t w = 0;
         for (uint64_t b = 0; b < n_streams; b++) {
             sizes[b] = c->hb_coders[b].size();

@@ -56,15 +56,24 @@ public:
                     uint64_t rem = range - q * t;
                     while (__builtin_expect(rem >= t, 0)) { q++; rem -= t; }     // (one short with probability < 2^-8)
                 } else q = range / t;
-                low += q * lo;
-                range = q * fr;
-                const uint64_t x = low ^ (low + range);
-                if (__builtin_expect(x >= kBottom && range >= kBottom, 1)) {
+                // both ends' products start together (the flag's path: multiply, add, xor, compare, select); the range is their difference
+                const uint64_t Lu = low + q * lo, Tu = low + q * (lo + fr);
+                const uint64_t Ru = Tu - Lu, x = Lu ^ Tu;
+                if (__builtin_expect(Ru >= kBottom, 1)) {          // (x < 2^48 implies Ru < 2^48: adding Ru flips a bit of Lu at or above Ru's highest one)
                     // no byte, or exactly one: selected without a branch (a byte leaves after every fourth symbol or so)
-                    *p = (uint8_t)(low >> 56);
+                    *p = (uint8_t)(Lu >> 56);
+                    low = Lu; range = Ru;
+#if defined(__x86_64__)
+                    asm("cmpq %[top], %[x]\n\tcmovbq %[L8], %[low]\n\tcmovbq %[R8], %[range]\n\tadcq $0, %[p]"
+                        : [low] "+r"(low), [range] "+r"(range), [p] "+r"(p)
+                        : [x] "r"(x), [top] "r"(kTop), [L8] "r"(Lu << 8), [R8] "r"(Ru << 8)
+                        : "cc");
+#else
                     const uint64_t one = x < kTop ? 1 : 0, sh = one << 3;
                     p += one; low <<= sh; range <<= sh;
+#endif
                 } else {
+                    low = Lu; range = Ru;
                     while ((low ^ (low + range)) < kTop || (range < kBottom && ((range = (0 - low) & (kBottom - 1)), true))) {
                         *p++ = (uint8_t)(low >> 56); range <<= 8; low <<= 8;
                     }
