@@ -401,6 +401,82 @@ struct SpecCoder {
         range_ = s.R; low_ = s.L;
         w_ = (size_t)(s.p - buf_.data());
     }
+    // CARRY: the flag without the exclusive-or.  With everything shifted left by 8, "exactly one byte leaves" is "adding the range to the
+    // low end's low 56 bits does not carry": a8 = (L << 8) + q * (lo << 8) = (Lu << 8) mod 2^64, r8 = q * (fr << 8) = (Ru << 8) mod 2^64, and the
+    // carry of a8 + r8 is the flag -- multiply, add, add-with-carry, select: a 6-cycle path with no prediction.  A range of 2^56 or more
+    // (no byte can leave; r8 has lost its top bits) is known from the quotient alone -- q >= ceil(2^56 / fr), a threshold the records carry --
+    // and forces the carry by saturating r8.  Record: C, lo << 8, fr << 8, floor((2^56 - 1) / fr); quotient in rdx, unrolled by two.
+    struct CarryRec { uint64_t c, lo8, fr8, qmm; };
+#define CARRY_STEP(OFF, LIN, LOUT, LOUT32, EXIT)                                                                      \
+                "movq  %%rdx, %%r14\n\t"                       /* the step's quotient, kept for a rare exit */           \
+                "mulxq " OFF "(%[r]), %%rbx, %%rbx\n\t"        /* Phi */                                                 \
+                "movq  " OFF "+8(%[r]), %%r12\n\t"                                                                     \
+                "imulq %%rdx, %%r12\n\t"                       /* q * lo8 */                                             \
+                "movq  " OFF "+16(%[r]), %%r13\n\t"                                                                    \
+                "imulq %%rdx, %%r13\n\t"                       /* r8 = q * fr8 */                                        \
+                "movl  " OFF "+9(%[r]), " LOUT32 "\n\t"        /* lo = bytes 1..4 of lo8 */                              \
+                "imulq %%rdx, " LOUT "\n\t"                    /* q * lo */                                              \
+                "cmpq  %%rdx, " OFF "+24(%[r])\n\t"            /* CF = floor((2^56 - 1) / fr) < q: the range is 2^56 or more */ \
+                "sbbq  %%r15, %%r15\n\t"                                                                               \
+                "shlxq %[eight], %%rdx, %%rax\n\t"             /* q8 */                                                  \
+                "mulq  " OFF "(%[r])\n\t"                      /* rdx = Phi8, rax = the low half */                      \
+                "cmpq  %[dbt], %%rax\n\t"                                                                              \
+                "ja    " EXIT "\n\t"                                                                                   \
+                "shlxq %[eight], " LIN ", %%rax\n\t"           /* L << 8 */                                              \
+                "addq  %%rax, %%r12\n\t"                       /* a8 = (Lu << 8) mod 2^64 */                             \
+                "addq  " LIN ", " LOUT "\n\t"                  /* Lu */                                                  \
+                "orq   %%r15, %%r13\n\t"                       /* r8, saturated */                                       \
+                "cmpq  %[top], %%r13\n\t"                                                                              \
+                "jb    " EXIT "\n\t"                           /* range below 2^48 */                                    \
+                "rorxq $56, " LOUT ", %%r15\n\t"                                                                       \
+                "movb  %%r15b, (%[p])\n\t"                                                                             \
+                "stc\n\t"                                                                                              \
+                "adcq  %%r12, %%r13\n\t"                       /* CF = a byte boundary is crossed: NO byte leaves */     \
+                "cmovcq %%rbx, %%rdx\n\t"                      /* q' = f ? Phi8 : Phi, in rdx */                         \
+                "cmovncq %%r12, " LOUT "\n\t"                  /* L' = f ? Lu << 8 : Lu */                               \
+                "sbbq  $-1, %[p]\n\t"                          /* p += f */
+    void encode_records_carry(const CarryRec* r, const SpecRec* plain_recs, uint64_t n, uint64_t t0) {
+        if (!n) return;
+        if (buf_.size() < w_ + 8 * n + 64) buf_.resize(buf_.size() * 2 + 8 * n + 4096);
+        settle();
+        uint8_t* p = buf_.data() + w_;
+        uint64_t L = low_;
+        const CarryRec* const r0 = r;
+        uint64_t q = range_ / (5 + t0);
+        const CarryRec* const e = r + n - 1;
+        const CarryRec* const e2 = e - 1;
+        const uint64_t doubt_above = ~(uint64_t)((((unsigned __int128)1) << 72) / (5 + t0));
+        while (r < e) {
+            if (r < e2) {
+                asm volatile(
+                    ".p2align 5\n"
+                    "1:\n\t"
+                    CARRY_STEP("0", "%[L]", "%%rcx", "%%ecx", "2f")
+                    CARRY_STEP("32", "%%rcx", "%[L]", "%k[L]", "3f")
+                    "addq  $64, %[r]\n\t"
+                    "cmpq  %[e], %[r]\n\t"
+                    "jb    1b\n\t"
+                    "jmp   4f\n"
+                    "3:\n\t"
+                    "movq  %%rcx, %[L]\n\t"
+                    "addq  $32, %[r]\n"
+                    "2:\n\t"
+                    "movq  %%r14, %%rdx\n"
+                    "4:\n"
+                    : [r] "+r"(r), [q] "+d"(q), [L] "+r"(L), [p] "+r"(p)
+                    : [e] "m"(e2), [top] "r"(kTop), [dbt] "r"(doubt_above), [eight] "r"((uint64_t)8)
+                    : "rax", "rbx", "rcx", "r12", "r13", "r14", "r15", "cc", "memory");
+            }
+            if (r >= e) break;
+            const Plain s = step_plain(plain_recs + (r - r0), false, 5 + t0 + (uint64_t)(r - r0) + 1, q, L, 0, p);
+            q = s.q; L = s.L; p = s.p;
+            r++;
+        }
+        const Plain s = step_plain(plain_recs + (r - r0), false, 5 + t0 + n, q, L, 0, p);
+        slow--;
+        range_ = s.R; low_ = s.L;
+        w_ = (size_t)(s.p - buf_.data());
+    }
 };
 
 int main(int argc, char** argv) {
@@ -430,6 +506,9 @@ int main(int argc, char** argv) {
         c[sy]++;
     }
     srecs[n * k] = SpecRec{0, 0, 0, 0, 0};
+    std::vector<SpecCoder::CarryRec> crecs(srecs.size());
+    for (size_t i = 0; i < srecs.size(); i++)
+        crecs[i] = SpecCoder::CarryRec{srecs[i].c, (uint64_t)srecs[i].lo << 8, (uint64_t)srecs[i].fr << 8, srecs[i].fr ? ((1ull << 56) - 1) / srecs[i].fr : 0};
     std::vector<SpecRec> lrecs(srecs);                              // the lean variant's records: {C, lo, lf = lo + fr, -, -} in the same 24 bytes
     for (auto& x : lrecs) x.g1 = x.lo + x.fr;
     const size_t plain = 20;
@@ -445,8 +524,8 @@ int main(int argc, char** argv) {
         ref.assign(cd.data(), cd.data() + cd.size());
         printf("AS IT STANDS, records from DRAM: %.3f ns/symbol, %zu bytes\n", dt / ((n - plain) * (double)k) * 1e9, cd.size());
     }
-    for (int rep = 0; rep < 12; rep++) {
-        const bool use_asm = rep >= 2 && rep < 4, use_lean = rep >= 4 && rep < 6, use_lean2 = rep >= 6 && rep < 8, use_lean2x2 = rep >= 8 && rep < 10, use_nomov = rep >= 10;
+    for (int rep = 0; rep < 14; rep++) {
+        const bool use_asm = rep >= 2 && rep < 4, use_lean = rep >= 4 && rep < 6, use_lean2 = rep >= 6 && rep < 8, use_lean2x2 = rep >= 8 && rep < 10, use_nomov = rep >= 10 && rep < 12, use_carry = rep >= 12;
         AnchorDictCoder head;
         head.encode_kmers(km.data(), plain, k);
         SpecCoder sc;
@@ -456,7 +535,8 @@ int main(int argc, char** argv) {
         auto t0 = std::chrono::steady_clock::now();
         for (uint64_t at = plain * k, end = n * k; at < end;) {         // segments of ~32 k symbols, as the library's feed hands them over
             const uint64_t m = std::min<uint64_t>(32767, end - at);
-            if (use_nomov) sc.encode_records_nomov(lrecs.data() + at, m, at);
+            if (use_carry) sc.encode_records_carry(crecs.data() + at, srecs.data() + at, m, at);
+            else if (use_nomov) sc.encode_records_nomov(lrecs.data() + at, m, at);
             else if (use_lean2 || use_lean2x2) sc.encode_records_lean2(lrecs.data() + at, m, at, use_lean2x2);
             else if (use_lean) sc.encode_records_lean(lrecs.data() + at, m, at);
             else if (use_asm) sc.encode_records_asm(srecs.data() + at, m, at); else sc.encode_records(srecs.data() + at, m, at);
@@ -466,7 +546,7 @@ int main(int argc, char** argv) {
         sc.flush();
         const bool same = sc.w_ == ref.size() && memcmp(sc.buf_.data(), ref.data(), ref.size()) == 0;
         printf("PREDICTED FLAG%s, records from DRAM: %.3f ns/symbol, %zu bytes, %s; mispredicted %llu, slow path %llu, in doubt %llu of %zu symbols\n",
-               use_nomov ? " -- none: NO-MOV x2 (asm)" : use_lean2x2 ? " -- none: LEAN2 x2 (asm)" : use_lean2 ? " -- none: LEAN2 (asm)" : use_lean ? " -- none: LEAN (asm)" : use_asm ? " (asm)" : "", dt / ((n - plain) * (double)k) * 1e9, sc.w_, same ? "IDENTICAL" : "DIFFERENT", (unsigned long long)sc.mispredicted,
+               use_carry ? " -- none: CARRY x2 (asm)" : use_nomov ? " -- none: NO-MOV x2 (asm)" : use_lean2x2 ? " -- none: LEAN2 x2 (asm)" : use_lean2 ? " -- none: LEAN2 (asm)" : use_lean ? " -- none: LEAN (asm)" : use_asm ? " (asm)" : "", dt / ((n - plain) * (double)k) * 1e9, sc.w_, same ? "IDENTICAL" : "DIFFERENT", (unsigned long long)sc.mispredicted,
                (unsigned long long)sc.slow, (unsigned long long)sc.doubt, (n - plain) * (size_t)k);
         if (!same) return 1;
     }
@@ -510,15 +590,15 @@ int main(int argc, char** argv) {
             double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             printf("NO PREDICTION, LEAN (asm), records in cache: %.3f ns/symbol (plain steps %llu of %zu)\n", dt / (300.0 * m) * 1e9, (unsigned long long)sc.slow, (size_t)300 * m);
         }
-        for (int u = 0; u < 3; u++) {
+        for (int u = 0; u < 4; u++) {
             AnchorDictCoder head;
             head.encode_kmers(km.data(), 20, k);
             SpecCoder sc;
             sc.buf_.resize(1 << 20); sc.low_ = head.low_; sc.range_ = head.range_;
             auto t0 = std::chrono::steady_clock::now();
-            for (int i = 0; i < 300; i++) { sc.w_ = 0; if (u == 2) sc.encode_records_nomov(lrecs.data() + start, m, start); else sc.encode_records_lean2(lrecs.data() + start, m, start, u == 1); }
+            for (int i = 0; i < 300; i++) { sc.w_ = 0; if (u == 3) sc.encode_records_carry(crecs.data() + start, srecs.data() + start, m, start); else if (u == 2) sc.encode_records_nomov(lrecs.data() + start, m, start); else sc.encode_records_lean2(lrecs.data() + start, m, start, u == 1); }
             double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            printf("NO PREDICTION, %s%s (asm), records in cache: %.3f ns/symbol (plain steps %llu of %zu)\n", u == 2 ? "NO-MOV" : "LEAN2", u ? " x2" : "", dt / (300.0 * m) * 1e9, (unsigned long long)sc.slow, (size_t)300 * m);
+            printf("NO PREDICTION, %s%s (asm), records in cache: %.3f ns/symbol (plain steps %llu of %zu)\n", u == 3 ? "CARRY" : u == 2 ? "NO-MOV" : "LEAN2", u ? " x2" : "", dt / (300.0 * m) * 1e9, (unsigned long long)sc.slow, (size_t)300 * m);
         }
     }
     return 0;
