@@ -280,6 +280,8 @@ def main():
             ctx.set_exchange(capi.XCH_EMULATE)
         else:
             ctx.set_exchange(capi.XCH_BY_ANCHOR, make_exchange(dist, device, backend, pg_rank, pg_world, capi))
+            if os.environ.get("LEON_XCH_LOOKUPS", "1") != "0":     # the resolution's window look-ups divided among the ranks as well
+                ctx.set_gather(make_gather(dist, device, backend, pg_rank, pg_world, capi))
     ctx.reserve(B, B * L)                      # what a host does while it parses: the first step then allocates nothing large
     nbytes = ctx.bloom_nbytes
     bcast_ms = 0.0
@@ -316,7 +318,7 @@ def main():
         payload[1] += 1
         return 0
     cb = capi.SINK(sink)
-    STAGES = ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder", "ms_d2h", "ms_total", "ms_exchange", "ms_exchange_call", "ms_emulated")
+    STAGES = ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder", "ms_d2h", "ms_total", "ms_exchange", "ms_exchange_call", "ms_emulated", "ms_emulated_lookups")
     COUNTS = ("n_symbols", "resolve_rounds", "resolve_windows", "walk_launches", "xch_words_sent", "xch_words_received", "walk_reads")
 
     def encode_stream(the_sink):
@@ -621,6 +623,29 @@ def make_exchange(dist, device, backend, pg_rank, pg_world, capi):
             torch.cuda.synchronize()
         keep["recv"] = recv                                          # stays alive until the next exchange
         return recv.data_ptr(), sum(recv_counts)
+    return fn
+
+
+def make_gather(dist, device, backend, pg_rank, pg_world, capi):
+    """the all-gather of leon_dna_set_gather: every rank's part of a device buffer (part r at d_buf + r * part_bytes) to every rank --
+    RCCL's all_gather_into_tensor between GPUs; over gloo (rehearsals on one device) through host memory"""
+    def fn(d_buf, part_bytes, world):
+        assert world == pg_world
+        words = part_bytes // 8
+        mine = torch.empty(max(words, 1), dtype=torch.int64, device=device)
+        if words:
+            capi.device_copy(mine.data_ptr(), d_buf + pg_rank * part_bytes, part_bytes, device_id=device.index or 0)
+        if backend == "nccl":
+            everybody = torch.empty(max(words, 1) * pg_world, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(everybody, mine)
+            torch.cuda.synchronize()
+        else:
+            parts = [torch.empty(max(words, 1), dtype=torch.int64) for _ in range(pg_world)]
+            dist.all_gather(parts, mine.cpu())
+            everybody = torch.cat(parts).to(device)
+            torch.cuda.synchronize()
+        if words:
+            capi.device_copy(d_buf, everybody.data_ptr(), part_bytes * pg_world, device_id=device.index or 0)    # (complete on return)
     return fn
 
 

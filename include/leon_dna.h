@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LEON_DNA_ABI_VERSION 3
+#define LEON_DNA_ABI_VERSION 4
 
 enum {
     LEON_OK = 0,
@@ -52,7 +52,7 @@ typedef struct leon_dna_cfg {
     int32_t  device_id;          /* HIP device ordinal */
     uint64_t bloom_tai;          /* tai_bloom as handed to BloomNeighborCoherent (bits, before its padding) */
     const uint64_t* random_values; /* optional 256-entry simplehash16 table; NULL = built-in */
-    uint64_t resolve_window;     /* reads per anchor-resolution window; 0 = default (1<<20) */
+    uint64_t resolve_window;     /* reads per anchor-resolution window; 0 = default (1<<21) */
     uint32_t flags;              /* LEON_F_* */
     uint32_t reserved;
 } leon_dna_cfg;
@@ -76,7 +76,7 @@ typedef struct leon_dna_stats {
     /* the walk divided by anchor (leon_dna_set_exchange), last batch: ms_walk above is then this rank's SLICE; ms_exchange = forming the
        words + the caller's exchange + scattering what came back (host wall-clock, the call waits for the device around it);
        ms_emulated = LEON_XCH_EMULATE only: the other ranks' slices walked here in their stead (not part of a real rank's time) */
-    float ms_exchange, ms_exchange_call, ms_emulated, reserved2;
+    float ms_exchange, ms_exchange_call, ms_emulated, ms_emulated_lookups;   /* ms_emulated_lookups: the part of ms_emulated (and of ms_resolve) spent on the other ranks' window look-ups */
     uint64_t xch_words_sent, xch_words_received, walk_reads;
 } leon_dna_stats;
 
@@ -143,6 +143,18 @@ typedef int (*leon_exchange_fn)(void* user, const uint64_t* d_send, const uint64
                                 const uint64_t** d_recv, uint64_t* recv_total);
 int leon_dna_set_exchange(leon_dna_ctx* ctx, uint32_t mode, leon_exchange_fn fn, void* user);
 
+/* The anchor resolution's look-ups (a good half of the stage every rank otherwise repeats for ALL reads) divided among the ranks as
+ * well: of every resolution window rank r looks up the r-th run of ceil(window / world) reads, and ONE all-gather per window --
+ * again the caller's -- tells every rank what every read's pass found: `fn` is called on the calling thread with a device buffer of
+ * world * part_bytes bytes whose part r (at d_buf + r * part_bytes) this rank has filled for r == its own rank, and must return with
+ * every part filled by its rank (ncclAllGather / all_gather_into_tensor, in place or through a copy).  Each rank then makes the
+ * other runs' results its own (the found key's slot, the proposals' entries in its dictionary), so the dictionaries stay identical.
+ * Takes effect with LEON_XCH_BY_ANCHOR and world > 1; LEON_XCH_EMULATE computes the other ranks' runs itself
+ * (stats.ms_emulated_lookups).  ~50 calls per 100 M reads, 16 MB each at the default window.  fn == NULL: every rank looks
+ * everything up (the default).  Must precede the first batch of a stream.  Non-zero return of fn = the batch fails. */
+typedef int (*leon_gather_fn)(void* user, void* d_buf, uint64_t part_bytes, uint32_t world);
+int leon_dna_set_gather(leon_dna_ctx* ctx, leon_gather_fn fn, void* user);
+
 /* Leon::endDnaCompression: flush the anchor-dictionary range coder (Leon::encodeInsertedAnchor stream).
  * payload stays owned by ctx until destroy. */
 int leon_dna_finish(leon_dna_ctx* ctx, const uint8_t** dict_payload, uint64_t* dict_size, uint64_t* n_anchors);
@@ -171,7 +183,7 @@ int leon_kmer_auto_cutoff(const uint64_t* histogram, uint32_t* cutoff);
 int leon_device_count(int* n_devices);
 int leon_device_alloc(int device_id, uint64_t bytes, void** d_ptr);
 int leon_device_upload(int device_id, void* d_dst, const void* src, uint64_t bytes);
-int leon_device_copy(int device_id, void* d_dst, const void* d_src, uint64_t bytes);
+int leon_device_copy(int device_id, void* d_dst, const void* d_src, uint64_t bytes);   /* device to device; complete on return */
 int leon_device_download(int device_id, void* dst, const void* d_src, uint64_t bytes);
 
 /* Host-only helper (no GPU, no ctx): the dictionary stream leon_dna_finish returns for a given anchor list, i.e.

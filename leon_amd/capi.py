@@ -34,7 +34,7 @@ class Stats(C.Structure):
                                          "ms_d2h", "ms_total")] + \
                [("walk_launches", C.c_uint32), ("reserved", C.c_uint32), ("ms_anchor_wait", C.c_float),
                 ("ms_chain_busy", C.c_float)] + \
-               [(n, C.c_float) for n in ("ms_exchange", "ms_exchange_call", "ms_emulated", "reserved2")] + \
+               [(n, C.c_float) for n in ("ms_exchange", "ms_exchange_call", "ms_emulated", "ms_emulated_lookups")] + \
                [(n, C.c_uint64) for n in ("xch_words_sent", "xch_words_received", "walk_reads")]
 
     def as_dict(self):
@@ -45,6 +45,8 @@ SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8), C.c_ui
 # leon_exchange_fn: (user, d_send, send_counts[world], world, &d_recv, &recv_total) -> 0 on success
 EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64))
 XCH_OFF, XCH_BY_ANCHOR, XCH_EMULATE = 0, 1, 2
+# leon_gather_fn: (user, d_buf, part_bytes, world) -> 0 on success
+GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32)
 
 _u8p, _u32p, _i32p, _u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_int32, C.c_uint64))
 
@@ -78,6 +80,7 @@ _EXPORTS = {
     "leon_header_symbols_free": (None, [C.c_void_p]),
     "leon_dna_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "leon_dna_set_exchange": (C.c_int, [C.c_void_p, C.c_uint32, EXCHANGE, C.c_void_p]),
+    "leon_dna_set_gather": (C.c_int, [C.c_void_p, GATHER, C.c_void_p]),
     "leon_dna_debug_walk_order": (C.c_int, [C.c_void_p, C.c_void_p]),
     "leon_kmer_solid_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                           C.POINTER(C.c_void_p), _u64p, _u64p]),
@@ -578,6 +581,22 @@ class DnaEncodeContext:
                     return 1
             self._xch_cb = EXCHANGE(thunk)
         self._chk(self.lib.leon_dna_set_exchange(self.h, mode, self._xch_cb, None))
+
+    def set_gather(self, fn=None):
+        """the window look-ups of the anchor resolution divided among the ranks too: `fn(d_buf, part_bytes, world)` all-gathers the
+        device buffer in place (part r at d_buf + r * part_bytes, this rank's part filled on entry)"""
+        if fn is None:
+            self._gather_cb = C.cast(None, GATHER)
+        else:
+            def thunk(user, d_buf, part_bytes, world):
+                try:
+                    fn(int(d_buf or 0), int(part_bytes), int(world))
+                    return 0
+                except Exception as e:                 # noqa: BLE001 -- nothing may cross the C boundary
+                    self._xch_error = e
+                    return 1
+            self._gather_cb = GATHER(thunk)
+        self._chk(self.lib.leon_dna_set_gather(self.h, self._gather_cb, None))
 
     def reset_stream(self):
         self._hdr_next = 0

@@ -122,7 +122,8 @@ struct leon_dna_ctx {
     uint32_t shard_rank = 0, shard_world = 1;    // leon_dna_set_shard
     uint32_t xch_mode = LEON_XCH_OFF;            // leon_dna_set_exchange: how the walk is divided among the ranks
     leon_exchange_fn xch_fn = nullptr; void* xch_user = nullptr;
-    DevBuf xch_slot, xch_off, xch_evoff, xch_events, xch_send, xch_split;
+    leon_gather_fn gather_fn = nullptr; void* gather_user = nullptr;   // leon_dna_set_gather: the look-ups of a window divided as well
+    DevBuf xch_slot, xch_off, xch_evoff, xch_events, xch_send, xch_split, xch_res;
     DevBuf resolve_trace;
     DevBuf round_hist;                           // the counts of a window's fixpoint rounds, read back together
     // small launches: the blocks' chains on host cores (host_blocks.h), fed by the device's modelers chunk by chunk
@@ -137,7 +138,7 @@ struct leon_dna_ctx {
     bool hdr_partial_seen = false;
     DevBuf hdr_first;
     const uint64_t* walk_keys = nullptr;         // leon_dna_debug_walk_order: the next batch's walk order (measurement hook)
-    uint32_t fbits_log2 = FBITS_LOG2;
+    uint32_t fbits_log2 = FBITS_LOG2_DEFAULT;
     bool poisoned = false;                       // a batch failed after it had started to change the stream: LEON_E_STATE until reset_stream
     // batch buffers
     DevBuf in_bases, in_off, slot_off, packed, nmask, rlen, ncount;
@@ -193,7 +194,8 @@ int dict_alloc(leon_dna_ctx* c, DictDev& D, uint64_t cap) {
     D.wbits = c->wbits.as<uint32_t>();
     D.fbits = c->fbits.as<uint32_t>();
     D.pbits = c->pbits.as<uint32_t>();
-    D.fshift = 64 - c->fbits_log2;
+    D.fwshift = 32 - (c->fbits_log2 - 6);
+    minimizer_geometry(c->cfg.kmer_size, D.mm_m, D.mm_P, D.mm_c);
     D.err = c->errflag.as<int>() + 2;
     launch_dict_init(c->stream, D, cap, W);
     return LEON_OK;
@@ -424,7 +426,7 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     leon_dna_ctx* c = new leon_dna_ctx();
     c->cfg = *cfg;
     c->cfg.random_values = nullptr;
-    if (c->cfg.resolve_window == 0) c->cfg.resolve_window = 1ull << 20;
+    if (c->cfg.resolve_window == 0) c->cfg.resolve_window = 1ull << 21;     // (2^20 until the look-ups got cheaper: 174 -> 168 ms per 100 M reads, profiles/r4_minimizer_filter.txt)
     c->device = cfg->device_id;
 #define CREATE_CHK(call)                                                                                         \
     do {                                                                                                         \
@@ -463,7 +465,7 @@ int leon_dna_ctx_create(const leon_dna_cfg* cfg, leon_dna_ctx** out) {
     CREATE_CHK(c->pbits.ensure((1ull << WBITS_LOG2) / 8));
     if (const char* e = getenv("LEON_FBITS_LOG2")) {          // measurement override: size of the final-key filter
         const int v = atoi(e);
-        if (v >= 16 && v <= (int)FBITS_LOG2_MAX) c->fbits_log2 = (uint32_t)v;
+        if (v >= 12 && v <= (int)FBITS_LOG2_MAX) c->fbits_log2 = (uint32_t)v;
     }
     CREATE_CHK(c->fbits.ensure((1ull << c->fbits_log2) / 8));
     CREATE_CHK(hipMemsetAsync(c->fbits.p, 0, (1ull << c->fbits_log2) / 8, c->stream));
@@ -485,7 +487,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
                        &c->flags, &c->sort_key, &c->ins_flag, &c->rank, &c->ulist0, &c->ulist1, &c->counters, &c->cub_tmp,
                        &c->sort_key2, &c->perm, &c->perm2, &c->events, &c->prev, &c->sym_off, &c->syms, &c->blk_begin,
                        &c->out_off, &c->out_size, &c->rc_out, &c->rc_scratch, &c->dst_off, &c->payload, &c->errflag, &c->nerr, &c->wbits, &c->fbits, &c->pbits, &c->hdr_first, &c->dc_cache, &c->dc_out, &c->dc_pay, &c->dc_len, &c->dc_pool, &c->dc_scr,
-                       &c->xch_slot, &c->xch_off, &c->xch_evoff, &c->xch_events, &c->xch_send, &c->xch_split, &c->round_hist, &c->resolve_trace, &c->hb_recs[0], &c->hb_recs[1], &c->hb_recoff, &c->hb_state };
+                       &c->xch_slot, &c->xch_off, &c->xch_evoff, &c->xch_events, &c->xch_send, &c->xch_split, &c->xch_res, &c->round_hist, &c->resolve_trace, &c->hb_recs[0], &c->hb_recs[1], &c->hb_recoff, &c->hb_state };
     for (DevBuf* b : bufs) b->release();
     if (c->d_bloom) (void)hipFree(c->d_bloom);
     if (c->d_rv16) (void)hipFree(c->d_rv16);
@@ -627,7 +629,7 @@ static uint64_t group_end(uint64_t a, uint64_t n, uint64_t window, bool /*stream
     if (a == 0) return std::min(n, first_window(window));
     // (resident input used to pack everything that was left in one go: 9.6 ms at 100 M reads between the first window and the
     // second, during which the dictionary chain ran out of the first window's anchors and idled)
-    return std::min(n, a + 8 * window);
+    return std::min(n, a + 8 * std::min<uint64_t>(window, 1ull << 20));
 }
 
 static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint64_t* d_off, uint64_t n,
@@ -763,6 +765,11 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     static const bool trace_resolve = getenv("LEON_TRACE_RESOLVE") != nullptr;
     unsigned long long* d_trace = nullptr;
     if (trace_resolve) { HIPCHK(c, c->resolve_trace.ensure(12 * 8)); d_trace = c->resolve_trace.as<unsigned long long>(); HIPCHK(c, hipMemsetAsync(d_trace, 0, 12 * 8, s)); }
+    // the look-ups shared out among the ranks of a job (leon_dna_set_gather; LEON_XCH_EMULATE plays the other ranks.  LEON_XCH_LOOKUPS=0: off, a measurement aid)
+    static const bool lookups_env_off = [] { const char* e = getenv("LEON_XCH_LOOKUPS"); return e && atoi(e) == 0; }();
+    const uint32_t Wn = c->shard_world;
+    const bool share_lookups = Wn > 1 && !lookups_env_off && ((c->xch_mode == LEON_XCH_BY_ANCHOR && c->gather_fn) || c->xch_mode == LEON_XCH_EMULATE);
+    float lk_call_ms = 0, lk_emul_ms = 0;
     int anchor_buf = 0;
     uint32_t hint = (uint32_t)std::min<uint64_t>(W, 1u << 20);      // grid-size hint of a window's first round (any size is correct: grid-stride loops)
     for (uint64_t w0 = 0, w1 = 0; w0 < n; w0 = w1) {
@@ -771,7 +778,36 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         HIPCHK(c, hipMemsetAsync(counters, 0, 8, s));
         HIPCHK(c, hipMemsetAsync(c->wbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
         HIPCHK(c, hipMemsetAsync(c->pbits.p, 0, (1ull << WBITS_LOG2) / 8, s));
-        launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters, d_trace);
+        if (!share_lookups) launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, w0, w1, first_read_index, lists[0], counters, d_trace);
+        else {
+            // The window's look-ups divided among the ranks (leon_dna_set_gather): rank r takes the r-th run of P reads, everybody
+            // learns what everybody found from ONE all-gather of a word per read -- the caller's -- and makes the other runs' results
+            // its own (k_lookup_apply): every rank's dictionary goes on holding every proposal, as if it had looked everything up.
+            const uint64_t P = (w1 - w0 + Wn - 1) / Wn;
+            auto run_of = [&](uint32_t r, uint64_t& a, uint64_t& b) { a = std::min(w1, w0 + (uint64_t)r * P); b = std::min(w1, a + P); };
+            HIPCHK(c, c->xch_res.ensure((uint64_t)Wn * P * 8));
+            uint64_t* xres = c->xch_res.as<uint64_t>();
+            uint64_t s0 = 0, s1 = 0;
+            run_of(c->shard_rank, s0, s1);
+            launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, s0, s1, first_read_index, lists[0], counters, d_trace, xres, w0, false);
+            HIPCHK(c, hipStreamSynchronize(s));
+            const auto t_l0 = std::chrono::steady_clock::now();
+            if (c->xch_mode == LEON_XCH_BY_ANCHOR) {
+                if (c->gather_fn(c->gather_user, xres, P * 8, Wn)) return fail(c, LEON_E_STATE, "the gather callback returned non-zero");
+                HIPCHK(c, hipSetDevice(c->device));               // (the callback may have changed the thread's device)
+                lk_call_ms += (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
+            } else {                                              // no other rank present: their runs computed here, leaving nothing but their words
+                for (uint32_t r = 0; r < Wn; r++) {
+                    if (r == c->shard_rank) continue;
+                    uint64_t a = 0, b = 0;
+                    run_of(r, a, b);
+                    launch_lookup_cand(s, R, c->B, c->d_rv16, c->D, V, a, b, first_read_index, lists[0], counters, nullptr, xres, w0, true);
+                }
+                HIPCHK(c, hipStreamSynchronize(s));
+                lk_emul_ms += (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
+            }
+            launch_lookup_apply(s, R, c->D, V, w0, w1, s0, s1, first_read_index, xres, lists[0], counters);
+        }
         HIPCHK(c, hipMemcpyAsync(d_hist, counters, 4, hipMemcpyDeviceToDevice, s));         // hist[0]: the window's unresolved reads
         int cur = 0;
         uint32_t n_hist = 1, cnt = 0, cnt0 = 0;
@@ -793,6 +829,8 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             if (first_wait) { hand_over(); first_wait = false; }
             if ((int)(uint32_t)c->h_rb[1]) {
                 HIPCHK(c, hipMemsetAsync(c->D.err, 0, 4, s));
+                if ((int)(uint32_t)c->h_rb[1] == 2)
+                    return fail(c, LEON_E_STATE, "the look-ups gathered from the other ranks do not fit this rank's reads or dictionary (were all ranks fed the same batches?)");
                 return fail(c, LEON_E_STATE, "anchor dictionary: a two-word key stayed half-written (a stalled wave); batch abandoned");
             }
             const uint32_t* hist = reinterpret_cast<const uint32_t*>(c->h_rb + 8);
@@ -841,7 +879,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             c->n_anchors += n_new;
         }
         launch_finalize_reads(s, R, c->D, V, w0, w1);
-        if (w1 < n && packed_upto < std::min(n, w1 + W)) { if (int rc = pack_group()) return rc; }   // the next window's reads
+        while (w1 < n && packed_upto < std::min(n, w1 + W)) { if (int rc = pack_group()) return rc; }   // the next window's reads
         c->stats.resolve_windows++;
     }
     if (pending.buf >= 0) { HIPCHK(c, spin_sync(s)); hand_over(); }
@@ -1011,6 +1049,9 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             HIPCHK(c, hipStreamSynchronize(s));
             c->stats.ms_emulated = since(t_e0);
         }
+        // (the window look-ups shared out among the ranks, earlier in this call: their gathers and, emulated, the other ranks' runs)
+        c->stats.ms_exchange_call += lk_call_ms; c->stats.ms_exchange += lk_call_ms;
+        c->stats.ms_emulated += lk_emul_ms; c->stats.ms_emulated_lookups = lk_emul_ms;
         HIPCHK(c, hipEventRecord(c->ev[9], s));                  // the symbols stage begins here
         int xerr = 0;
         HIPCHK(c, hipMemcpy(&xerr, c->errflag.as<int>() + 1, 4, hipMemcpyDeviceToHost));
@@ -1529,6 +1570,13 @@ int leon_dna_set_exchange(leon_dna_ctx* c, uint32_t mode, leon_exchange_fn fn, v
     if (mode == LEON_XCH_BY_ANCHOR && !fn) return fail(c, LEON_E_INVALID, "set_exchange: LEON_XCH_BY_ANCHOR needs the exchange callback");
     if (c->next_read) return fail(c, LEON_E_STATE, "set_exchange must precede the first batch of a stream");
     c->xch_mode = mode; c->xch_fn = fn; c->xch_user = user;
+    return LEON_OK;
+}
+
+int leon_dna_set_gather(leon_dna_ctx* c, leon_gather_fn fn, void* user) {
+    if (!c) return LEON_E_INVALID;
+    if (c->next_read) return fail(c, LEON_E_STATE, "set_gather must precede the first batch of a stream");
+    c->gather_fn = fn; c->gather_user = user;
     return LEON_OK;
 }
 

@@ -185,8 +185,56 @@ __device__ inline uint32_t dict_find(const DictDev& D, u128 key, uint64_t& fin) 
         slot = (slot + 1) & D.mask;
     }
 }
-template <typename K> __device__ inline uint32_t window_bit(K key) { return (uint32_t)(key_hash(key) >> (64 - WBITS_LOG2)); }
-template <typename K> __device__ inline uint32_t final_bit(const DictDev& D, K key) { return (uint32_t)(key_hash(key) >> D.fshift); }
+// (the bit of a key in the per-window filters: one 32-bit multiply, where key_hash -- the dictionary's, two 64-bit multiplies per k-mer
+// of every read that k_check and k_final_pos look at -- was a good part of those kernels' instructions)
+__device__ inline uint32_t fold32(uint64_t x) { return (uint32_t)x ^ (uint32_t)(x >> 32); }
+__device__ inline uint32_t fold32(u128 x) { return fold32((uint64_t)x) ^ (fold32((uint64_t)(x >> 64)) * 0x85EBCA6Bu); }
+template <typename K> __device__ inline uint32_t window_bit(K key) { return ((fold32(key) ^ 0x5bd1e995u) * 0xCC9E2D51u) >> (32 - WBITS_LOG2); }
+// ---- the final keys' filter (DictDev::fbits, kernels.h minimizer_geometry) ----
+// Look-ups of it were most of the resolution's memory traffic when a key's bit sat at a place of the key's own hash: ~50 k-mers of
+// every read, each in another 64-byte sector of a table that no L2 keeps beside the dictionary's probes.  A key's WORD is now chosen by
+// its minimizer, which ~P/2 consecutive k-mers of a read share, and only the two bits inside the word by the key's hash: the lanes
+// of a step ask for two or three words between them, and the next step mostly for the same ones.
+__device__ inline uint32_t mmer_hash(uint32_t x, uint32_t m) {          // x: an m-mer, right-aligned; the hash of its canonical form
+    const uint32_t y = rev2bit32(x) >> (32 - 2 * m);
+    const uint32_t h = (y < x ? y : x) * 0x9E3779B1u;
+    return h ^ (h >> 15);
+}
+template <typename K> __device__ inline uint32_t mmer_of(K km, uint32_t k, uint32_t m, uint32_t t) {    // the m-mer at offset t of a k-mer
+    const uint32_t x = (uint32_t)(km >> (2 * (k - m - t)));
+    return m == 16 ? x : x & ((1u << (2 * m)) - 1u);
+}
+__device__ inline uint32_t filter_word(const DictDev& D, uint32_t hmin) { return (hmin * 0x85EBCA6Bu) >> D.fwshift; }
+// (a hash of its own, one 32-bit multiply: the dictionary's key_hash -- two 64-bit multiplies -- is now only formed behind a "maybe")
+template <typename K> __device__ inline uint64_t filter_bits(K key) {
+    const uint32_t h = fold32(key) * 0x9E3779B1u;
+    return (1ull << (h >> 26)) | (1ull << ((h >> 20) & 63u));
+}
+// the minimizer of ONE key, by a whole wave: lane t < P takes the m-mer at offset c + t (every lane returns the minimum of lanes 0..31)
+template <typename K> __device__ inline uint32_t key_minimizer_wave(const DictDev& D, K key, uint32_t k, uint32_t lane) {
+    uint32_t h = 0xFFFFFFFFu;
+    if (lane < D.mm_P) h = mmer_hash(mmer_of(key, k, D.mm_m, D.mm_c + lane), D.mm_m);
+    for (int d = 1; d < 32; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)h, d); h = o < h ? o : h; }
+    return h;
+}
+// Sliding minima along a read, 16 positions (one per lane of a quarter-wave = a DPP row) per step: level j of a position is the
+// minimum over the 2^j positions ending there; what lies before the row's first lane comes from the step before (`prev`).
+struct MinLevels { uint32_t L0, L1, L2, L3, L4; };
+#define LEON_ROW_SHR(x, n) ((uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(x), 0x110 + (n), 0xF, 0xF, false))   /* lane l <- lane l - n */
+#define LEON_ROW_SHL(x, n) ((uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(x), 0x100 + (n), 0xF, 0xF, false))   /* lane l <- lane l + n */
+__device__ inline uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t t = a < b ? a : b; return t < c ? t : c; }
+__device__ inline MinLevels sliding_levels(uint32_t L0, const MinLevels& prev) {
+    MinLevels c;
+    c.L0 = L0;
+    c.L1 = umin3(c.L0, LEON_ROW_SHR(c.L0, 1), LEON_ROW_SHL(prev.L0, 15));
+    c.L2 = umin3(c.L1, LEON_ROW_SHR(c.L1, 2), LEON_ROW_SHL(prev.L1, 14));
+    c.L3 = umin3(c.L2, LEON_ROW_SHR(c.L2, 4), LEON_ROW_SHL(prev.L2, 12));
+    c.L4 = umin3(c.L3, LEON_ROW_SHR(c.L3, 8), LEON_ROW_SHL(prev.L3, 8));
+    return c;
+}
+__device__ inline uint32_t window_minimum(const MinLevels& c, const MinLevels& prev, uint32_t P) {
+    return P == 32 ? (c.L4 < prev.L4 ? c.L4 : prev.L4) : P == 16 ? c.L4 : P == 8 ? c.L3 : P == 4 ? c.L2 : P == 2 ? c.L1 : c.L0;
+}
 // (`created` is set when the key was not there: the caller counts new keys, one atomic per wave where it matters)
 // ---- find or insert.  SPIN = true: called by ONE lane per wave (a lane may wait for another wave's insert to
 // complete); SPIN = false: the keys being inserted are all distinct (rehash), a locked slot is someone else's.
@@ -283,19 +331,19 @@ template <typename K> __device__ inline K canon_at(const uint32_t* pk, uint32_t 
 }
 
 // 16-lane variant of canon_from_words: lanes gbase .. gbase+7 of each quarter-wave hold the dwords of that quarter's read
-template <typename K> __device__ inline K canon_from_words16(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k);
-template <> __device__ inline uint64_t canon_from_words16<uint64_t>(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k) {
+template <typename K> __device__ inline K fwd_from_words16(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k);
+template <> __device__ inline uint64_t fwd_from_words16<uint64_t>(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k) {
     const int d = (int)(gbase + (p >> 4) - (base >> 4));
-    const uint64_t km = kmer_from3((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1),
-                                   (uint32_t)__shfl((int)words, d + 2), p & 15, k);
-    const uint64_t rc = revcomp(km, k);
-    return rc < km ? rc : km;
+    return kmer_from3((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1), (uint32_t)__shfl((int)words, d + 2), p & 15, k);
 }
-template <> __device__ inline u128 canon_from_words16<u128>(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k) {
+template <> __device__ inline u128 fwd_from_words16<u128>(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k) {
     const int d = (int)(gbase + (p >> 4) - (base >> 4));             // p - base < 16: d - gbase <= 1, d + 4 - gbase <= 5 < 8
-    const u128 km = kmer_from5((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1), (uint32_t)__shfl((int)words, d + 2),
-                               (uint32_t)__shfl((int)words, d + 3), (uint32_t)__shfl((int)words, d + 4), p & 15, k);
-    const u128 rc = revcomp(km, k);
+    return kmer_from5((uint32_t)__shfl((int)words, d), (uint32_t)__shfl((int)words, d + 1), (uint32_t)__shfl((int)words, d + 2),
+                      (uint32_t)__shfl((int)words, d + 3), (uint32_t)__shfl((int)words, d + 4), p & 15, k);
+}
+template <typename K> __device__ inline K canon_from_words16(uint32_t words, uint32_t gbase, uint32_t base, uint32_t p, uint32_t k) {
+    const K km = fwd_from_words16<K>(words, gbase, base, p, k);
+    const K rc = revcomp(km, k);
     return rc < km ? rc : km;
 }
 
@@ -309,7 +357,11 @@ template <> __device__ inline u128 canon_from_words16<u128>(uint32_t words, uint
 template <typename K, bool TRACE>
 __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, const uint16_t* rv16g, DictDev D, ResolveDev V,
                                                     uint64_t w0, uint64_t w1, uint64_t first_global,
-                                                    uint32_t* ulist, uint32_t* ucount, unsigned long long* trace) {
+                                                    uint32_t* ulist, uint32_t* ucount, unsigned long long* trace,
+                                                    uint64_t* xres, uint64_t xbase, uint32_t dry) {
+    // xres (the look-ups of a window divided among the ranks of a job, leon_dna_set_gather): what the pass found for read i, as
+    // (position << 8) | status at xres[i - xbase], for the ranks that did not look this read up; dry: ONLY that -- no status, no
+    // proposal, no list entry (LEON_XCH_EMULATE: another rank's share, computed here in its stead)
     __shared__ uint16_t rv16[256];
     load_rv16(rv16, rv16g);
     const uint32_t lane = lane_id(), k = R.k;
@@ -344,6 +396,9 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
     uint32_t len = 0, nk = 0, iMin = 0, iMax = 0, phase = PH_DONE, base = 0, limit = 0;
     uint64_t g = 0;
     const uint32_t* pk = R.packed;
+    const uint32_t mm_m = D.mm_m, mm_P = D.mm_P, mm_c = D.mm_c;
+    const uint64_t* const fwords = (const uint64_t*)D.fbits;
+    MinLevels prev = {~0u, ~0u, ~0u, ~0u, ~0u};                   // this quarter-wave's read: the m-mers' sliding minima as of the step before
     for (;;) {
         if (phase == PH_DONE && !exhausted) {                     // this quarter-wave's next read
             if (started) i += 4 * nwaves;
@@ -358,7 +413,8 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
                 // Leon::findAndInsertAnchor scan order: [n/2, n/2+10), [0, n/2), [n/2+10, n)
                 iMin = nk / 2; iMax = nk / 2 + 10 > nk ? nk : nk / 2 + 10;
                 base = 0; limit = nk;
-                if (nk) phase = PH_LOOKUP; else { if (l == 0) V.status[i] = ST_NOANCHOR; trace_done(2); }      // (stays PH_DONE: the next round takes another read)
+                if (nk) phase = PH_LOOKUP;
+                else { if (l == 0) { if (!dry) V.status[i] = ST_NOANCHOR; if (xres) xres[i - xbase] = ST_NOANCHOR; } trace_done(2); }      // (stays PH_DONE: the next round takes another read)
             }
         }
         if (!__any(have)) break;                                  // every quarter-wave has run out of reads
@@ -369,20 +425,38 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
                 if (phase == PH_LOOKUP) { phase = PH_SEG_A; base = iMin; limit = iMax; }
                 else if (phase == PH_SEG_A) { phase = PH_SEG_B; base = 0; limit = iMin; }
                 else if (phase == PH_SEG_B) { phase = PH_SEG_C; base = iMax; limit = nk; }
-                else { phase = PH_DONE; if (l == 0) V.status[i] = ST_NOANCHOR; trace_done(2); }
+                else { phase = PH_DONE; if (l == 0) { if (!dry) V.status[i] = ST_NOANCHOR; if (xres) xres[i - xbase] = ST_NOANCHOR; } trace_done(2); }
             }
             const bool run = phase != PH_DONE && base < limit;
             const uint32_t p = base + l;
             const bool valid = run && p < limit;
             const uint32_t words = (run && l < 8) ? pk[(base >> 4) + l] : 0u;
-            const K cn = canon_from_words16<K>(words, gbase, base, valid ? p : (run ? limit - 1 : 0), k);   // all 64 lanes
+            const K km = fwd_from_words16<K>(words, gbase, base, valid ? p : (run ? limit - 1 : 0), k);     // all 64 lanes
+            const K rck = revcomp(km, k);
+            const K cn = rck < km ? rck : km;
+            // The filter word of every k-mer of the step: the smallest of the P m-mer hashes ending at offset c + P - 1 of the lane's own
+            // k-mer -- one new m-mer per lane and step, the ones before it from the lanes below and from the step before.
+            const bool look = run && phase == PH_LOOKUP;              // (the same for the 16 lanes of a quarter-wave: a DPP row)
+            if (look && base == 0) {                                  // a read begins: the P - 1 m-mers before its first step's
+                prev = MinLevels{~0u, ~0u, ~0u, ~0u, ~0u};
+                for (int r = mm_P == 32 ? 1 : 0; r >= 0; r--) {
+                    const int x = (int)(mm_c + mm_P - 1) - 16 * (r + 1) + (int)l;
+                    const uint32_t xc = x > 0 ? (uint32_t)x : 0u;
+                    const uint32_t w0 = (uint32_t)__shfl((int)words, (int)(gbase + (xc >> 4))), w1 = (uint32_t)__shfl((int)words, (int)(gbase + (xc >> 4) + 1));
+                    const uint32_t mm = (uint32_t)((((((uint64_t)w0) << 32) | w1) << (2 * (xc & 15))) >> (64 - 2 * mm_m));
+                    prev = sliding_levels(x >= (int)mm_c && xc + mm_m <= len ? mmer_hash(mm, mm_m) : ~0u, prev);
+                }
+            }
+            const MinLevels cur = sliding_levels(look && valid ? mmer_hash(mmer_of(km, k, mm_m, mm_c + mm_P - 1), mm_m) : ~0u, prev);
+            const uint32_t hmin = window_minimum(cur, prev, mm_P);
+            if (look) prev = cur;
             bool hit = false; uint32_t slot = 0xFFFFFFFFu;
             if (valid) {
                 if (phase == PH_LOOKUP) {
-                    // ~95 % of the look-ups miss (one k-mer in ~35 is an anchor): a 2 MiB bit filter of the final keys, resident
-                    // in L2, answers most of them without a random sector from HBM
-                    const uint32_t fb = final_bit(D, cn);
-                    const bool maybe = (D.fbits[fb >> 5] >> (fb & 31)) & 1u;
+                    // ~95 % of the look-ups miss (one k-mer in ~35 is an anchor): the filter answers most of them without a random
+                    // sector of the dictionary
+                    const uint64_t fb = filter_bits(cn);
+                    const bool maybe = (fwords[filter_word(D, hmin)] & fb) == fb;
                     if (maybe) { uint64_t fin = IDX_INF; slot = dict_find(D, cn, fin); hit = slot != 0xFFFFFFFFu && fin < g; }
                     if (TRACE) {
                         const uint32_t nf = (uint32_t)__popcll(__ballot(true) >> gbase & 0xFFFFull), nd = (uint32_t)__popcll(__ballot(maybe) >> gbase & 0xFFFFull);
@@ -398,8 +472,17 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
                 if (gb) {
                     const uint32_t f = (uint32_t)__builtin_ctz(gb);
                     const uint32_t hs = __shfl(slot, (int)(gbase + f));
-                    if (phase == PH_LOOKUP) { if (l == 0) { V.status[i] = ST_HIT; V.hit_pos[i] = base + f; V.hit_slot[i] = hs; } trace_done(0); }
-                    else { want_insert = (l == 0); cpos = base + f; trace_done(1); }
+                    if (phase == PH_LOOKUP) {
+                        if (l == 0) {
+                            if (!dry) { V.status[i] = ST_HIT; V.hit_pos[i] = base + f; V.hit_slot[i] = hs; }
+                            if (xres) xres[i - xbase] = ((uint64_t)(base + f) << 8) | ST_HIT;
+                        }
+                        trace_done(0);
+                    } else {
+                        want_insert = (l == 0) && !dry; cpos = base + f;
+                        if (l == 0 && xres) xres[i - xbase] = ((uint64_t)cpos << 8) | ST_UNRESOLVED;
+                        trace_done(1);
+                    }
                     phase = PH_DONE;
                 } else base += 16;
             }
@@ -439,14 +522,83 @@ __global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, con
     }
 }
 void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
-                        uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount, unsigned long long* trace) {
+                        uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount, unsigned long long* trace,
+                        uint64_t* xres, uint64_t xbase, bool dry) {
     if (w1 <= w0) return;
-    if (trace) { DISPATCH_K(R.k, hipLaunchKernelGGL((k_lookup_cand<K, true>), dim3(grid_for(w1 - w0, 16, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
-                                                    first_global, ulist, ucount, trace)); return; }
+    if (trace && !dry) { DISPATCH_K(R.k, hipLaunchKernelGGL((k_lookup_cand<K, true>), dim3(grid_for(w1 - w0, 16, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
+                                                           first_global, ulist, ucount, trace, xres, xbase, 0u)); return; }
     // 4 reads per wave, 64 waves launched per CU (32 resident).  Measured and no better (resolve stage, 100 M reads): 32 waves per
     // CU in a grid-stride loop 312 ms, 128 per CU 287, workgroups of 64 or 128 threads 310-330, against 290 for this geometry.
-    DISPATCH_K(R.k, hipLaunchKernelGGL((k_lookup_cand<K, false>), dim3(grid_for(w1 - w0, 16, 256 * 16)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
-                                       first_global, ulist, ucount, trace));
+    const uint32_t per_cu = [] { const char* e = getenv("LEON_LOOKUP_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 1024 ? (uint32_t)v : 16u; }();   // (measurement)
+    DISPATCH_K(R.k, hipLaunchKernelGGL((k_lookup_cand<K, false>), dim3(grid_for(w1 - w0, 16, 256 * per_cu)), dim3(256), 0, s, R, B, rv16, D, V, w0, w1,
+                                       first_global, ulist, ucount, trace, xres, xbase, dry ? 1u : 0u));
+}
+
+// The look-ups of a window divided among the ranks of a job: what ANOTHER rank's pass found for the reads of [w0, w1) outside this
+// rank's own share [s0, s1) -- xres, gathered from all ranks -- becomes this rank's state exactly as its own pass would have left it:
+// the status and position, the slot of the key found (one probe of the dictionary, which holds the same final keys on every rank),
+// and for a read that goes on to propose: its candidate in the dictionary, its index in `tent`, the window's filter bit, the list.
+template <typename K>
+__global__ void __launch_bounds__(256) k_lookup_apply(ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t s0, uint64_t s1,
+                                                     uint64_t first_global, const uint64_t* xres, uint32_t* ulist, uint32_t* ucount) {
+    __shared__ uint32_t wave_n[4], wave_new[4], block_at;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, k = R.k;
+    const uint64_t before = s0 - w0, n_out = (w1 - w0) - (s1 - s0);
+    for (uint64_t e0 = blockIdx.x * (uint64_t)blockDim.x; e0 < n_out; e0 += (uint64_t)gridDim.x * blockDim.x) {   // (whole workgroups stay in the loop)
+        const uint64_t e = e0 + threadIdx.x;
+        const bool have = e < n_out;
+        const uint64_t i = !have ? w0 : (e < before ? w0 + e : s1 + (e - before));
+        const uint64_t x = have ? xres[i - w0] : (uint64_t)ST_NOANCHOR;
+        const uint32_t st = (uint32_t)(x & 0xFFu), pos = (uint32_t)(x >> 8);
+        const uint64_t g = first_global + i;
+        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
+        const bool sane = have && (st == ST_NOANCHOR || ((st == ST_HIT || st == ST_UNRESOLVED) && R.len[i] >= k && pos <= R.len[i] - k));
+        if (have && !sane) atomicExch(D.err, 2);                   // (what another rank sent is input)
+        if (sane && st == ST_NOANCHOR) V.status[i] = ST_NOANCHOR;
+        if (sane && st == ST_HIT) {
+            uint64_t fin = IDX_INF;
+            const uint32_t slot = dict_find(D, canon_at<K>(pk, pos, k), fin);
+            if (slot == 0xFFFFFFFFu || !(fin < g)) atomicExch(D.err, 2);     // the ranks' dictionaries differ
+            else { V.status[i] = ST_HIT; V.hit_pos[i] = pos; V.hit_slot[i] = slot; }
+        }
+        const bool want = sane && st == ST_UNRESOLVED;
+        bool created = false;
+        auto propose = [&]() {
+            const K ck = canon_at<K>(pk, pos, k);
+            const uint32_t sl = dict_find_or_insert<true>(D, ck, created);
+            atomicMin((unsigned long long*)tent_ptr(D, sl), (unsigned long long)g);
+            const uint32_t pb = window_bit(ck);
+            atomicOr(&D.pbits[pb >> 5], 1u << (pb & 31));
+            V.status[i] = ST_UNRESOLVED; V.cand_pos[i] = pos; V.cand_slot[i] = sl;
+        };
+        const unsigned long long wm = __ballot(want);
+        if (KT<K>::W == 1) { if (want) propose(); }
+        else {                                                     // two-word keys: one inserting lane of a wave at a time (dict_find_or_insert)
+            for (unsigned long long m = wm; m; m &= m - 1) if (lane == (uint32_t)__builtin_ctzll(m)) propose();
+        }
+        // one atomic per workgroup and pass on each of the window's two counters
+        const unsigned long long cm = __ballot(created);
+        if (lane == 0) { wave_n[wv] = (uint32_t)__popcll(wm); wave_new[wv] = (uint32_t)__popcll(cm); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3], fresh = wave_new[0] + wave_new[1] + wave_new[2] + wave_new[3];
+            block_at = tot ? atomicAdd(ucount, tot) : 0u;
+            if (fresh) atomicAdd(D.n_keys, (unsigned long long)fresh);
+        }
+        __syncthreads();
+        if (want) {
+            uint32_t at = block_at + (uint32_t)__popcll(wm & ((1ull << lane) - 1));
+            for (uint32_t w = 0; w < wv; w++) at += wave_n[w];
+            ulist[at] = (uint32_t)i;
+        }
+        __syncthreads();
+    }
+}
+void launch_lookup_apply(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t s0, uint64_t s1,
+                         uint64_t first_global, const uint64_t* xres, uint32_t* ulist, uint32_t* ucount) {
+    if (w1 - w0 <= s1 - s0) return;
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_lookup_apply<K>, dim3(grid_for((w1 - w0) - (s1 - s0), 256, 256 * 16)), dim3(256), 0, s, R, D, V, w0, w1, s0, s1,
+                                       first_global, xres, ulist, ucount));
 }
 
 // One resolution round over the unresolved reads: a read becomes a non-inserter as soon as one of its
@@ -513,9 +665,12 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
                 const K key = dict_key<K>(D, slot);
                 const uint32_t wb = window_bit(key);                        // k_final_pos only looks up keys whose bit is set
                 atomicOr(&D.wbits[wb >> 5], 1u << (wb & 31));
-                const uint32_t fb = final_bit(D, key);                         // and k_lookup_cand, from the next window on
-                atomicOr(&D.fbits[fb >> 5], 1u << (fb & 31));
             }
+        }
+        if (!anyfin && !anyblock) {                                // (wave-uniform) ... and k_lookup_cand, from the next window on
+            const K key = dict_key<K>(D, V.cand_slot[i]);
+            const uint32_t hmin = key_minimizer_wave(D, key, k, lane);
+            if (lane == 0) atomicOr((unsigned long long*)D.fbits + filter_word(D, hmin), (unsigned long long)filter_bits(key));
         }
     }
     flush_list();

@@ -32,14 +32,29 @@ struct DictDev {
     uint64_t mask;      // capacity - 1
     unsigned long long* n_keys;
     uint32_t* wbits;    // 2^WBITS_LOG2-bit filter of the keys made final in the current resolution window (k_final_pos)
-    uint32_t* fbits;    // 2^FBITS_LOG2-bit filter of ALL final keys, small enough to stay in every XCD's L2 (k_lookup_cand, k_check)
+    uint32_t* fbits;    // filter of ALL final keys (k_lookup_cand; set by k_check): 64-bit words, a key's word chosen by its MINIMIZER
+                        // (consecutive k-mers of a read mostly share it), its two bits inside the word by the key's hash
     uint32_t* pbits;    // 2^WBITS_LOG2-bit filter of the keys PROPOSED in the current window (k_check)
-    uint32_t fshift;    // 64 - log2(bits of fbits)
+    uint32_t fwshift;   // 32 - log2(words of fbits)
+    uint32_t mm_m, mm_P, mm_c;   // the minimizer's geometry (minimizer_geometry below)
     int* err;           // set by a kernel that gave up waiting for another wave's half-written two-word key
 };
 constexpr uint32_t WBITS_LOG2 = 23;       // the two per-window filters: 1 MiB each (a window makes <= 2^20 keys final: <= 12 % full, ~2 % at steady state)
-constexpr uint32_t FBITS_LOG2_MAX = 27;
-constexpr uint32_t FBITS_LOG2 = 25;       // 4 MiB.  Random dword loads run at ~260 G/s from a table of <= 2 MiB (L2 hits), 100-250 G/s
+// The word of the final keys' filter a k-mer belongs to: the smallest hash among P of its canonical m-mers -- the P in the MIDDLE of
+// the k-mer (offsets c .. c + P - 1 of its k - m + 1), P a power of two (the sliding minimum along a read is then log2(P) shifted
+// minima, no remainder), m = 16 or 15 bases so that the middle is symmetric: the same m-mers whichever strand the k-mer is read on.
+inline void minimizer_geometry(uint32_t k, uint32_t& m, uint32_t& P, uint32_t& c) {
+    if (k <= 16) { m = k; P = 1; c = 0; return; }
+    for (m = 16;; m--) {
+        const uint32_t w = k - m + 1;
+        P = 1;
+        while (P * 2 <= w && P < 32) P *= 2;
+        if (((w - P) & 1) == 0) { c = (w - P) / 2; return; }         // (m = 15 always gets here: w grows by one, P stays or w == P)
+    }
+}
+constexpr uint32_t FBITS_LOG2_MAX = 31;
+constexpr uint32_t FBITS_LOG2_DEFAULT = 28;   // 32 MiB (the sweep that chose it)
+constexpr uint32_t FBITS_LOG2 = 25;       // (round 3's filter, one bit per key at a position of the key's own hash:) 4 MiB.  Random dword loads run at ~260 G/s from a table of <= 2 MiB (L2 hits), 100-250 G/s
                                           // from 4 MiB, ~52 G/s from HBM (profiles/r2_gather_ceiling_by_table_size.txt); measured on the
                                           // path itself (100 M reads, resolve stage): 2^22 bits 336 ms, 2^24 300, 2^25 283, 2^26 287, 2^27 285.
                                           // Round 3, measured and dropped (profiles/r3_resolve_sweep.txt; 217 ms as it stands): the dictionary
@@ -70,7 +85,12 @@ void launch_dict_init(hipStream_t s, DictDev D, uint64_t cap, uint32_t W);
 void launch_dict_rehash(hipStream_t s, DictDev from, uint64_t from_cap, DictDev to, uint32_t k);
 void launch_lookup_cand(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, DictDev D, ResolveDev V,
                         uint64_t w0, uint64_t w1, uint64_t first_global, uint32_t* ulist, uint32_t* ucount,
-                        unsigned long long* trace = nullptr /* 12 counters, zeroed by the caller: the traced instantiation (LEON_TRACE_RESOLVE) */);
+                        unsigned long long* trace = nullptr /* 12 counters, zeroed by the caller: the traced instantiation (LEON_TRACE_RESOLVE) */,
+                        uint64_t* xres = nullptr /* per read of the pass, at [i - xbase]: (position << 8) | status, for the other ranks */,
+                        uint64_t xbase = 0, bool dry = false /* xres only: nothing of the pass stays in this context */);
+// the reads of [w0, w1) outside [s0, s1), from what the ranks that looked them up found (xres, indexed from w0)
+void launch_lookup_apply(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1, uint64_t s0, uint64_t s1,
+                         uint64_t first_global, const uint64_t* xres, uint32_t* ulist, uint32_t* ucount);
 void launch_check(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global,
                   const uint32_t* ulist, const uint32_t* ucount, uint32_t max_count, uint32_t* next_list, uint32_t* next_count);
 void launch_reset_tent(hipStream_t s, DictDev D, ResolveDev V, const uint32_t* list, const uint32_t* count, uint32_t max_count);

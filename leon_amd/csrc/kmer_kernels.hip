@@ -292,7 +292,12 @@ int leon_device_upload(int device_id, void* d_dst, const void* src, uint64_t byt
 int leon_device_copy(int device_id, void* d_dst, const void* d_src, uint64_t bytes) {
     if (bytes && (!d_dst || !d_src)) return LEON_E_INVALID;
     KCHK(hipSetDevice(device_id));
-    if (bytes) KCHK(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+    if (bytes) {
+        KCHK(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+        // (a device-to-device hipMemcpy may return before the copy has run: a caller that hands d_dst to work on ANOTHER stream next --
+        // the exchange callbacks of leon_dna_set_exchange / leon_dna_set_gather do -- must find it complete)
+        KCHK(hipStreamSynchronize(nullptr));
+    }
     return LEON_OK;
 }
 

@@ -60,10 +60,12 @@ struct BloomDev {
 
 // ---- k-mer arithmetic ----
 template <typename K> __device__ inline K kmask(uint32_t nbases) { return (((K)1) << (2 * nbases)) - 1; }   // nbases < 32 * W
-__device__ inline uint64_t rev2bit64(uint64_t x) {                   // reverse the 32 2-bit groups and complement them
-    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-    return __builtin_bswap64(x) ^ 0xAAAAAAAAAAAAAAAAULL;
+__device__ inline uint32_t rev2bit32(uint32_t x) {                   // reverse the 16 2-bit groups and complement them
+    x = __builtin_bitreverse32(x);                                   // (v_bfrev_b32: the groups in order, the two bits of each swapped)
+    return (((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1)) ^ 0xAAAAAAAAu;
+}
+__device__ inline uint64_t rev2bit64(uint64_t x) {                   // ... of the 32 groups: the halves change places
+    return ((uint64_t)rev2bit32((uint32_t)x) << 32) | rev2bit32((uint32_t)(x >> 32));
 }
 __device__ inline uint64_t revcomp(uint64_t x, uint32_t k) { return rev2bit64(x) >> (64 - 2 * k); }
 __device__ inline u128 revcomp(u128 x, uint32_t k) {

@@ -201,6 +201,8 @@ __device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint64_t&
         }
         const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
         // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq)
+        // (a third product and not `low + range`: the add waits for both products, and the step is bound by its dependent path as
+        // much as by its issue slots -- 128 ms per launch at 100 M reads this way, 133 with the add; profiles/r4_minimizer_filter.txt)
         uint64_t top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
         low = (uint64_t)q0 * s_lo + low;            low += (uint64_t)(q1 * s_lo) << 32;
         range = (uint64_t)q0 * s_fr;                range += (uint64_t)(q1 * s_fr) << 32;

@@ -30,7 +30,7 @@ torch.cuda.synchronize()
 d_solid, n_solid = capi.kmer_solid_device(reads.data_ptr(), offsets.data_ptr(), N, K, 3)
 tai = n_solid * 12
 VARIANTS = json.loads(os.environ.get("SWEEP_VARIANTS", "[{}]"))
-KEYS = ("LEON_DICT_NT", "LEON_FBITS_LOG2", "LEON_FBITS2_LOG2", "LEON_RESOLVE_WINDOW", "LEON_WALK_ORDER")
+KEYS = ("LEON_LOOKUP_BLOCKS_PER_CU", "LEON_DICT_NT", "LEON_FBITS_LOG2", "LEON_FBITS2_LOG2", "LEON_RESOLVE_WINDOW", "LEON_WALK_ORDER")
 ref = None
 for var in VARIANTS:
     for k_ in KEYS:

@@ -207,6 +207,29 @@ def test_small_windows_and_batches():
     _full_compare(bases, off, 31, 500, window=1000, batches=3)
 
 
+@pytest.mark.parametrize("k0", [5, 17, 29, 41, 53])
+def test_final_key_filter_under_every_kmer_size(k0):
+    # The filter of the final keys is addressed by a minimizer whose geometry (m-mer size, window, offset) depends on k
+    # (kernels.h minimizer_geometry): a k-mer it failed to find again in a later window would anchor a read elsewhere than the
+    # oracle does.  Every k of 5 .. 63 with windows of 48 reads, on reads that share their k-mers many times over -- and
+    # on low-complexity reads, whose m-mers repeat inside one k-mer.
+    for k in range(k0, min(k0 + 12, 64)):
+        bases, off = common.synthetic(600, max(90, 2 * k + 20), 1500, seed=100 + k)
+        _full_compare(bases, off, k, 200, window=48)
+    k = min(k0 + 11, 63)
+    rnd = np.random.default_rng(k)
+    units = [b"A", b"AC", b"ACG", b"AACCGGTT", b"ACGTTGCATG"]
+    reads = []
+    for i in range(300):
+        u = units[int(rnd.integers(len(units)))]
+        r = bytearray((u * (200 // len(u) + 1))[:140 + int(rnd.integers(20))])
+        for j in rnd.integers(0, len(r), size=2):
+            r[int(j)] = b"ACGT"[int(rnd.integers(4))]
+        reads.append(bytes(r))
+    b2, off2 = O.reads_to_arrays(reads)
+    _full_compare(b2, off2, k, 100, window=32)
+
+
 def test_other_kmer_sizes_and_lengths():
     bases, off = common.synthetic(3000, 250, 15000, seed=9, n_rate=0.001)
     _full_compare(bases, off, 21, 700)
@@ -371,9 +394,11 @@ def test_walk_divided_by_anchor_with_a_real_exchange_between_contexts():
     bases, off = common.synthetic(4000, 150, 15000, seed=77, n_rate=0.001, junk_reads=25)
     bl, solid, tai = common.make_bloom(bases, off, k)
     ref = O.encode(bases, off, k, rpb, bl, trace=False)
-    for world in (2, 8):
+    for world, share_lookups in ((2, False), (2, True), (8, True)):
         barrier = threading.Barrier(world)
         posted = [None] * world                      # rank -> (d_send, counts)
+        posted_g = [None] * world                    # rank -> its gather buffer
+        gathers = [0] * world
         recv_bufs = [None] * world                   # rank -> device pointer it owns (freed at the next call)
         import leon_amd
         lib = leon_amd.load_library()
@@ -401,11 +426,27 @@ def test_walk_divided_by_anchor_with_a_real_exchange_between_contexts():
                 return ptr.value, total
             return fn
 
+        def gather(rank):
+            # leon_dna_set_gather: the window's look-ups divided among the ranks, every rank's part copied into everybody's buffer
+            def fn(d_buf, part_bytes, w):
+                assert w == world
+                posted_g[rank] = (d_buf, part_bytes)
+                barrier.wait()
+                assert all(pg[1] == part_bytes for pg in posted_g)
+                for src in range(world):
+                    if src != rank and part_bytes:
+                        assert lib.leon_device_copy(0, C.c_void_p(d_buf + src * part_bytes), C.c_void_p(posted_g[src][0] + src * part_bytes), part_bytes) == 0
+                gathers[rank] += 1
+                barrier.wait()
+            return fn
+
         def run(rank):
             try:
                 ctx = _ctx(k, rpb, tai, resolve_window=1000)
                 ctx.set_shard(rank, world)
                 ctx.set_exchange(capi.XCH_BY_ANCHOR, exchange(rank))
+                if share_lookups:
+                    ctx.set_gather(gather(rank))
                 ctx.bloom_upload(bl.bits)
                 cut = 6 * rpb
                 blocks = ctx.encode_batch(bases, off[:cut + 1]) + ctx.encode_batch(bases, off[cut:])
@@ -430,6 +471,7 @@ def test_walk_divided_by_anchor_with_a_real_exchange_between_contexts():
         assert [g[1] for g in got] == ref.blocks and [g[2] for g in got] == ref.block_nreads, world
         assert results[0][1] == ref.anchor_dict and all(len(r[1]) == 0 for r in results[1:])
         assert sum(r[3]["xch_words_sent"] for r in results) == sum(r[3]["xch_words_received"] for r in results)
+        assert all(g == (results[0][3]["resolve_windows"] + 2 if share_lookups else 0) for g in gathers), gathers   # one per window (first batch: 2 windows)
 
 
 def test_dictionary_stream_on_device_equals_host_thread():
