@@ -114,6 +114,46 @@ def test_rccl_path_with_one_rank():
     assert line["verify"]["blocks_sha256"] == plain["verify"]["blocks_sha256"] and line["verify"]["dict_sha256"] == plain["verify"]["dict_sha256"]
 
 
+def test_exchange_callbacks_over_rccl_with_one_rank():
+    """bench.py's two callbacks for leon_dna_set_exchange / leon_dna_set_gather in their RCCL form (all_to_all_single,
+    all_gather_into_tensor on device tensors): the library only calls them with world > 1, which RCCL cannot have on one device, and
+    the multi-process tests go over gloo -- so the branch the 8-GPU run takes is called here directly, on a process group of ONE:
+    what a rank sends itself comes back, a gathered buffer keeps its one part."""
+    script = r"""
+import ctypes, os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+import bench, leon_amd
+from leon_amd import capi
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[1], rank=0, world_size=1, device_id=dev)
+leon_amd.load_library()
+words = torch.arange(1000, dtype=torch.int64, device=dev) * 7 + 3
+xch = bench.make_exchange(dist, dev, "nccl", 0, 1, capi)
+ptr, total = xch(words.data_ptr(), [1000])
+assert total == 1000
+back = torch.empty(1000, dtype=torch.int64, device=dev)
+capi.device_copy(back.data_ptr(), ptr, 8000)
+assert torch.equal(back, words)
+ptr, total = xch(0, [0])                                   # a rank with nothing to send
+assert total == 0
+buf = torch.arange(4096, dtype=torch.int64, device=dev)
+want = buf.clone()
+bench.make_gather(dist, dev, "nccl", 0, 1, capi)(buf.data_ptr(), 4096 * 8, 1)
+torch.cuda.synchronize()
+assert torch.equal(buf, want)
+dist.barrier()
+dist.destroy_process_group()
+print("callbacks ok")
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LEON_BENCH_BACKEND"):
+        env.pop(v, None)
+    p = subprocess.run([sys.executable, "-c", script, str(_free_port())], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "callbacks ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_bench_as_rank_r_of_8_seats_add_up_to_the_single_stream():
     """LEON_BENCH_AS_RANK=r:N: ONE process takes the seat of rank r of an N-rank job (leon_dna_set_shard(r, N), every collective of
     the N-rank code on an RCCL process group of one).  The eight seats of an 8-rank job, one after the other on the one GPU: every seat
