@@ -1,6 +1,7 @@
 """-m gpu: a seeded random sweep over the path's parameters -- k (one- and two-word k-mers), block size, bloom geometry
 (number of hashes, block bits), read length / raggedness / error and N rates, resolution window.  For every draw:
-the HIP encoder's bytes == the oracle's, and the device decoder gives the input back."""
+the HIP encoder's bytes == the oracle's, and the device decoder gives the input back; every third draw also as an N-rank job
+(walk and window look-ups divided among emulated ranks): the union of the ranks' blocks == the oracle's."""
 import random
 
 import pytest
@@ -38,3 +39,20 @@ def test_random_parameter_sweep(chunk):
         got = ctx.decode_blocks(capi.anchor_dict_decode(d, na, k), blocks, nb)
         assert got == [bytes(c if c in b"ACGT" else ord("N") for c in r) for r in reads], what
         ctx.close()
+        if it % 3 == 0:
+            # the same file as an N-rank job (leon_dna_set_shard + LEON_XCH_EMULATE: the walk divided by anchor and the resolution's
+            # window look-ups divided among the ranks, every context playing the other ranks' parts): the union of the ranks' blocks
+            world = rnd.choice([2, 3, 5])
+            union = []
+            for rank in range(world):
+                ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=rpb, bloom_tai=tai, bloom_n_hash=n_hash,
+                                                bloom_block_nbits=nbits, resolve_window=rnd.choice([0, 16, 300]))
+                ctx.set_shard(rank, world)
+                ctx.set_exchange(capi.XCH_EMULATE)
+                ctx.bloom_upload(bl.bits)
+                union += ctx.encode_batch(bases, off)
+                d2, na2 = ctx.finish()
+                assert na2 == ref.n_anchors and (d2 == ref.anchor_dict if rank == 0 else len(d2) == 0), (what, world, rank)
+                ctx.close()
+            union.sort()
+            assert [b[0] for b in union] == list(range(len(ref.blocks))) and [b[1] for b in union] == ref.blocks, (what, world)
