@@ -217,7 +217,9 @@ __device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint64_t&
         *(uint32_t*)(dst + (nout < cap4 ? nout : cap4)) = __builtin_bswap32(lh);
         uint64_t low_n = low << sh, range_n = range_s;
         uint32_t nout_n = nout + (sh >> 3);
-        if (__builtin_expect(rare, 0)) {
+        // (the step is paid in instructions, ~5 cycles each for a wave alone on its SIMD -- profiles/r4_issue_costs.txt --: the rare case
+        // is ONE scalar branch on "any lane", not an exec mask saved and restored around the lanes' own test)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0) && rare) {
             low_n = low; range_n = range; nout_n = nout;
             while ((low_n ^ (low_n + range_n)) < (1ull << 56) ||
                    (range_n < RC_BOTTOM && ((range_n = (0 - low_n) & (RC_BOTTOM - 1)), true))) {
