@@ -17,7 +17,7 @@ draws = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rnd = random.Random(int(os.environ.get("LEON_FUZZ_SEED", 777)))
 t0 = time.time()
 for it in range(draws):
-    k = rnd.choice([5, 9, 15, 21, 27, 31, 32, 33, 40, 47, 55, 63])
+    k = rnd.choice([5, 9, 15, 21, 27, 31, 32, 33, 40, 47, 55, 63]) if it % 2 else rnd.randrange(5, 64)      # (every k: every geometry of the final keys' filter)
     rpb = rnd.choice([1, 7, 50, 333, 1000, 5000])
     n_hash, nbits = rnd.choice([1, 3, 7, 10]), rnd.choice([6, 9, 12, 14])
     L = max(rnd.choice([k, k + 1, 40, 100, 151, 260, 600]), 8)
@@ -48,6 +48,20 @@ for it in range(draws):
     got = ctx.decode_blocks(capi.anchor_dict_decode(d, na, k), blocks, nb)
     assert got == [bytes(c if c in b"ACGT" else ord("N") for c in r) for r in reads], what
     ctx.close()
+    if it % 4 == 0:                                              # the same file as an N-rank job: walk and window look-ups divided among emulated ranks
+        world = rnd.choice([2, 3, 5, 8])
+        union = []
+        for rank in range(world):
+            ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=rpb, bloom_tai=tai, bloom_n_hash=n_hash, bloom_block_nbits=nbits, resolve_window=window)
+            ctx.set_shard(rank, world)
+            ctx.set_exchange(capi.XCH_EMULATE)
+            ctx.bloom_upload(bl.bits)
+            union += ctx.encode_batch(bases, off)
+            d2, na2 = ctx.finish()
+            assert na2 == na and (d2 == d if rank == 0 else len(d2) == 0), (what, world, rank)
+            ctx.close()
+        union.sort()
+        assert [b[0] for b in union] == list(range(len(ref.blocks))) and [b[1] for b in union] == ref.blocks, (what, world)
     if it % 10 == 9:
         print("draw %d ok (%.0f s)" % (it + 1, time.time() - t0), flush=True)
 print("long fuzz: %d draws, all bit-exact and round-tripping, %.0f s" % (draws, time.time() - t0))
