@@ -853,7 +853,7 @@ __device__ inline void walk_apply(uint32_t res4, uint32_t k, K kmask_k, K& x, K&
     y = (y >> 2) | ((K)(f ^ 2u) << (2 * (k - 1)));
 }
 
-template <typename K>
+template <typename K, uint32_t NH>
 __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
                                              const uint8_t* flags, const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off) {
     __shared__ uint16_t rv16[256];
@@ -912,7 +912,7 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
                 return 0x100u;
             }
         }
-        return bloom_contains4<K>(B, rv16, x, y, true);
+        return bloom_contains4<K, NH>(B, rv16, x, y, true);
     };
     for (uint32_t j = 0; j < nmax; j++) {
         uint32_t posA = 0, ntA = 0, posB = 0, ntB = 0;
@@ -1034,7 +1034,9 @@ void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, co
     uint64_t g = (n_walk + 255) / 256;
     static const bool tile = getenv("LEON_WALK_TILE") != nullptr && getenv("LEON_WALK_TILE")[0] == '1';       // measurement only
     if (tile && !ev_off) { DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk_tile<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events)); return; }
-    DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events, ev_off));
+    // (Leon's seven hash functions: an instantiation without the per-hash branches; any other number takes them)
+    if (B.n_hash == 7) { DISPATCH_K(R.k, hipLaunchKernelGGL((k_walk<K, 7>), dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events, ev_off)); return; }
+    DISPATCH_K(R.k, hipLaunchKernelGGL((k_walk<K, 0>), dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events, ev_off));
 }
 
 // ================================================================================================

@@ -104,6 +104,10 @@ __device__ inline uint64_t key_hash(uint64_t k) { return mix64(k); }
 __device__ inline uint64_t key_hash(u128 k) { return mix64((uint64_t)k ^ mix64((uint64_t)(k >> 64) + 0x9E3779B97F4A7C15ULL)); }
 // cano2[16] of BloomNeighborCoherent as 16 nibbles
 __device__ inline uint32_t cano2(uint32_t v) { return (uint32_t)(0x51D9409873543210ULL >> (4 * v)) & 15u; }
+// the four values contains4 needs at once, a nibble per neighbour nt: cano2(4 p + nt) for a fixed prefix p -- 16 consecutive bits of
+// the table itself -- and cano2(4 nt + s) for a fixed suffix s (the same nibbles regrouped): one shift instead of four look-ups
+__device__ inline uint32_t cano2_right(uint32_t p) { return (uint32_t)(0x51D9409873543210ULL >> (16 * p)) & 0xFFFFu; }
+__device__ inline uint32_t cano2_left(uint32_t s) { return (uint32_t)(0x54731032D9519840ULL >> (16 * s)) & 0xFFFFu; }
 
 // ---- packed reads: 16 bases per dword, base j of a read at bits 30-2*(j&15) of dword j>>4 ----
 __device__ inline uint32_t base_at(const uint32_t* pk, uint32_t pos) {
@@ -137,15 +141,18 @@ template <> __device__ inline u128 kmer_at<u128>(const uint32_t* pk, uint32_t p,
 // racine and the per-hash offsets depend only on the canonical middle (k-2)-mer
 struct BloomKeys { uint64_t racine; uint32_t key[10]; };
 
-template <typename K>
+// NH: the number of hash functions when the kernel was built for it (the walk: Leon's 7), 0 = B.n_hash at run time -- a ladder of
+// scalar branches, one per hash, in the middle of the walk's step
+template <typename K, uint32_t NH = 0>
 __device__ inline void bloom_keys(const BloomDev& B, const uint16_t* rv16, K hp_fwd, K hp_rc, BloomKeys& Kk) {
     const K hp = hp_rc < hp_fwd ? hp_rc : hp_fwd;
     Kk.racine = fastmod(hash1(hp, B.seed0), B.reduced_tai, B.mod_magic);
     Kk.key[0] = 0;
     const uint32_t low = (uint32_t)(uint64_t)hp;                  // simplehash16 looks at value[0] >> i, 16 bits
+    const uint32_t n_hash = NH ? NH : B.n_hash;
 #pragma unroll
     for (uint32_t i = 1; i < 10; i++) {
-        if (i < B.n_hash) {
+        if (i < n_hash) {
             const uint32_t in = low >> i;
             Kk.key[i] = (uint32_t)(rv16[in & 255] ^ rv16[(in >> 8) & 255]) & B.block_mask;
         }
@@ -161,11 +168,13 @@ __device__ inline uint32_t bloom_window(const BloomDev& B, uint64_t bitpos) {
 // contains4: pv4 packs the four canonical prefix+suffix values (4 bits each, neighbour nt in nibble nt).
 // Hash i of neighbour n sits at bit racine + key[i] + pv[n]: the same offset pv[n] inside every hash's window, so the
 // windows are ANDed first and the four bits are extracted once (the kernel is VALU-issue bound, not memory bound).
+template <uint32_t NH = 0>
 __device__ inline uint32_t bloom_probe4(const BloomDev& B, const BloomKeys& Kk, uint32_t pv4) {
     uint32_t w = 0xFFFFFFFFu;
+    const uint32_t n_hash = NH ? NH : B.n_hash;
 #pragma unroll
     for (uint32_t i = 0; i < 10; i++) {
-        if (i < B.n_hash) w &= bloom_window(B, Kk.racine + Kk.key[i]);
+        if (i < n_hash) w &= bloom_window(B, Kk.racine + Kk.key[i]);
     }
     return ((w >> (pv4 & 15)) & 1u) | (((w >> ((pv4 >> 4) & 15)) & 1u) << 1) |
            (((w >> ((pv4 >> 8) & 15)) & 1u) << 2) | (((w >> ((pv4 >> 12) & 15)) & 1u) << 3);
@@ -206,7 +215,7 @@ template <typename K> __device__ inline bool bloom_contains_xr(const BloomDev& B
     return ((w >> pv) & 1u) != 0;
 }
 // BloomNeighborCoherent::contains4(item, right) from a k-mer and its reverse complement
-template <typename K>
+template <typename K, uint32_t NH = 0>
 __device__ inline uint32_t bloom_contains4(const BloomDev& B, const uint16_t* rv16, K kmer, K rc, bool right) {
     const uint32_t k = B.k;
     const K mkm2 = kmask<K>(k - 2);
@@ -214,15 +223,15 @@ __device__ inline uint32_t bloom_contains4(const BloomDev& B, const uint16_t* rv
     if (right) {          // elem = kmer[1..k-1] + X : middle = kmer[2..k-1], prefix = kmer[1], suffix varies
         hpf = kmer & mkm2; hpr = rc >> 4;
         const uint32_t p = (uint32_t)(uint64_t)(kmer >> (2 * (k - 2))) & 3u;
-        pv4 = cano2(p << 2) | (cano2((p << 2) | 1) << 4) | (cano2((p << 2) | 2) << 8) | (cano2((p << 2) | 3) << 12);
+        pv4 = cano2_right(p);
     } else {              // elem = X + kmer[0..k-2] : middle = kmer[0..k-3], prefix varies, suffix = kmer[k-2]
         hpf = kmer >> 4; hpr = rc & mkm2;
         const uint32_t s = (uint32_t)(uint64_t)(kmer >> 2) & 3u;
-        pv4 = cano2(s) | (cano2(4 | s) << 4) | (cano2(8 | s) << 8) | (cano2(12 | s) << 12);
+        pv4 = cano2_left(s);
     }
     BloomKeys Kk;
-    bloom_keys<K>(B, rv16, hpf, hpr, Kk);
-    return bloom_probe4(B, Kk, pv4);
+    bloom_keys<K, NH>(B, rv16, hpf, hpr, Kk);
+    return bloom_probe4<NH>(B, Kk, pv4);
 }
 
 // stage the low 16 bits of the 256-entry simplehash16 table in LDS
