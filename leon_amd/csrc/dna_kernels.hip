@@ -857,7 +857,7 @@ template <typename K, uint32_t NH>
 __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
                                              const uint8_t* flags, const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off) {
     __shared__ uint16_t rv16[256];
-    load_rv16(rv16, rv16g);
+    load_rv16(rv16, rv16g, NH ? B.block_mask : 0xFFFFu);
     // (measured, round 3: giving every XCD one contiguous eighth of the order -- workgroup b takes chunk (b % 8) * n/8 + b / 8 --
     // changes nothing, 311 -> 313 ms; nor does it with the reads in true genome order, 277 -> 281 ms: profiles/r3_walk_order.txt)
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;

@@ -89,10 +89,10 @@ __device__ inline uint64_t hash64(uint64_t key, uint64_t seed) {
 __device__ inline uint64_t hash1(uint64_t x, uint64_t seed) { return hash64(x, seed); }
 __device__ inline uint64_t hash1(u128 x, uint64_t seed) { return hash64((uint64_t)x, seed) ^ hash64((uint64_t)(x >> 64), seed); }
 // n mod d with magic = floor((2^64-1)/d): one mulhi, one multiply, conditional subtracts
+// (ONE: magic * d >= 2^64 - d, so n * magic / 2^64 > n / d - 1 and the quotient is the true one or one short: r < 2 d)
 __device__ inline uint64_t fastmod(uint64_t n, uint64_t d, uint64_t magic) {
     uint64_t q = __umul64hi(n, magic);
     uint64_t r = n - q * d;
-    if (r >= d) r -= d;
     if (r >= d) r -= d;
     return r;
 }
@@ -154,7 +154,8 @@ __device__ inline void bloom_keys(const BloomDev& B, const uint16_t* rv16, K hp_
     for (uint32_t i = 1; i < 10; i++) {
         if (i < n_hash) {
             const uint32_t in = low >> i;
-            Kk.key[i] = (uint32_t)(rv16[in & 255] ^ rv16[(in >> 8) & 255]) & B.block_mask;
+            // (NH != 0: the kernel staged the table already masked -- load_rv16(.., B.block_mask) -- and spares an `and` per hash)
+            Kk.key[i] = NH ? (uint32_t)(rv16[in & 255] ^ rv16[(in >> 8) & 255]) : (uint32_t)(rv16[in & 255] ^ rv16[(in >> 8) & 255]) & B.block_mask;
         }
     }
 }
@@ -235,8 +236,8 @@ __device__ inline uint32_t bloom_contains4(const BloomDev& B, const uint16_t* rv
 }
 
 // stage the low 16 bits of the 256-entry simplehash16 table in LDS
-__device__ inline void load_rv16(uint16_t* lds, const uint16_t* g) {
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) lds[i] = g[i];
+__device__ inline void load_rv16(uint16_t* lds, const uint16_t* g, uint32_t mask = 0xFFFFu) {
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) lds[i] = (uint16_t)(g[i] & mask);
     __syncthreads();
 }
 
