@@ -257,7 +257,8 @@ __global__ void k_pc_init(uint64_t* slots, uint64_t n_words, uint32_t words_per_
 
 // err[0]: 0 ok; otherwise 1 + the first failing block in err[1] (code: 1 address/position out of range, 2 output
 // overflow, 3 too many N / error positions in one read)
-template <typename K, bool DEEP>
+// NH: the bloom's number of hash functions when the instantiation is for it (Leon's 7), 0 = at run time (leon_device.h bloom_keys)
+template <typename K, bool DEEP, uint32_t NH>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_decode_blocks(BloomDev B, PathCache PCc, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors,
                                                      const uint8_t* payloads, const uint64_t* pay_off, const uint32_t* blk_reads,
                                                      const uint64_t* blk_read0, const uint64_t* blk_out0, uint64_t n_blocks,
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     __shared__ uint32_t models[RC_SMALL_WORDS + DC_NSLOT * RC_STRIDE];
     __shared__ uint8_t slotmap[RC_NNUM];
     __shared__ uint32_t lstN_[DC_LIST_LDS], lstE_[DC_LIST_LDS];  // the first entries of the read's N / error positions (the usual read has a few)
-    load_rv16(rv16, rv16g);
+    load_rv16(rv16, rv16g, NH ? B.block_mask : 0xFFFFu);
     volatile lds_u32* const lstN = (volatile lds_u32*)lstN_;
     volatile lds_u32* const lstE = (volatile lds_u32*)lstE_;
     const uint32_t lane = lane_id(), k = B.k;
@@ -470,7 +471,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                 if (lane >= 1 && lane <= 4) km = succ(kmer, (lane - 1) & 3u);
                                 if (DEEP && lane >= 5 && lane <= 20) km = succ(succ(kmer, ((lane - 5) >> 2) & 3u), (lane - 5) & 3u);
                             }
-                            res = bloom_contains4<K>(B, rv16, km, revcomp(km, k), dir == 1);
+                            res = bloom_contains4<K, NH>(B, rv16, km, revcomp(km, k), dir == 1);
                         }
                         if (cache_on) {
                             if (mode == HYBRID) {
@@ -584,11 +585,11 @@ template <typename K> __device__ inline void pc_insert_now(const PathCache& C, K
         }
     }
 }
-template <typename K>
+template <typename K, uint32_t NH>
 __global__ void __launch_bounds__(256) k_pc_prewalk(BloomDev B, PathCache C, const uint16_t* rv16g, const uint64_t* anchors, uint64_t n_anchors, uint32_t max_steps) {
     __shared__ uint16_t rv16[256];
     __shared__ K todo[3][256];                                // k-mers beyond a branch, still to be walked from (per lane)
-    load_rv16(rv16, rv16g);
+    load_rv16(rv16, rv16g, NH ? B.block_mask : 0xFFFFu);
     const uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (idx >= 2 * n_anchors) return;
     const uint32_t k = B.k, t = threadIdx.x;
@@ -603,7 +604,7 @@ __global__ void __launch_bounds__(256) k_pc_prewalk(BloomDev B, PathCache C, con
         uint32_t run = 0, res4 = 0;
         while (budget) {
             budget--;
-            res4 = bloom_contains4<K>(B, rv16, y, rc, true);
+            res4 = bloom_contains4<K, NH>(B, rv16, y, rc, true);
             if (__popc(res4) != 1) break;
             const uint32_t e = (uint32_t)__builtin_ctz(res4);
             y = ((y << 2) | (K)e) & kmk;
@@ -628,8 +629,10 @@ __global__ void __launch_bounds__(256) k_pc_prewalk(BloomDev B, PathCache C, con
 void launch_path_cache_prewalk(hipStream_t s, BloomDev B, PathCache C, const uint16_t* rv16, const uint64_t* anchors, uint64_t n_anchors, uint32_t max_steps) {
     if (!C.slots || !n_anchors) return;
     const uint64_t nb = (2 * n_anchors + 255) / 256;
-    if (B.k >= 32) hipLaunchKernelGGL(k_pc_prewalk<u128>, dim3((uint32_t)nb), dim3(256), 0, s, B, C, rv16, anchors, n_anchors, max_steps);
-    else hipLaunchKernelGGL(k_pc_prewalk<uint64_t>, dim3((uint32_t)nb), dim3(256), 0, s, B, C, rv16, anchors, n_anchors, max_steps);
+#define PW_LAUNCH(KT, NHV) hipLaunchKernelGGL((k_pc_prewalk<KT, NHV>), dim3((uint32_t)nb), dim3(256), 0, s, B, C, rv16, anchors, n_anchors, max_steps)
+    if (B.k >= 32) { if (B.n_hash == 7) PW_LAUNCH(u128, 7); else PW_LAUNCH(u128, 0); }
+    else { if (B.n_hash == 7) PW_LAUNCH(uint64_t, 7); else PW_LAUNCH(uint64_t, 0); }
+#undef PW_LAUNCH
 }
 
 // ---- header blocks: the symbols of the stream, decoded on the device ----------------------------------------------------
@@ -740,10 +743,12 @@ void launch_decode_blocks(hipStream_t s, BloomDev B, PathCache C, const uint16_t
     const uint32_t g = (uint32_t)(n_blocks > 256 * 8 ? 256 * 8 : n_blocks);   // 8 waves per CU: the kernel's registers allow two per SIMD
     static const char* force = getenv("LEON_DC_DEEP");       // measurement override
     const bool deep = force ? force[0] == '1' : true;        // 21 probe sets per round and wave: measured better at 200 and at 2 000 blocks
-#define DC_LAUNCH(KT, D) hipLaunchKernelGGL((k_decode_blocks<KT, D>), dim3(g), dim3(64), 0, s, B, C, rv16, anchors, n_anchors, payloads, pay_off, \
-                                            blk_reads, blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err, stats)
+#define DC_LAUNCH2(KT, D, NHV) hipLaunchKernelGGL((k_decode_blocks<KT, D, NHV>), dim3(g), dim3(64), 0, s, B, C, rv16, anchors, n_anchors, payloads, pay_off, \
+                                                  blk_reads, blk_read0, blk_out0, n_blocks, out, out_len, scratch, pool, pool_cursor, pool_words, err, stats)
+#define DC_LAUNCH(KT, D) do { if (B.n_hash == 7) DC_LAUNCH2(KT, D, 7); else DC_LAUNCH2(KT, D, 0); } while (0)
     if (B.k >= 32) { if (deep) DC_LAUNCH(u128, true); else DC_LAUNCH(u128, false); }
     else { if (deep) DC_LAUNCH(uint64_t, true); else DC_LAUNCH(uint64_t, false); }
+#undef DC_LAUNCH2
 #undef DC_LAUNCH
 }
 

@@ -199,11 +199,11 @@ void launch_mpos_from_anchors(hipStream_t s, ReadsDev R, const int32_t* anchor_p
     hipLaunchKernelGGL(k_mpos_from_anchors, dim3((uint32_t)std::min<uint64_t>((R.n + 255) / 256, 8192)), dim3(256), 0, s, R, anchor_pos, anchor_addr, flags, key, mpos);
 }
 
-template <typename K>
+template <typename K, uint32_t NH>       // NH: the bloom's number of hash functions when built for it (7), 0 = at run time (leon_device.h bloom_keys)
 __global__ void __launch_bounds__(256) k_solid_flags(ReadsDev R, BloomDev B, const uint16_t* rv16g, const uint32_t* perm, const uint32_t* mpos,
                                                     uint32_t* flags) {
     __shared__ uint16_t rv16[256];
-    load_rv16(rv16, rv16g);
+    load_rv16(rv16, rv16g, NH ? B.block_mask : 0xFFFFu);
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= R.n) return;
     const uint32_t i = perm[t], k = R.k, len = R.len[i];
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) k_solid_flags(ReadsDev R, BloomDev B, con
     uint32_t wP = 0, wP_idx = 0xFFFFFFFFu, wM = 0, wM_idx = 0xFFFFFFFFu;
     // flags collected per 32-position word and side, handed over when the side moves on to another word
     uint32_t aP = 0, aP_idx = m >> 5, aM = 0, aM_idx = m >> 5;
-    if (bloom_contains_xr<K>(B, rv16, xP, rP)) aP |= 1u << (m & 31);
+    if (bloom_contains_xr<K, NH>(B, rv16, xP, rP)) aP |= 1u << (m & 31);
     const uint32_t nP = nk - 1 - m, nM = m, nmax = nP > nM ? nP : nM;
     for (uint32_t g = 1; g <= nmax; g++) {
         // "A" = the side towards the canonical minimizer's right (P for a read that carries it forwards, M otherwise), "B" = the other
@@ -241,8 +241,8 @@ __global__ void __launch_bounds__(256) k_solid_flags(ReadsDev R, BloomDev B, con
         const bool onA = fwd ? onP : onM, onB = fwd ? onM : onP;
         // (both sides' first hashes in flight together, then the rest of both: measured, no different -- 487 against 471 ms; the
         // kernel is bound by its sectors, 1.76 TB at 100 M reads, not by their latency)
-        const bool sA = onA && bloom_contains_xr<K>(B, rv16, fwd ? xP : xM, fwd ? rP : rM);
-        const bool sB = onB && bloom_contains_xr<K>(B, rv16, fwd ? xM : xP, fwd ? rM : rP);
+        const bool sA = onA && bloom_contains_xr<K, NH>(B, rv16, fwd ? xP : xM, fwd ? rP : rM);
+        const bool sB = onB && bloom_contains_xr<K, NH>(B, rv16, fwd ? xM : xP, fwd ? rM : rP);
         const bool sP = fwd ? sA : sB, sM = fwd ? sB : sA;
         if (onP) {
             const uint32_t p = m + g;
@@ -333,8 +333,10 @@ void launch_read_minimizer(hipStream_t s, ReadsDev R, uint32_t* key, uint32_t* m
 void launch_solid_flags(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const uint32_t* perm, const uint32_t* mpos, uint32_t* flags) {
     if (!R.n) return;
     const uint32_t g = (uint32_t)((R.n + 255) / 256);
-    if (R.k >= 32) hipLaunchKernelGGL(k_solid_flags<u128>, dim3(g), dim3(256), 0, s, R, B, rv16, perm, mpos, flags);
-    else hipLaunchKernelGGL(k_solid_flags<uint64_t>, dim3(g), dim3(256), 0, s, R, B, rv16, perm, mpos, flags);
+#define SF_LAUNCH(KT, NHV) hipLaunchKernelGGL((k_solid_flags<KT, NHV>), dim3(g), dim3(256), 0, s, R, B, rv16, perm, mpos, flags)
+    if (R.k >= 32) { if (B.n_hash == 7) SF_LAUNCH(u128, 7); else SF_LAUNCH(u128, 0); }
+    else { if (B.n_hash == 7) SF_LAUNCH(uint64_t, 7); else SF_LAUNCH(uint64_t, 0); }
+#undef SF_LAUNCH
 }
 void launch_qual_rewrite(hipStream_t s, ReadsDev R, const uint32_t* flags, uint8_t* quals) {
     if (!R.n) return;

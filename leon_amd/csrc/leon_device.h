@@ -198,20 +198,21 @@ template <typename K> __device__ inline bool bloom_contains(const BloomDev& B, c
 }
 // contains(min(x, r)) for a k-mer x whose reverse complement r is at hand (kernels that keep both incrementally): no reverse
 // complement is formed
-template <typename K> __device__ inline bool bloom_contains_xr(const BloomDev& B, const uint16_t* rv16, K x, K r) {
+template <typename K, uint32_t NH = 0> __device__ inline bool bloom_contains_xr(const BloomDev& B, const uint16_t* rv16, K x, K r) {
     const uint32_t k = B.k;
     const K item = r < x ? r : x;
     const uint32_t pv = cano2((uint32_t)((uint64_t)(item >> (2 * (k - 1))) & 3) << 2 | ((uint32_t)(uint64_t)item & 3u));
     const K mk = kmask<K>(k - 2);
     BloomKeys Kk;
-    bloom_keys<K>(B, rv16, (x >> 2) & mk, (r >> 2) & mk, Kk);        // the middle (k-2)-mer and ITS reverse complement
+    bloom_keys<K, NH>(B, rv16, (x >> 2) & mk, (r >> 2) & mk, Kk);    // the middle (k-2)-mer and ITS reverse complement
     // the first hash alone, then the others together: a k-mer that is not there (every k-mer over a sequencing error) mostly stops
     // at its first sector, one that is there costs two round trips instead of seven
     uint32_t w = bloom_window(B, Kk.racine);
     if (!((w >> pv) & 1u)) return false;
+    const uint32_t n_hash = NH ? NH : B.n_hash;
 #pragma unroll
     for (uint32_t i = 1; i < 10; i++) {
-        if (i < B.n_hash) w &= bloom_window(B, Kk.racine + Kk.key[i]);
+        if (i < n_hash) w &= bloom_window(B, Kk.racine + Kk.key[i]);
     }
     return ((w >> pv) & 1u) != 0;
 }
