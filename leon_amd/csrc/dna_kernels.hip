@@ -603,15 +603,19 @@ void launch_lookup_apply(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uin
 
 // One resolution round over the unresolved reads: a read becomes a non-inserter as soon as one of its
 // k-mers is finally owned by an earlier read, an inserter when no earlier read even proposes one of them.
+// Four reads per wave, 16 positions per read and step (like k_lookup_cand and k_final_pos): the round is a chain of dependent
+// loads per read -- list entry, length and slot, packed words, filter word, dictionary slot -- and with one read per wave the
+// vector units sat at a fifth of their issue slots (profiles/r4_minimizer_filter.txt); four reads keep four chains in flight.
 template <typename K>
 __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global,
                                               const uint32_t* ulist, const uint32_t* ucount,
                                               uint32_t* next_list, uint32_t* next_count) {
-    uint32_t lane = lane_id(), k = R.k;
-    uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    uint32_t count = *ucount;
-    __shared__ uint32_t lists[4][64];                             // per wave: the reads it found blocked, handed over 64 at a time
+    const uint32_t lane = lane_id(), k = R.k;
+    const uint32_t grp = lane >> 4, l = lane & 15, gbase = grp * 16;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t count = *ucount;
+    __shared__ uint32_t lists[4][64];                             // per wave: the reads it found blocked, handed over in batches
     uint32_t* my_list = lists[threadIdx.x >> 6];
     uint32_t n_list = 0;                                          // wave-uniform
     auto flush_list = [&]() {
@@ -624,51 +628,70 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
         __builtin_amdgcn_wave_barrier();
         n_list = 0;
     };
-    for (uint64_t e = wave; e < count; e += nwaves) {
-        uint32_t i = ulist[e];
-        uint64_t g = first_global + i;
-        uint32_t nk = R.len[i] - k + 1;
-        const uint32_t* pk = R.packed + 2 * R.slot_off[i];
-        bool anyfin = false, anyblock = false;
-        for (uint32_t base = 0; base < nk && !anyfin; base += 64) {
-            uint32_t p = base + lane;
+    for (uint64_t e0 = 4 * wave; e0 < count; e0 += 4 * nwaves) {
+        const uint64_t e = e0 + grp;
+        const bool have = e < count;
+        const uint32_t i = have ? ulist[e] : 0u;
+        const uint64_t g = first_global + i;
+        const uint32_t nk = have ? R.len[i] - k + 1 : 0u;
+        const uint32_t* pk = R.packed + 2 * (have ? R.slot_off[i] : 0);
+        bool anyfin = false, anyblock = false;                    // (the same in the 16 lanes of a quarter-wave)
+        uint32_t base = 0;
+        bool done = !have;
+        while (__any(!done)) {
+            const bool run = !done;
+            const uint32_t p = base + l;
+            const bool valid = run && p < nk;
+            const uint32_t words = (run && l < 8) ? pk[(base >> 4) + l] : 0u;
+            const K cn = canon_from_words16<K>(words, gbase, base, valid ? p : (run ? nk - 1 : 0), k);
             bool f = false, t = false;
-            const K cn = canon_from_words<K>(pass_words(pk, base, lane), base, p < nk ? p : nk - 1, k);
-            if (p < nk) {
+            if (valid) {
                 // Every read on this list went through ALL of its k-mers in k_lookup_cand without meeting a key that was final
                 // before the window, so only keys PROPOSED in this window (which include the ones made final in it) can matter:
                 // the 1 MiB array of those, a few per cent full, answers for all but a handful of the read's ~120 k-mers
                 const uint32_t pb = window_bit(cn);
                 if ((D.pbits[pb >> 5] >> (pb & 31)) & 1u) {
                     uint64_t fin = IDX_INF;
-                    uint32_t slot = dict_find(D, cn, fin);
+                    const uint32_t slot = dict_find(D, cn, fin);
                     if (slot != 0xFFFFFFFFu) {
                         f = fin < g;
                         t = *tent_ptr(D, slot) < g;
                     }
                 }
             }
-            anyfin = __ballot(f) != 0;
-            anyblock = anyblock || (__ballot(t) != 0);
+            const uint32_t fq = (uint32_t)(__ballot(f) >> gbase) & 0xFFFFu, tq = (uint32_t)(__ballot(t) >> gbase) & 0xFFFFu;
+            if (run) {
+                anyfin = anyfin || fq != 0;
+                anyblock = anyblock || tq != 0;
+                base += 16;
+                done = anyfin || base >= nk;
+            }
         }
-        if (!anyfin && anyblock) {                                // (wave-uniform)
-            if (lane == 0) my_list[n_list] = i;
-            if (++n_list == 64) flush_list();
+        // blocked reads go on to the next round
+        const bool blocked = have && !anyfin && anyblock;
+        const unsigned long long bm = __ballot(blocked && l == 0);
+        if (bm) {
+            if (blocked && l == 0) my_list[n_list + (uint32_t)__popcll(bm & ((1ull << lane) - 1))] = i;
+            n_list += (uint32_t)__popcll(bm);
+            if (n_list > 64 - 4) flush_list();
         }
-        if (lane == 0) {
+        const bool inserter = have && !anyfin && !anyblock;
+        if (have && l == 0) {
             if (anyfin) V.status[i] = ST_HITNEW;
-            else if (anyblock) {}
-            else {
+            else if (inserter) {
                 V.status[i] = ST_INSERTER;
                 const uint32_t slot = V.cand_slot[i];
                 __hip_atomic_store(fin_ptr<K>(D, slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const K key = dict_key<K>(D, slot);
-                const uint32_t wb = window_bit(key);                        // k_final_pos only looks up keys whose bit is set
+                const uint32_t wb = window_bit(dict_key<K>(D, slot));              // k_final_pos only looks up keys whose bit is set
                 atomicOr(&D.wbits[wb >> 5], 1u << (wb & 31));
             }
         }
-        if (!anyfin && !anyblock) {                                // (wave-uniform) ... and k_lookup_cand, from the next window on
-            const K key = dict_key<K>(D, V.cand_slot[i]);
+        // ... and k_lookup_cand, from the next window on: the inserters' keys into the filter of the final keys, one read of the wave
+        // at a time (the key's minimizer takes the wave: 32 lanes)
+        for (unsigned long long im = __ballot(inserter && l == 0); im; im &= im - 1) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(im);
+            const uint32_t ii = (uint32_t)__shfl((int)i, (int)src);
+            const K key = dict_key<K>(D, V.cand_slot[ii]);
             const uint32_t hmin = key_minimizer_wave(D, key, k, lane);
             if (lane == 0) atomicOr((unsigned long long*)D.fbits + filter_word(D, hmin), (unsigned long long)filter_bits(key));
         }
@@ -678,7 +701,7 @@ __global__ void __launch_bounds__(256) k_check(ReadsDev R, DictDev D, ResolveDev
 void launch_check(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* ulist,
                   const uint32_t* ucount, uint32_t max_count, uint32_t* next_list, uint32_t* next_count) {
     if (!max_count) return;
-    DISPATCH_K(R.k, hipLaunchKernelGGL(k_check<K>, dim3(grid_for(max_count, 4, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, ulist,
+    DISPATCH_K(R.k, hipLaunchKernelGGL(k_check<K>, dim3(grid_for(max_count, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, ulist,
                                        ucount, next_list, next_count));
 }
 
