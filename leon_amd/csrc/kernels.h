@@ -54,12 +54,9 @@ inline void minimizer_geometry(uint32_t k, uint32_t& m, uint32_t& P, uint32_t& c
 }
 constexpr uint32_t FBITS_LOG2_MAX = 31;
 constexpr uint32_t FBITS_LOG2_DEFAULT = 28;   // 32 MiB (the sweep that chose it)
-constexpr uint32_t FBITS_LOG2 = 25;       // (round 3's filter, one bit per key at a position of the key's own hash:) 4 MiB.  Random dword loads run at ~260 G/s from a table of <= 2 MiB (L2 hits), 100-250 G/s
-                                          // from 4 MiB, ~52 G/s from HBM (profiles/r2_gather_ceiling_by_table_size.txt); measured on the
-                                          // path itself (100 M reads, resolve stage): 2^22 bits 336 ms, 2^24 300, 2^25 283, 2^26 287, 2^27 285.
-                                          // Round 3, measured and dropped (profiles/r3_resolve_sweep.txt; 217 ms as it stands): the dictionary
-                                          // probes as non-temporal loads 219 ms, a second-level 32 MiB filter behind this one 219, both with
-                                          // a 2 MiB first level 233-238, windows of 2^19 / 2^21 / 2^22 reads 244 / 229 / 230
+// (Rounds 2-3, for the record: one bit per key at a place of the key's own hash, 4 MiB = an XCD's L2 -- 2^22 bits 336 ms for the resolve
+// stage at 100 M reads, 2^24 300, 2^25 283, 2^26 287, 2^27 285; non-temporal dictionary probes, a second-level filter, windows of
+// 2^19 / 2^21 / 2^22 reads: nothing better than 217 ms, profiles/r3_resolve_sweep.txt.  Addressed by minimizer: 166-184 ms.)
 
 enum : uint8_t { ST_NOANCHOR = 0, ST_HIT = 1, ST_UNRESOLVED = 2, ST_INSERTER = 3, ST_HITNEW = 4 };
 
