@@ -821,6 +821,55 @@ def test_crafted_payloads_cannot_make_the_decoder_write_out_of_bounds():
     ctx.close()
 
 
+def test_what_the_gather_delivers_is_checked():
+    """leon_dna_set_gather: the parts of the other ranks are INPUT.  A part that does not fit this rank's reads (a status that does not
+    exist, a position past the read) or its dictionary (a 'found' k-mer that is no final key here) fails the batch with LEON_E_STATE
+    instead of anchoring reads somewhere else; so does a callback that fails; the stream is poisoned until reset and then codes the
+    file as if nothing had happened (emulated ranks)."""
+    import leon_amd
+    from leon_amd import capi
+    k, rpb = 31, 200
+    bases, off = common.synthetic(2000, 120, 8000, seed=12)
+    bl, solid, tai = common.make_bloom(bases, off, k)
+    ref = O.encode(bases, off, k, rpb, bl, trace=False)
+    lib = leon_amd.load_library()
+
+    def poke(word):
+        def fn(d_buf, part_bytes, world):                         # rank 0 of 2: rank 1's part arrives as `word` for every read
+            n = part_bytes // 8
+            host = np.full(n, word, dtype=np.uint64)
+            assert lib.leon_device_upload(0, C.c_void_p(d_buf + part_bytes), host.ctypes.data_as(C.c_void_p), n * 8) == 0
+        return fn
+
+    def boom(d_buf, part_bytes, world):
+        raise RuntimeError("the collective failed")
+    ctx = _ctx(k, rpb, tai, resolve_window=500)
+    ctx.bloom_upload(bl.bits)
+    for fn, what in ((poke(7), "do not fit"), (poke((5000 << 8) | 1), "do not fit"), (poke((3 << 8) | 1), "do not fit"), (boom, "gather callback")):
+        ctx.set_shard(0, 2)
+        ctx.set_exchange(capi.XCH_BY_ANCHOR, lambda d_send, counts: (0, 0))
+        ctx.set_gather(fn)
+        with pytest.raises(leon_amd.LeonDnaError) as e:
+            ctx.encode_batch(bases, off)
+        assert e.value.code == -4 and what in str(e.value), str(e.value)
+        with pytest.raises(leon_amd.LeonDnaError) as e:
+            ctx.encode_batch(bases, off)
+        assert e.value.code == -4 and "reset_stream" in str(e.value)
+        ctx.reset_stream()
+    got = []
+    for rank in range(2):
+        ctx.reset_stream()
+        ctx.set_shard(rank, 2)
+        ctx.set_exchange(capi.XCH_EMULATE)
+        ctx.set_gather(None)
+        got += ctx.encode_batch(bases, off)
+        d, na = ctx.finish()
+        assert na == ref.n_anchors
+    got.sort()
+    assert [g[1] for g in got] == ref.blocks
+    ctx.close()
+
+
 def test_failed_batch_poisons_the_stream_until_reset():
     """include/leon_dna.h LEON_E_STATE: a batch refused for its arguments leaves the context untouched; one that fails after it
     began to change the stream (here: the sink) poisons it until leon_dna_reset_stream"""
