@@ -755,7 +755,7 @@ __global__ void __launch_bounds__(256) k_final_pos(ReadsDev R, DictDev D, Resolv
             bool hit = false; uint32_t slot = 0xFFFFFFFFu;
             if (valid) {
                 // every position examined here missed the dictionary as it stood before the window, so only a key made
-                // final in THIS window can match: a 8 MB bit filter (L2 / Infinity Cache resident, ~1 % full) answers
+                // final in THIS window can match: a 1 MiB bit filter (L2 resident, a few per cent full) answers
                 // "not one of those" for nearly all of them without touching the dictionary
                 const uint32_t wb = window_bit(cn);
                 if ((D.wbits[wb >> 5] >> (wb & 31)) & 1u) {
@@ -1079,14 +1079,16 @@ __global__ void k_lower_bound(const uint64_t* sorted, uint64_t n, uint64_t bound
 void launch_lower_bound(hipStream_t s, const uint64_t* sorted, uint64_t n, uint64_t bound, unsigned long long* out) {
     hipLaunchKernelGGL(k_lower_bound, dim3(1), dim3(64), 0, s, sorted, n, bound, out);
 }
-// Where the slices begin.  A slice's walk costs about 2 ns per read plus 9 ns per anchor GROUP (the group's bloom sectors are fetched
+// Where the slices begin.  A slice's walk costs about 1 ns per read plus 10 ns per anchor GROUP (the group's bloom sectors are fetched
 // once and shared by its reads): equal numbers of reads would give the rank with the late, thinly covered anchors twice the work
 // of the rank with the early ones (64 against 32 ms at 100 M reads over 8 ranks).  Reads are weighted 1, plus SLICE_GROUP_WEIGHT
-// for the first read of every anchor; the slices are cut at equal weight.
-constexpr uint64_t SLICE_GROUP_WEIGHT = 4;
-__global__ void k_slice_weights(const uint64_t* sorted_keys, uint64_t n, uint64_t* w) {
+// for the first read of every anchor; the slices are cut at equal weight.  (4 until the walk's step lost a quarter of its
+// instructions -- what is left is the sectors, which come per group: first / last of eight ranks 26 / 37 ms with 4, 31 / 34 with 8,
+// 34 / 29 with 16, 35 / 26 with 32.)
+constexpr uint64_t SLICE_GROUP_WEIGHT = 10;
+__global__ void k_slice_weights(const uint64_t* sorted_keys, uint64_t n, uint64_t* w, uint64_t group_weight) {
     for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t <= n; t += (uint64_t)gridDim.x * blockDim.x)
-        w[t] = t == n ? 0 : 1 + ((t == 0 || sorted_keys[t] != sorted_keys[t - 1]) ? SLICE_GROUP_WEIGHT : 0);
+        w[t] = t == n ? 0 : 1 + ((t == 0 || sorted_keys[t] != sorted_keys[t - 1]) ? group_weight : 0);
 }
 // cum = exclusive sums of the weights (n + 1 entries): split[d] = first t whose cum >= total * d / world
 __global__ void k_slice_splits(const uint64_t* cum, uint64_t n, uint32_t world, unsigned long long* split) {
@@ -1099,7 +1101,9 @@ __global__ void k_slice_splits(const uint64_t* cum, uint64_t n, uint32_t world, 
     split[d] = d == world ? n : lo;
 }
 void launch_slice_weights(hipStream_t s, const uint64_t* sorted_keys, uint64_t n, uint64_t* w) {
-    hipLaunchKernelGGL(k_slice_weights, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, sorted_keys, n, w);
+    // (LEON_SLICE_GROUP_WEIGHT: a measurement override -- the SAME value on every rank, or the ranks cut different slices)
+    static const uint64_t group_weight = [] { const char* e = getenv("LEON_SLICE_GROUP_WEIGHT"); const long v = e ? atol(e) : 0; return v > 0 && v <= 1024 ? (uint64_t)v : SLICE_GROUP_WEIGHT; }();
+    hipLaunchKernelGGL(k_slice_weights, dim3(grid_for(n + 1, 256)), dim3(256), 0, s, sorted_keys, n, w, group_weight);
 }
 void launch_slice_splits(hipStream_t s, const uint64_t* cum, uint64_t n, uint32_t world, unsigned long long* split) {
     hipLaunchKernelGGL(k_slice_splits, dim3((world + 1 + 63) / 64), dim3(64), 0, s, cum, n, world, split);
