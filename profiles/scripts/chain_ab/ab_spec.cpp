@@ -453,6 +453,7 @@ struct SpecCoder {
                     "1:\n\t"
                     CARRY_STEP("0", "%[L]", "%%rcx", "%%ecx", "2f")
                     CARRY_STEP("32", "%%rcx", "%[L]", "%k[L]", "3f")
+                    "prefetcht0 2048(%[r])\n\t"                  /* (the records come from other cores' caches or from memory: a line per two symbols) */
                     "addq  $64, %[r]\n\t"
                     "cmpq  %[e], %[r]\n\t"
                     "jb    1b\n\t"
