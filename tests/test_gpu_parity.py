@@ -1,6 +1,7 @@
 """-m gpu: the HIP path, called through the C-ABI, against the CPU oracle on the same seeded inputs.
 Bit-exact everywhere (integer / byte work)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -471,7 +472,8 @@ def test_walk_divided_by_anchor_with_a_real_exchange_between_contexts():
         assert [g[1] for g in got] == ref.blocks and [g[2] for g in got] == ref.block_nreads, world
         assert results[0][1] == ref.anchor_dict and all(len(r[1]) == 0 for r in results[1:])
         assert sum(r[3]["xch_words_sent"] for r in results) == sum(r[3]["xch_words_received"] for r in results)
-        assert all(g == (results[0][3]["resolve_windows"] + 2 if share_lookups else 0) for g in gathers), gathers   # one per window (first batch: 2 windows)
+        lookups_on = share_lookups and os.environ.get("LEON_XCH_LOOKUPS") != "0"        # (the measurement override keeps every look-up on every rank)
+        assert all(g == (results[0][3]["resolve_windows"] + 2 if lookups_on else 0) for g in gathers), gathers   # one per window (first batch: 2 windows)
 
 
 def test_dictionary_stream_on_device_equals_host_thread():
@@ -828,6 +830,8 @@ def test_what_the_gather_delivers_is_checked():
     file as if nothing had happened (emulated ranks)."""
     import leon_amd
     from leon_amd import capi
+    if os.environ.get("LEON_XCH_LOOKUPS") == "0":
+        pytest.skip("LEON_XCH_LOOKUPS=0: the measurement override keeps every look-up on every rank, nothing is gathered")
     k, rpb = 31, 200
     bases, off = common.synthetic(2000, 120, 8000, seed=12)
     bl, solid, tai = common.make_bloom(bases, off, k)
