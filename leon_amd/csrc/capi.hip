@@ -293,7 +293,15 @@ bool rc_on_host(uint64_t n_blocks, uint64_t n_syms, uint64_t max_block_syms) {
 int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_blk_begin, uint64_t nbl, uint64_t n_syms, uint32_t small_sizes,
                       uint32_t n_small) {
     hipStream_t s = c->stream;
-    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->copy_stream) {
+        // A stream of HIGH priority: the runtime maps streams onto a few hardware queues, and in a process that also holds a
+        // communicator's streams (RCCL: every rank of an N-rank job) this one landed on the queue of `s` -- every chunk's copy then
+        // waited behind all sixteen modeler launches and the chains started when the modelers had finished (a seat of 8: 110 ms for
+        // the stage instead of ~75).  Streams of another priority get queues of their own.
+        int lo = 0, hi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, hi));
+    }
     std::vector<uint64_t> bb(nbl + 1);
     HIPCHK(c, hipMemcpyAsync(bb.data(), d_blk_begin, (nbl + 1) * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -372,15 +380,15 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
         HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->hb_ev[2 * ch], 0));
         const uint64_t bytes = (chunk_base[ch + 1] - chunk_base[ch]) * 8;
         if (bytes) HIPCHK(c, hipMemcpyAsync(c->h_recs + chunk_base[ch], c->hb_recs[ch & 1].p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+        // (the modelers' one refusal travels with the first chunk, on this stream: a blocking hipMemcpy of the flag waited for EVERY launch
+        // queued on `s` in a process that holds a communicator -- each rank of an N-rank job --, and the chains began when the modelers had finished)
+        if (ch == 0) HIPCHK(c, hipMemcpyAsync(c->h_rb + 500, c->errflag.p, 4, hipMemcpyDeviceToHost, c->copy_stream));
         HIPCHK(c, hipEventRecord(c->hb_ev[2 * ch + 1], c->copy_stream));
     }
+    const double t_enqueued = ms_now();
     for (uint32_t ch = 0; ch < n_chunks; ch++) {
         HIPCHK(c, hipEventSynchronize(c->hb_ev[2 * ch + 1]));
-        if (ch == 0) {                                           // (the modelers' one refusal comes with the first chunk)
-            int errflag = 0;
-            HIPCHK(c, hipMemcpy(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost));
-            if (errflag) return fail(c, LEON_E_OVERFLOW, "a block has more symbols than the host chains' records can count");
-        }
+        if (ch == 0 && (int)(uint32_t)c->h_rb[500]) return fail(c, LEON_E_OVERFLOW, "a block has more symbols than the host chains' records can count");
         chunks_ready.store(ch + 1, std::memory_order_release);
         t_copied[ch] = ms_now();
     }
@@ -388,7 +396,7 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
     join.ok = true;
     if (abort_flag.load() == 2) return fail(c, LEON_E_OVERFLOW, "a host chain ran out of memory for its output");
     if (trace) {
-        fprintf(stderr, "[leon rc host] %llu blocks, %llu symbols, %u chunks, %u threads:", (unsigned long long)nbl, (unsigned long long)n_syms, n_chunks, n_thr);
+        fprintf(stderr, "[leon rc host] %llu blocks, %llu symbols, %u chunks, %u threads, launches enqueued at %.1f ms:", (unsigned long long)nbl, (unsigned long long)n_syms, n_chunks, n_thr, t_enqueued);
         for (uint32_t ch = 0; ch < n_chunks; ch++) fprintf(stderr, " chunk %u in host memory at %.1f ms, coded at %.1f;", ch, t_copied[ch], t_coded[ch]);
         fprintf(stderr, " done at %.1f ms\n", ms_now());
     }
