@@ -252,6 +252,7 @@ struct Upload {
     }
     ~Upload() { for (auto& t : th) if (t.joinable()) t.join(); }
 };
+constexpr uint32_t kRbHostChainsErr = 500;   // slot of the pinned read-back words (h_rb, 512 of them) the host chains' first chunk brings the modelers' error flag to
 int ensure_cub(leon_dna_ctx* c, size_t bytes) { HIPCHK(c, c->cub_tmp.ensure(bytes)); return LEON_OK; }
 
 }  // namespace
@@ -382,13 +383,13 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
         if (bytes) HIPCHK(c, hipMemcpyAsync(c->h_recs + chunk_base[ch], c->hb_recs[ch & 1].p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
         // (the modelers' one refusal travels with the first chunk, on this stream: a blocking hipMemcpy of the flag waited for EVERY launch
         // queued on `s` in a process that holds a communicator -- each rank of an N-rank job --, and the chains began when the modelers had finished)
-        if (ch == 0) HIPCHK(c, hipMemcpyAsync(c->h_rb + 500, c->errflag.p, 4, hipMemcpyDeviceToHost, c->copy_stream));
+        if (ch == 0) HIPCHK(c, hipMemcpyAsync(c->h_rb + kRbHostChainsErr, c->errflag.p, 4, hipMemcpyDeviceToHost, c->copy_stream));
         HIPCHK(c, hipEventRecord(c->hb_ev[2 * ch + 1], c->copy_stream));
     }
     const double t_enqueued = ms_now();
     for (uint32_t ch = 0; ch < n_chunks; ch++) {
         HIPCHK(c, hipEventSynchronize(c->hb_ev[2 * ch + 1]));
-        if (ch == 0 && (int)(uint32_t)c->h_rb[500]) return fail(c, LEON_E_OVERFLOW, "a block has more symbols than the host chains' records can count");
+        if (ch == 0 && (int)(uint32_t)c->h_rb[kRbHostChainsErr]) return fail(c, LEON_E_OVERFLOW, "a block has more symbols than the host chains' records can count");
         chunks_ready.store(ch + 1, std::memory_order_release);
         t_copied[ch] = ms_now();
     }
