@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LEON_DNA_ABI_VERSION 4
+#define LEON_DNA_ABI_VERSION 5
 
 enum {
     LEON_OK = 0,
@@ -78,6 +78,11 @@ typedef struct leon_dna_stats {
        ms_emulated = LEON_XCH_EMULATE only: the other ranks' slices walked here in their stead (not part of a real rank's time) */
     float ms_exchange, ms_exchange_call, ms_emulated, ms_emulated_lookups;   /* ms_emulated_lookups: the part of ms_emulated (and of ms_resolve) spent on the other ranks' window look-ups */
     uint64_t xch_words_sent, xch_words_received, walk_reads;
+    /* anchor resolution, last batch: resolve_rounds above counts the parallel rounds; what they left unsettled (reads each waiting for the
+       one before it: files in genome-position order) went through the exact sequential pass -- that many reads, in that many windows,
+       ms_resolve_chain of ms_resolve (ABI 5) */
+    uint64_t resolve_chain_reads, resolve_chain_windows;
+    float ms_resolve_chain, reserved2;
 } leon_dna_stats;
 
 /* -- lifecycle (DnaEncoder ctor / dtor bracket one thread's work upstream) -- */

@@ -6,6 +6,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
+ABI_VERSION = 5          # include/leon_dna.h LEON_DNA_ABI_VERSION this binding (Stats, _EXPORTS) was written for
 LEON_F_KEEP_TRACE = 1
 LEON_F_DICT_ON_DEVICE = 2
 
@@ -35,7 +36,8 @@ class Stats(C.Structure):
                [("walk_launches", C.c_uint32), ("reserved", C.c_uint32), ("ms_anchor_wait", C.c_float),
                 ("ms_chain_busy", C.c_float)] + \
                [(n, C.c_float) for n in ("ms_exchange", "ms_exchange_call", "ms_emulated", "ms_emulated_lookups")] + \
-               [(n, C.c_uint64) for n in ("xch_words_sent", "xch_words_received", "walk_reads")]
+               [(n, C.c_uint64) for n in ("xch_words_sent", "xch_words_received", "walk_reads", "resolve_chain_reads", "resolve_chain_windows")] + \
+               [("ms_resolve_chain", C.c_float), ("reserved2", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
@@ -133,6 +135,10 @@ def load_library():
     for name, (res, args) in _EXPORTS.items():
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
+    if lib.leon_dna_abi_version() != ABI_VERSION:
+        # (a stale library under a new binding reads wrong stats and misses symbols; a new one under an old binding overruns Stats)
+        raise LeonDnaError(-2, "%s has ABI %d, this binding is written for %d: rebuild it (leon_amd.build_library())"
+                           % (path, lib.leon_dna_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

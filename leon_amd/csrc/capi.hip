@@ -126,6 +126,8 @@ struct leon_dna_ctx {
     DevBuf xch_slot, xch_off, xch_evoff, xch_events, xch_send, xch_split, xch_res;
     DevBuf resolve_trace;
     DevBuf round_hist;                           // the counts of a window's fixpoint rounds, read back together
+    DevBuf chain_cnt, chain_own, chain_ins, chain_rows, chain_ent, chain_trace;   // the sequential pass behind the rounds (k_chain_*)
+    std::vector<hipEvent_t> chain_ev;            // pairs around the sequential passes of a batch
     // small launches: the blocks' chains on host cores (host_blocks.h), fed by the device's modelers chunk by chunk
     DevBuf hb_recs[2], hb_recoff, hb_state;
     uint64_t* h_recs = nullptr; size_t h_recs_cap = 0;          // pinned: the records of a launch
@@ -509,6 +511,7 @@ void leon_dna_ctx_destroy(leon_dna_ctx* c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pack_ev) (void)hipEventDestroy(e);
+    for (auto& e : c->chain_ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -754,7 +757,14 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     // next wait; and a window's new anchors travel to pinned memory behind the kernels and are handed to the dictionary chain at
     // the NEXT window's first wait (the first window's at once: the chain, the longest piece of a step, starts with them).
     const uint64_t KW = kmer_words(k);                              // 64-bit words per anchor k-mer
-    constexpr uint32_t kRoundsAhead = 3, kRoundsMore = 2, kHist = 64;
+    // The rounds are NOT asked to finish: their count is the longest chain of reads each waiting for the one before it, which no valid
+    // input bounds (reads in genome-position order make one chain of a whole window).  After kRoundsAhead rounds -- more while the
+    // list keeps halving, kRoundsMax at most -- what is left goes, in read order, through the exact sequential pass (chain_tail below).
+    // LEON_RESOLVE_ROUNDS=a[:m]: rounds launched ahead / at most (measurement aid; any values give the same bytes).
+    static const uint32_t kRoundsAhead = [] { const char* e = getenv("LEON_RESOLVE_ROUNDS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (uint32_t)v : 3u; }();
+    static const uint32_t kRoundsMax = [] { const char* e = getenv("LEON_RESOLVE_ROUNDS"); const char* q = e ? strchr(e, ':') : nullptr; const int v = q ? atoi(q + 1) : 0;
+                                            return std::max<uint32_t>(kRoundsAhead, v >= 1 && v <= 62 ? (uint32_t)v : 9u); }();
+    constexpr uint32_t kRoundsMore = 2, kHist = 64;
     HIPCHK(c, c->round_hist.ensure(kHist * 4));
     uint32_t* d_hist = c->round_hist.as<uint32_t>();
     if (c->h_anchor_cap < W * 8 * KW) {
@@ -781,6 +791,61 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     float lk_call_ms = 0, lk_emul_ms = 0;
     int anchor_buf = 0;
     uint32_t hint = (uint32_t)std::min<uint64_t>(W, 1u << 20);      // grid-size hint of a window's first round (any size is correct: grid-stride loops)
+    // ---- the exact sequential pass behind the rounds (dna_kernels.hip, k_chain_*): the `left` reads the rounds did not settle ----
+    static const bool trace_chain = getenv("LEON_TRACE_CHAIN") != nullptr;
+    uint32_t n_chain_ev = 0;
+    auto chain_tail = [&](uint32_t left, uint64_t w0, uint64_t w1, uint32_t* clist) -> int {
+        if (c->chain_ev.size() < 2 * (size_t)(n_chain_ev + 1)) {
+            hipEvent_t e0, e1;
+            HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+            c->chain_ev.push_back(e0); c->chain_ev.push_back(e1);
+        }
+        HIPCHK(c, hipEventRecord(c->chain_ev[2 * n_chain_ev], s));
+        // in read order: flags over the window, their ranks (a read's chain index), the compacted list
+        uint32_t* rank = c->rank.as<uint32_t>();
+        launch_chain_flags(s, V, w0, w1, V.ins_flag);
+        HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, scan_tmp, V.ins_flag, rank, w1 - w0, s));
+        launch_chain_compact(s, V, w0, w1, rank, clist);
+        constexpr uint32_t CH = 1u << CHAIN_LOG2;
+        unsigned long long* d_ctrace = nullptr;
+        if (trace_chain) { HIPCHK(c, c->chain_trace.ensure(4 * 8)); d_ctrace = c->chain_trace.as<unsigned long long>(); HIPCHK(c, hipMemsetAsync(d_ctrace, 0, 4 * 8, s)); }
+        for (uint32_t c0 = 0; c0 < left; c0 += CH) {
+            const uint32_t nc = std::min(CH, left - c0), nG = (nc + 63) / 64;
+            // a later chunk: tent still names reads of the chunk before (settled now) -- cleared, and what is left proposes again
+            if (c0) launch_chain_repropose(s, c->D, V, first_read_index, clist + (c0 - CH), left - (c0 - CH), clist + c0, left - c0);
+            HIPCHK(c, c->chain_cnt.ensure((uint64_t)nc * 4)); HIPCHK(c, c->chain_own.ensure((uint64_t)nc * 4));
+            HIPCHK(c, c->chain_ins.ensure(nc)); HIPCHK(c, c->chain_rows.ensure(((uint64_t)nG + 1) * 8));
+            uint64_t* rows = c->chain_rows.as<uint64_t>();
+            size_t rows_tmp = 0;
+            HIPCHK(c, prim::ExclusiveSum(nullptr, rows_tmp, rows, rows, nG + 1, s));
+            if (rows_tmp > c->cub_tmp.cap) { HIPCHK(c, hipStreamSynchronize(s)); if (int rc = ensure_cub(c, std::max(rows_tmp, scan_tmp))) return rc; }
+            launch_chain_prep(s, false, R, c->D, V, first_read_index, w0, clist + c0, nc, c0, rank, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), nullptr, nullptr);
+            launch_chain_group_rows(s, c->chain_cnt.as<uint32_t>(), nc, rows);
+            HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, rows_tmp, rows, rows, nG + 1, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, rows + nG, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, spin_sync(s));
+            const uint64_t total_rows = c->h_rb[0];
+            HIPCHK(c, c->chain_ent.ensure(std::max<uint64_t>(total_rows, 1) * 64 * 4));
+            launch_chain_prep(s, true, R, c->D, V, first_read_index, w0, clist + c0, nc, c0, rank, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), rows, c->chain_ent.as<uint32_t>());
+            if (launch_chain_seq(s, nc, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), rows, c->chain_ent.as<uint32_t>(), c->chain_ins.as<uint8_t>(), d_ctrace))
+                return fail(c, LEON_E_HIP, "the sequential resolution pass could not be launched (its LDS request was refused)");
+            launch_chain_apply(s, c->D, V, first_read_index, clist + c0, nc, c->chain_ins.as<uint8_t>(), k);
+            HIPCHK(c, hipGetLastError());
+        }
+        // (the rounds end with every tent they touched cleared; so must this: a tent that still named a settled read would block whoever
+        // proposes the key in a later window)
+        { const uint32_t c_last = ((left - 1) >> CHAIN_LOG2) << CHAIN_LOG2; launch_chain_repropose(s, c->D, V, first_read_index, clist + c_last, left - c_last, nullptr, 0); }
+        HIPCHK(c, hipEventRecord(c->chain_ev[2 * n_chain_ev + 1], s));
+        n_chain_ev++;
+        c->stats.resolve_chain_reads += left; c->stats.resolve_chain_windows++;
+        if (trace_chain) {
+            unsigned long long t[4];
+            HIPCHK(c, hipMemcpy(t, d_ctrace, sizeof t, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[leon chain] window [%llu, %llu): %u reads left by the rounds; %llu steps of 64, %.2f ballot iterations per step, %llu late lanes, %llu inserters\n",
+                    (unsigned long long)w0, (unsigned long long)w1, left, t[0], t[0] ? (double)t[1] / t[0] : 0.0, t[2], t[3]);
+        }
+        return LEON_OK;
+    };
     for (uint64_t w0 = 0, w1 = 0; w0 < n; w0 = w1) {
         w1 = std::min(n, w0 + (w0 == 0 ? first_window(W) : W));
         if (int rc = dict_reserve(c, c->n_keys + (w1 - w0))) return rc;
@@ -851,7 +916,13 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
                 for (uint32_t r = 1; r < n_hist; r++) if (hist[r - 1] > 0) c->stats.resolve_rounds++;
                 break;
             }
-            if (n_hist >= kHist) return fail(c, LEON_E_STATE, "anchor resolution did not settle in its rounds (internal error)");
+            // more rounds only while they pay: the list at least halved in the last round and the budget is not spent
+            const bool halving = n_hist >= 2 && 2ull * hist[n_hist - 1] <= hist[n_hist - 2];
+            if (!halving || n_hist - 1 >= kRoundsMax || n_hist + kRoundsMore > kHist) {
+                for (uint32_t r = 1; r < n_hist; r++) if (hist[r - 1] > 0) c->stats.resolve_rounds++;
+                if (int rc = chain_tail(cnt, w0, w1, lists[cur ^ 1])) return rc;
+                break;
+            }
         }
         hint = std::max<uint32_t>(2 * cnt0, 4096);
         if (cnt0 > 0) {
@@ -920,6 +991,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     const uint64_t nl_bases = off_r1 - off_r0;
     R.ev_origin = r0;
     auto ms = [&](int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, c->ev[a], c->ev[b]); return v; };
+    auto chain_ms = [&]() { float t = 0; for (uint32_t e = 0; e < n_chain_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->chain_ev[2 * e], c->chain_ev[2 * e + 1]); t += v; } return t; };
     c->stats.n_reads = nl; c->stats.n_bases = nl_bases; c->stats.n_blocks = nbl; c->stats.n_anchors = c->n_anchors;
     c->last_n = n; c->last_bases = nl_bases;
     c->last_d_bases = d_bases; c->last_d_off = d_off;
@@ -927,7 +999,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     if (nl == 0 && !(by_anchor && c->xch_mode == LEON_XCH_BY_ANCHOR)) {   // nothing of this batch is ours to encode (and nobody waits for our slice)
         HIPCHK(c, hipStreamSynchronize(s));
         float pack2 = 0; for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
-        c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_total = ms(0, 2);
+        c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_resolve_chain = chain_ms(); c->stats.ms_total = ms(0, 2);
         c->next_read += n; c->next_block += n_blocks;
         if (n % rpb) c->partial_seen = true;
         c->poisoned = false;
@@ -1067,7 +1139,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         if (xerr) return fail(c, LEON_E_STATE, "the exchange delivered a word that lies outside this rank's blocks");
         if (nl == 0) {                                           // our slice is delivered; no block of the batch is ours to code
             float pack2 = 0; for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
-            c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5); c->stats.ms_total = ms(0, 5);
+            c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_resolve_chain = chain_ms(); c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5); c->stats.ms_total = ms(0, 5);
             c->next_read += n; c->next_block += n_blocks;
             if (n % rpb) c->partial_seen = true;
             c->poisoned = false;
@@ -1156,7 +1228,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     c->stats.n_symbols = n_syms; c->stats.payload_bytes = payload_bytes;
     float pack2 = 0;                                                   // the part of the pack stage that ran inside the resolution loop
     for (uint32_t e = 1; e < n_pack_ev; e++) { float v = 0; (void)hipEventElapsedTime(&v, c->pack_ev[2 * e], c->pack_ev[2 * e + 1]); pack2 += v; }
-    c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5);
+    c->stats.ms_pack = ms(0, 1) + pack2; c->stats.ms_resolve = ms(1, 2) - pack2; c->stats.ms_resolve_chain = chain_ms(); c->stats.ms_sort = ms(2, 3); c->stats.ms_walk = ms(4, 5);
     c->stats.ms_symbols = by_anchor ? ms(9, 6) : ms(5, 6); c->stats.ms_rangecoder = ms(6, 7); c->stats.ms_d2h = ms(7, 8); c->stats.ms_total = ms(0, 8);
 
     // ---- Leon::writeBlock, in block order ----

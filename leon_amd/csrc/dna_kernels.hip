@@ -833,6 +833,279 @@ void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, u
     DISPATCH_K(R.k, hipLaunchKernelGGL(k_finalize_reads<K>, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, R, D, V, w0, w1));
 }
 
+// ================================================================================================
+// The exact sequential pass behind the rounds (round 5).  The rounds above settle a window in as many launches as its longest
+// chain of reads each waiting for the one before it: 3-6 for reads placed at random, but reads in genome-position order
+// (a sorted BAM turned back into FASTQ, tiled amplicons) make ONE chain of the whole window -- read j + 1 contains the k-mer
+// read j proposes -- and a window of 2^21 reads would need ~3 * 10^5 rounds.  What the rounds leave is therefore handed, in read
+// order, to ONE wave that walks it like Leon's single thread does, with everything that can be done ahead done ahead and in parallel:
+//   k_chain_prep  (parallel, like a round of k_check): per unresolved read r, `dead` -- one of its k-mers is ALREADY final with an
+//                 earlier owner -- else its ENTRIES: for every k-mer of r that an earlier unresolved read proposes, the chain index
+//                 of that key's FIRST proposer (the key's name in this pass), and `own`: the name of r's own candidate;
+//   k_chain_seq   (one workgroup): for r in read order: r inserts <=> not dead and no entry names a key inserted so far.  A bit per key
+//                 name in LDS; 64 reads per step, lane per read: entries that name keys of earlier steps are tested against the bits,
+//                 entries that name keys of THIS step become a 64-bit mask of the lanes the read waits for, and the step's own order
+//                 is settled with ballots (as many iterations as the longest chain inside the 64 reads).  Three producer waves
+//                 stage the steps' records from global memory into an LDS ring ahead of the consumer wave;
+//   k_chain_apply (parallel): what k_check does for the reads it settles (status, fin, the filters' bits).
+// A key's name is the chain index of its first proposer in the chunk, so at most 2^CHAIN_LOG2 reads go through one k_chain_seq;
+// a longer list goes chunk by chunk (tent re-proposed by what is left).  The result is the file-order result by construction:
+// `inserted` is only ever consulted for keys, and set by reads, in read order.
+// ================================================================================================
+__global__ void k_chain_flags(const uint8_t* status, uint64_t w0, uint64_t w1, uint32_t* flag) {
+    for (uint64_t i = w0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < w1; i += (uint64_t)gridDim.x * blockDim.x)
+        flag[i - w0] = status[i] == ST_UNRESOLVED ? 1u : 0u;
+}
+__global__ void k_chain_compact(const uint8_t* status, uint64_t w0, uint64_t w1, const uint32_t* rank, uint32_t* list) {
+    for (uint64_t i = w0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < w1; i += (uint64_t)gridDim.x * blockDim.x)
+        if (status[i] == ST_UNRESOLVED) list[rank[i - w0]] = (uint32_t)i;
+}
+void launch_chain_flags(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1, uint32_t* flag) {
+    if (w1 <= w0) return;
+    hipLaunchKernelGGL(k_chain_flags, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, V.status, w0, w1, flag);
+}
+void launch_chain_compact(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1, const uint32_t* rank, uint32_t* list) {
+    if (w1 <= w0) return;
+    hipLaunchKernelGGL(k_chain_compact, dim3(grid_for(w1 - w0, 256)), dim3(256), 0, s, V.status, w0, w1, rank, list);
+}
+// tent of the candidates of list[0 .. n): cleared, then proposed again (a later chunk of the chain: what is left proposes)
+__global__ void k_chain_reset(DictDev D, ResolveDev V, const uint32_t* list, uint32_t n) {
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x)
+        *tent_ptr(D, V.cand_slot[list[e]]) = IDX_INF;
+}
+__global__ void k_chain_propose(DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n) {
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = list[e];
+        atomicMin((unsigned long long*)tent_ptr(D, V.cand_slot[i]), (unsigned long long)(first_global + i));
+    }
+}
+void launch_chain_repropose(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* reset_list, uint32_t n_reset,
+                            const uint32_t* list, uint32_t n) {
+    if (n_reset) hipLaunchKernelGGL(k_chain_reset, dim3(grid_for(n_reset, 256)), dim3(256), 0, s, D, V, reset_list, n_reset);
+    if (n) hipLaunchKernelGGL(k_chain_propose, dim3(grid_for(n, 256)), dim3(256), 0, s, D, V, first_global, list, n);
+}
+
+// list: the chunk's reads in read order; rank: the window's exclusive ranks of the unresolved reads (a read's chain index), c0 the
+// chunk's first chain index.  FILL = false: cnt[e] = entries | dead << 31, own[e]; FILL = true: the entries, transposed per group
+// of 64 reads -- entry j of read e at ent[(gbase[e / 64] + j) * 64 + e % 64] -- so that a wave takes a step's entries row by row.
+// Four reads per wave, 16 positions per read and step, like k_check.
+template <typename K, bool FILL>
+__global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, uint64_t w0,
+                                                   const uint32_t* list, uint32_t n, uint32_t c0, const uint32_t* rank,
+                                                   uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent) {
+    const uint32_t lane = lane_id(), k = R.k;
+    const uint32_t grp = lane >> 4, l = lane & 15, gbase16 = grp * 16;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t e0 = 4 * wave; e0 < n; e0 += 4 * nwaves) {
+        const uint64_t e = e0 + grp;
+        const bool have = e < n;
+        const uint32_t i = have ? list[e] : 0u;
+        const uint64_t g = first_global + i;
+        const uint32_t nk = have ? R.len[i] - k + 1 : 0u;
+        const uint32_t* pk = R.packed + 2 * (have ? R.slot_off[i] : 0);
+        uint32_t total = 0;
+        bool dead = false;
+        bool done = !have;
+        uint64_t at = 0;
+        if (FILL) {
+            const uint32_t cd = have ? cnt[e] : 0x80000000u;
+            done = !have || (cd >> 31) || (cd & 0x7FFFFFFFu) == 0;           // nothing to write for this read
+            at = have ? gbase[e >> 6] * 64 + (e & 63) : 0;
+        }
+        uint32_t base = 0;
+        while (__any(!done)) {
+            const bool run = !done;
+            const uint32_t p = base + l;
+            const bool valid = run && p < nk;
+            const uint32_t words = (run && l < 8) ? pk[(base >> 4) + l] : 0u;
+            const K cn = canon_from_words16<K>(words, gbase16, base, valid ? p : (run ? nk - 1 : 0), k);
+            bool f = false, t = false;
+            uint64_t tv = IDX_INF;
+            if (valid) {
+                const uint32_t pb = window_bit(cn);                        // (keys proposed in this window, final or not: k_check's filter)
+                if ((D.pbits[pb >> 5] >> (pb & 31)) & 1u) {
+                    uint64_t fin = IDX_INF;
+                    const uint32_t slot = dict_find(D, cn, fin);
+                    if (slot != 0xFFFFFFFFu) {
+                        f = fin < g;
+                        tv = *tent_ptr(D, slot);
+                        t = tv < g;
+                    }
+                }
+            }
+            const uint32_t fq = (uint32_t)(__ballot(f) >> gbase16) & 0xFFFFu, tq = (uint32_t)(__ballot(t) >> gbase16) & 0xFFFFu;
+            if (run) {
+                if (FILL) {
+                    if (t) ent[at + 64ull * (total + (uint32_t)__popc(tq & ((1u << l) - 1u)))] = rank[tv - first_global - w0] - c0;
+                } else dead = dead || fq != 0;
+                total += (uint32_t)__popc(tq);
+                base += 16;
+                done = dead || base >= nk;
+            }
+        }
+        if (!FILL && have && l == 0) {
+            cnt[e] = dead ? 0x80000000u : total;
+            own[e] = rank[*tent_ptr(D, V.cand_slot[i]) - first_global - w0] - c0;     // (the read proposes its candidate itself: tent <= g)
+        }
+    }
+}
+void launch_chain_prep(hipStream_t s, bool fill, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, uint64_t w0, const uint32_t* list,
+                       uint32_t n, uint32_t c0, const uint32_t* rank, uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent) {
+    if (!n) return;
+    if (fill) DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, true>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent));
+    else DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, false>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent));
+}
+// per group of 64 reads: the rows its entries take (the longest list among its reads), as a 64-bit count for the scan
+__global__ void k_chain_group_rows(const uint32_t* cnt, uint32_t n, uint64_t* rows) {
+    const uint32_t lane = lane_id();
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t nG = ((uint64_t)n + 63) / 64;
+    for (uint64_t G = wave; G <= nG; G += nwaves) {
+        const uint64_t e = G * 64 + lane;
+        uint32_t c = (G < nG && e < n) ? cnt[e] : 0u;
+        c = (c >> 31) ? 0u : c;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)c, d); c = o > c ? o : c; }
+        if (lane == 0) rows[G] = c;                                   // (rows[nG] = 0: the scan's total lands there)
+    }
+}
+void launch_chain_group_rows(hipStream_t s, const uint32_t* cnt, uint32_t n, uint64_t* rows) {
+    hipLaunchKernelGGL(k_chain_group_rows, dim3(grid_for((n + 63) / 64 + 1, 4)), dim3(256), 0, s, cnt, n, rows);
+}
+
+struct ChainSlot { uint32_t own[64], cnt[64], ent[CHAIN_EL][64]; uint64_t gb; uint32_t rows, pad; };
+constexpr uint32_t CHAIN_BITS_WORDS = 1u << (CHAIN_LOG2 - 5);
+size_t chain_seq_lds_bytes() { return CHAIN_BITS_WORDS * 4 + CHAIN_DEPTH * sizeof(ChainSlot) + 64 * 8 + (CHAIN_DEPTH + 2) * 4; }
+__global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* cnt, const uint32_t* own, const uint64_t* gbase /* nG + 1 */,
+                                                  const uint32_t* ent, uint8_t* ins, unsigned long long* trace /* nullptr or 4 counters */) {
+    extern __shared__ uint32_t chain_lds[];
+    uint32_t* bits = chain_lds;                                                  // a bit per key name: inserted so far
+    ChainSlot* ring = reinterpret_cast<ChainSlot*>(chain_lds + CHAIN_BITS_WORDS);
+    unsigned long long* om = reinterpret_cast<unsigned long long*>(ring + CHAIN_DEPTH);   // per key name of the step: the lanes that propose it
+    uint32_t* ready = reinterpret_cast<uint32_t*>(om + 64);                      // [CHAIN_DEPTH]: step + 1 once the slot holds it
+    uint32_t* consumed = ready + CHAIN_DEPTH;                                    // steps the consumer is done with
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t nG = (n + 63) / 64;
+    for (uint32_t w = threadIdx.x; w < CHAIN_BITS_WORDS; w += blockDim.x) bits[w] = 0u;
+    if (threadIdx.x < CHAIN_DEPTH) ready[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) *consumed = 0u;
+    __syncthreads();
+    if (wv > 0) {
+        // ---- producers: step G's records from global memory into ring[G % CHAIN_DEPTH]; wave w takes G = w - 1, w + 2, ...
+        for (uint32_t G = wv - 1; G < nG; G += 3) {
+            const uint32_t e = G * 64 + lane;
+            const uint64_t gb = gbase[G];
+            const uint32_t rows = (uint32_t)(gbase[G + 1] - gb);
+            const uint32_t o = e < n ? own[e] : 0u, cd = e < n ? cnt[e] : 0x80000000u;
+            uint32_t v[CHAIN_EL];
+#pragma unroll
+            for (uint32_t j = 0; j < CHAIN_EL; j++) v[j] = j < rows ? ent[(gb + j) * 64 + lane] : 0u;
+            while (G >= __hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + CHAIN_DEPTH) __builtin_amdgcn_s_sleep(2);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            ChainSlot& S = ring[G % CHAIN_DEPTH];
+            S.own[lane] = o; S.cnt[lane] = cd;
+            if (lane == 0) { S.gb = gb; S.rows = rows; }
+#pragma unroll
+            for (uint32_t j = 0; j < CHAIN_EL; j++) if (j < rows) S.ent[j][lane] = v[j];
+            // (the flags: LDS operations of a wave execute in order and the LDS is one memory for the workgroup, so a compiler barrier
+            // and a relaxed store are the release -- an atomic release would also wait for every global access in flight)
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __hip_atomic_store(&ready[G % CHAIN_DEPTH], G + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    // ---- the consumer wave: steps in order
+    unsigned long long tr_iter = 0, tr_late = 0, tr_ins = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t G = 0; G < nG; G++) {
+        while (__hip_atomic_load(&ready[G % CHAIN_DEPTH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != G + 1) __builtin_amdgcn_s_sleep(0);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const ChainSlot& S = ring[G % CHAIN_DEPTH];
+        const uint32_t g0 = G * 64, e = g0 + lane;
+        const uint64_t gb = S.gb;
+        const uint32_t rows = S.rows;
+        const uint32_t o = S.own[lane], cd = S.cnt[lane];
+        const uint32_t c = (cd >> 31) ? 0u : cd;
+        bool dead = (cd >> 31) != 0;                                             // (lanes past the list's end arrive dead)
+        om[lane] = 0ull;
+        if (e < n && o >= g0) atomicOr(&om[o - g0], 1ull << lane);               // (LDS operations of one wave execute in order)
+        auto entry = [&](uint32_t j) -> uint32_t { return j < CHAIN_EL ? S.ent[j][lane] : ent[(gb + j) * 64 + lane]; };
+        unsigned long long dep = 0ull;
+        for (uint32_t j = 0; j < rows; j++) {
+            if (j < c) {
+                const uint32_t kid = entry(j);
+                if (kid >= g0) dep |= om[kid - g0];                              // a key first proposed in this step: whoever proposes it here
+                else dead = dead || ((bits[kid >> 5] >> (kid & 31)) & 1u);       // a key of an earlier step: inserted by now, or never before this step ends ...
+            }
+        }
+        dep &= below;
+        // ... unless a read of THIS step proposes it too (its first proposer, in an earlier step, did not insert): rare, taken one such lane at a time
+        for (unsigned long long late = __ballot(!dead && o < g0); late; late &= late - 1) {
+            const uint32_t a = (uint32_t)__builtin_ctzll(late);
+            const uint32_t ka = (uint32_t)__shfl((int)o, (int)a);
+            bool hit = false;
+            for (uint32_t j = 0; j < rows; j++) if (j < c && entry(j) == ka) hit = true;
+            if (hit && lane > a) dep |= 1ull << a;
+            tr_late++;
+        }
+        // the step's own order: a lane is settled once every lane it waits for is; it inserts iff none of those did
+        unsigned long long decided = __ballot(dead || dep == 0ull), insm = __ballot(!dead && dep == 0ull);
+        while (~decided) {
+            const bool und = !((decided >> lane) & 1ull);
+            const bool kill = und && (dep & insm) != 0ull;
+            const bool win = und && !kill && (dep & ~decided) == 0ull;
+            const unsigned long long km = __ballot(kill), wm = __ballot(win);
+            decided |= km | wm; insm |= wm;
+            tr_iter++;
+        }
+        const bool inserts = (insm >> lane) & 1ull;
+        if (inserts) atomicOr(&bits[o >> 5], 1u << (o & 31));
+        if (e < n) ins[e] = inserts ? 1 : 0;
+        tr_ins += (unsigned long long)__popcll(insm);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __hip_atomic_store(consumed, G + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (trace && lane == 0) { atomicAdd(trace + 0, (unsigned long long)nG); atomicAdd(trace + 1, tr_iter); atomicAdd(trace + 2, tr_late); atomicAdd(trace + 3, tr_ins); }
+}
+int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint32_t* own, const uint64_t* gbase, const uint32_t* ent, uint8_t* ins,
+                     unsigned long long* trace) {
+    if (!n) return 0;
+    if (n > (1u << CHAIN_LOG2)) return 1;
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_seq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_seq_lds_bytes());
+    if (attr != hipSuccess) return 2;
+    hipLaunchKernelGGL(k_chain_seq, dim3(1), dim3(256), chain_seq_lds_bytes(), s, n, cnt, own, gbase, ent, ins, trace);
+    return 0;
+}
+// what k_check does for the reads it settles: status; an inserter's fin, its bit in the window's filter, its key in the final keys' filter
+template <typename K>
+__global__ void __launch_bounds__(256) k_chain_apply(DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n, const uint8_t* ins, uint32_t k) {
+    const uint32_t lane = lane_id();
+    for (uint64_t e0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) & ~63ull; e0 < n; e0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = e0 + lane;
+        const bool have = e < n;
+        const uint32_t i = have ? list[e] : 0u;
+        const bool inserter = have && ins[e] != 0;
+        if (have) V.status[i] = inserter ? ST_INSERTER : ST_HITNEW;
+        if (inserter) {
+            const uint32_t slot = V.cand_slot[i];
+            __hip_atomic_store(fin_ptr<K>(D, slot), first_global + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t wb = window_bit(dict_key<K>(D, slot));
+            atomicOr(&D.wbits[wb >> 5], 1u << (wb & 31));
+        }
+        for (unsigned long long im = __ballot(inserter); im; im &= im - 1) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(im);
+            const uint32_t ii = (uint32_t)__shfl((int)i, (int)src);
+            const K key = dict_key<K>(D, V.cand_slot[ii]);
+            const uint32_t hmin = key_minimizer_wave(D, key, k, lane);
+            if (lane == 0) atomicOr((unsigned long long*)D.fbits + filter_word(D, hmin), (unsigned long long)filter_bits(key));
+        }
+    }
+}
+void launch_chain_apply(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n, const uint8_t* ins, uint32_t k) {
+    if (!n) return;
+    DISPATCH_K(k, hipLaunchKernelGGL(k_chain_apply<K>, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, D, V, first_global, list, n, ins, k));
+}
+
 // the dictionary stream's symbols: k bases per anchor, first base first, on a 5-symbol Order0Model (_anchorDictModel)
 template <typename K>
 __global__ void k_anchor_symbols(const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms) {

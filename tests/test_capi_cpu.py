@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
     for name in declared:
         assert hasattr(raw, name), "libleon_dna.so does not export " + name
     assert sorted(capi.EXPORTED_SYMBOLS) == declared, "the Python binding and the header disagree"
-    assert lib.leon_dna_abi_version() == 4
+    assert lib.leon_dna_abi_version() == 5 == capi.ABI_VERSION
 
 
 def test_no_cpu_fallback(lib):
