@@ -107,6 +107,135 @@ def gen_reads_chunk(genome, chunk_id, n, err, device, L=None):
     return lut[codes.long()]
 
 
+def gen_structured_genome(G, device, families=0, microsats=0, seed=52):
+    """a genome with the structure real ones have: dispersed repeats (`families` segments of 0.1-5 kbp copied to 2-6 other places, half of
+    the copies reverse-complemented) and tandem repeats (`microsats` units of 1-6 bp repeated over 40-400 bp) written into an i.i.d. one.
+    Defaults scale with G: one family per 250 kbp, one microsatellite per 25 kbp."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    genome = torch.randint(0, 4, (G,), dtype=torch.uint8, device=device, generator=g)
+    rnd = np.random.default_rng(seed + 1)
+    for _ in range(families or max(4, G // 250_000)):
+        seg = int(min(max(100, G // 8), rnd.integers(100, 5001)))
+        src = int(rnd.integers(0, G - seg))
+        piece = genome[src:src + seg].clone()
+        for _ in range(int(rnd.integers(2, 7))):
+            dst = int(rnd.integers(0, G - seg))
+            genome[dst:dst + seg] = (piece.flip(0) ^ 2) if rnd.random() < 0.5 else piece
+    for _ in range(microsats or max(4, G // 25_000)):
+        unit = torch.from_numpy(rnd.integers(0, 4, size=int(rnd.integers(1, 7))).astype(np.uint8)).to(device)
+        span = int(min(max(8, G // 10), rnd.integers(40, 401)))
+        dst = int(rnd.integers(0, max(1, G - span)))
+        genome[dst:dst + span] = unit.repeat(span // unit.numel() + 1)[:span]
+    return genome
+
+
+def gen_structured_reads(genome, n, L, device, order="sorted", err=0.01, dup_rate=0.1, skew=0.3, ragged=True, seed=53):
+    """reads with the structure real files have, flat ASCII + offsets (int64) on the device:
+    order "sorted" = by start position (a position-sorted BAM turned back into FASTQ), "pairs" = mates interleaved (forward read, then a
+    reverse read ~2.2 read lengths downstream), "random"; dup_rate = share of PCR duplicates (another read's placement, own errors);
+    skew = share of the reads that fall into a tenth of the genome; ragged = lengths uniform in [L/2, L]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    G = genome.numel()
+    u = torch.rand(n, device=device, generator=g)
+    if skew > 0:
+        hot = torch.rand(n, device=device, generator=g) < skew
+        u = torch.where(hot, 0.45 + 0.1 * u, u)
+    starts = (u * (G - L + 1)).long()
+    rev = torch.rand(n, device=device, generator=g) < 0.5
+    if order == "pairs":
+        half = n // 2
+        starts[1:2 * half:2] = torch.clamp(starts[0:2 * half:2] + int(2.2 * L), max=G - L)
+        rev[0:2 * half:2] = False
+        rev[1:2 * half:2] = True
+    if dup_rate > 0:
+        dup = torch.rand(n, device=device, generator=g) < dup_rate
+        src = torch.randint(0, n, (n,), device=device, generator=g)
+        starts = torch.where(dup, starts[src], starts)
+        rev = torch.where(dup, rev[src], rev)
+    if order == "sorted":
+        starts, o = torch.sort(starts, stable=True)
+        rev = rev[o]
+    lens = torch.randint(L // 2, L + 1, (n,), device=device, generator=g) if ragged else torch.full((n,), L, device=device, dtype=torch.int64)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    offsets[1:] = torch.cumsum(lens, 0)
+    total = int(offsets[-1].item())
+    flat = torch.empty(total, dtype=torch.uint8, device=device)
+    lut = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=device)          # A C T G
+    ar = torch.arange(L, device=device)[None, :]
+    for lo in range(0, n, CHUNK):
+        hi = min(n, lo + CHUNK)
+        codes = genome[starts[lo:hi, None] + ar]
+        codes = torch.where(rev[lo:hi, None], codes.flip(1) ^ 2, codes)              # reverse complement of the L-base window, then cut to length
+        if err > 0:
+            m = torch.rand(hi - lo, L, device=device, generator=g) < err
+            sub = (codes + torch.randint(1, 4, (hi - lo, L), dtype=torch.uint8, device=device, generator=g)) & 3
+            codes = torch.where(m, sub, codes)
+        keep = ar < lens[lo:hi, None]
+        flat[int(offsets[lo].item()):int(offsets[hi].item())] = lut[codes.long()][keep]
+        del codes, keep
+    return flat, offsets.contiguous()
+
+
+def structured_case(n=10_000_000, order="sorted", k=None, L_=None, G=0, decode=True, device=None, steps=2, **kw):
+    """One file with real-genome structure through the whole device path, never `value`: repeats, duplicates, coverage skew, ragged
+    lengths, reads in `order`.  Returns the stage times of the last of `steps` passes, what the anchor resolution did (parallel rounds,
+    reads left to the sequential pass), and -- decode=True -- whether the device decoder gives every base back."""
+    import leon_amd
+    from leon_amd import capi
+    k = k or K
+    L_ = L_ or L
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    n = max(RPB, n // RPB * RPB)
+    G = G or max(n * L_ * 3 // 4 // 30, 10 * L_)             # ~30x at the mean ragged length
+    genome = gen_structured_genome(G, device)
+    flat, offsets = gen_structured_reads(genome, n, L_, device, order=order, **kw)
+    del genome
+    n_bases = int(offsets[-1].item())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d_solid, n_solid = capi.kmer_solid_device(flat.data_ptr(), offsets.data_ptr(), n, k, ABUNDANCE, device_id=device.index or 0)
+    ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=RPB, bloom_tai=max(n_solid, 100) * BITS_PER_KMER, bloom_n_hash=N_HASH,
+                                    device_id=device.index or 0, resolve_window=int(os.environ.get("LEON_RESOLVE_WINDOW", 0)))
+    ctx.bloom_insert_device(d_solid, n_solid)
+    capi.device_free(d_solid)
+    bloom_s = time.perf_counter() - t0
+    kept = []
+    keep = capi.SINK(lambda user, bid, ptr, size, nreads: (kept.append((int(bid), ctypes.string_at(ptr, size), int(nreads))), 0)[1])
+    best = None
+    for _ in range(steps):
+        kept.clear()
+        ctx.reset_stream()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.encode_batch_device(flat.data_ptr(), offsets.data_ptr(), n, sink=keep)
+        st = ctx.stats()
+        dstream, n_anch = ctx.finish()
+        dt = time.perf_counter() - t0
+        st2 = ctx.stats()
+        best = dt if best is None else min(best, dt)
+    out = {"reads": n, "bases": n_bases, "read_len": "%d..%d" % (L_ // 2, L_) if kw.get("ragged", True) else L_, "kmer_size": k, "order": order,
+           "genome": G, "dup_rate": kw.get("dup_rate", 0.1), "skew": kw.get("skew", 0.3), "solid_kmers": int(n_solid),
+           "step_ms": round(best * 1e3, 1), "MBps": round(n_bases / 1e6 / best, 1),
+           "stages_ms": {s_: round(st[s_], 2) for s_ in ("ms_pack", "ms_resolve", "ms_resolve_chain", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder", "ms_d2h", "ms_total")},
+           "chain_busy_ms": round(st2["ms_chain_busy"], 1),
+           "resolve": {"windows": int(st["resolve_windows"]), "parallel_rounds": int(st["resolve_rounds"]),
+                       "reads_left_to_the_sequential_pass": int(st["resolve_chain_reads"]), "windows_with_a_sequential_pass": int(st["resolve_chain_windows"])},
+           "anchors": int(n_anch), "bits_per_base": round(8.0 * (sum(len(b[1]) for b in kept) + len(dstream)) / n_bases, 4),
+           "kmer_count_and_bloom_s": round(bloom_s, 2)}
+    if decode:
+        anchors = capi.anchor_dict_decode(dstream, n_anch, k)
+        off_h = offsets.cpu().numpy()
+        nb = [int(off_h[min(n, (b[0] + 1) * RPB)] - off_h[b[0] * RPB]) for b in sorted(kept)]
+        t0 = time.perf_counter()
+        out_bases, out_lens = ctx.decode_blocks_raw(anchors, kept, nb)
+        out["decode_s"] = round(time.perf_counter() - t0, 2)
+        out["decode_equals_input"] = bool(np.array_equal(out_bases, flat.cpu().numpy())) and bool(np.array_equal(out_lens.astype(np.int64), np.diff(off_h)))
+    ctx.close()
+    return out
+
+
 def genome_kmers_chunk(genome, lo, hi, k):
     """canonical k-mers starting at genome positions [lo, hi) as the C-ABI wants them (one uint64 below k = 32, else
     (low word, high word) pairs), computed with torch on the device: the `--bloom-from genome` source of solid k-mers"""

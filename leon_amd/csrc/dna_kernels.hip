@@ -886,13 +886,17 @@ void launch_chain_repropose(hipStream_t s, DictDev D, ResolveDev V, uint64_t fir
 }
 
 // list: the chunk's reads in read order; rank: the window's exclusive ranks of the unresolved reads (a read's chain index), c0 the
-// chunk's first chain index.  FILL = false: cnt[e] = entries | dead << 31, own[e]; FILL = true: the entries, transposed per group
-// of 64 reads -- entry j of read e at ent[(gbase[e / 64] + j) * 64 + e % 64] -- so that a wave takes a step's entries row by row.
+// chunk's first chain index.  A STEP of k_chain_seq is 64 consecutive reads of the chunk; read e sits in lane e % 64 of step e / 64.
+// FILL = false: own[e], and cnt[e] = dead << 31 | the number of its entries that name keys of EARLIER steps;
+// FILL = true (after k_chain_tables): those entries, transposed per step -- entry j of read e at ent[(gbase[e / 64] + j) * 64 + e % 64],
+//   so that a wave takes a step's entries row by row -- and dep[e]: the lanes of its own step the read waits for (every earlier
+//   lane that proposes one of its k-mers: through `om` for keys first proposed in the step, through the step's late lanes for the others).
 // Four reads per wave, 16 positions per read and step, like k_check.
 template <typename K, bool FILL>
 __global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, uint64_t w0,
                                                    const uint32_t* list, uint32_t n, uint32_t c0, const uint32_t* rank,
-                                                   uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent) {
+                                                   uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent,
+                                                   const unsigned long long* om, const unsigned long long* late, unsigned long long* dep_out) {
     const uint32_t lane = lane_id(), k = R.k;
     const uint32_t grp = lane >> 4, l = lane & 15, gbase16 = grp * 16;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
@@ -904,14 +908,16 @@ __global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, Resol
         const uint64_t g = first_global + i;
         const uint32_t nk = have ? R.len[i] - k + 1 : 0u;
         const uint32_t* pk = R.packed + 2 * (have ? R.slot_off[i] : 0);
+        const uint32_t g0 = (uint32_t)e & ~63u, le = (uint32_t)e & 63u;       // the read's step and its lane in it
         uint32_t total = 0;
         bool dead = false;
         bool done = !have;
         uint64_t at = 0;
+        unsigned long long dep = 0ull, late_below = 0ull;
         if (FILL) {
-            const uint32_t cd = have ? cnt[e] : 0x80000000u;
-            done = !have || (cd >> 31) || (cd & 0x7FFFFFFFu) == 0;           // nothing to write for this read
-            at = have ? gbase[e >> 6] * 64 + (e & 63) : 0;
+            done = !have || (cnt[e] >> 31);                                  // nothing to do for a read that is dead already
+            at = have ? gbase[e >> 6] * 64 + le : 0;
+            late_below = have ? late[e >> 6] & ((1ull << le) - 1ull) : 0ull;
         }
         uint32_t base = 0;
         while (__any(!done)) {
@@ -921,7 +927,7 @@ __global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, Resol
             const uint32_t words = (run && l < 8) ? pk[(base >> 4) + l] : 0u;
             const K cn = canon_from_words16<K>(words, gbase16, base, valid ? p : (run ? nk - 1 : 0), k);
             bool f = false, t = false;
-            uint64_t tv = IDX_INF;
+            uint32_t kid = 0;
             if (valid) {
                 const uint32_t pb = window_bit(cn);                        // (keys proposed in this window, final or not: k_check's filter)
                 if ((D.pbits[pb >> 5] >> (pb & 31)) & 1u) {
@@ -929,60 +935,87 @@ __global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, Resol
                     const uint32_t slot = dict_find(D, cn, fin);
                     if (slot != 0xFFFFFFFFu) {
                         f = fin < g;
-                        tv = *tent_ptr(D, slot);
+                        const uint64_t tv = *tent_ptr(D, slot);
                         t = tv < g;
+                        if (t) kid = rank[tv - first_global - w0] - c0;     // the key's name: the chain index of its first proposer
                     }
                 }
             }
-            const uint32_t fq = (uint32_t)(__ballot(f) >> gbase16) & 0xFFFFu, tq = (uint32_t)(__ballot(t) >> gbase16) & 0xFFFFu;
+            const bool outer = t && kid < g0;                               // names a key of an earlier step: an entry
+            const uint32_t fq = (uint32_t)(__ballot(f) >> gbase16) & 0xFFFFu, oq = (uint32_t)(__ballot(outer) >> gbase16) & 0xFFFFu;
+            if (FILL) {
+                if (outer) {
+                    ent[at + 64ull * (total + (uint32_t)__popc(oq & ((1u << l) - 1u)))] = kid;
+                    for (unsigned long long m = late_below; m; m &= m - 1) {          // a lane of this step that proposes the key too (rare)
+                        const uint32_t a = (uint32_t)__builtin_ctzll(m);
+                        if (own[g0 + a] == kid) dep |= 1ull << a;
+                    }
+                } else if (t) dep |= om[(uint64_t)g0 + (kid - g0)];          // first proposed in this step: whoever proposes it here
+            } else dead = dead || fq != 0;
             if (run) {
-                if (FILL) {
-                    if (t) ent[at + 64ull * (total + (uint32_t)__popc(tq & ((1u << l) - 1u)))] = rank[tv - first_global - w0] - c0;
-                } else dead = dead || fq != 0;
-                total += (uint32_t)__popc(tq);
+                total += (uint32_t)__popc(oq);
                 base += 16;
                 done = dead || base >= nk;
             }
         }
-        if (!FILL && have && l == 0) {
+        if (FILL) {
+            for (int d = 1; d < 16; d <<= 1) dep |= (unsigned long long)__shfl_xor((long long)dep, d);
+            if (have && l == 0) dep_out[e] = (cnt[e] >> 31) ? 0ull : dep & ((1ull << le) - 1ull);
+        } else if (have && l == 0) {
             cnt[e] = dead ? 0x80000000u : total;
             own[e] = rank[*tent_ptr(D, V.cand_slot[i]) - first_global - w0] - c0;     // (the read proposes its candidate itself: tent <= g)
         }
     }
 }
 void launch_chain_prep(hipStream_t s, bool fill, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, uint64_t w0, const uint32_t* list,
-                       uint32_t n, uint32_t c0, const uint32_t* rank, uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent) {
+                       uint32_t n, uint32_t c0, const uint32_t* rank, uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent,
+                       const unsigned long long* om, const unsigned long long* late, unsigned long long* dep) {
     if (!n) return;
-    if (fill) DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, true>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent));
-    else DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, false>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent));
+    if (fill) DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, true>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent, om, late, dep));
+    else DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, false>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent, om, late, dep));
 }
-// per group of 64 reads: the rows its entries take (the longest list among its reads), as a 64-bit count for the scan
-__global__ void k_chain_group_rows(const uint32_t* cnt, uint32_t n, uint64_t* rows) {
-    const uint32_t lane = lane_id();
+// per step of 64 reads, a wave: the rows its entries take (the longest list among its reads; a 64-bit count for the scan), om[step][x] =
+// the lanes that propose the key first proposed by lane x of the step, late[step] = the lanes (not dead already) whose key was first
+// proposed in an EARLIER step
+__global__ void __launch_bounds__(256) k_chain_tables(const uint32_t* cnt, const uint32_t* own, uint32_t n, uint64_t* rows, unsigned long long* om, unsigned long long* late) {
+    __shared__ unsigned long long tab[4][64];
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t nG = ((uint64_t)n + 63) / 64;
     for (uint64_t G = wave; G <= nG; G += nwaves) {
         const uint64_t e = G * 64 + lane;
-        uint32_t c = (G < nG && e < n) ? cnt[e] : 0u;
-        c = (c >> 31) ? 0u : c;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)c, d); c = o > c ? o : c; }
+        const bool have = G < nG && e < n;
+        const uint32_t cd = have ? cnt[e] : 0x80000000u, o = have ? own[e] : 0u;
+        const uint32_t g0 = (uint32_t)G * 64;
+        uint32_t c = (cd >> 31) ? 0u : cd;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)c, d); c = x > c ? x : c; }
         if (lane == 0) rows[G] = c;                                   // (rows[nG] = 0: the scan's total lands there)
+        if (G < nG) {
+            tab[wv][lane] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            if (have && o >= g0) atomicOr(&tab[wv][o - g0], 1ull << lane);
+            __builtin_amdgcn_wave_barrier();
+            om[G * 64 + lane] = tab[wv][lane];
+            const unsigned long long lm = __ballot(have && !(cd >> 31) && o < g0);
+            if (lane == 0) late[G] = lm;
+        }
     }
 }
-void launch_chain_group_rows(hipStream_t s, const uint32_t* cnt, uint32_t n, uint64_t* rows) {
-    hipLaunchKernelGGL(k_chain_group_rows, dim3(grid_for((n + 63) / 64 + 1, 4)), dim3(256), 0, s, cnt, n, rows);
+void launch_chain_tables(hipStream_t s, const uint32_t* cnt, const uint32_t* own, uint32_t n, uint64_t* rows, unsigned long long* om, unsigned long long* late) {
+    hipLaunchKernelGGL(k_chain_tables, dim3(grid_for((n + 63) / 64 + 1, 4)), dim3(256), 0, s, cnt, own, n, rows, om, late);
 }
 
-struct ChainSlot { uint32_t own[64], cnt[64], ent[CHAIN_EL][64]; uint64_t gb; uint32_t rows, pad; };
+struct ChainSlot { uint32_t own[64], cnt[64], dep_lo[64], dep_hi[64], ent[CHAIN_EL][64]; uint64_t gb; uint32_t rows, pad; };
 constexpr uint32_t CHAIN_BITS_WORDS = 1u << (CHAIN_LOG2 - 5);
-size_t chain_seq_lds_bytes() { return CHAIN_BITS_WORDS * 4 + CHAIN_DEPTH * sizeof(ChainSlot) + 64 * 8 + (CHAIN_DEPTH + 2) * 4; }
-__global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* cnt, const uint32_t* own, const uint64_t* gbase /* nG + 1 */,
-                                                  const uint32_t* ent, uint8_t* ins, unsigned long long* trace /* nullptr or 4 counters */) {
+size_t chain_seq_lds_bytes() { return CHAIN_BITS_WORDS * 4 + CHAIN_DEPTH * sizeof(ChainSlot) + (CHAIN_DEPTH + 2) * 4; }
+template <bool TRACE>
+__global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* depv,
+                                                  const uint64_t* gbase /* steps + 1 */, const uint32_t* ent, uint8_t* ins,
+                                                  unsigned long long* trace /* nullptr or 4 counters */) {
     extern __shared__ uint32_t chain_lds[];
     uint32_t* bits = chain_lds;                                                  // a bit per key name: inserted so far
     ChainSlot* ring = reinterpret_cast<ChainSlot*>(chain_lds + CHAIN_BITS_WORDS);
-    unsigned long long* om = reinterpret_cast<unsigned long long*>(ring + CHAIN_DEPTH);   // per key name of the step: the lanes that propose it
-    uint32_t* ready = reinterpret_cast<uint32_t*>(om + 64);                      // [CHAIN_DEPTH]: step + 1 once the slot holds it
+    uint32_t* ready = reinterpret_cast<uint32_t*>(ring + CHAIN_DEPTH);           // [CHAIN_DEPTH]: step + 1 once the slot holds it
     uint32_t* consumed = ready + CHAIN_DEPTH;                                    // steps the consumer is done with
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nG = (n + 63) / 64;
@@ -997,13 +1030,14 @@ __global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* c
             const uint64_t gb = gbase[G];
             const uint32_t rows = (uint32_t)(gbase[G + 1] - gb);
             const uint32_t o = e < n ? own[e] : 0u, cd = e < n ? cnt[e] : 0x80000000u;
+            const unsigned long long dp = e < n ? depv[e] : 0ull;
             uint32_t v[CHAIN_EL];
 #pragma unroll
             for (uint32_t j = 0; j < CHAIN_EL; j++) v[j] = j < rows ? ent[(gb + j) * 64 + lane] : 0u;
             while (G >= __hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + CHAIN_DEPTH) __builtin_amdgcn_s_sleep(2);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             ChainSlot& S = ring[G % CHAIN_DEPTH];
-            S.own[lane] = o; S.cnt[lane] = cd;
+            S.own[lane] = o; S.cnt[lane] = cd; S.dep_lo[lane] = (uint32_t)dp; S.dep_hi[lane] = (uint32_t)(dp >> 32);
             if (lane == 0) { S.gb = gb; S.rows = rows; }
 #pragma unroll
             for (uint32_t j = 0; j < CHAIN_EL; j++) if (j < rows) S.ent[j][lane] = v[j];
@@ -1015,39 +1049,42 @@ __global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* c
         return;
     }
     // ---- the consumer wave: steps in order
-    unsigned long long tr_iter = 0, tr_late = 0, tr_ins = 0;
-    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long tr_iter = 0, tr_rows = 0, tr_ins = 0, tr_wait = 0, tr_ent = 0, tr_res = 0;
     for (uint32_t G = 0; G < nG; G++) {
+        const unsigned long long t_a = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
         while (__hip_atomic_load(&ready[G % CHAIN_DEPTH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != G + 1) __builtin_amdgcn_s_sleep(0);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const unsigned long long t_b = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
         const ChainSlot& S = ring[G % CHAIN_DEPTH];
-        const uint32_t g0 = G * 64, e = g0 + lane;
+        const uint32_t e = G * 64 + lane;
         const uint64_t gb = S.gb;
         const uint32_t rows = S.rows;
         const uint32_t o = S.own[lane], cd = S.cnt[lane];
+        const unsigned long long dep = ((unsigned long long)S.dep_hi[lane] << 32) | S.dep_lo[lane];
         const uint32_t c = (cd >> 31) ? 0u : cd;
-        bool dead = (cd >> 31) != 0;                                             // (lanes past the list's end arrive dead)
-        om[lane] = 0ull;
-        if (e < n && o >= g0) atomicOr(&om[o - g0], 1ull << lane);               // (LDS operations of one wave execute in order)
-        auto entry = [&](uint32_t j) -> uint32_t { return j < CHAIN_EL ? S.ent[j][lane] : ent[(gb + j) * 64 + lane]; };
-        unsigned long long dep = 0ull;
-        for (uint32_t j = 0; j < rows; j++) {
-            if (j < c) {
-                const uint32_t kid = entry(j);
-                if (kid >= g0) dep |= om[kid - g0];                              // a key first proposed in this step: whoever proposes it here
-                else dead = dead || ((bits[kid >> 5] >> (kid & 31)) & 1u);       // a key of an earlier step: inserted by now, or never before this step ends ...
-            }
+        uint32_t hitw = 0;                                                       // (lanes past the list's end arrive dead)
+        // the entries -- keys of earlier steps: inserted by now, or not before this step ends -- eight rows at a time
+        const uint32_t rows_lds = rows < CHAIN_EL ? rows : CHAIN_EL;
+        for (uint32_t j0 = 0; j0 < rows_lds; j0 += 8) {
+            // (every load unconditional and its address independent of the others: the eight bit words are in flight together.
+            // Rows past a lane's own count hold whatever the buffer held: masked into range here, ignored below.  All the blocks
+            // of a step issued before the first is waited for -- two LDS round trips per step instead of two per block -- was no faster:
+            // the wave is bound by the ~8 cycles a lone wave takes per instruction, not by the LDS.)
+            uint32_t kid[8], w[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) kid[u] = S.ent[(j0 + u) % CHAIN_EL][lane] & ((1u << CHAIN_LOG2) - 1u);
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) w[u] = bits[kid[u] >> 5];
+            uint32_t hb = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) hb |= ((w[u] >> (kid[u] & 31)) & 1u) << u;
+            const uint32_t nv = c > j0 ? c - j0 : 0u;                            // this lane's rows in the eight
+            hitw |= hb & (nv >= 8 ? 0xFFu : (1u << nv) - 1u);
         }
-        dep &= below;
-        // ... unless a read of THIS step proposes it too (its first proposer, in an earlier step, did not insert): rare, taken one such lane at a time
-        for (unsigned long long late = __ballot(!dead && o < g0); late; late &= late - 1) {
-            const uint32_t a = (uint32_t)__builtin_ctzll(late);
-            const uint32_t ka = (uint32_t)__shfl((int)o, (int)a);
-            bool hit = false;
-            for (uint32_t j = 0; j < rows; j++) if (j < c && entry(j) == ka) hit = true;
-            if (hit && lane > a) dep |= 1ull << a;
-            tr_late++;
-        }
+        for (uint32_t j = CHAIN_EL; j < rows; j++)                               // (lists longer than the ring's rows: from global memory)
+            if (j < c) { const uint32_t kk = ent[(gb + j) * 64 + lane]; hitw |= (bits[kk >> 5] >> (kk & 31)) & 1u; }
+        const bool dead = (cd >> 31) != 0 || hitw != 0;
+        const unsigned long long t_c = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
         // the step's own order: a lane is settled once every lane it waits for is; it inserts iff none of those did
         unsigned long long decided = __ballot(dead || dep == 0ull), insm = __ballot(!dead && dep == 0ull);
         while (~decided) {
@@ -1056,24 +1093,30 @@ __global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* c
             const bool win = und && !kill && (dep & ~decided) == 0ull;
             const unsigned long long km = __ballot(kill), wm = __ballot(win);
             decided |= km | wm; insm |= wm;
-            tr_iter++;
+            if (TRACE) tr_iter++;
         }
         const bool inserts = (insm >> lane) & 1ull;
         if (inserts) atomicOr(&bits[o >> 5], 1u << (o & 31));
         if (e < n) ins[e] = inserts ? 1 : 0;
-        tr_ins += (unsigned long long)__popcll(insm);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __hip_atomic_store(consumed, G + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (TRACE) {
+            const unsigned long long t_d = __builtin_amdgcn_s_memtime();
+            tr_ins += (unsigned long long)__popcll(insm); tr_rows += rows;
+            tr_wait += t_b - t_a; tr_ent += t_c - t_b; tr_res += t_d - t_c;
+        }
     }
-    if (trace && lane == 0) { atomicAdd(trace + 0, (unsigned long long)nG); atomicAdd(trace + 1, tr_iter); atomicAdd(trace + 2, tr_late); atomicAdd(trace + 3, tr_ins); }
+    if (TRACE && lane == 0) { atomicAdd(trace + 0, (unsigned long long)nG); atomicAdd(trace + 1, tr_iter); atomicAdd(trace + 2, tr_rows); atomicAdd(trace + 3, tr_ins);
+                              atomicAdd(trace + 4, tr_wait); atomicAdd(trace + 5, tr_ent); atomicAdd(trace + 6, tr_res); }
 }
-int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint32_t* own, const uint64_t* gbase, const uint32_t* ent, uint8_t* ins,
-                     unsigned long long* trace) {
+int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* dep, const uint64_t* gbase,
+                     const uint32_t* ent, uint8_t* ins, unsigned long long* trace) {
     if (!n) return 0;
     if (n > (1u << CHAIN_LOG2)) return 1;
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_seq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_seq_lds_bytes());
-    if (attr != hipSuccess) return 2;
-    hipLaunchKernelGGL(k_chain_seq, dim3(1), dim3(256), chain_seq_lds_bytes(), s, n, cnt, own, gbase, ent, ins, trace);
+    const void* fn = trace ? reinterpret_cast<const void*>(k_chain_seq<true>) : reinterpret_cast<const void*>(k_chain_seq<false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_seq_lds_bytes()) != hipSuccess) return 2;
+    if (trace) hipLaunchKernelGGL(k_chain_seq<true>, dim3(1), dim3(256), chain_seq_lds_bytes(), s, n, cnt, own, dep, gbase, ent, ins, trace);
+    else hipLaunchKernelGGL(k_chain_seq<false>, dim3(1), dim3(256), chain_seq_lds_bytes(), s, n, cnt, own, dep, gbase, ent, ins, trace);
     return 0;
 }
 // what k_check does for the reads it settles: status; an inserter's fin, its bit in the window's filter, its key in the final keys' filter

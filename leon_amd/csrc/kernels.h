@@ -99,17 +99,19 @@ void launch_assign_addr(hipStream_t s, DictDev D, ResolveDev V, uint64_t w0, uin
                         uint64_t addr_base, uint64_t* anchor_kmers, uint32_t k);
 // the exact sequential pass behind the rounds (dna_kernels.hip, "k_chain_*"): what the rounds leave, in read order
 constexpr uint32_t CHAIN_LOG2 = 19;      // reads per k_chain_seq: a bit per read in LDS (64 KB)
-constexpr uint32_t CHAIN_EL = 24;        // entry rows of a step (64 reads) staged in LDS; longer lists read the rest from global memory
-constexpr uint32_t CHAIN_DEPTH = 6;      // steps staged ahead of the consumer wave
+constexpr uint32_t CHAIN_EL = 32;        // entry rows of a step (64 reads) staged in LDS; longer lists read the rest from global memory
+constexpr uint32_t CHAIN_DEPTH = 5;      // steps staged ahead of the consumer wave
 void launch_chain_flags(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1, uint32_t* flag);
 void launch_chain_compact(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1, const uint32_t* rank, uint32_t* list);
 void launch_chain_repropose(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* reset_list, uint32_t n_reset,
                             const uint32_t* list, uint32_t n);
 void launch_chain_prep(hipStream_t s, bool fill, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, uint64_t w0, const uint32_t* list,
-                       uint32_t n, uint32_t c0, const uint32_t* rank, uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent);
-void launch_chain_group_rows(hipStream_t s, const uint32_t* cnt, uint32_t n, uint64_t* rows /* n / 64 rounded up, + 1 */);
-int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint32_t* own, const uint64_t* gbase, const uint32_t* ent, uint8_t* ins,
-                     unsigned long long* trace /* nullptr or 4 counters: steps, ballot iterations, late lanes, inserters */);
+                       uint32_t n, uint32_t c0, const uint32_t* rank, uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent,
+                       const unsigned long long* om, const unsigned long long* late, unsigned long long* dep);
+void launch_chain_tables(hipStream_t s, const uint32_t* cnt, const uint32_t* own, uint32_t n, uint64_t* rows /* steps + 1 */,
+                         unsigned long long* om /* 64 per step */, unsigned long long* late /* per step */);
+int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* dep, const uint64_t* gbase,
+                     const uint32_t* ent, uint8_t* ins, unsigned long long* trace /* nullptr or 4 counters: steps, ballot iterations, entry rows, inserters */);
 void launch_chain_apply(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n, const uint8_t* ins, uint32_t k);
 void launch_anchor_symbols(hipStream_t s, const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms);
 void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1);
