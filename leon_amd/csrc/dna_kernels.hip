@@ -1031,16 +1031,24 @@ __global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* c
             const uint32_t rows = (uint32_t)(gbase[G + 1] - gb);
             const uint32_t o = e < n ? own[e] : 0u, cd = e < n ? cnt[e] : 0x80000000u;
             const unsigned long long dp = e < n ? depv[e] : 0ull;
-            uint32_t v[CHAIN_EL];
+            // the entry rows in passes of 32: the first pass's loads are in flight while the slot is waited for
+            constexpr uint32_t PASS = 32;
+            uint32_t v[PASS];
 #pragma unroll
-            for (uint32_t j = 0; j < CHAIN_EL; j++) v[j] = j < rows ? ent[(gb + j) * 64 + lane] : 0u;
+            for (uint32_t j = 0; j < PASS; j++) v[j] = j < rows ? ent[(gb + j) * 64 + lane] : 0u;
             while (G >= __hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + CHAIN_DEPTH) __builtin_amdgcn_s_sleep(2);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             ChainSlot& S = ring[G % CHAIN_DEPTH];
             S.own[lane] = o; S.cnt[lane] = cd; S.dep_lo[lane] = (uint32_t)dp; S.dep_hi[lane] = (uint32_t)(dp >> 32);
             if (lane == 0) { S.gb = gb; S.rows = rows; }
 #pragma unroll
-            for (uint32_t j = 0; j < CHAIN_EL; j++) if (j < rows) S.ent[j][lane] = v[j];
+            for (uint32_t j = 0; j < PASS; j++) if (j < rows) S.ent[j][lane] = v[j];
+            for (uint32_t p0 = PASS; p0 < rows && p0 < CHAIN_EL; p0 += PASS) {
+#pragma unroll
+                for (uint32_t j = 0; j < PASS; j++) v[j] = p0 + j < rows ? ent[(gb + p0 + j) * 64 + lane] : 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < PASS; j++) if (p0 + j < rows) S.ent[p0 + j][lane] = v[j];
+            }
             // (the flags: LDS operations of a wave execute in order and the LDS is one memory for the workgroup, so a compiler barrier
             // and a relaxed store are the release -- an atomic release would also wait for every global access in flight)
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -1081,8 +1089,18 @@ __global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* c
             const uint32_t nv = c > j0 ? c - j0 : 0u;                            // this lane's rows in the eight
             hitw |= hb & (nv >= 8 ? 0xFFu : (1u << nv) - 1u);
         }
-        for (uint32_t j = CHAIN_EL; j < rows; j++)                               // (lists longer than the ring's rows: from global memory)
-            if (j < c) { const uint32_t kk = ent[(gb + j) * 64 + lane]; hitw |= (bits[kk >> 5] >> (kk & 31)) & 1u; }
+        for (uint32_t j0 = CHAIN_EL; j0 < rows; j0 += 8) {                       // (lists longer than the ring's rows: the rest from global memory, eight loads in flight)
+            uint32_t kid[8], w[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) kid[u] = (j0 + u < rows ? ent[(gb + j0 + u) * 64 + lane] : 0u) & ((1u << CHAIN_LOG2) - 1u);
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) w[u] = bits[kid[u] >> 5];
+            uint32_t hb = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) hb |= ((w[u] >> (kid[u] & 31)) & 1u) << u;
+            const uint32_t nv = c > j0 ? c - j0 : 0u;
+            hitw |= hb & (nv >= 8 ? 0xFFu : (1u << nv) - 1u);
+        }
         const bool dead = (cd >> 31) != 0 || hitw != 0;
         const unsigned long long t_c = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
         // the step's own order: a lane is settled once every lane it waits for is; it inserts iff none of those did

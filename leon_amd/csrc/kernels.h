@@ -99,8 +99,8 @@ void launch_assign_addr(hipStream_t s, DictDev D, ResolveDev V, uint64_t w0, uin
                         uint64_t addr_base, uint64_t* anchor_kmers, uint32_t k);
 // the exact sequential pass behind the rounds (dna_kernels.hip, "k_chain_*"): what the rounds leave, in read order
 constexpr uint32_t CHAIN_LOG2 = 19;      // reads per k_chain_seq: a bit per read in LDS (64 KB)
-constexpr uint32_t CHAIN_EL = 32;        // entry rows of a step (64 reads) staged in LDS; longer lists read the rest from global memory
-constexpr uint32_t CHAIN_DEPTH = 5;      // steps staged ahead of the consumer wave
+constexpr uint32_t CHAIN_EL = 96;        // entry rows of a step (64 reads) staged in LDS; longer lists read the rest from global memory
+constexpr uint32_t CHAIN_DEPTH = 3;      // steps staged ahead of the consumer wave
 void launch_chain_flags(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1, uint32_t* flag);
 void launch_chain_compact(hipStream_t s, ResolveDev V, uint64_t w0, uint64_t w1, const uint32_t* rank, uint32_t* list);
 void launch_chain_repropose(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* reset_list, uint32_t n_reset,

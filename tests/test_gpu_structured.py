@@ -50,6 +50,17 @@ def test_tandem_repeat_genome_and_duplicates():
     _full_compare(bases, off, 47, 700, window=512)
 
 
+def test_deep_coverage_and_long_reads_in_order():
+    # amplicon depth: 9 000 reads over 900 bases, sorted -- a read contains the proposals of more than a hundred reads before it (the
+    # sequential pass's entry lists outgrow the rows it stages in LDS) -- and sorted long reads (k-mers by the thousand per read)
+    bases, off = _reads(9000, 150, 900, "sorted", seed=14, err=0.02)
+    _full_compare(bases, off, 31, 1000)
+    bases, off = _reads(9000, 150, 900, "sorted", seed=15, err=0.03, ragged=True, dup_rate=0.3)
+    _full_compare(bases, off, 21, 1000, window=3000)
+    bases, off = _reads(1500, 2500, 60000, "sorted", seed=16, err=0.01)
+    _full_compare(bases, off, 31, 300)
+
+
 def test_every_read_the_same():
     # 3 000 copies of one read, then of its reverse complement: one anchor, every later read finds it
     g = synth.make_genome(400, seed=13)
