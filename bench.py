@@ -60,8 +60,8 @@ def parse():
                     help="where the bloom's solid k-mers come from, outside the timed region: `count` = the device k-mer counter over the "
                          "reads (abundance >= 3), `genome` = the genome's own k-mers (the counter's partitions would take minutes on "
                          "configuration #5's 94 G k-mers); auto = count up to 200 M reads")
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("LEON_BENCH_CPU_SAMPLE", 4_000_000)),
-                    help="reads timed through the CPU restatement on rank 0 at N=1 (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("LEON_BENCH_CPU_SAMPLE", 250_000)),
+                    help="reads PER WORKER timed through the CPU restatement on rank 0 at N=1, one worker per allowed CPU (0 = skip)")
     ap.add_argument("--err", type=float, default=0.01)
     ap.add_argument("--kmer-max-keys", type=int, default=0, help="k-mers sorted per pass by the solid k-mer counter (0 = sized by the library)")
     ap.add_argument("--walk-by", choices=("auto", "block", "anchor"), default=os.environ.get("LEON_BENCH_WALK_BY", "auto"),
@@ -75,6 +75,11 @@ def parse():
     ap.add_argument("--host-input", action="store_true", help="(always on at N = 1 unless --quick) one step through leon_dna_encode_batch, PCIe included")
     ap.add_argument("--e2e-reads", type=int, default=int(os.environ.get("LEON_BENCH_E2E_READS", 10_000_000)),
                     help="reads of the FASTQ that `end_to_end` takes through the leon CLI (0 = skip)")
+    ap.add_argument("--other-configs", default=os.environ.get("LEON_BENCH_OTHER_CONFIGS"),
+                    help="reads:k:L,... -- BASELINE's other single-GPU configurations, 5 timed steps each after the headline steps, reported under `other_configs` "
+                         "(default, for the headline workload only: 10000000:31:150 = configuration #2, 20000000:63:250 = configuration #5's read shape); '' = none")
+    ap.add_argument("--structured-reads", type=int, default=int(os.environ.get("LEON_BENCH_STRUCTURED_READS", 10_000_000)),
+                    help="reads of the `structured` entry: a file with repeats, duplicates, coverage skew and ragged lengths in genome-position order (0 = skip)")
     ap.add_argument("--streams", action="store_true",
                     help="(always on at N = 1 unless --quick) also time the kernels of the streams either side of the DNA stream on device-resident synthetic data: the header "
                          "stream (records + range coder, 10 M SRA-style headers) and the lossy quality smoothing (the workload's reads); "
@@ -236,6 +241,69 @@ def structured_case(n=10_000_000, order="sorted", k=None, L_=None, G=0, decode=T
     return out
 
 
+def other_config(n, k, L_, device, steps=5, warmup=1):
+    """another single-GPU configuration of BASELINE.json driven through the same timed loop as the headline one:
+    its own reads (the headline generator at this shape), solid k-mers, bloom and context; `steps` timed steps back to back after `warmup`,
+    bracketed once; reported under `other_configs`, never as `value`"""
+    import leon_amd
+    from leon_amd import capi
+    n = max(RPB, n // RPB * RPB)
+    G = max(n * L_ // 30, 10 * L_)
+    genome = gen_genome(G, device)
+    reads = torch.empty((n, L_), dtype=torch.uint8, device=device)
+    for c0 in range((n + CHUNK - 1) // CHUNK):
+        lo, hi = c0 * CHUNK, min(n, (c0 + 1) * CHUNK)
+        reads[lo:hi] = gen_reads_chunk(genome, c0, CHUNK, 0.01, device, L=L_)[:hi - lo]
+    del genome
+    offsets = (torch.arange(n + 1, dtype=torch.int64, device=device) * L_).contiguous()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d_solid, n_solid = capi.kmer_solid_device(reads.data_ptr(), offsets.data_ptr(), n, k, ABUNDANCE, device_id=device.index or 0)
+    ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=RPB, bloom_tai=n_solid * BITS_PER_KMER, bloom_n_hash=N_HASH, device_id=device.index or 0)
+    ctx.reserve(n, n * L_)
+    ctx.bloom_insert_device(d_solid, n_solid)
+    capi.device_free(d_solid)
+    prep_s = time.perf_counter() - t0
+    got = [0, 0]
+
+    def sink(user, block_id, p, size, n_reads):
+        got[0] += size; got[1] += 1
+        return 0
+    cb = capi.SINK(sink)
+
+    def one():
+        got[0] = got[1] = 0
+        ctx.reset_stream()
+        ctx.encode_batch_device(reads.data_ptr(), offsets.data_ptr(), n, sink=cb)
+        st = ctx.stats()
+        dsz, na = ctx.finish(copy=False)
+        return st, ctx.stats(), dsz, na
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = t_prev = time.perf_counter()
+    per, walk, dev, chain = [], [], [], []
+    for _ in range(steps):
+        st, st2, dsz, na = one()
+        now = time.perf_counter()
+        per.append((now - t_prev) * 1e3); t_prev = now
+        walk.append(st["ms_walk"]); dev.append(st["ms_total"]); chain.append(st2["ms_chain_busy"])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    wb = ((L_ + 3) // 4) * 2 + (L_ - k) * 64
+    ach = n * wb / (float(np.mean(walk)) * 1e-3) / 1e9
+    out = {"workload": "%d x %d bp synthetic reads, k=%d, genome %d bp (30x), 1%% substitutions" % (n, L_, k, G),
+           "value": round(n * L_ / 1e6 / dt, 1), "unit": "MB/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 2),
+           "step_ms": [round(v, 1) for v in per], "device_ms": round(float(np.mean(dev)), 2), "host_chain_ms": round(float(np.mean(chain)), 2),
+           "stages_ms": {k_: round(st[k_], 2) for k_ in ("ms_pack", "ms_resolve", "ms_resolve_chain", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder", "ms_d2h", "ms_total")},
+           "roofline": {"kernel": "k_walk", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                        "traffic": None, "algorithmic_bytes_per_launch": n * wb, "avg_launch_ms": round(float(np.mean(walk)), 3)},
+           "anchors": int(na), "blocks": got[1], "bits_per_base": round(8.0 * (got[0] + dsz) / (n * L_), 4), "solid_kmers": int(n_solid),
+           "resolve_rounds": int(st["resolve_rounds"]), "kmer_count_and_bloom_s": round(prep_s, 2)}
+    ctx.close()
+    return out
+
+
 def genome_kmers_chunk(genome, lo, hi, k):
     """canonical k-mers starting at genome positions [lo, hi) as the C-ABI wants them (one uint64 below k = 32, else
     (low word, high word) pairs), computed with torch on the device: the `--bloom-from genome` source of solid k-mers"""
@@ -280,6 +348,61 @@ def walk_source_id():
     for f in ("dna_kernels.hip", "leon_device.h"):
         h.update(open(os.path.join(ROOT, "leon_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+class Watch:
+    """Every collective of the N-rank path (and every call that holds one: the C-ABI's exchange / gather callbacks) runs inside
+    `with WATCH("name"):`.  A thread looks at what is open once a second; one that has been open for more than LEON_BENCH_COLL_TIMEOUT
+    seconds (120) is reported BY NAME on stderr, with the rank and the device memory in use, and the process exits non-zero at once --
+    os._exit, never a re-exec -- so that the launcher tears the job down instead of the job sitting in a collective until the driver's
+    limit.  An exception inside the block is reported the same way (a failed rank must not leave the others waiting for it)."""
+    def __init__(self, rank, device):
+        import threading
+        self.rank, self.device = rank, device
+        self.limit = float(os.environ.get("LEON_BENCH_COLL_TIMEOUT", 120))
+        self.open = None
+        self.log = {}                       # name -> [calls, seconds]
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _mem(self):
+        try:
+            f, t = torch.cuda.mem_get_info(self.device)
+            return round((t - f) / 1e9, 1)
+        except Exception:                   # noqa: BLE001
+            return None
+
+    def die(self, what, code=3):
+        print(json.dumps({"bench_error": what, "rank": self.rank, "hbm_in_use_GB": self._mem()}), file=sys.stderr)
+        sys.stderr.flush(); sys.stdout.flush()
+        os._exit(code)
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            cur = self.open
+            if cur and time.perf_counter() - cur[1] > self.limit:
+                self.die("collective `%s` did not complete in %.0f s (LEON_BENCH_COLL_TIMEOUT)" % (cur[0], self.limit))
+
+    def __call__(self, name):
+        w = self
+
+        class _Ctx:
+            def __enter__(self_):
+                w.open = (name, time.perf_counter())
+
+            def __exit__(self_, et, ev, tb):
+                t0 = w.open[1]
+                w.open = None
+                rec = w.log.setdefault(name.split(" [")[0], [0, 0.0])
+                rec[0] += 1; rec[1] += time.perf_counter() - t0
+                if et is not None and not issubclass(et, SystemExit):
+                    w.die("collective `%s` failed: %s: %s" % (name, et.__name__, str(ev)[:300]))
+                return False
+        return _Ctx()
+
+    def summary(self):
+        return {k: {"calls": v[0], "ms": round(v[1] * 1e3, 2)} for k, v in self.log.items()}
 
 
 def self_launch(a):
@@ -345,10 +468,13 @@ def main():
             import socket
             sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
             kw = dict(init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("LEON_BENCH_COLL_TIMEOUT", 120)))   # (the process group's own; WATCH below names the collective)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device, **kw)
         else:
             dist.init_process_group(backend, **kw)
+    WATCH = Watch(pg_rank, device)
     is_root = pg_rank == 0                   # the process that prints the line (and, in the job, the rank that codes the dictionary: rank 0)
 
     import leon_amd
@@ -377,7 +503,9 @@ def main():
     if use_dist:                            # the replicated anchor resolution needs the SAME reads on every rank
         chk = torch.stack([reads[::97].sum(dtype=torch.int64), reads[-1].sum(dtype=torch.int64)])
         lo_, hi_ = chk.clone(), chk.clone()
-        dist.all_reduce(lo_, op=dist.ReduceOp.MIN); dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        with WATCH("all_reduce (the ranks' read sets compared)"):
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN); dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
         if not torch.equal(lo_, hi_):
             raise SystemExit("rank %d: the synthetic read set differs between ranks" % rank)
 
@@ -396,7 +524,9 @@ def main():
         n_solid_t[0] = G - K + 1
     count_s = time.time() - t_b
     if use_dist:
-        dist.broadcast(n_solid_t, src=0)
+        with WATCH("broadcast (solid k-mer count)"):
+            dist.broadcast(n_solid_t, src=0)
+            torch.cuda.synchronize()
     n_solid = int(n_solid_t.item())
     tai = n_solid * BITS_PER_KMER
     ctx = leon_amd.DnaEncodeContext(kmer_size=K, reads_per_block=RPB, bloom_tai=tai, bloom_n_hash=N_HASH, device_id=local,
@@ -408,9 +538,9 @@ def main():
         if as_rank:
             ctx.set_exchange(capi.XCH_EMULATE)
         else:
-            ctx.set_exchange(capi.XCH_BY_ANCHOR, make_exchange(dist, device, backend, pg_rank, pg_world, capi))
+            ctx.set_exchange(capi.XCH_BY_ANCHOR, make_exchange(dist, device, backend, pg_rank, pg_world, capi, WATCH))
             if os.environ.get("LEON_XCH_LOOKUPS", "1") != "0":     # the resolution's window look-ups divided among the ranks as well
-                ctx.set_gather(make_gather(dist, device, backend, pg_rank, pg_world, capi))
+                ctx.set_gather(make_gather(dist, device, backend, pg_rank, pg_world, capi, WATCH))
     ctx.reserve(B, B * L)                      # what a host does while it parses: the first step then allocates nothing large
     nbytes = ctx.bloom_nbytes
     bcast_ms = 0.0
@@ -430,10 +560,14 @@ def main():
         bits = torch.empty(nbytes, dtype=torch.uint8, device=device)
         if is_root:
             ctx.bloom_download_device(bits.data_ptr(), nbytes)
-        torch.cuda.synchronize(); dist.barrier()
+        if os.environ.get("LEON_BENCH_TEST_STALL_RANK") == str(pg_rank):     # test hook: this rank never reaches the broadcast (tests/test_gpu_multiprocess.py)
+            time.sleep(10 ** 6)
+        with WATCH("barrier (before the bloom broadcast)"):
+            torch.cuda.synchronize(); dist.barrier()
         t0 = time.time()
-        dist.broadcast(bits, src=0)
-        torch.cuda.synchronize()
+        with WATCH("broadcast (bloom, %d bytes)" % nbytes):
+            dist.broadcast(bits, src=0)
+            torch.cuda.synchronize()
         bcast_ms = (time.time() - t0) * 1e3
         if rank != 0:                          # (a rehearsed seat r > 0 takes the receiving side too: the same bits back into its context)
             ctx.bloom_upload_device(bits.data_ptr(), nbytes)
@@ -447,8 +581,8 @@ def main():
         payload[1] += 1
         return 0
     cb = capi.SINK(sink)
-    STAGES = ("ms_pack", "ms_resolve", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder", "ms_d2h", "ms_total", "ms_exchange", "ms_exchange_call", "ms_emulated", "ms_emulated_lookups")
-    COUNTS = ("n_symbols", "resolve_rounds", "resolve_windows", "walk_launches", "xch_words_sent", "xch_words_received", "walk_reads")
+    STAGES = ("ms_pack", "ms_resolve", "ms_resolve_chain", "ms_sort", "ms_walk", "ms_symbols", "ms_rangecoder", "ms_d2h", "ms_total", "ms_exchange", "ms_exchange_call", "ms_gather_call", "ms_emulated", "ms_emulated_lookups")
+    COUNTS = ("n_symbols", "resolve_rounds", "resolve_windows", "walk_launches", "xch_words_sent", "xch_words_received", "walk_reads", "resolve_chain_reads")
 
     def encode_stream(the_sink):
         """one file: every batch in order through leon_dna_encode_batch_device; returns the stage times summed over the batches"""
@@ -477,8 +611,9 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
+            with WATCH("barrier (around the timed steps)"):
+                dist.barrier()
+                torch.cuda.synchronize()
 
     # the very first pass through the path in this process (whether it is a warm-up or a timed step): what `leon -c`,
     # which encodes a file exactly once, sees -- code-object loads and whatever leon_dna_reserve did not size
@@ -500,7 +635,7 @@ def main():
     # leon_dna_finish, which has every block delivered and the dictionary stream complete, so nothing of it is still in flight.
     # (Bracketing every step cost up to two scheduler ticks per step: torch.cuda.synchronize() on an idle device returns on a
     # 10 ms boundary here -- steps of exactly 820.0 / 830.0 ms around a chain of 800.)
-    times, walk_ms, walk_n, dev_ms, chain_ms, stage = [], [], [], [], [], None
+    times, walk_ms, walk_n, dev_ms, chain_ms, emul_ms, stage = [], [], [], [], [], [], None
     sync()
     t_begin = t_prev = time.perf_counter()
     for _ in range(a.steps):
@@ -511,15 +646,20 @@ def main():
         chain_ms.append(acc["ms_chain_busy"])
         walk_ms.append(acc["ms_walk"]); walk_n.append(max(acc["walk_launches"], 1))
         dev_ms.append(acc["ms_total"] - acc["ms_emulated"])      # (a rehearsed seat's own work: not the other ranks' slices it walked in their stead)
+        emul_ms.append(acc["ms_emulated"])
         stage = acc
     sync()
     wall_s = time.perf_counter() - t_begin
+    if as_rank:                                                  # a seat's wall time without what it walked and looked up in the other ranks' stead
+        wall_s = max(wall_s - sum(emul_ms) * 1e-3, 1e-9)
     if cold_ms[0] is None:                                       # (no warm-up: the first timed step was the process's first)
         cold_ms[0] = times[0] * 1e3
     # max over ranks: whole step, device stages alone (HIP events on each rank's stream), cold first step
     red = torch.tensor([wall_s, float(np.mean(dev_ms)), cold_ms[0]], dtype=torch.float64, device=device)
     if use_dist:
-        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        with WATCH("all_reduce (max over ranks of the timings)"):
+            dist.all_reduce(red, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
     total_s, device_ms_max, cold_first_step_ms = float(red[0].item()), float(red[1].item()), float(red[2].item())
     ms_per_step = total_s / a.steps * 1e3
     value = n_total * L / 1e6 / (total_s / a.steps)
@@ -539,7 +679,8 @@ def main():
         tables = [mine]
         if use_dist:
             tables = [None] * pg_world
-            dist.all_gather_object(tables, mine)
+            with WATCH("all_gather_object (block checksums)"):
+                dist.all_gather_object(tables, mine)
         if is_root and as_rank:                                      # one seat of an N-rank job: its own blocks only (the union needs the other seats)
             h = hashlib.sha256()
             for bid, digest, nr in sorted(mine):
@@ -644,24 +785,40 @@ def main():
     decode = guarded(do_decode) if (a.decode or extras) and world == 1 else None
     streams = guarded(lambda: bench_streams(ctx, capi, reads, offsets, n_total, device)) if (a.streams or extras) and world == 1 else None
     e2e = guarded(lambda: end_to_end(min(a.e2e_reads, n_total), device)) if extras and world == 1 and rank == 0 and a.e2e_reads > 0 else None
-    cpu = guarded(lambda: cpu_baseline(ctx, reads, min(a.cpu_sample, n_total))) if rank == 0 and world == 1 and a.cpu_sample > 0 else None
+    cpu = guarded(lambda: cpu_baseline(ctx, reads, a.cpu_sample)) if rank == 0 and world == 1 and a.cpu_sample > 0 else None
+    # a file with real-genome structure in genome-position order, and BASELINE's other single-GPU configurations: each with a context of its own
+    structured = None
+    if extras and world == 1 and not as_rank and a.structured_reads > 0:
+        structured = guarded(lambda: structured_case(min(a.structured_reads, n_total), order="sorted", device=device))
+    oc = a.other_configs
+    if oc is None:
+        oc = "10000000:31:150,20000000:63:250" if (n_total, K, L) == (100_000_000, 31, 150) else ""
+    other_configs = None
+    if extras and world == 1 and not as_rank and oc:
+        other_configs = {}
+        for spec in oc.split(","):
+            n_, k_, l_ = (int(v) for v in spec.split(":"))
+            other_configs["%dM_x_%dbp_k%d" % (n_ // 1_000_000, l_, k_) if n_ >= 1_000_000 else "%d_x_%dbp_k%d" % (n_, l_, k_)] = guarded(lambda: other_config(n_, k_, l_, device))
 
     # what an N-rank curve needs, rank by rank: every rank's device stages and what it coded (gathered; one entry at N = 1)
     mine_rank = {"rank": rank, "blocks": payload[1], "payload_bytes": payload[0], "device_ms": round(float(np.mean(dev_ms)), 2),
                  "chain_ms": round(stage["ms_chain_busy"], 2),
                  # (device memory in use on this rank's GPU after the timed steps: the read set, the context's per-batch buffers, the dictionary, the bloom)
                  "hbm_in_use_GB": round((lambda f, t: (t - f) / 1e9)(*torch.cuda.mem_get_info(device)), 1),
-                 "stages_ms": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")}}
+                 "stages_ms": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
+                 "collectives": WATCH.summary() if use_dist else None}
     per_rank = [mine_rank]
     if use_dist:
         per_rank = [None] * pg_world
-        dist.all_gather_object(per_rank, mine_rank)
+        with WATCH("all_gather_object (per-rank stages)"):
+            dist.all_gather_object(per_rank, mine_rank)
 
     if is_root:
         out = {
             "metric": "compressed input MB/s (DNA encode path)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": pg_world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
-            **({"as_rank": as_rank, "as_rank_note": "ONE process in the seat of rank %d of a %d-rank job (leon_dna_set_shard): `value` is what that job would "
+            **({"as_rank": as_rank, "as_rank_note": "ONE process in the seat of rank %d of a %d-rank job (leon_dna_set_shard): `value` and `ms_per_step` are the wall time "
+                                                     "MINUS what this process did in the other ranks' stead (ms_emulated: their slices of the walk, their window look-ups) -- what that job would "
                                                      "report if this rank were its slowest, not a measured %d-GPU figure" % (rank, world, world)} if as_rank else {}),
             "value_hbm_resident": round(value, 1),
             "value_h2d_inclusive": pcie.get("value") if pcie else None,
@@ -696,6 +853,9 @@ def main():
             "verify": verify,
             "end_to_end": e2e,
             "streams": streams,
+            "structured": structured,
+            "other_configs": other_configs,
+            "collectives": WATCH.summary() if use_dist else None,
             "stages_ms_rank0": {k: round(v, 2) for k, v in stage.items() if k.startswith("ms_")},
             # every timed step on rank 0 (ms_per_step is their mean, max over ranks): the whole step, and the dictionary chain inside it
             "step_ms_rank0": [round(t * 1e3, 1) for t in times], "chain_ms_rank0": [round(c, 1) for c in chain_ms],
@@ -704,17 +864,18 @@ def main():
             # `value` is the host chain's (one core of rank 0): which CPU that was, and what a dictionary symbol cost on it
             "host": host_info(stage["ms_chain_busy"], n_anchors * K),
             "rank0": {"anchors": n_anchors, "payload_bytes": payload[0] + dict_bytes, "blocks": payload[1],
-                      "symbols": int(stage["n_symbols"]), "resolve_rounds": int(stage["resolve_rounds"]),
+                      "symbols": int(stage["n_symbols"]), "resolve_rounds": int(stage["resolve_rounds"]), "resolve_chain_reads": int(stage["resolve_chain_reads"]),
                       "bits_per_base": round(8.0 * (payload[0] + dict_bytes) / (max(n_local, 1) * L), 4)},
         }
         print(json.dumps(out))
         sys.stdout.flush()
     if use_dist:
-        dist.barrier()
+        with WATCH("barrier (end of the run)"):
+            dist.barrier()
         dist.destroy_process_group()
 
 
-def make_exchange(dist, device, backend, pg_rank, pg_world, capi):
+def make_exchange(dist, device, backend, pg_rank, pg_world, capi, WATCH):
     """the all-to-all of leon_dna_set_exchange: 64-bit words in device memory, send_counts[d] of them for rank d, over the process
     group -- RCCL's all_to_all_single between GPUs (the words never touch the host); over gloo (rehearsals on one device) every rank
     gathers everybody's words through host memory and keeps its own pieces"""
@@ -728,20 +889,24 @@ def make_exchange(dist, device, backend, pg_rank, pg_world, capi):
         mine = torch.tensor(counts, dtype=torch.int64)
         if backend == "nccl":
             mat = torch.empty(pg_world * pg_world, dtype=torch.int64, device=device)
-            dist.all_gather_into_tensor(mat, mine.to(device))
-            mat = mat.cpu().view(pg_world, pg_world)                 # mat[src][dst]
+            with WATCH("all_gather_into_tensor (walk exchange: the counts)"):
+                dist.all_gather_into_tensor(mat, mine.to(device))
+                mat = mat.cpu().view(pg_world, pg_world)             # mat[src][dst]
             recv_counts = [int(mat[src][pg_rank]) for src in range(pg_world)]
             recv = torch.empty(max(sum(recv_counts), 1), dtype=torch.int64, device=device)
-            dist.all_to_all_single(recv[:sum(recv_counts)], send[:n_send], output_split_sizes=recv_counts, input_split_sizes=list(counts))
-            torch.cuda.synchronize()
+            with WATCH("all_to_all_single (walk exchange: the event words) [%d sent, %d received]" % (n_send, sum(recv_counts))):
+                dist.all_to_all_single(recv[:sum(recv_counts)], send[:n_send], output_split_sizes=recv_counts, input_split_sizes=list(counts))
+                torch.cuda.synchronize()
         else:
             rows = [torch.empty(pg_world, dtype=torch.int64) for _ in range(pg_world)]
-            dist.all_gather(rows, mine)
+            with WATCH("all_gather (walk exchange: the counts)"):
+                dist.all_gather(rows, mine)
             width = max(int(r.sum()) for r in rows)
             padded = torch.zeros(max(width, 1), dtype=torch.int64)
             padded[:n_send] = send[:n_send].cpu()
             bufs = [torch.empty_like(padded) for _ in range(pg_world)]
-            dist.all_gather(bufs, padded)
+            with WATCH("all_gather (walk exchange: the event words, through host memory)"):
+                dist.all_gather(bufs, padded)
             pieces = []
             for src in range(pg_world):
                 at = int(rows[src][:pg_rank].sum())
@@ -755,7 +920,7 @@ def make_exchange(dist, device, backend, pg_rank, pg_world, capi):
     return fn
 
 
-def make_gather(dist, device, backend, pg_rank, pg_world, capi):
+def make_gather(dist, device, backend, pg_rank, pg_world, capi, WATCH):
     """the all-gather of leon_dna_set_gather: every rank's part of a device buffer (part r at d_buf + r * part_bytes) to every rank --
     RCCL's all_gather_into_tensor between GPUs; over gloo (rehearsals on one device) through host memory"""
     def fn(d_buf, part_bytes, world):
@@ -766,11 +931,13 @@ def make_gather(dist, device, backend, pg_rank, pg_world, capi):
             capi.device_copy(mine.data_ptr(), d_buf + pg_rank * part_bytes, part_bytes, device_id=device.index or 0)
         if backend == "nccl":
             everybody = torch.empty(max(words, 1) * pg_world, dtype=torch.int64, device=device)
-            dist.all_gather_into_tensor(everybody, mine)
-            torch.cuda.synchronize()
+            with WATCH("all_gather_into_tensor (a window's look-ups)"):
+                dist.all_gather_into_tensor(everybody, mine)
+                torch.cuda.synchronize()
         else:
             parts = [torch.empty(max(words, 1), dtype=torch.int64) for _ in range(pg_world)]
-            dist.all_gather(parts, mine.cpu())
+            with WATCH("all_gather (a window's look-ups, through host memory)"):
+                dist.all_gather(parts, mine.cpu())
             everybody = torch.cat(parts).to(device)
             torch.cuda.synchronize()
         if words:
@@ -1024,56 +1191,81 @@ def end_to_end(n, device):
     return out
 
 
-def _cpu_worker(args):
-    """one host core: the CPU restatement over its own slice of the sample (own anchor dictionary, like one Leon thread
-    would have on its own file); returns (bases, seconds)"""
-    tests_dir, bloom_path, reads_path, tai, lo, hi = args
-    sys.path.insert(0, tests_dir)
+def _cpu_topology():
+    """(CPUs this process may run on, physical cores among them): siblings of one core share `thread_siblings_list`"""
+    cpus = sorted(os.sched_getaffinity(0))
+    cores = set()
+    for c in cpus:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                cores.add(f.read().strip())
+        except OSError:
+            cores.add(str(c))
+    return cpus, len(cores)
+
+
+def cpu_baseline(ctx, reads, per_worker):
+    """The CPU restatement (oracle/leon_oracle.c, kind = "port") on EVERY CPU this process may run on, two figures:
+    `value`: one worker thread per allowed CPU (the C code runs outside the GIL), each coding its own slice of the workload's first reads as
+             an independent stream against the file's bloom -- how Leon's threads would fare on as many files: small dictionaries, nothing
+             shared but the read-only bloom; an upper bound on the port, not a measurement of Leon.  value = all bases / slowest worker;
+    `one_stream`: ONE thread, one shared stream (`-nb-cores 1`, the only order byte parity is defined against)."""
+    import concurrent.futures as cf
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    bits = np.load(bloom_path, mmap_mode="r")
-    bl = O.Bloom(tai, K, N_HASH, 12)
-    bl.set_bits(np.ascontiguousarray(bits))
-    arr = np.load(reads_path, mmap_mode="r")[lo:hi]
-    bases = np.ascontiguousarray(arr).tobytes()
-    off = np.arange(hi - lo + 1, dtype=np.uint64) * L
-    t0 = time.perf_counter()
-    O.encode(bases, off, K, RPB, bl, trace=False)
-    return (hi - lo) * L, time.perf_counter() - t0
+    cpus, n_phys = _cpu_topology()
+    workers = len(cpus)
+    n_avail = reads.shape[0]
+    per = max(1000, min(per_worker, n_avail // workers))
+    per = per // RPB * RPB if per >= RPB else per
+    bl = O.Bloom(ctx.bloom_tai, K, N_HASH, 12)
+    bl.set_bits(ctx.bloom_download())
+    h_reads = reads[:per * workers].contiguous().cpu().numpy()
+    off = np.arange(per + 1, dtype=np.uint64) * L
 
-
-def cpu_baseline(ctx, reads, n):
-    """the CPU restatement (oracle, kind=port) on the box's host cores: `cores` worker processes, each timed over its own
-    slice of the first n reads of the workload; value = bases of all slices / slowest worker's time"""
-    import multiprocessing as mp
-    import tempfile
-    cores = max(1, min(16, (os.cpu_count() or 1)))
-    per = max(RPB, n // cores // RPB * RPB) if n >= cores * RPB else n
-    cores = max(1, min(cores, n // per))
-    tmp = tempfile.mkdtemp(prefix="leon_cpu_")
-    bloom_path, reads_path = os.path.join(tmp, "bloom.npy"), os.path.join(tmp, "reads.npy")
-    try:
-        np.save(bloom_path, ctx.bloom_download())
-        np.save(reads_path, reads[:per * cores].contiguous().cpu().numpy())
-        jobs = [(os.path.join(ROOT, "tests"), bloom_path, reads_path, ctx.bloom_tai, i * per, (i + 1) * per) for i in range(cores)]
+    def work(i):
+        bases = h_reads[i * per:(i + 1) * per].tobytes()
         t0 = time.perf_counter()
-        if cores == 1:
-            res = [_cpu_worker(jobs[0])]
-        else:
-            with mp.get_context("spawn").Pool(cores) as pool:
-                res = pool.map(_cpu_worker, jobs)
-        wall = time.perf_counter() - t0
-        slowest = max(r[1] for r in res)
-        total = sum(r[0] for r in res)
-        return {"value": round(total / 1e6 / slowest, 2), "unit": "MB/s", "cores": cores, "kind": "port",
-                "sample": "first %d reads of the workload, %d reads per worker process, slowest worker %.1f s (%.1f s with "
-                          "start-up); oracle/leon_oracle.c, one independent stream per core; reference Leon itself cannot be "
-                          "built here (gatb-core absent)" % (per * cores, per, slowest, wall)}
-    finally:
-        for f in (bloom_path, reads_path):
-            if os.path.exists(f):
-                os.remove(f)
-        os.rmdir(tmp)
+        O.encode(bases, off, K, RPB, bl, trace=False)
+        return time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(workers) as pool:
+        secs = list(pool.map(work, range(workers)))
+    wall = time.perf_counter() - t0
+    slowest = max(secs)
+    # one shared stream on one core: as many reads as ~15 s of one worker's rate take
+    rate1 = per * L / (sum(secs) / len(secs))
+    one_n = int(min(n_avail, max(per, 15.0 * rate1 / L)))
+    one_n = max(RPB, one_n // RPB * RPB) if one_n >= RPB else one_n
+    one_bases = reads[:one_n].contiguous().cpu().numpy().tobytes()
+    t0 = time.perf_counter()
+    O.encode(one_bases, np.arange(one_n + 1, dtype=np.uint64) * L, K, RPB, bl, trace=False)
+    one_s = time.perf_counter() - t0
+    return {"value": round(per * workers * L / 1e6 / slowest, 2), "unit": "MB/s", "cores": workers, "physical_cores": n_phys,
+            "smt": "%d hardware threads on %d physical cores" % (workers, n_phys) if n_phys != workers else "one thread per physical core",
+            "kind": "port",
+            "sample": "first %d reads of the workload, %d reads per worker thread (an independent stream each, the file's bloom shared read-only), "
+                      "slowest worker %.1f s, mean %.1f s (%.1f s with start-up); oracle/leon_oracle.c; reference Leon itself cannot be "
+                      "built here (gatb-core absent)" % (per * workers, per, slowest, sum(secs) / len(secs), wall),
+            "one_stream": {"value": round(one_n * L / 1e6 / one_s, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+                           "sample": "first %d reads of the workload as ONE stream on one core (-nb-cores 1: file order, one dictionary), %.1f s" % (one_n, one_s)}}
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:              # noqa: BLE001 -- a rank that fails must END, non-zero and at once: the launcher then tears the job down
+        import traceback                    # instead of the other ranks waiting in their next collective for this one
+        traceback.print_exc()
+        mem = None
+        try:
+            f_, t_ = torch.cuda.mem_get_info()
+            mem = round((t_ - f_) / 1e9, 1)
+        except Exception:                   # noqa: BLE001
+            pass
+        print(json.dumps({"bench_error": "%s: %s" % (type(e).__name__, str(e)[:400]), "rank": int(os.environ.get("RANK", "0")), "hbm_in_use_GB": mem}), file=sys.stderr)
+        sys.stderr.flush(); sys.stdout.flush()
+        os._exit(1)

@@ -82,7 +82,7 @@ typedef struct leon_dna_stats {
        one before it: files in genome-position order) went through the exact sequential pass -- that many reads, in that many windows,
        ms_resolve_chain of ms_resolve (ABI 5) */
     uint64_t resolve_chain_reads, resolve_chain_windows;
-    float ms_resolve_chain, reserved2;
+    float ms_resolve_chain, ms_gather_call;   /* ms_gather_call: host ms inside the caller's gather callback (leon_dna_set_gather), part of ms_exchange_call */
 } leon_dna_stats;
 
 /* -- lifecycle (DnaEncoder ctor / dtor bracket one thread's work upstream) -- */

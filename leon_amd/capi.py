@@ -37,7 +37,7 @@ class Stats(C.Structure):
                 ("ms_chain_busy", C.c_float)] + \
                [(n, C.c_float) for n in ("ms_exchange", "ms_exchange_call", "ms_emulated", "ms_emulated_lookups")] + \
                [(n, C.c_uint64) for n in ("xch_words_sent", "xch_words_received", "walk_reads", "resolve_chain_reads", "resolve_chain_windows")] + \
-               [("ms_resolve_chain", C.c_float), ("reserved2", C.c_float)]
+               [("ms_resolve_chain", C.c_float), ("ms_gather_call", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
@@ -360,10 +360,15 @@ class DnaEncodeContext:
         self.bloom_tai, self.bloom_n_hash, self.bloom_block_nbits = int(bloom_tai), bloom_n_hash, bloom_block_nbits
         self.next_read = 0
         self._hdr_next = 0
+        self._xch_error = None               # what a Python exchange / gather callback raised inside the last call (nothing may cross the C boundary)
 
     def _chk(self, rc):
+        cause, self._xch_error = getattr(self, "_xch_error", None), None
         if rc:
-            raise LeonDnaError(rc, (self.lib.leon_last_error(self.h) or b"").decode())
+            err = LeonDnaError(rc, (self.lib.leon_last_error(self.h) or b"").decode())
+            if cause is not None:            # the callback's own exception is the cause, not lost behind "the callback returned non-zero"
+                raise err from cause
+            raise err
 
     def close(self):
         if getattr(self, "h", None):

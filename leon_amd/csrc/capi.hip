@@ -1137,7 +1137,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             c->stats.ms_emulated = since(t_e0);
         }
         // (the window look-ups shared out among the ranks, earlier in this call: their gathers and, emulated, the other ranks' runs)
-        c->stats.ms_exchange_call += lk_call_ms; c->stats.ms_exchange += lk_call_ms;
+        c->stats.ms_exchange_call += lk_call_ms; c->stats.ms_exchange += lk_call_ms; c->stats.ms_gather_call = lk_call_ms;
         c->stats.ms_emulated += lk_emul_ms; c->stats.ms_emulated_lookups = lk_emul_ms;
         HIPCHK(c, hipEventRecord(c->ev[9], s));                  // the symbols stage begins here
         int xerr = 0;

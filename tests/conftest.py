@@ -9,6 +9,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # On a GPU box torch must be the FIRST to initialise HIP in the test process: its wheel carries a HIP runtime of its own under the
+    # soname libleon_dna.so also links (/opt/rocm's), and whichever is loaded first serves both.  With the library's first (a test file
+    # that never touches torch running before one that does) torch then finds "no ROCm-capable device".  bench.py imports torch first too.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:                       # noqa: BLE001 -- no torch, no GPU: nothing to order
+        pass
 
 
 @pytest.fixture(scope="session")

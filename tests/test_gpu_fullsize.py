@@ -236,3 +236,73 @@ def test_configuration_5_as_rank_0_of_8_sees_it():
     assert [(b[0], b[1]) for b in one[lb0:lb1]] == [(b[0], b[1]) for b in blocks[:lb1 - lb0]]
     ctx.close()
     print("dictionary decode %.1f s; whole test %.1f s" % (t_dict, time.perf_counter() - t_start))
+
+
+@pytest.mark.parametrize("order,k,L", [("sorted", 31, 150), ("pairs", 63, 250)])
+def test_full_size_structured_file(order, k, L):
+    """10 M reads with the structure real files have -- a genome with dispersed and tandem repeats, 10 % PCR duplicates, a third of the reads
+    piled on a tenth of the genome, ragged lengths, reads in genome-position order (what `samtools sort | samtools fastq` writes) or mates
+    interleaved -- through the whole device path (bench.structured_case): run-to-run determinism by a checksum of block checksums, the
+    union of 3 shards with the walk divided by anchor == the single stream, the device decoder gives every base back, sampled blocks
+    through the ORACLE's decoder.  (Stand-in for the reference's acceptance input, a real SRA file: /root/reference/scripts/simple_test.sh:11-34.)"""
+    import torch
+    import bench
+    import leon_amd
+    from leon_amd import capi
+    dev = torch.device("cuda", 0)
+    N = 10_000_000
+    genome = bench.gen_structured_genome(N * L * 3 // 4 // 30, dev)
+    flat, offsets = bench.gen_structured_reads(genome, N, L, dev, order=order)
+    del genome
+    torch.cuda.synchronize()
+    d_solid, n_solid = capi.kmer_solid_device(flat.data_ptr(), offsets.data_ptr(), N, k, 3)
+    tai = n_solid * 12
+
+    def run(rank=0, world=1):
+        ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=RPB, bloom_tai=tai)
+        ctx.set_shard(rank, world)
+        if world > 1:
+            ctx.set_exchange(capi.XCH_EMULATE)
+        ctx.bloom_insert_device(d_solid, n_solid)
+        blocks = ctx.encode_batch_device(flat.data_ptr(), offsets.data_ptr(), N)
+        d, na = ctx.finish()
+        st = ctx.stats()
+        return ctx, blocks, d, na, st
+
+    ctx, blocks, d, na, st = run()
+    assert [b[0] for b in blocks] == list(range(N // RPB)) and st["n_reads"] == N and na > 0
+    if order == "sorted":
+        assert st["resolve_chain_reads"] > N // 10          # position order leaves the rounds a long chain: the sequential pass took it
+    # the device decoder on every base
+    off_h = offsets.cpu().numpy()
+    nb = [int(off_h[(b[0] + 1) * RPB] - off_h[b[0] * RPB]) for b in blocks]
+    anchors = capi.anchor_dict_decode(d, na, k)
+    out_bases, out_lens = ctx.decode_blocks_raw(anchors, blocks, nb)
+    flat_h = flat.cpu().numpy()
+    assert np.array_equal(out_lens.astype(np.int64), np.diff(off_h)) and np.array_equal(out_bases, flat_h)
+    bits = ctx.bloom_download()
+    ctx.close()
+    # sampled blocks through the oracle's decoder (an independent implementation of the format)
+    bl = O.Bloom(tai, k)
+    bl.set_bits(bits)
+    oa = O.decode_anchor_dict(d, na, k)
+    for bid in (0, len(blocks) // 2, len(blocks) - 1):
+        dec = O.decode_block(k, bl, oa, blocks[bid][1], RPB, 10 ** 8)
+        r0 = bid * RPB
+        for j in (0, 1, RPB // 2, RPB - 1):
+            assert dec[j] == flat_h[off_h[r0 + j]:off_h[r0 + j + 1]].tobytes()
+    # determinism, and the 3-way split with the walk divided by anchor
+    want = _checksum(blocks)
+    del out_bases, blocks
+    ctx2, blocks2, d2, na2, _ = run()
+    ctx2.close()
+    assert _checksum(blocks2) == want and d2 == d and na2 == na
+    del blocks2
+    union = []
+    for rank in range(3):
+        c3, b3, d3, na3, st3 = run(rank, 3)
+        c3.close()
+        union += b3
+        assert na3 == na and (d3 == d if rank == 0 else len(d3) == 0)
+    assert _checksum(union) == want
+    capi.device_free(d_solid)

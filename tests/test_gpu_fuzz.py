@@ -8,6 +8,7 @@ import pytest
 
 import common
 import oracle_lib as O
+import synth
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("rc_chains")]
 
@@ -25,7 +26,18 @@ def test_random_parameter_sweep(chunk):
         n = rnd.choice([1, 17, 400, 1500])
         kw = dict(err=rnd.choice([0, 0.01, 0.08]), n_rate=rnd.choice([0, 0.002, 0.05]), ragged=rnd.random() < 0.5)
         what = dict(k=k, rpb=rpb, n_hash=n_hash, nbits=nbits, L=L, n=n, **kw)
-        bases, off = common.synthetic(n, L, rnd.choice([300, 3000, 20000]), seed=1000 * chunk + it, **kw)
+        # every draw picks a structure: the i.i.d. genome with reads at random places in random order (rounds 1-4's only input), or a genome
+        # with dispersed and tandem repeats read in one of the orders real files come in, with PCR duplicates and coverage skew
+        shape = rnd.choice(["iid", "sorted", "pairs", "random", "sorted-strands"])
+        G = rnd.choice([300, 3000, 20000])
+        if shape == "iid":
+            bases, off = common.synthetic(n, L, G, seed=1000 * chunk + it, **kw)
+        else:
+            g = synth.make_structured_genome(G, seed=1000 * chunk + it, dispersed=rnd.choice([0, 3, 10]), tandem=rnd.choice([0, 4, 30]))
+            b_, off = synth.make_structured_reads(g, n, L, seed=1000 * chunk + it + 1, order=shape, dup_rate=rnd.choice([0, 0.1, 0.5]),
+                                                  skew=rnd.choice([0, 0.5]), stride=rnd.choice([None, None, 1, 7]), **kw)
+            bases = b_.tobytes()
+        what["shape"] = shape
         bl, solid, tai = common.make_bloom(bases, off, k, rnd.choice([1, 2, 3]), n_hash, nbits)
         ref = O.encode(bases, off, k, rpb, bl, trace=False)
         ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=rpb, bloom_tai=tai, bloom_n_hash=n_hash,

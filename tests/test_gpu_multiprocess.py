@@ -75,7 +75,7 @@ def test_default_bench_line_fills_every_key():
     for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(v, None)
     cmd = [sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--reads", "1000000", "--batch-reads", "400000", "--cpu-sample", "100000",
-           "--e2e-reads", "200000"]
+           "--e2e-reads", "200000", "--other-configs", "200000:31:150,100000:63:250"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-4000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
@@ -88,11 +88,34 @@ def test_default_bench_line_fills_every_key():
     assert line["streams"]["header_decode"]["equal_input"] is True and line["streams"]["qual_smooth"]["MBps"] > 0
     assert line["streams"]["qual_deflate"]["inflates_to_input"] is True and 0 < line["streams"]["qual_deflate"]["ratio"] < 0.6
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+    # the CPU restatement on every CPU the process may use, and as one shared stream on one core; both labelled a port
+    assert line["cpu_baseline"]["cores"] == line["host"]["cpus_allowed"] and line["cpu_baseline"]["kind"] == "port"
+    assert line["cpu_baseline"]["one_stream"]["cores"] == 1 and line["cpu_baseline"]["one_stream"]["value"] > 0
+    # a file with real-genome structure in genome-position order, and the other single-GPU configurations: driven by the same run
+    st = line["structured"]
+    assert st["decode_equals_input"] is True and st["order"] == "sorted" and st["resolve"]["reads_left_to_the_sequential_pass"] > 0
+    assert sorted(line["other_configs"]) == ["100000_x_250bp_k63", "200000_x_150bp_k31"]
+    assert all(v["value"] > 0 and v["roofline"]["frac"] > 0 and v["steps"] == 5 for v in line["other_configs"].values())
     assert "UNPINNED" in line["parity"]
     assert line["host"]["cpus_allowed"] >= 1 and line["host"]["chain_ns_per_symbol"] > 0
     # the same file as ONE batch: same bytes
     one = _bench(1, extra_args=("--reads", "1000000"))
     assert one["verify"]["blocks_sha256"] == line["verify"]["blocks_sha256"] and one["verify"]["dict_sha256"] == line["verify"]["dict_sha256"]
+
+
+def test_a_rank_that_never_arrives_ends_the_job_by_name():
+    """No collective may sit until the driver's limit: rank 1 never reaches the bloom broadcast (test hook), rank 0's watch names the
+    collective it is stuck in after LEON_BENCH_COLL_TIMEOUT seconds and exits non-zero, the launcher tears the job down."""
+    env = dict(os.environ, LEON_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", LEON_BENCH_TEST_STALL_RANK="1", LEON_BENCH_COLL_TIMEOUT="8")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(v, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads", "200000", "--cpu-sample", "0", "--quick"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    # (the process group's own timeout raises inside the collective at the same moment the watch would fire: either way the collective is named)
+    assert "bench_error" in p.stderr and "barrier (before the bloom broadcast)" in p.stderr and ("did not complete" in p.stderr or "failed" in p.stderr), p.stderr[-3000:]
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]          # and no line pretending to be a result
 
 
 def test_rccl_path_with_one_rank():
@@ -130,7 +153,8 @@ torch.cuda.set_device(dev)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[1], rank=0, world_size=1, device_id=dev)
 leon_amd.load_library()
 words = torch.arange(1000, dtype=torch.int64, device=dev) * 7 + 3
-xch = bench.make_exchange(dist, dev, "nccl", 0, 1, capi)
+W = bench.Watch(0, dev)
+xch = bench.make_exchange(dist, dev, "nccl", 0, 1, capi, W)
 ptr, total = xch(words.data_ptr(), [1000])
 assert total == 1000
 back = torch.empty(1000, dtype=torch.int64, device=dev)
@@ -140,7 +164,8 @@ ptr, total = xch(0, [0])                                   # a rank with nothing
 assert total == 0
 buf = torch.arange(4096, dtype=torch.int64, device=dev)
 want = buf.clone()
-bench.make_gather(dist, dev, "nccl", 0, 1, capi)(buf.data_ptr(), 4096 * 8, 1)
+bench.make_gather(dist, dev, "nccl", 0, 1, capi, W)(buf.data_ptr(), 4096 * 8, 1)
+assert W.summary()["all_to_all_single (walk exchange: the event words)"]["calls"] == 2 and "all_gather_into_tensor (a window's look-ups)" in W.summary()
 torch.cuda.synchronize()
 assert torch.equal(buf, want)
 dist.barrier()
