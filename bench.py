@@ -955,7 +955,9 @@ def host_info(chain_ms, chain_symbols):
                     break
     except OSError:
         pass
-    return {"cpu": model, "cpus_allowed": len(os.sched_getaffinity(0)),
+    q = _cpu_quota()
+    return {"cpu": model, "cpus_allowed": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": round(q, 2) if q else None,
+            "cpus_usable": len(os.sched_getaffinity(0)) if not q else max(1, min(len(os.sched_getaffinity(0)), int(q + 0.5))),
             "chain_ns_per_symbol": round(chain_ms * 1e6 / chain_symbols, 3) if chain_symbols else None}
 
 
@@ -1204,6 +1206,22 @@ def _cpu_topology():
     return cpus, len(cores)
 
 
+def _cpu_quota():
+    """the cgroup's CPU quota in CPUs (None = none): a box may ALLOW 256 CPUs (affinity) and grant 16 CPUs' worth of time"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 and per > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(ctx, reads, per_worker):
     """The CPU restatement (oracle/leon_oracle.c, kind = "port") on EVERY CPU this process may run on, two figures:
     `value`: one worker thread per allowed CPU (the C code runs outside the GIL), each coding its own slice of the workload's first reads as
@@ -1214,7 +1232,11 @@ def cpu_baseline(ctx, reads, per_worker):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     cpus, n_phys = _cpu_topology()
-    workers = len(cpus)
+    quota = _cpu_quota()
+    # one worker per CPU this process can actually USE: the allowed CPUs, or the cgroup's quota when that is smaller (measured on a box that
+    # allows 256 hardware threads and grants 16 CPUs: 256 workers finish 64 M reads in 205 s -- 47 MB/s, the quota's rate -- and the run
+    # takes five minutes; 16 workers say the same in 12 s)
+    workers = len(cpus) if not quota else max(1, min(len(cpus), int(quota + 0.5)))
     n_avail = reads.shape[0]
     per = max(1000, min(per_worker, n_avail // workers))
     per = per // RPB * RPB if per >= RPB else per
@@ -1242,8 +1264,10 @@ def cpu_baseline(ctx, reads, per_worker):
     t0 = time.perf_counter()
     O.encode(one_bases, np.arange(one_n + 1, dtype=np.uint64) * L, K, RPB, bl, trace=False)
     one_s = time.perf_counter() - t0
-    return {"value": round(per * workers * L / 1e6 / slowest, 2), "unit": "MB/s", "cores": workers, "physical_cores": n_phys,
-            "smt": "%d hardware threads on %d physical cores" % (workers, n_phys) if n_phys != workers else "one thread per physical core",
+    return {"value": round(per * workers * L / 1e6 / slowest, 2), "unit": "MB/s", "cores": workers,
+            "cpus_allowed": len(cpus), "physical_cores_allowed": n_phys, "cgroup_cpu_quota": round(quota, 2) if quota else None,
+            "smt": "%d hardware threads allowed on %d physical cores" % (len(cpus), n_phys) if n_phys != len(cpus) else "one thread per physical core",
+            "cores_note": "cores = the CPUs this process can use at once: min(allowed CPUs, cgroup CPU quota)",
             "kind": "port",
             "sample": "first %d reads of the workload, %d reads per worker thread (an independent stream each, the file's bloom shared read-only), "
                       "slowest worker %.1f s, mean %.1f s (%.1f s with start-up); oracle/leon_oracle.c; reference Leon itself cannot be "

@@ -89,7 +89,7 @@ def test_default_bench_line_fills_every_key():
     assert line["streams"]["qual_deflate"]["inflates_to_input"] is True and 0 < line["streams"]["qual_deflate"]["ratio"] < 0.6
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
     # the CPU restatement on every CPU the process may use, and as one shared stream on one core; both labelled a port
-    assert line["cpu_baseline"]["cores"] == line["host"]["cpus_allowed"] and line["cpu_baseline"]["kind"] == "port"
+    assert line["cpu_baseline"]["cores"] == line["host"]["cpus_usable"] and line["cpu_baseline"]["kind"] == "port"
     assert line["cpu_baseline"]["one_stream"]["cores"] == 1 and line["cpu_baseline"]["one_stream"]["value"] > 0
     # a file with real-genome structure in genome-position order, and the other single-GPU configurations: driven by the same run
     st = line["structured"]
