@@ -126,7 +126,7 @@ struct leon_dna_ctx {
     DevBuf xch_slot, xch_off, xch_evoff, xch_events, xch_send, xch_split, xch_res;
     DevBuf resolve_trace;
     DevBuf round_hist;                           // the counts of a window's fixpoint rounds, read back together
-    DevBuf chain_cnt, chain_own, chain_ins, chain_rows, chain_ent, chain_trace, chain_dep, chain_om, chain_late;   // the sequential pass behind the rounds (k_chain_*)
+    DevBuf chain_cnt, chain_own, chain_ins, chain_rows, chain_ent, chain_trace, chain_dep, chain_xdep, chain_om, chain_late;   // the sequential pass behind the rounds (k_chain_*)
     std::vector<hipEvent_t> chain_ev;            // pairs around the sequential passes of a batch
     // small launches: the blocks' chains on host cores (host_blocks.h), fed by the device's modelers chunk by chunk
     DevBuf hb_recs[2], hb_recoff, hb_state;
@@ -815,22 +815,22 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             if (c0) launch_chain_repropose(s, c->D, V, first_read_index, clist + (c0 - CH), left - (c0 - CH), clist + c0, left - c0);
             HIPCHK(c, c->chain_cnt.ensure((uint64_t)nc * 4)); HIPCHK(c, c->chain_own.ensure((uint64_t)nc * 4));
             HIPCHK(c, c->chain_ins.ensure(nc)); HIPCHK(c, c->chain_rows.ensure(((uint64_t)nG + 1) * 8));
-            HIPCHK(c, c->chain_dep.ensure((uint64_t)nc * 8)); HIPCHK(c, c->chain_om.ensure((uint64_t)nG * 64 * 8)); HIPCHK(c, c->chain_late.ensure((uint64_t)nG * 8));
+            HIPCHK(c, c->chain_dep.ensure((uint64_t)nc * 8)); HIPCHK(c, c->chain_xdep.ensure((uint64_t)nc * 8)); HIPCHK(c, c->chain_om.ensure((uint64_t)nG * 64 * 8)); HIPCHK(c, c->chain_late.ensure((uint64_t)nG * 8));
             uint64_t* rows = c->chain_rows.as<uint64_t>();
             unsigned long long* om = c->chain_om.as<unsigned long long>(); unsigned long long* late = c->chain_late.as<unsigned long long>();
-            unsigned long long* dep = c->chain_dep.as<unsigned long long>();
+            unsigned long long* dep = c->chain_dep.as<unsigned long long>(); unsigned long long* xdep = c->chain_xdep.as<unsigned long long>();
             size_t rows_tmp = 0;
             HIPCHK(c, prim::ExclusiveSum(nullptr, rows_tmp, rows, rows, nG + 1, s));
             if (rows_tmp > c->cub_tmp.cap) { HIPCHK(c, hipStreamSynchronize(s)); if (int rc = ensure_cub(c, std::max(rows_tmp, scan_tmp))) return rc; }
-            launch_chain_prep(s, false, R, c->D, V, first_read_index, w0, clist + c0, nc, c0, rank, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr, nullptr);
+            launch_chain_prep(s, false, R, c->D, V, first_read_index, w0, clist + c0, nc, c0, rank, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
             launch_chain_tables(s, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), nc, rows, om, late);
             HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, rows_tmp, rows, rows, nG + 1, s));
             HIPCHK(c, hipMemcpyAsync(c->h_rb + 0, rows + nG, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(c, spin_sync(s));
             const uint64_t total_rows = c->h_rb[0];
             HIPCHK(c, c->chain_ent.ensure(std::max<uint64_t>(total_rows, 1) * 64 * 4));
-            launch_chain_prep(s, true, R, c->D, V, first_read_index, w0, clist + c0, nc, c0, rank, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), rows, c->chain_ent.as<uint32_t>(), om, late, dep);
-            if (launch_chain_seq(s, nc, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), dep, rows, c->chain_ent.as<uint32_t>(), c->chain_ins.as<uint8_t>(), d_ctrace))
+            launch_chain_prep(s, true, R, c->D, V, first_read_index, w0, clist + c0, nc, c0, rank, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), rows, c->chain_ent.as<uint32_t>(), om, late, dep, xdep);
+            if (launch_chain_seq(s, nc, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), dep, xdep, rows, c->chain_ent.as<uint32_t>(), c->chain_ins.as<uint8_t>(), d_ctrace))
                 return fail(c, LEON_E_HIP, "the sequential resolution pass could not be launched (its LDS request was refused)");
             launch_chain_apply(s, c->D, V, first_read_index, clist + c0, nc, c->chain_ins.as<uint8_t>(), k);
             HIPCHK(c, hipGetLastError());
@@ -846,7 +846,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             HIPCHK(c, hipStreamSynchronize(s));
             HIPCHK(c, hipMemcpy(t, d_ctrace, sizeof t, hipMemcpyDeviceToHost));
             float cms = 0; (void)hipEventElapsedTime(&cms, c->chain_ev[2 * n_chain_ev - 2], c->chain_ev[2 * n_chain_ev - 1]);
-            fprintf(stderr, "[leon chain] window [%llu, %llu): %u reads left by the rounds; %llu steps of 64, %.2f ballot iterations and %.1f entry rows per step, %llu inserters; %.2f ms; per step the consumer waited %.0f, tested entries %.0f, settled + published %.0f ticks of s_memtime (100 MHz)\n",
+            fprintf(stderr, "[leon chain] window [%llu, %llu): %u reads left by the rounds; %llu steps of 64, %.2f ballot iterations and %.1f entry rows per step, %llu inserters; %.2f ms; per step the settler waited %.0f (tester: %.0f), settled + published %.0f ticks of s_memtime\n",
                     (unsigned long long)w0, (unsigned long long)w1, left, t[0], t[0] ? (double)t[1] / t[0] : 0.0, t[0] ? (double)t[2] / t[0] : 0.0, t[3], cms,
                     t[0] ? (double)t[4] / t[0] : 0.0, t[0] ? (double)t[5] / t[0] : 0.0, t[0] ? (double)t[6] / t[0] : 0.0);
         }

@@ -896,7 +896,8 @@ template <typename K, bool FILL>
 __global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, uint64_t w0,
                                                    const uint32_t* list, uint32_t n, uint32_t c0, const uint32_t* rank,
                                                    uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent,
-                                                   const unsigned long long* om, const unsigned long long* late, unsigned long long* dep_out) {
+                                                   const unsigned long long* om, const unsigned long long* late, unsigned long long* dep_out,
+                                                   unsigned long long* xdep_out) {
     const uint32_t lane = lane_id(), k = R.k;
     const uint32_t grp = lane >> 4, l = lane & 15, gbase16 = grp * 16;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
@@ -909,15 +910,17 @@ __global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, Resol
         const uint32_t nk = have ? R.len[i] - k + 1 : 0u;
         const uint32_t* pk = R.packed + 2 * (have ? R.slot_off[i] : 0);
         const uint32_t g0 = (uint32_t)e & ~63u, le = (uint32_t)e & 63u;       // the read's step and its lane in it
+        const uint32_t p0 = g0 >= 64 ? g0 - 64 : 0u;                          // the step before it (none for the chunk's first step: p0 == g0)
         uint32_t total = 0;
         bool dead = false;
         bool done = !have;
         uint64_t at = 0;
-        unsigned long long dep = 0ull, late_below = 0ull;
+        unsigned long long dep = 0ull, xdep = 0ull, late_below = 0ull, late_prev = 0ull;
         if (FILL) {
             done = !have || (cnt[e] >> 31);                                  // nothing to do for a read that is dead already
             at = have ? gbase[e >> 6] * 64 + le : 0;
             late_below = have ? late[e >> 6] & ((1ull << le) - 1ull) : 0ull;
+            late_prev = have && g0 >= 64 ? late[(e >> 6) - 1] : 0ull;
         }
         uint32_t base = 0;
         while (__any(!done)) {
@@ -941,16 +944,22 @@ __global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, Resol
                     }
                 }
             }
-            const bool outer = t && kid < g0;                               // names a key of an earlier step: an entry
+            const bool outer = t && kid < p0;                               // names a key older than the step before: an entry
             const uint32_t fq = (uint32_t)(__ballot(f) >> gbase16) & 0xFFFFu, oq = (uint32_t)(__ballot(outer) >> gbase16) & 0xFFFFu;
             if (FILL) {
-                if (outer) {
-                    ent[at + 64ull * (total + (uint32_t)__popc(oq & ((1u << l) - 1u)))] = kid;
-                    for (unsigned long long m = late_below; m; m &= m - 1) {          // a lane of this step that proposes the key too (rare)
+                if (outer) ent[at + 64ull * (total + (uint32_t)__popc(oq & ((1u << l) - 1u)))] = kid;
+                if (t && kid >= g0) dep |= om[kid];                          // first proposed in this step: whoever proposes it here
+                else if (t) {
+                    if (kid >= p0) xdep |= om[kid];                          // first proposed in the step before: whoever proposes it there ...
+                    for (unsigned long long m = late_prev; m; m &= m - 1) {  // ... or an older key that a lane of the step before proposes too (rare)
+                        const uint32_t a = (uint32_t)__builtin_ctzll(m);
+                        if (own[p0 + a] == kid) xdep |= 1ull << a;
+                    }
+                    for (unsigned long long m = late_below; m; m &= m - 1) { // an older key that an earlier lane of THIS step proposes too (rare)
                         const uint32_t a = (uint32_t)__builtin_ctzll(m);
                         if (own[g0 + a] == kid) dep |= 1ull << a;
                     }
-                } else if (t) dep |= om[(uint64_t)g0 + (kid - g0)];          // first proposed in this step: whoever proposes it here
+                }
             } else dead = dead || fq != 0;
             if (run) {
                 total += (uint32_t)__popc(oq);
@@ -959,8 +968,8 @@ __global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, Resol
             }
         }
         if (FILL) {
-            for (int d = 1; d < 16; d <<= 1) dep |= (unsigned long long)__shfl_xor((long long)dep, d);
-            if (have && l == 0) dep_out[e] = (cnt[e] >> 31) ? 0ull : dep & ((1ull << le) - 1ull);
+            for (int d = 1; d < 16; d <<= 1) { dep |= (unsigned long long)__shfl_xor((long long)dep, d); xdep |= (unsigned long long)__shfl_xor((long long)xdep, d); }
+            if (have && l == 0) { const bool dd = (cnt[e] >> 31) != 0; dep_out[e] = dd ? 0ull : dep & ((1ull << le) - 1ull); xdep_out[e] = dd ? 0ull : xdep; }
         } else if (have && l == 0) {
             cnt[e] = dead ? 0x80000000u : total;
             own[e] = rank[*tent_ptr(D, V.cand_slot[i]) - first_global - w0] - c0;     // (the read proposes its candidate itself: tent <= g)
@@ -969,10 +978,10 @@ __global__ void __launch_bounds__(256) k_chain_prep(ReadsDev R, DictDev D, Resol
 }
 void launch_chain_prep(hipStream_t s, bool fill, ReadsDev R, DictDev D, ResolveDev V, uint64_t first_global, uint64_t w0, const uint32_t* list,
                        uint32_t n, uint32_t c0, const uint32_t* rank, uint32_t* cnt, uint32_t* own, const uint64_t* gbase, uint32_t* ent,
-                       const unsigned long long* om, const unsigned long long* late, unsigned long long* dep) {
+                       const unsigned long long* om, const unsigned long long* late, unsigned long long* dep, unsigned long long* xdep) {
     if (!n) return;
-    if (fill) DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, true>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent, om, late, dep));
-    else DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, false>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent, om, late, dep));
+    if (fill) DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, true>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent, om, late, dep, xdep));
+    else DISPATCH_K(R.k, hipLaunchKernelGGL((k_chain_prep<K, false>), dim3(grid_for(n, 16, 256 * 16)), dim3(256), 0, s, R, D, V, first_global, w0, list, n, c0, rank, cnt, own, gbase, ent, om, late, dep, xdep));
 }
 // per step of 64 reads, a wave: the rows its entries take (the longest list among its reads; a 64-bit count for the scan), om[step][x] =
 // the lanes that propose the key first proposed by lane x of the step, late[step] = the lanes (not dead already) whose key was first
@@ -1005,41 +1014,59 @@ void launch_chain_tables(hipStream_t s, const uint32_t* cnt, const uint32_t* own
     hipLaunchKernelGGL(k_chain_tables, dim3(grid_for((n + 63) / 64 + 1, 4)), dim3(256), 0, s, cnt, own, n, rows, om, late);
 }
 
-struct ChainSlot { uint32_t own[64], cnt[64], dep_lo[64], dep_hi[64], ent[CHAIN_EL][64]; uint64_t gb; uint32_t rows, pad; };
+struct ChainSlot { uint32_t own[64], cnt[64], dep_lo[64], dep_hi[64], xdep_lo[64], xdep_hi[64], ent[CHAIN_EL][64]; uint64_t gb, hit; uint32_t rows, pad; };
 constexpr uint32_t CHAIN_BITS_WORDS = 1u << (CHAIN_LOG2 - 5);
-size_t chain_seq_lds_bytes() { return CHAIN_BITS_WORDS * 4 + CHAIN_DEPTH * sizeof(ChainSlot) + (CHAIN_DEPTH + 2) * 4; }
+size_t chain_seq_lds_bytes() { return CHAIN_BITS_WORDS * 4 + CHAIN_DEPTH * sizeof(ChainSlot) + (2 * CHAIN_DEPTH + 2) * 4; }
+// One workgroup, a step (64 reads) at a time through a ring of CHAIN_DEPTH slots in LDS:
+//   waves 2, 3, 6, 7  PRODUCERS  step G's records from global memory into slot G % CHAIN_DEPTH (every fourth step each), loads in flight while they wait for the slot;
+//   wave 1      TESTER      step G's entries -- keys older than step G - 1 -- against the bits, as soon as step G - 2 is settled: a 64-bit hit mask;
+//   wave 0      SETTLER     step G: dead = dead already | hit | waits for an inserter of step G - 1 (xdep & that step's inserters); then the step's own
+//                           order by ballots over `dep`; the inserters' bits; ins[].
+// The tester works on step G while the settler is on step G - 1: a lone wave issues an instruction every ~8 cycles whatever it is, so what
+// bounds the pass is the instruction count of its slowest wave, and the two halves of a step now run side by side.
+// Flags are LDS words written with relaxed stores behind a compiler barrier: LDS operations of a wave execute in order and the LDS is one
+// memory for the workgroup (an atomic release would also wait for every global access in flight).  Every wait is on a wave of the same
+// workgroup that does not wait for the waiter: producers wait for the settler (slot reuse), the tester for producers and the settler
+// (two steps back), the settler for the tester.
 template <bool TRACE>
-__global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* depv,
+__global__ void __launch_bounds__(512) k_chain_seq(uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* depv, const unsigned long long* xdepv,
                                                   const uint64_t* gbase /* steps + 1 */, const uint32_t* ent, uint8_t* ins,
-                                                  unsigned long long* trace /* nullptr or 4 counters */) {
+                                                  unsigned long long* trace /* nullptr or 8 counters */) {
     extern __shared__ uint32_t chain_lds[];
     uint32_t* bits = chain_lds;                                                  // a bit per key name: inserted so far
     ChainSlot* ring = reinterpret_cast<ChainSlot*>(chain_lds + CHAIN_BITS_WORDS);
     uint32_t* ready = reinterpret_cast<uint32_t*>(ring + CHAIN_DEPTH);           // [CHAIN_DEPTH]: step + 1 once the slot holds it
-    uint32_t* consumed = ready + CHAIN_DEPTH;                                    // steps the consumer is done with
+    uint32_t* tested = ready + CHAIN_DEPTH;                                      // [CHAIN_DEPTH]: step + 1 once its hit mask is in the slot
+    uint32_t* settled = tested + CHAIN_DEPTH;                                    // steps the settler is done with
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nG = (n + 63) / 64;
     for (uint32_t w = threadIdx.x; w < CHAIN_BITS_WORDS; w += blockDim.x) bits[w] = 0u;
-    if (threadIdx.x < CHAIN_DEPTH) ready[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) *consumed = 0u;
+    if (threadIdx.x < 2 * CHAIN_DEPTH) ready[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) *settled = 0u;
     __syncthreads();
-    if (wv > 0) {
-        // ---- producers: step G's records from global memory into ring[G % CHAIN_DEPTH]; wave w takes G = w - 1, w + 2, ...
-        for (uint32_t G = wv - 1; G < nG; G += 3) {
+    auto flag = [](uint32_t* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto raise = [](uint32_t* f, uint32_t v) { __atomic_signal_fence(__ATOMIC_SEQ_CST); __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    if (wv >= 2) {
+        // ---- producers: waves 2, 3, 6, 7 (two on each of the SIMDs the tester and the settler do not use; waves 4 and 5 would share
+        // theirs and leave at once).  A producer's step costs it a global round trip (~2 us): four of them keep ahead of a settler
+        // that takes ~0.5 us per step; two did not (the settler waited 400-800 cycles per step).
+        if (wv == 4 || wv == 5) return;
+        for (uint32_t G = wv < 4 ? wv - 2 : wv - 4; G < nG; G += 4) {
             const uint32_t e = G * 64 + lane;
             const uint64_t gb = gbase[G];
             const uint32_t rows = (uint32_t)(gbase[G + 1] - gb);
             const uint32_t o = e < n ? own[e] : 0u, cd = e < n ? cnt[e] : 0x80000000u;
-            const unsigned long long dp = e < n ? depv[e] : 0ull;
+            const unsigned long long dp = e < n ? depv[e] : 0ull, xd = e < n ? xdepv[e] : 0ull;
             // the entry rows in passes of 32: the first pass's loads are in flight while the slot is waited for
             constexpr uint32_t PASS = 32;
             uint32_t v[PASS];
 #pragma unroll
             for (uint32_t j = 0; j < PASS; j++) v[j] = j < rows ? ent[(gb + j) * 64 + lane] : 0u;
-            while (G >= __hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + CHAIN_DEPTH) __builtin_amdgcn_s_sleep(2);
+            while (G >= flag(settled) + CHAIN_DEPTH) __builtin_amdgcn_s_sleep(2);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             ChainSlot& S = ring[G % CHAIN_DEPTH];
             S.own[lane] = o; S.cnt[lane] = cd; S.dep_lo[lane] = (uint32_t)dp; S.dep_hi[lane] = (uint32_t)(dp >> 32);
+            S.xdep_lo[lane] = (uint32_t)xd; S.xdep_hi[lane] = (uint32_t)(xd >> 32);
             if (lane == 0) { S.gb = gb; S.rows = rows; }
 #pragma unroll
             for (uint32_t j = 0; j < PASS; j++) if (j < rows) S.ent[j][lane] = v[j];
@@ -1049,60 +1076,71 @@ __global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* c
 #pragma unroll
                 for (uint32_t j = 0; j < PASS; j++) if (p0 + j < rows) S.ent[p0 + j][lane] = v[j];
             }
-            // (the flags: LDS operations of a wave execute in order and the LDS is one memory for the workgroup, so a compiler barrier
-            // and a relaxed store are the release -- an atomic release would also wait for every global access in flight)
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            __hip_atomic_store(&ready[G % CHAIN_DEPTH], G + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            raise(&ready[G % CHAIN_DEPTH], G + 1);
         }
         return;
     }
-    // ---- the consumer wave: steps in order
-    unsigned long long tr_iter = 0, tr_rows = 0, tr_ins = 0, tr_wait = 0, tr_ent = 0, tr_res = 0;
+    if (wv == 1) {
+        // ---- the tester: a step's entries name keys older than the step before it; whoever inserts one of those does so in a step that is
+        // settled by now, or is a lane of the step before (then the settler sees it through xdep)
+        for (uint32_t G = 0; G < nG; G++) {
+            while (flag(&ready[G % CHAIN_DEPTH]) != G + 1) __builtin_amdgcn_s_sleep(0);
+            while (flag(settled) + 1 < G) __builtin_amdgcn_s_sleep(0);              // steps 0 .. G - 2 settled
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            ChainSlot& S = ring[G % CHAIN_DEPTH];
+            const uint64_t gb = S.gb;
+            const uint32_t rows = S.rows;
+            const uint32_t cd = S.cnt[lane];
+            const uint32_t c = (cd >> 31) ? 0u : cd;
+            uint32_t hitw = 0;
+            const uint32_t rows_lds = rows < CHAIN_EL ? rows : CHAIN_EL;
+            for (uint32_t j0 = 0; j0 < rows_lds; j0 += 8) {
+                // (every load unconditional and its address independent of the others: the eight bit words are in flight together.
+                // Rows past a lane's own count hold whatever the buffer held: masked into range here, ignored below.)
+                uint32_t kid[8], w[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) kid[u] = S.ent[(j0 + u) % CHAIN_EL][lane] & ((1u << CHAIN_LOG2) - 1u);
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) w[u] = bits[kid[u] >> 5];
+                uint32_t hb = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) hb |= ((w[u] >> (kid[u] & 31)) & 1u) << u;
+                const uint32_t nv = c > j0 ? c - j0 : 0u;                            // this lane's rows in the eight
+                hitw |= hb & (nv >= 8 ? 0xFFu : (1u << nv) - 1u);
+            }
+            for (uint32_t j0 = CHAIN_EL; j0 < rows; j0 += 8) {                       // (lists longer than the ring's rows: the rest from global memory, eight loads in flight)
+                uint32_t kid[8], w[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) kid[u] = (j0 + u < rows ? ent[(gb + j0 + u) * 64 + lane] : 0u) & ((1u << CHAIN_LOG2) - 1u);
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) w[u] = bits[kid[u] >> 5];
+                uint32_t hb = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) hb |= ((w[u] >> (kid[u] & 31)) & 1u) << u;
+                const uint32_t nv = c > j0 ? c - j0 : 0u;
+                hitw |= hb & (nv >= 8 ? 0xFFu : (1u << nv) - 1u);
+            }
+            const unsigned long long hm = __ballot(hitw != 0);
+            if (lane == 0) S.hit = hm;
+            raise(&tested[G % CHAIN_DEPTH], G + 1);
+        }
+        return;
+    }
+    // ---- the settler: steps in order
+    unsigned long long tr_iter = 0, tr_rows = 0, tr_ins = 0, tr_wait = 0, tr_res = 0;
+    unsigned long long ins_prev = 0ull;                                          // the inserters of the step before
     for (uint32_t G = 0; G < nG; G++) {
         const unsigned long long t_a = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
-        while (__hip_atomic_load(&ready[G % CHAIN_DEPTH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != G + 1) __builtin_amdgcn_s_sleep(0);
+        while (flag(&tested[G % CHAIN_DEPTH]) != G + 1) __builtin_amdgcn_s_sleep(0);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         const unsigned long long t_b = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
         const ChainSlot& S = ring[G % CHAIN_DEPTH];
         const uint32_t e = G * 64 + lane;
-        const uint64_t gb = S.gb;
-        const uint32_t rows = S.rows;
         const uint32_t o = S.own[lane], cd = S.cnt[lane];
         const unsigned long long dep = ((unsigned long long)S.dep_hi[lane] << 32) | S.dep_lo[lane];
-        const uint32_t c = (cd >> 31) ? 0u : cd;
-        uint32_t hitw = 0;                                                       // (lanes past the list's end arrive dead)
-        // the entries -- keys of earlier steps: inserted by now, or not before this step ends -- eight rows at a time
-        const uint32_t rows_lds = rows < CHAIN_EL ? rows : CHAIN_EL;
-        for (uint32_t j0 = 0; j0 < rows_lds; j0 += 8) {
-            // (every load unconditional and its address independent of the others: the eight bit words are in flight together.
-            // Rows past a lane's own count hold whatever the buffer held: masked into range here, ignored below.  All the blocks
-            // of a step issued before the first is waited for -- two LDS round trips per step instead of two per block -- was no faster:
-            // the wave is bound by the ~8 cycles a lone wave takes per instruction, not by the LDS.)
-            uint32_t kid[8], w[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) kid[u] = S.ent[(j0 + u) % CHAIN_EL][lane] & ((1u << CHAIN_LOG2) - 1u);
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) w[u] = bits[kid[u] >> 5];
-            uint32_t hb = 0;
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) hb |= ((w[u] >> (kid[u] & 31)) & 1u) << u;
-            const uint32_t nv = c > j0 ? c - j0 : 0u;                            // this lane's rows in the eight
-            hitw |= hb & (nv >= 8 ? 0xFFu : (1u << nv) - 1u);
-        }
-        for (uint32_t j0 = CHAIN_EL; j0 < rows; j0 += 8) {                       // (lists longer than the ring's rows: the rest from global memory, eight loads in flight)
-            uint32_t kid[8], w[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) kid[u] = (j0 + u < rows ? ent[(gb + j0 + u) * 64 + lane] : 0u) & ((1u << CHAIN_LOG2) - 1u);
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) w[u] = bits[kid[u] >> 5];
-            uint32_t hb = 0;
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) hb |= ((w[u] >> (kid[u] & 31)) & 1u) << u;
-            const uint32_t nv = c > j0 ? c - j0 : 0u;
-            hitw |= hb & (nv >= 8 ? 0xFFu : (1u << nv) - 1u);
-        }
-        const bool dead = (cd >> 31) != 0 || hitw != 0;
-        const unsigned long long t_c = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long xdep = ((unsigned long long)S.xdep_hi[lane] << 32) | S.xdep_lo[lane];
+        const unsigned long long hm = S.hit;
+        const bool dead = (cd >> 31) != 0 || ((hm >> lane) & 1ull) != 0 || (xdep & ins_prev) != 0ull;    // (lanes past the list's end arrive dead)
         // the step's own order: a lane is settled once every lane it waits for is; it inserts iff none of those did
         unsigned long long decided = __ballot(dead || dep == 0ull), insm = __ballot(!dead && dep == 0ull);
         while (~decided) {
@@ -1116,25 +1154,25 @@ __global__ void __launch_bounds__(256) k_chain_seq(uint32_t n, const uint32_t* c
         const bool inserts = (insm >> lane) & 1ull;
         if (inserts) atomicOr(&bits[o >> 5], 1u << (o & 31));
         if (e < n) ins[e] = inserts ? 1 : 0;
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        __hip_atomic_store(consumed, G + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ins_prev = insm;
+        raise(settled, G + 1);
         if (TRACE) {
             const unsigned long long t_d = __builtin_amdgcn_s_memtime();
-            tr_ins += (unsigned long long)__popcll(insm); tr_rows += rows;
-            tr_wait += t_b - t_a; tr_ent += t_c - t_b; tr_res += t_d - t_c;
+            tr_ins += (unsigned long long)__popcll(insm); tr_rows += S.rows;
+            tr_wait += t_b - t_a; tr_res += t_d - t_b;
         }
     }
     if (TRACE && lane == 0) { atomicAdd(trace + 0, (unsigned long long)nG); atomicAdd(trace + 1, tr_iter); atomicAdd(trace + 2, tr_rows); atomicAdd(trace + 3, tr_ins);
-                              atomicAdd(trace + 4, tr_wait); atomicAdd(trace + 5, tr_ent); atomicAdd(trace + 6, tr_res); }
+                              atomicAdd(trace + 4, tr_wait); atomicAdd(trace + 6, tr_res); }
 }
-int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* dep, const uint64_t* gbase,
-                     const uint32_t* ent, uint8_t* ins, unsigned long long* trace) {
+int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* dep, const unsigned long long* xdep,
+                     const uint64_t* gbase, const uint32_t* ent, uint8_t* ins, unsigned long long* trace) {
     if (!n) return 0;
     if (n > (1u << CHAIN_LOG2)) return 1;
     const void* fn = trace ? reinterpret_cast<const void*>(k_chain_seq<true>) : reinterpret_cast<const void*>(k_chain_seq<false>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_seq_lds_bytes()) != hipSuccess) return 2;
-    if (trace) hipLaunchKernelGGL(k_chain_seq<true>, dim3(1), dim3(256), chain_seq_lds_bytes(), s, n, cnt, own, dep, gbase, ent, ins, trace);
-    else hipLaunchKernelGGL(k_chain_seq<false>, dim3(1), dim3(256), chain_seq_lds_bytes(), s, n, cnt, own, dep, gbase, ent, ins, trace);
+    if (trace) hipLaunchKernelGGL(k_chain_seq<true>, dim3(1), dim3(512), chain_seq_lds_bytes(), s, n, cnt, own, dep, xdep, gbase, ent, ins, trace);
+    else hipLaunchKernelGGL(k_chain_seq<false>, dim3(1), dim3(512), chain_seq_lds_bytes(), s, n, cnt, own, dep, xdep, gbase, ent, ins, trace);
     return 0;
 }
 // what k_check does for the reads it settles: status; an inserter's fin, its bit in the window's filter, its key in the final keys' filter
