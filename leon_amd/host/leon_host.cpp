@@ -785,6 +785,12 @@ void Leon::executeDecompression() {
     //                     meanwhile) and, beside them, its quality blocks; one round at a time;
     //   C (a task)        formatting and writing, in file order, once A and B of the round are done.
     // A never waits for B or C of its own rounds -- only for C of rounds further back (memory).
+    // (Round 5, measured at configuration #3 and not kept -- profiles/r5_cli_decode_trials.txt: all four rounds in ONE call, one chain instead
+    // of two: 9.96 s for this stage against 7.15, `-d -test-file` 23.9 s against 20.2 -- the header and quality blocks of ALL rounds then run
+    // beside the call on the same 16 CPUs that stage its 15 GB of output back; and -test-file's comparison moved into the formatting threads
+    // (each compares its share with the original as it writes it) instead of both files read back at the end: 22.2 s.  What bounds -d on a
+    // box that grants 16 CPUs is the host's share -- header text 6.2 s, quality blocks 3.2-3.5 s, formatting + writing 6.8-7.8 s of all
+    // cores each -- not the number of device calls or where the comparison runs.)
     uint64_t dna_rounds = n_blocks >= 800 ? 2 : 1;
     if (const char* e = getenv("LEON_DECODE_DNA_ROUNDS")) { const long v = atol(e); if (v > 0) dna_rounds = (uint64_t)v; }   // (tests)
     // (what the header-symbol task and the rounds' tasks read: declared before `drain`, so destroyed after it has waited for them)

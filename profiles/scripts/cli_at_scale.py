@@ -58,8 +58,9 @@ timed("compress_lossless", "-file", fq, "-c", "-lossless", "-verbose", "1")
 out["leon_bytes_lossless"] = os.path.getsize(fq + ".leon") if os.path.exists(fq + ".leon") else None
 if only != "lossless":
     timed("decompress", "-file", fq + ".leon", "-d", "-test-file", "-verbose", "1")
-    timed("compress_lossy", "-file", fq, "-c", "-verbose", "1")
-    out["leon_bytes_lossy"] = os.path.getsize(fq + ".leon") if os.path.exists(fq + ".leon") else None
+    if os.environ.get("LEON_CLI_SKIP_LOSSY") != "1":
+        timed("compress_lossy", "-file", fq, "-c", "-verbose", "1")
+        out["leon_bytes_lossy"] = os.path.getsize(fq + ".leon") if os.path.exists(fq + ".leon") else None
 for f in (fq, fq + ".leon", fq + ".d"):
     if os.path.exists(f):
         os.remove(f)
