@@ -687,6 +687,7 @@ def main():
                 h.update(bytes.fromhex(digest) + bid.to_bytes(8, "little") + nr.to_bytes(4, "little"))
             lo_b, hi_b = (min(b[0] for b in mine), max(b[0] for b in mine)) if mine else (None, None)
             verify = {"blocks_sha256_of_this_seat": h.hexdigest(), "n_blocks": len(mine), "first_block": lo_b, "last_block": hi_b,
+                      "block_digests": {str(b[0]): b[1][:16] for b in mine} if n_blocks <= 256 else None,     # (small files: block by block, for a union over seats)
                       "dict_sha256": hashlib.sha256(dstream).hexdigest(), "n_anchors": int(na_v),
                       "what": "this seat's blocks only (checksum of block checksums) + the dictionary stream's (empty unless the seat is rank 0)"}
         elif is_root:
@@ -695,6 +696,7 @@ def main():
             for bid, digest, nr in merge_block_tables(tables):       # raises on a gap or a duplicate block
                 h.update(bytes.fromhex(digest) + bid.to_bytes(8, "little") + nr.to_bytes(4, "little"))
             verify = {"blocks_sha256": h.hexdigest(), "n_blocks": sum(len(t) for t in tables),
+                      "block_digests": {str(b[0]): b[1][:16] for t in tables for b in t} if n_blocks <= 256 else None,
                       "dict_sha256": hashlib.sha256(dstream).hexdigest(), "n_anchors": int(na_v),
                       "blocks_per_rank": [len(t) for t in tables],
                       "what": "checksum of block checksums over the union of all ranks' blocks (gap-free table checked) + the dictionary "

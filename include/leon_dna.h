@@ -159,6 +159,15 @@ int leon_dna_set_exchange(leon_dna_ctx* ctx, uint32_t mode, leon_exchange_fn fn,
  * everything up (the default).  Must precede the first batch of a stream.  Non-zero return of fn = the batch fails. */
 typedef int (*leon_gather_fn)(void* user, void* d_buf, uint64_t part_bytes, uint32_t world);
 int leon_dna_set_gather(leon_dna_ctx* ctx, leon_gather_fn fn, void* user);
+/* FAILURE WITH CALLBACKS SET -- a rule for the caller.  The two callbacks put the caller's collectives INSIDE leon_dna_encode_batch*: one
+ * all-gather per resolution window, one all-to-all per batch.  A rank whose call fails for a reason of its own (no memory for a buffer,
+ * a HIP error, its sink, input the other ranks did not get) returns at once with its error code and does NOT enter the collectives it
+ * has not reached: the library cannot "meet" them with empty parts, it does not know the caller's communicator.  The other ranks are
+ * then waiting in theirs.  So a caller that sets a callback MUST treat a non-zero return of leon_dna_encode_batch* on any rank as the
+ * end of the job on all of them: abort the communicator (ncclCommAbort), or run with a collective timeout and end the process non-zero
+ * so that the launcher tears the job down -- bench.py does the latter: `Watch` names the collective that did not complete within
+ * LEON_BENCH_COLL_TIMEOUT seconds and exits, a failed rank exits at once.  The context itself is poisoned (LEON_E_STATE) like after any
+ * failure part-way through a batch; leon_dna_reset_stream starts a new stream once the communicator is whole again. */
 
 /* Leon::endDnaCompression: flush the anchor-dictionary range coder (Leon::encodeInsertedAnchor stream).
  * payload stays owned by ctx until destroy. */

@@ -204,3 +204,31 @@ def test_bench_as_rank_r_of_8_seats_add_up_to_the_single_stream():
         assert line["bloom_bcast_ms"] > 0
         seats.append(v["n_blocks"])
     assert sum(seats) == n_blocks == one["verify"]["n_blocks"]
+
+
+def test_configuration_5_shape_every_seat_of_8_at_reduced_size():
+    """BASELINE configuration #5's shape -- 250 bp reads, k = 63 (two-word k-mers), FIVE batches per file, 8 ranks, the walk divided by anchor and
+    the window look-ups divided too -- from EVERY seat of the 8-rank job at a size one GPU runs in seconds (2 M reads: 40 blocks, batches of 8
+    blocks, so every rank codes one block of every batch).  At full size only rank 0's seat has ever run (tests/test_gpu_fullsize.py::
+    test_configuration_5_as_rank_0_of_8_sees_it); here the eight seats' blocks add up to the one-GPU stream's, rank 0 alone carries the dictionary."""
+    import hashlib
+    from leon_amd.shard import block_range
+    shape = {"LEON_BENCH_K": "63", "LEON_BENCH_L": "250"}
+    args = ("--quick", "--verify", "--batch-reads", "400000")
+    n_blocks, per_batch = READS // 50000, 8
+    one = _bench(1, extra_env=shape, extra_args=args)
+    assert one["config"]["batches"] == 5 and one["config"]["kmer_size"] == 63 and one["verify"]["n_blocks"] == n_blocks
+    total = 0
+    for r in range(8):
+        line = _bench(1, extra_env=dict(shape, LEON_BENCH_BACKEND="nccl", LEON_BENCH_AS_RANK="%d:8" % r), extra_args=args)
+        lo, hi = block_range(r, 8, per_batch)
+        v = line["verify"]
+        assert line["as_rank"] == "%d:8" % r and line["config"]["walk_by"] == "anchor" and line["config"]["batches"] == 5
+        assert v["n_blocks"] == 5 * (hi - lo) and v["first_block"] == lo and v["last_block"] == 4 * per_batch + hi - 1, (r, v)
+        assert v["n_anchors"] == one["verify"]["n_anchors"]
+        assert (v["dict_sha256"] == one["verify"]["dict_sha256"]) if r == 0 else (v["dict_sha256"] == hashlib.sha256(b"").hexdigest())
+        assert line["per_rank"][0]["stages_ms"]["ms_emulated"] > 0 and line["per_rank"][0]["stages_ms"]["ms_walk"] > 0
+        # the seat's blocks, digest by digest, are the one-GPU stream's
+        assert v["block_digests"] and all(one["verify"]["block_digests"][b] == d for b, d in v["block_digests"].items()), r
+        total += v["n_blocks"]
+    assert total == n_blocks
