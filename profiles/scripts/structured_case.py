@@ -14,4 +14,7 @@ L = int(sys.argv[4]) if len(sys.argv) > 4 else 150
 kw = {}
 if os.environ.get("PLAIN") == "1":            # the i.i.d. shape in another order: no duplicates, no skew, fixed length
     kw = dict(dup_rate=0.0, skew=0.0, ragged=False)
+for name, key in (("DUP_RATE", "dup_rate"), ("SKEW", "skew")):      # e.g. DUP_RATE=0.5 SKEW=0.9: half the reads duplicates, nine tenths of them on a tenth of the genome
+    if name in os.environ:
+        kw[key] = float(os.environ[name])
 print(json.dumps(bench.structured_case(n, order=order, k=k, L_=L, decode=os.environ.get("DECODE", "1") == "1", **kw)))
