@@ -814,7 +814,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             // a later chunk: tent still names reads of the chunk before (settled now) -- cleared, and what is left proposes again
             if (c0) launch_chain_repropose(s, c->D, V, first_read_index, clist + (c0 - CH), left - (c0 - CH), clist + c0, left - c0);
             HIPCHK(c, c->chain_cnt.ensure((uint64_t)nc * 4)); HIPCHK(c, c->chain_own.ensure((uint64_t)nc * 4));
-            HIPCHK(c, c->chain_ins.ensure(nc)); HIPCHK(c, c->chain_rows.ensure(((uint64_t)nG + 1) * 8));
+            HIPCHK(c, c->chain_ins.ensure(((uint64_t)nG + 1) * 8)); HIPCHK(c, c->chain_rows.ensure(((uint64_t)nG + 1) * 8));
             HIPCHK(c, c->chain_dep.ensure((uint64_t)nc * 8)); HIPCHK(c, c->chain_xdep.ensure((uint64_t)nc * 8)); HIPCHK(c, c->chain_om.ensure((uint64_t)nG * 64 * 8)); HIPCHK(c, c->chain_late.ensure((uint64_t)nG * 8));
             uint64_t* rows = c->chain_rows.as<uint64_t>();
             unsigned long long* om = c->chain_om.as<unsigned long long>(); unsigned long long* late = c->chain_late.as<unsigned long long>();
@@ -830,9 +830,9 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             const uint64_t total_rows = c->h_rb[0];
             HIPCHK(c, c->chain_ent.ensure(std::max<uint64_t>(total_rows, 1) * 64 * 4));
             launch_chain_prep(s, true, R, c->D, V, first_read_index, w0, clist + c0, nc, c0, rank, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), rows, c->chain_ent.as<uint32_t>(), om, late, dep, xdep);
-            if (launch_chain_seq(s, nc, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), dep, xdep, rows, c->chain_ent.as<uint32_t>(), c->chain_ins.as<uint8_t>(), d_ctrace))
+            if (launch_chain_seq(s, nc, c->chain_cnt.as<uint32_t>(), c->chain_own.as<uint32_t>(), dep, xdep, rows, c->chain_ent.as<uint32_t>(), c->chain_ins.as<unsigned long long>(), d_ctrace))
                 return fail(c, LEON_E_HIP, "the sequential resolution pass could not be launched (its LDS request was refused)");
-            launch_chain_apply(s, c->D, V, first_read_index, clist + c0, nc, c->chain_ins.as<uint8_t>(), k);
+            launch_chain_apply(s, c->D, V, first_read_index, clist + c0, nc, c->chain_ins.as<unsigned long long>(), k);
             HIPCHK(c, hipGetLastError());
         }
         // (the rounds end with every tent they touched cleared; so must this: a tent that still named a settled read would block whoever

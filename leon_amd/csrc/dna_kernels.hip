@@ -1014,7 +1014,7 @@ void launch_chain_tables(hipStream_t s, const uint32_t* cnt, const uint32_t* own
     hipLaunchKernelGGL(k_chain_tables, dim3(grid_for((n + 63) / 64 + 1, 4)), dim3(256), 0, s, cnt, own, n, rows, om, late);
 }
 
-struct ChainSlot { uint32_t own[64], cnt[64], dep_lo[64], dep_hi[64], xdep_lo[64], xdep_hi[64], ent[CHAIN_EL][64]; uint64_t gb, hit; uint32_t rows, pad; };
+struct ChainSlot { uint32_t own[64], cnt[64], dep_lo[64], dep_hi[64], xdep_lo[64], xdep_hi[64], hit[64], ent[CHAIN_EL][64]; uint64_t gb; uint32_t rows, pad; };
 constexpr uint32_t CHAIN_BITS_WORDS = 1u << (CHAIN_LOG2 - 5);
 size_t chain_seq_lds_bytes() { return CHAIN_BITS_WORDS * 4 + CHAIN_DEPTH * sizeof(ChainSlot) + (2 * CHAIN_DEPTH + 2) * 4; }
 // One workgroup, a step (64 reads) at a time through a ring of CHAIN_DEPTH slots in LDS:
@@ -1030,7 +1030,7 @@ size_t chain_seq_lds_bytes() { return CHAIN_BITS_WORDS * 4 + CHAIN_DEPTH * sizeo
 // (two steps back), the settler for the tester.
 template <bool TRACE>
 __global__ void __launch_bounds__(512) k_chain_seq(uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* depv, const unsigned long long* xdepv,
-                                                  const uint64_t* gbase /* steps + 1 */, const uint32_t* ent, uint8_t* ins,
+                                                  const uint64_t* gbase /* steps + 1 */, const uint32_t* ent, unsigned long long* insmask /* per step: its inserters */,
                                                   unsigned long long* trace /* nullptr or 8 counters */) {
     extern __shared__ uint32_t chain_lds[];
     uint32_t* bits = chain_lds;                                                  // a bit per key name: inserted so far
@@ -1120,8 +1120,7 @@ __global__ void __launch_bounds__(512) k_chain_seq(uint32_t n, const uint32_t* c
                 const uint32_t nv = c > j0 ? c - j0 : 0u;
                 hitw |= hb & (nv >= 8 ? 0xFFu : (1u << nv) - 1u);
             }
-            const unsigned long long hm = __ballot(hitw != 0);
-            if (lane == 0) S.hit = hm;
+            S.hit[lane] = hitw;
             raise(&tested[G % CHAIN_DEPTH], G + 1);
         }
         return;
@@ -1135,25 +1134,23 @@ __global__ void __launch_bounds__(512) k_chain_seq(uint32_t n, const uint32_t* c
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         const unsigned long long t_b = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
         const ChainSlot& S = ring[G % CHAIN_DEPTH];
-        const uint32_t e = G * 64 + lane;
         const uint32_t o = S.own[lane], cd = S.cnt[lane];
         const unsigned long long dep = ((unsigned long long)S.dep_hi[lane] << 32) | S.dep_lo[lane];
         const unsigned long long xdep = ((unsigned long long)S.xdep_hi[lane] << 32) | S.xdep_lo[lane];
-        const unsigned long long hm = S.hit;
-        const bool dead = (cd >> 31) != 0 || ((hm >> lane) & 1ull) != 0 || (xdep & ins_prev) != 0ull;    // (lanes past the list's end arrive dead)
-        // the step's own order: a lane is settled once every lane it waits for is; it inserts iff none of those did
+        const bool dead = (cd >> 31) != 0 || S.hit[lane] != 0 || (xdep & ins_prev) != 0ull;    // (lanes past the list's end arrive dead)
+        // the step's own order: a lane is settled once every lane it waits for is; it inserts iff none of those did.  The masks are wave-wide
+        // scalars: per iteration two ANDs of `dep` with a scalar and two compares in the vector unit, the rest on the scalar unit.
         unsigned long long decided = __ballot(dead || dep == 0ull), insm = __ballot(!dead && dep == 0ull);
         while (~decided) {
-            const bool und = !((decided >> lane) & 1ull);
-            const bool kill = und && (dep & insm) != 0ull;
-            const bool win = und && !kill && (dep & ~decided) == 0ull;
-            const unsigned long long km = __ballot(kill), wm = __ballot(win);
-            decided |= km | wm; insm |= wm;
+            const unsigned long long nd = ~decided;
+            const unsigned long long blocked = __ballot((dep & nd) != 0ull);      // still waits for an unsettled lane
+            const unsigned long long killed = __ballot((dep & insm) != 0ull);     // waits for a lane that inserted
+            insm |= nd & ~blocked & ~killed;
+            decided |= nd & (~blocked | killed);
             if (TRACE) tr_iter++;
         }
-        const bool inserts = (insm >> lane) & 1ull;
-        if (inserts) atomicOr(&bits[o >> 5], 1u << (o & 31));
-        if (e < n) ins[e] = inserts ? 1 : 0;
+        if ((insm >> lane) & 1ull) atomicOr(&bits[o >> 5], 1u << (o & 31));
+        if (lane == 0) insmask[G] = insm;                                        // (one 8-byte store per step; k_chain_apply takes a read's bit)
         ins_prev = insm;
         raise(settled, G + 1);
         if (TRACE) {
@@ -1166,7 +1163,7 @@ __global__ void __launch_bounds__(512) k_chain_seq(uint32_t n, const uint32_t* c
                               atomicAdd(trace + 4, tr_wait); atomicAdd(trace + 6, tr_res); }
 }
 int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* dep, const unsigned long long* xdep,
-                     const uint64_t* gbase, const uint32_t* ent, uint8_t* ins, unsigned long long* trace) {
+                     const uint64_t* gbase, const uint32_t* ent, unsigned long long* ins, unsigned long long* trace) {
     if (!n) return 0;
     if (n > (1u << CHAIN_LOG2)) return 1;
     const void* fn = trace ? reinterpret_cast<const void*>(k_chain_seq<true>) : reinterpret_cast<const void*>(k_chain_seq<false>);
@@ -1177,13 +1174,13 @@ int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint3
 }
 // what k_check does for the reads it settles: status; an inserter's fin, its bit in the window's filter, its key in the final keys' filter
 template <typename K>
-__global__ void __launch_bounds__(256) k_chain_apply(DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n, const uint8_t* ins, uint32_t k) {
+__global__ void __launch_bounds__(256) k_chain_apply(DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n, const unsigned long long* ins, uint32_t k) {
     const uint32_t lane = lane_id();
     for (uint64_t e0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) & ~63ull; e0 < n; e0 += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t e = e0 + lane;
         const bool have = e < n;
         const uint32_t i = have ? list[e] : 0u;
-        const bool inserter = have && ins[e] != 0;
+        const bool inserter = have && ((ins[e >> 6] >> (e & 63)) & 1ull) != 0;
         if (have) V.status[i] = inserter ? ST_INSERTER : ST_HITNEW;
         if (inserter) {
             const uint32_t slot = V.cand_slot[i];
@@ -1200,7 +1197,7 @@ __global__ void __launch_bounds__(256) k_chain_apply(DictDev D, ResolveDev V, ui
         }
     }
 }
-void launch_chain_apply(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n, const uint8_t* ins, uint32_t k) {
+void launch_chain_apply(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n, const unsigned long long* ins, uint32_t k) {
     if (!n) return;
     DISPATCH_K(k, hipLaunchKernelGGL(k_chain_apply<K>, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, D, V, first_global, list, n, ins, k));
 }

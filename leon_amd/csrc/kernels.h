@@ -111,8 +111,8 @@ void launch_chain_prep(hipStream_t s, bool fill, ReadsDev R, DictDev D, ResolveD
 void launch_chain_tables(hipStream_t s, const uint32_t* cnt, const uint32_t* own, uint32_t n, uint64_t* rows /* steps + 1 */,
                          unsigned long long* om /* 64 per step */, unsigned long long* late /* per step */);
 int launch_chain_seq(hipStream_t s, uint32_t n, const uint32_t* cnt, const uint32_t* own, const unsigned long long* dep, const unsigned long long* xdep,
-                     const uint64_t* gbase, const uint32_t* ent, uint8_t* ins, unsigned long long* trace /* nullptr or 8 counters */);
-void launch_chain_apply(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n, const uint8_t* ins, uint32_t k);
+                     const uint64_t* gbase, const uint32_t* ent, unsigned long long* ins /* per step of 64 reads: its inserters */, unsigned long long* trace /* nullptr or 8 counters */);
+void launch_chain_apply(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_global, const uint32_t* list, uint32_t n, const unsigned long long* ins, uint32_t k);
 void launch_anchor_symbols(hipStream_t s, const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms);
 void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1);
 // ---- walk ----
