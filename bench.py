@@ -353,13 +353,13 @@ def walk_source_id():
 class Watch:
     """Every collective of the N-rank path (and every call that holds one: the C-ABI's exchange / gather callbacks) runs inside
     `with WATCH("name"):`.  A thread looks at what is open once a second; one that has been open for more than LEON_BENCH_COLL_TIMEOUT
-    seconds (120) is reported BY NAME on stderr, with the rank and the device memory in use, and the process exits non-zero at once --
+    seconds (180: the longest legitimate wait is a rank without the dictionary chain waiting for rank 0's, 8 s per step at configuration #5) is reported BY NAME on stderr, with the rank and the device memory in use, and the process exits non-zero at once --
     os._exit, never a re-exec -- so that the launcher tears the job down instead of the job sitting in a collective until the driver's
     limit.  An exception inside the block is reported the same way (a failed rank must not leave the others waiting for it)."""
     def __init__(self, rank, device):
         import threading
         self.rank, self.device = rank, device
-        self.limit = float(os.environ.get("LEON_BENCH_COLL_TIMEOUT", 120))
+        self.limit = float(os.environ.get("LEON_BENCH_COLL_TIMEOUT", 180))
         self.open = None
         self.log = {}                       # name -> [calls, seconds]
         self.t = threading.Thread(target=self._run, daemon=True)
@@ -469,7 +469,7 @@ def main():
             sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
             kw = dict(init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
         import datetime
-        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("LEON_BENCH_COLL_TIMEOUT", 120)))   # (the process group's own; WATCH below names the collective)
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("LEON_BENCH_COLL_TIMEOUT", 180)))   # (the process group's own; WATCH below names the collective)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device, **kw)
         else:
