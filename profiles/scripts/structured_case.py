@@ -17,4 +17,5 @@ if os.environ.get("PLAIN") == "1":            # the i.i.d. shape in another orde
 for name, key in (("DUP_RATE", "dup_rate"), ("SKEW", "skew")):      # e.g. DUP_RATE=0.5 SKEW=0.9: half the reads duplicates, nine tenths of them on a tenth of the genome
     if name in os.environ:
         kw[key] = float(os.environ[name])
-print(json.dumps(bench.structured_case(n, order=order, k=k, L_=L, decode=os.environ.get("DECODE", "1") == "1", **kw)))
+G = int(os.environ.get("GENOME", 0))               # GENOME=30000: amplicon depth (reads * L / GENOME)
+print(json.dumps(bench.structured_case(n, order=order, k=k, L_=L, G=G, decode=os.environ.get("DECODE", "1") == "1", **kw)))
