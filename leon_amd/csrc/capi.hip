@@ -806,7 +806,9 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         launch_chain_flags(s, V, w0, w1, V.ins_flag);
         HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, scan_tmp, V.ins_flag, rank, w1 - w0, s));
         launch_chain_compact(s, V, w0, w1, rank, clist);
-        constexpr uint32_t CH = 1u << CHAIN_LOG2;
+        // (LEON_CHAIN_CHUNK: reads per k_chain_seq, at most the 2^CHAIN_LOG2 its LDS holds a bit for -- a test hook: the path a window of more than
+        // half a million unsettled reads takes, chunk after chunk with tent re-proposed in between, on inputs the oracle codes in seconds)
+        static const uint32_t CH = [] { const char* e = getenv("LEON_CHAIN_CHUNK"); const long v = e ? atol(e) : 0; return v >= 1 && v <= (1l << CHAIN_LOG2) ? (uint32_t)v : 1u << CHAIN_LOG2; }();
         unsigned long long* d_ctrace = nullptr;
         if (trace_chain) { HIPCHK(c, c->chain_trace.ensure(8 * 8)); d_ctrace = c->chain_trace.as<unsigned long long>(); HIPCHK(c, hipMemsetAsync(d_ctrace, 0, 8 * 8, s)); }
         for (uint32_t c0 = 0; c0 < left; c0 += CH) {
@@ -837,7 +839,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         }
         // (the rounds end with every tent they touched cleared; so must this: a tent that still named a settled read would block whoever
         // proposes the key in a later window)
-        { const uint32_t c_last = ((left - 1) >> CHAIN_LOG2) << CHAIN_LOG2; launch_chain_repropose(s, c->D, V, first_read_index, clist + c_last, left - c_last, nullptr, 0); }
+        { const uint32_t c_last = (left - 1) / CH * CH; launch_chain_repropose(s, c->D, V, first_read_index, clist + c_last, left - c_last, nullptr, 0); }
         HIPCHK(c, hipEventRecord(c->chain_ev[2 * n_chain_ev + 1], s));
         n_chain_ev++;
         c->stats.resolve_chain_reads += left; c->stats.resolve_chain_windows++;

@@ -1130,14 +1130,22 @@ __global__ void __launch_bounds__(512) k_chain_seq(uint32_t n, const uint32_t* c
     unsigned long long ins_prev = 0ull;                                          // the inserters of the step before
     for (uint32_t G = 0; G < nG; G++) {
         const unsigned long long t_a = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
-        while (flag(&tested[G % CHAIN_DEPTH]) != G + 1) __builtin_amdgcn_s_sleep(0);
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        const unsigned long long t_b = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
+        // the slot's words are read in the same breath as its flag -- LDS operations execute in order, so what follows a flag read that
+        // saw G + 1 is the step's data -- one LDS round trip per step instead of two when the tester is ahead (it nearly always is)
         const ChainSlot& S = ring[G % CHAIN_DEPTH];
-        const uint32_t o = S.own[lane], cd = S.cnt[lane];
-        const unsigned long long dep = ((unsigned long long)S.dep_hi[lane] << 32) | S.dep_lo[lane];
-        const unsigned long long xdep = ((unsigned long long)S.xdep_hi[lane] << 32) | S.xdep_lo[lane];
-        const bool dead = (cd >> 31) != 0 || S.hit[lane] != 0 || (xdep & ins_prev) != 0ull;    // (lanes past the list's end arrive dead)
+        uint32_t o, cd, dlo, dhi, xlo, xhi, hitf;
+        for (;;) {
+            const uint32_t f = flag(&tested[G % CHAIN_DEPTH]);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            o = S.own[lane]; cd = S.cnt[lane]; dlo = S.dep_lo[lane]; dhi = S.dep_hi[lane]; xlo = S.xdep_lo[lane]; xhi = S.xdep_hi[lane]; hitf = S.hit[lane];
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if (f == G + 1) break;
+            __builtin_amdgcn_s_sleep(0);
+        }
+        const unsigned long long t_b = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long dep = ((unsigned long long)dhi << 32) | dlo;
+        const unsigned long long xdep = ((unsigned long long)xhi << 32) | xlo;
+        const bool dead = (cd >> 31) != 0 || hitf != 0 || (xdep & ins_prev) != 0ull;    // (lanes past the list's end arrive dead)
         // the step's own order: a lane is settled once every lane it waits for is; it inserts iff none of those did.  The masks are wave-wide
         // scalars: per iteration two ANDs of `dep` with a scalar and two compares in the vector unit, the rest on the scalar unit.
         unsigned long long decided = __ballot(dead || dep == 0ull), insm = __ballot(!dead && dep == 0ull);

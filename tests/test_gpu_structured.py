@@ -61,6 +61,22 @@ def test_deep_coverage_and_long_reads_in_order():
     _full_compare(bases, off, 31, 300)
 
 
+@pytest.mark.parametrize("chunk", ["1000", "64", "1"])
+def test_the_sequential_pass_chunk_by_chunk(chunk, monkeypatch):
+    # A window that leaves more than 2^19 reads unsettled goes through the sequential pass in chunks (a bit per key name in LDS), tent
+    # re-proposed by what is left between two of them.  At full size that path is only checked by round trips (which any valid anchor
+    # choice passes); LEON_CHAIN_CHUNK makes the chunks small -- 1000 reads (not a multiple of a step), one step, ONE read -- so that the
+    # oracle checks its every stage: anchors, events, bytes.
+    monkeypatch.setenv("LEON_CHAIN_CHUNK", chunk)
+    n = 20000 if chunk != "1" else 3000
+    bases, off = _reads(n, 150, 5 * n, "sorted", seed=21, dup_rate=0.2)
+    ref, st = _full_compare(bases, off, 31, 1000)
+    assert st["resolve_chain_reads"] > n // 4
+    g = synth.make_structured_genome(20000, seed=22, dispersed=6, tandem=60)
+    bases, off = _reads(n // 2, 200, 0, "sorted", seed=23, genome=g, ragged=True, dup_rate=0.3)
+    _full_compare(bases, off, 41, 500, window=2500)
+
+
 def test_every_read_the_same():
     # 3 000 copies of one read, then of its reverse complement: one anchor, every later read finds it
     g = synth.make_genome(400, seed=13)
