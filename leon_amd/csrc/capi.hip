@@ -126,6 +126,7 @@ struct leon_dna_ctx {
     DevBuf xch_slot, xch_off, xch_evoff, xch_events, xch_send, xch_split, xch_res;
     DevBuf resolve_trace;
     DevBuf round_hist;                           // the counts of a window's fixpoint rounds, read back together
+    DevBuf wcache;                               // the walk's path cache (dna_kernels.hip): cleared at every batch
     DevBuf chain_cnt, chain_own, chain_ins, chain_rows, chain_ent, chain_trace, chain_dep, chain_xdep, chain_om, chain_late;   // the sequential pass behind the rounds (k_chain_*)
     std::vector<hipEvent_t> chain_ev;            // pairs around the sequential passes of a batch
     // small launches: the blocks' chains on host cores (host_blocks.h), fed by the device's modelers chunk by chunk
@@ -1018,6 +1019,29 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     }
     HIPCHK(c, c->events.ensure(nl_bases + 16));
     HIPCHK(c, hipMemsetAsync(c->events.p, 0, nl_bases + 16, s));
+    // the walk's path cache: a 64-byte bucket per ~8 solid k-mers (the bloom's size says how many there are), at most an eighth of the
+    // free device memory; EMPTY again at every batch -- what a batch's walkers learn from the bloom is shared among THEM, a later
+    // batch (or a bench step) starts cold.  LEON_WALK_CACHE=0: off; LEON_WALK_CACHE_LOG2: log2 of the buckets (measurement)
+    WalkCache wc{nullptr, 0, 28, 0};
+    {
+        static const int wc_env = [] { const char* e = getenv("LEON_WALK_CACHE"); return e ? atoi(e) : 1; }();
+        static const int wc_log2 = [] { const char* e = getenv("LEON_WALK_CACHE_LOG2"); return e ? atoi(e) : 0; }();
+        if (wc_env && c->B.n_hash == 7) {
+            uint64_t want = c->cfg.bloom_tai / 12 / 8, buckets = 1024;
+            while (buckets < want && buckets < (1ull << 31)) buckets <<= 1;
+            if (wc_log2 >= 10 && wc_log2 <= 31) buckets = 1ull << wc_log2;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) while (buckets > 1024 && buckets * 64 > c->wcache.cap && buckets * 64 > free_b / 8) buckets >>= 1;
+            if (c->wcache.ensure(buckets * 64) == hipSuccess) {
+                wc.slots = c->wcache.as<uint64_t>(); wc.bucket_mask = buckets - 1;
+                static const int hop_log2 = [] { const char* e = getenv("LEON_WALK_HOP_LOG2"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 8 ? v : 4; }();
+                wc.hop_shift = 32 - hop_log2;
+
+                launch_walk_cache_init(s, wc, k);
+
+            } else (void)hipGetLastError();
+        }
+    }
     HIPCHK(c, c->perm.ensure(n * 4));
     hipLaunchKernelGGL(k_iota, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, c->perm.as<uint32_t>(), n);
     size_t sort_tmp = 0;
@@ -1036,7 +1060,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         HIPCHK(c, hipEventRecord(c->ev[3], s));
         // ---- walk ----
         HIPCHK(c, hipEventRecord(c->ev[4], s));
-        launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, V.flags, c->perm2.as<uint32_t>(), nl, c->events.as<uint8_t>());
+        launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, V.flags, c->perm2.as<uint32_t>(), nl, c->events.as<uint8_t>(), nullptr, wc);
         HIPCHK(c, hipEventRecord(c->ev[5], s));
         c->stats.walk_launches = 1; c->stats.walk_reads = nl;
     } else {
@@ -1091,7 +1115,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
             HIPCHK(c, c->xch_events.ensure(slice_bases + 16));
             HIPCHK(c, hipMemsetAsync(c->xch_events.p, 0, slice_bases + 16, s));
             if (timed) HIPCHK(c, hipEventRecord(c->ev[4], s));
-            launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, V.flags, slice, ns, c->xch_events.as<uint8_t>(), c->xch_evoff.as<uint64_t>());
+            launch_walk(s, R, c->B, c->d_rv16, V.anchor_pos, V.flags, slice, ns, c->xch_events.as<uint8_t>(), c->xch_evoff.as<uint64_t>(), wc);
             if (timed) { HIPCHK(c, hipEventRecord(c->ev[5], s)); c->stats.walk_launches = 1; c->stats.walk_reads = ns; }
             launch_ev_words(s, R, c->xch_slot.as<uint32_t>(), c->xch_evoff.as<uint64_t>(), c->xch_events.as<uint8_t>(), n, rpb, n_blocks, Wd,
                             c->xch_off.as<uint64_t>(), nullptr);

@@ -1253,9 +1253,86 @@ __device__ inline void walk_apply(uint32_t res4, uint32_t k, K kmask_k, K& x, K&
     y = (y >> 2) | ((K)(f ^ 2u) << (2 * (k - 1)));
 }
 
-template <typename K, uint32_t NH>
-__global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
-                                             const uint8_t* flags, const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off) {
+// ---- the walk's path cache (round 5) ---------------------------------------------------------------------------------------------
+// Every genome position is walked by ~5.6 anchor groups (an anchor every ~35 bases, walks of ~100 steps each way), ~2.8 of them in
+// each direction, and each of them asks the bloom the same question at the same oriented k-mer: "which successors are solid?".
+// Where the answer is "exactly one, b" the walk's next k-mer is x.b whatever the read holds (a read base other than b is a
+// sequencing error that FOLLOWS b: walk_step), so a run of such steps is a fact about the bloom alone.  The first walker through
+// a region leaves those facts behind: at every HOP POINT -- an oriented k-mer whose hash ends in four zero bits, the same for every
+// walker -- it starts recording the unique successors of the steps that follow (up to 28, to the next hop point, or to the first
+// step that is not unique) and publishes them under the hop point's k-mer; a later walker that reaches the hop point takes the run
+// and makes those steps without a probe.  Write-once slots in 64-byte buckets: a key is claimed by compare-and-swap, its payload
+// (count << 56 | bases, first base lowest) only grows (atomic max: two runs from one k-mer are prefixes of one another), readers
+// take a key without a payload, a bucket that is full or a line that is stale in their L1 as a miss.  The events are the probes'
+// own, byte for byte: a cached step hands walk_apply the mask the probe would have returned.
+constexpr uint64_t WC_EMPTY = ~0ull;
+constexpr uint32_t WC_MAX = 28;
+template <typename K> struct WCL;
+template <> struct WCL<uint64_t> { static constexpr uint32_t SLOTS = 4, WORDS = 2, PAY = 1; };     // {key, payload}
+template <> struct WCL<u128> { static constexpr uint32_t SLOTS = 2, WORDS = 4, PAY = 2; };         // {lo, hi, payload, -}
+template <typename K> __device__ inline bool wc_is_hop(const WalkCache& C, K x) { return ((fold32(x) * 0x9E3779B1u) >> C.hop_shift) == 0u; }
+template <typename K> __device__ inline uint64_t wc_lookup(const WalkCache& C, K x) {
+    const uint64_t* b = C.slots + (key_hash(x) & C.bucket_mask) * 8;
+    const uint64_t lo = (uint64_t)x, hi = KT<K>::W == 2 ? (uint64_t)(x >> (KT<K>::W == 2 ? 64 : 0)) : 0;
+    uint64_t pay = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < WCL<K>::SLOTS; i++) {
+        const uint64_t* sp = b + i * WCL<K>::WORDS;
+        const bool same = sp[0] == lo && (KT<K>::W == 1 || sp[1] == hi);
+        const uint64_t pv = sp[WCL<K>::PAY];
+        if (same) pay = pv;
+    }
+    return lo == WC_EMPTY ? 0ull : pay;
+}
+template <typename K> __device__ inline void wc_insert(const WalkCache& C, K x, uint64_t pay) {
+    uint64_t* b = C.slots + (key_hash(x) & C.bucket_mask) * 8;
+    const uint64_t lo = (uint64_t)x, hi = KT<K>::W == 2 ? (uint64_t)(x >> (KT<K>::W == 2 ? 64 : 0)) : 0;
+    if (lo == WC_EMPTY) return;
+    for (uint32_t i = 0; i < WCL<K>::SLOTS; i++) {
+        uint64_t* sp = b + i * WCL<K>::WORDS;
+        unsigned long long expect = WC_EMPTY;
+        const bool mine = __hip_atomic_compare_exchange_strong((unsigned long long*)sp, &expect, (unsigned long long)lo, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mine) {
+            if (KT<K>::W == 2) __hip_atomic_store(sp + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_max(sp + WCL<K>::PAY, pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (expect == lo) {
+            if (KT<K>::W == 1) { (void)__hip_atomic_fetch_max(sp + WCL<K>::PAY, pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+            const uint64_t h = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (h == hi) { (void)__hip_atomic_fetch_max(sp + WCL<K>::PAY, pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+            if (h == WC_EMPTY) return;                               // its writer is between its two stores: let it be
+        }
+    }
+}
+// one side's state, packed (the kernel's registers decide how many waves a SIMD holds): st = run | rec_n << 8 | rec_on << 16 | rec_new << 17 --
+// `run` steps left of a run taken from the cache, whose bases are rec_b's own (base i of the run at bits 2i: the next one is base
+// rec_n - run); rec_n bases recorded under rec_key since the last hop point (rec_new: more of them than the cache holds)
+template <typename K> struct WalkRun { uint32_t st = 0; uint64_t rec_b = 0; K rec_key = 0; };
+constexpr uint32_t WR_ON = 1u << 16, WR_NEW = 1u << 17;
+// the lanes of an anchor group walk in lockstep and publish the same run at the same moment: only the first of a row of equal
+// neighbours goes to the slot (same-address atomics serialise in L2)
+template <typename K> __device__ inline void wc_publish(const WalkCache& C, WalkRun<K>& W) {
+    const uint64_t pay = ((uint64_t)((W.st >> 8) & 31u) << 56) | W.rec_b, klo = (uint64_t)W.rec_key;
+    const unsigned long long m = __ballot(true);
+    const uint32_t lane = lane_id();
+    const uint64_t up_k = (uint64_t)__shfl_up((long long)klo, 1), up_p = (uint64_t)__shfl_up((long long)pay, 1);
+    const bool dup = lane > 0 && ((m >> (lane - 1)) & 1ull) && up_k == klo && up_p == pay;
+    if (!dup) wc_insert<K>(C, W.rec_key, pay);
+    W.st &= ~WR_NEW;
+}
+__global__ void k_wc_init(uint64_t* slots, uint64_t n_words, uint32_t words_per_slot, uint32_t pay) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
+        slots[i] = (uint32_t)(i % words_per_slot) < pay ? WC_EMPTY : 0ull;
+}
+void launch_walk_cache_init(hipStream_t s, WalkCache C, uint32_t k) {
+    if (!C.slots) return;
+    const uint64_t n_words = (C.bucket_mask + 1) * 8;
+    hipLaunchKernelGGL(k_wc_init, dim3(grid_for(n_words, 256, 256 * 64)), dim3(256), 0, s, C.slots, n_words, k >= 32 ? 4u : 2u, k >= 32 ? 2u : 1u);
+}
+template <typename K, uint32_t NH, bool CACHE>
+__global__ void __launch_bounds__(256, 7) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
+                                             const uint8_t* flags, const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off, WalkCache WC) {
     __shared__ uint16_t rv16[256];
     load_rv16(rv16, rv16g, NH ? B.block_mask : 0xFFFFu);
     // (measured, round 3: giving every XCD one contiguous eighth of the order -- workgroup b takes chunk (b % 8) * n/8 + b / 8 --
@@ -1297,8 +1374,9 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
     // one step of a side in two halves, so that the probes of BOTH sides are in flight before either is waited for:
     // side_probe returns the successor mask (0x100 = nothing to probe: past the side's end, or an N position, whose
     // 'A' is pushed into the k-mer right away), side_apply classifies it, stores the event and moves the k-mer on
+    WalkRun<K> WA, WB;
     auto side_probe = [&](bool on, bool left, uint32_t j, K& x, K& y, uint32_t& pw, uint32_t& pw_idx, uint32_t& nw, uint32_t& nw_idx,
-                          uint32_t& pos, uint32_t& nt) -> uint32_t {
+                          uint32_t& pos, uint32_t& nt, WalkRun<K>& W) -> uint32_t {
         if (!on) return 0x100u;
         pos = left ? (uint32_t)a - 1 - j : (uint32_t)a + k + j;
         if ((pos >> 4) != pw_idx) { pw_idx = pos >> 4; pw = pk[pw_idx]; }
@@ -1306,20 +1384,55 @@ __global__ void __launch_bounds__(256) k_walk(ReadsDev R, BloomDev B, const uint
         if (hasN) {
             if ((pos >> 5) != nw_idx) { nw_idx = pos >> 5; nw = nm[nw_idx]; }
             if ((nw >> (pos & 31)) & 1u) {                            // N: coded as 'A' on the read strand, nothing stored
+                if (CACHE) {                                         // the 'A' leaves the path the cache knows; what was recorded up to here stands
+                    if ((W.st & (WR_ON | WR_NEW)) == (WR_ON | WR_NEW)) wc_publish<K>(WC, W);
+                    W.st = 0;
+                }
                 const uint32_t f = left ? 2u : 0u;
                 x = ((x << 2) | (K)f) & kmask_k;
                 y = (y >> 2) | ((K)(f ^ 2u) << (2 * (k - 1)));
                 return 0x100u;
             }
         }
+        if (CACHE) {
+            if (W.st & 31u) {                                        // a step the cache knows: no probe
+                const uint32_t i = ((W.st >> 8) & 31u) - (W.st & 31u);
+                W.st--;
+                return 1u << ((uint32_t)(W.rec_b >> (2 * i)) & 3u);
+            }
+            if (wc_is_hop(WC, x)) {
+                if ((W.st & (WR_ON | WR_NEW)) == (WR_ON | WR_NEW)) wc_publish<K>(WC, W);
+                const uint64_t pay = wc_lookup<K>(WC, x);
+                // (a run that ends before the next hop point -- its recorder's read ended there -- is EXTENDED by whoever takes it: the
+                // walker goes on recording under the same key from where the run stops)
+                const uint32_t m = (uint32_t)(pay >> 56);
+                W.rec_key = x; W.rec_b = pay & ((1ull << 56) - 1);
+                W.st = WR_ON | (m << 8) | (m ? m - 1 : 0u);
+                if (m) return 1u << ((uint32_t)pay & 3u);
+            }
+            const uint32_t r4 = bloom_contains4<K, NH>(B, rv16, x, y, true);
+            if (W.st & WR_ON) {
+                const uint32_t n = (W.st >> 8) & 31u;
+                if (__popc(r4) == 1 && n < WC_MAX) { W.rec_b |= (uint64_t)__builtin_ctz(r4) << (2 * n); W.st += 1u << 8; W.st |= WR_NEW; }
+                else { if (W.st & WR_NEW) wc_publish<K>(WC, W); W.st = 0; }
+            }
+            return r4;
+        }
         return bloom_contains4<K, NH>(B, rv16, x, y, true);
     };
+    // (Measured and dropped: every side with its own step count, a side that holds a run making ALL of its steps at once -- no probe, no
+    // look-up -- before the two sides' probing step: 232 ms against 200.  The lanes of a wave belong to ~9 anchor groups at
+    // different places between their hop points; in nearly every iteration one of them starts a run, and the other lanes wait for it.)
     for (uint32_t j = 0; j < nmax; j++) {
         uint32_t posA = 0, ntA = 0, posB = 0, ntB = 0;
-        const uint32_t rA = side_probe(j < nA, leftA, j, xA, yA, pwA, pwA_idx, nwA, nwA_idx, posA, ntA);
-        const uint32_t rB = side_probe(j < nB, leftB, j, xB, yB, pwB, pwB_idx, nwB, nwB_idx, posB, ntB);
+        const uint32_t rA = side_probe(j < nA, leftA, j, xA, yA, pwA, pwA_idx, nwA, nwA_idx, posA, ntA, WA);
+        const uint32_t rB = side_probe(j < nB, leftB, j, xB, yB, pwB, pwB_idx, nwB, nwB_idx, posB, ntB, WB);
         if (rA != 0x100u) walk_apply<K>(rA, k, kmask_k, xA, yA, ntA, leftA, ev + posA);
         if (rB != 0x100u) walk_apply<K>(rB, k, kmask_k, xB, yB, ntB, leftB, ev + posB);
+    }
+    if (CACHE) {                                                         // what was being recorded when a side ended is a valid (shorter) run
+        if ((WA.st & (WR_ON | WR_NEW)) == (WR_ON | WR_NEW)) wc_publish<K>(WC, WA);
+        if ((WB.st & (WR_ON | WR_NEW)) == (WR_ON | WR_NEW)) wc_publish<K>(WC, WB);
     }
 }
 // ---- measurement only (LEON_WALK_TILE=1): the LDS-tile form of the probe.  The seven probes of a step all fall in the
@@ -1429,14 +1542,15 @@ __global__ void __launch_bounds__(256) k_walk_tile(ReadsDev R, BloomDev B, const
     }
 }
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos, const uint8_t* flags,
-                 const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off) {
+                 const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off, WalkCache wc) {
     if (!n_walk) return;
     uint64_t g = (n_walk + 255) / 256;
     static const bool tile = getenv("LEON_WALK_TILE") != nullptr && getenv("LEON_WALK_TILE")[0] == '1';       // measurement only
     if (tile && !ev_off) { DISPATCH_K(R.k, hipLaunchKernelGGL(k_walk_tile<K>, dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events)); return; }
     // (Leon's seven hash functions: an instantiation without the per-hash branches; any other number takes them)
-    if (B.n_hash == 7) { DISPATCH_K(R.k, hipLaunchKernelGGL((k_walk<K, 7>), dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events, ev_off)); return; }
-    DISPATCH_K(R.k, hipLaunchKernelGGL((k_walk<K, 0>), dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events, ev_off));
+    if (B.n_hash == 7 && wc.slots) { DISPATCH_K(R.k, hipLaunchKernelGGL((k_walk<K, 7, true>), dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events, ev_off, wc)); return; }
+    if (B.n_hash == 7) { DISPATCH_K(R.k, hipLaunchKernelGGL((k_walk<K, 7, false>), dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events, ev_off, wc)); return; }
+    DISPATCH_K(R.k, hipLaunchKernelGGL((k_walk<K, 0, false>), dim3((uint32_t)g), dim3(256), 0, s, R, B, rv16, anchor_pos, flags, perm, n_walk, events, ev_off, wc));
 }
 
 // ================================================================================================

@@ -116,8 +116,12 @@ void launch_chain_apply(hipStream_t s, DictDev D, ResolveDev V, uint64_t first_g
 void launch_anchor_symbols(hipStream_t s, const uint64_t* kmers, uint64_t n_anchors, uint32_t k, uint8_t* syms);
 void launch_finalize_reads(hipStream_t s, ReadsDev R, DictDev D, ResolveDev V, uint64_t w0, uint64_t w1);
 // ---- walk ----
+// what earlier walkers learnt from the bloom, shared in HBM (dna_kernels.hip, "the walk's path cache"): 64-byte buckets of write-once slots
+struct WalkCache { uint64_t* slots; uint64_t bucket_mask; uint32_t hop_shift, pad; };          // slots == nullptr: off; a k-mer is a hop point when its 32-bit hash >> hop_shift is 0
+void launch_walk_cache_init(hipStream_t s, WalkCache C, uint32_t k);
 void launch_walk(hipStream_t s, ReadsDev R, BloomDev B, const uint16_t* rv16, const int32_t* anchor_pos, const uint8_t* flags,
-                 const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off = nullptr /* per walked read: its place in `events` */);
+                 const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off = nullptr /* per walked read: its place in `events` */,
+                 WalkCache wc = WalkCache{nullptr, 0, 28, 0});
 // ---- the walk divided by anchor among the ranks of a job (leon_dna_set_exchange) ----
 void launch_lower_bound(hipStream_t s, const uint64_t* sorted, uint64_t n, uint64_t bound, unsigned long long* out);
 void launch_slice_weights(hipStream_t s, const uint64_t* sorted_keys, uint64_t n, uint64_t* w /* n + 1 */);
