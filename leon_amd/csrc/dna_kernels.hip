@@ -1330,8 +1330,9 @@ void launch_walk_cache_init(hipStream_t s, WalkCache C, uint32_t k) {
     const uint64_t n_words = (C.bucket_mask + 1) * 8;
     hipLaunchKernelGGL(k_wc_init, dim3(grid_for(n_words, 256, 256 * 64)), dim3(256), 0, s, C.slots, n_words, k >= 32 ? 4u : 2u, k >= 32 ? 2u : 1u);
 }
+// (waves per SIMD: seven for one-word k-mers -- 72 registers, five of them spilt, 198-201 ms against 209-214 at six waves -- five for two-word ones)
 template <typename K, uint32_t NH, bool CACHE>
-__global__ void __launch_bounds__(256, 7) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
+__global__ void __launch_bounds__(256, (KT<K>::W == 2 ? 5 : 7)) k_walk(ReadsDev R, BloomDev B, const uint16_t* rv16g, const int32_t* anchor_pos,
                                              const uint8_t* flags, const uint32_t* perm, uint64_t n_walk, uint8_t* events, const uint64_t* ev_off, WalkCache WC) {
     __shared__ uint16_t rv16[256];
     load_rv16(rv16, rv16g, NH ? B.block_mask : 0xFFFFu);
