@@ -1026,9 +1026,11 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     {
         static const int wc_env = [] { const char* e = getenv("LEON_WALK_CACHE"); return e ? atoi(e) : 1; }();
         static const int wc_log2 = [] { const char* e = getenv("LEON_WALK_CACHE_LOG2"); return e ? atoi(e) : 0; }();
-        if (wc_env && c->B.n_hash == 7) {
+        // (not for a rank of four or more: the walkers that cover one genome region are spread over all ranks' slices, a rank's own cache
+        // would answer a fifth of its look-ups and cost as much as it saves)
+        if (wc_env && c->B.n_hash == 7 && c->shard_world <= 2) {
             uint64_t want = c->cfg.bloom_tai / 12 / 8, buckets = 1024;
-            while (buckets < want && buckets < (1ull << 31)) buckets <<= 1;
+            while (buckets < want && buckets < (1ull << 27)) buckets <<= 1;          // at most 2^27 buckets = 8 GiB
             if (wc_log2 >= 10 && wc_log2 <= 31) buckets = 1ull << wc_log2;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) while (buckets > 1024 && buckets * 64 > c->wcache.cap && buckets * 64 > free_b / 8) buckets >>= 1;
