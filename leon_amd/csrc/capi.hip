@@ -278,17 +278,21 @@ uint32_t rc_host_threads(uint64_t n_blocks) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_thr, n_blocks));
 }
 // Who codes a launch's chains.  The device's coder waves take about as long as the LONGEST block's chain whatever the number of
-// blocks (~100 ns per symbol of it, up to 8 blocks per CU); the host's threads take the modelers' pass over the longest block
-// (~45 ns per symbol, the records crossing PCIe chunk by chunk beside it), with the chains (~3.5 ns per symbol and thread) running a
-// chunk behind and going on alone if they are the slower.  10 M reads of 150 bp in 200 blocks: 116 against ~60 ms, the host (measured
-// 134 and 64); 20 M reads of 250 bp in 400 blocks of 1.9 M symbols: 190 against ~190: the device (measured 181 and 230 with 12 threads).
+// blocks (~100 ns per symbol of it, up to 8 blocks per CU); the host's way takes the slowest of three things that run side by side --
+// the modelers' pass over the longest block (four waves per block since round 5), the records' 8 bytes per symbol over PCIe, the host
+// threads' chains (two side by side per thread) -- a chunk behind one another.  10 M reads of 150 bp in 200 blocks: 116 against ~42 ms,
+// the host (measured 134 and 45); 20 M reads of 250 bp in 400 blocks of 1.9 M symbols: 190 against ~140 (measured 174 and 142): left to the device, see below.
 bool rc_on_host(uint64_t n_blocks, uint64_t n_syms, uint64_t max_block_syms) {
     if (!n_blocks || n_blocks > rc_host_blocks() || max_block_syms + 1024 >= (1ull << HB_COUNT_BITS) || n_syms * 8 > (12ull << 30)) return false;
     if (getenv("LEON_RC_HOST_BLOCKS")) return true;              // (asked for by name: the tests, measurements)
     const double device_ns = 100.0 * (double)max_block_syms * (double)((n_blocks + 2047) / 2048);
-    const double host_ns = 45.0 * (double)max_block_syms + std::max(0.16 * (double)n_syms, 3.5 * (double)n_syms / rc_host_threads(n_blocks)) / 16.0
-                           + std::max(0.0, 3.5 * (double)n_syms / rc_host_threads(n_blocks) - 45.0 * (double)max_block_syms);
-    return host_ns < 0.9 * device_ns;                            // (a tie goes to the device: the host's cores have other work)
+    // (round 5: four modeler waves per block -- ~12 ns per symbol of the longest block --, the records' 8 bytes per symbol over PCIe at ~52 GB/s,
+    // the chains two side by side per thread at ~2.6 ns per symbol; whichever is slowest, a sixteenth later for the first chunk's way in)
+    const double thr = (double)rc_host_threads(n_blocks);
+    const double host_ns = 1.0625 * std::max(12.0 * (double)max_block_syms, std::max(0.16 * (double)n_syms, 2.6 * (double)n_syms / thr));
+    // (a near tie goes to the device: the host's cores have other work -- the dictionary chain, which is what a step waits for: at the k = 63 / 250 bp
+    // shape, 400 blocks of 1.9 M symbols, the host's way takes 142 ms against the device's 174 and the step 554 ms against 542)
+    return host_ns < 0.7 * device_ns;
 }
 
 // The range coder stage of a small launch: the device's modeler waves turn the symbols of every block into records, chunk of tiles
@@ -367,8 +371,17 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
                     if (abort_flag.load()) return;
                     if (spin < 2000) __builtin_ia32_pause(); else std::this_thread::yield();
                 }
-                for (uint64_t b = w; b < nbl; b += n_thr)
-                    coders[b].code(h_recs + chunk_base[ch] + rec_off[(size_t)ch * nbl + b], rec_cnt[(size_t)ch * nbl + b]);
+                // two of the thread's blocks side by side (HostBlockCoder::code2: two dependent chains fill the core one leaves half idle)
+                static const bool pairs = [] { const char* e = getenv("LEON_RC_HOST_PAIRS"); return !(e && e[0] == '0'); }();
+                for (uint64_t b = w; b < nbl; b += 2 * (uint64_t)n_thr) {
+                    const uint64_t b2 = b + n_thr;
+                    const uint64_t* ra = h_recs + chunk_base[ch] + rec_off[(size_t)ch * nbl + b];
+                    if (b2 < nbl && pairs) HostBlockCoder::code2(coders[b], ra, rec_cnt[(size_t)ch * nbl + b], coders[b2], h_recs + chunk_base[ch] + rec_off[(size_t)ch * nbl + b2], rec_cnt[(size_t)ch * nbl + b2]);
+                    else {
+                        coders[b].code(ra, rec_cnt[(size_t)ch * nbl + b]);
+                        if (b2 < nbl) coders[b2].code(h_recs + chunk_base[ch] + rec_off[(size_t)ch * nbl + b2], rec_cnt[(size_t)ch * nbl + b2]);
+                    }
+                }
                 if (trace) { const double t = ms_now(); std::lock_guard<std::mutex> g(trace_mu); t_coded[ch] = std::max(t_coded[ch], t); }
             }
             for (uint64_t b = w; b < nbl; b += n_thr) coders[b].flush();

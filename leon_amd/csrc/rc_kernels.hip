@@ -23,6 +23,47 @@ size_t rc_model_scratch_bytes(uint64_t n_blocks) {
 // vector instruction; the other waves are the modelers.
 __host__ __device__ constexpr uint32_t rc_waves(uint32_t g) { return g + 1 + (g - 1) / 3; }
 
+// The earlier symbols of a tile, lane = symbol: lo += #(same model, smaller symbol), hi += #(same model, symbol <= mine),
+// tot += #(same model) over the lanes before this one -- 64 steps of a broadcast and three compare/add-with-carry pairs; the lane
+// mask "after lane i" is exec itself, shifted once per step (one asm block, exec restored inside it).  key = model << 8 | symbol.
+__device__ inline void rc_rank_loop(uint32_t key, uint32_t c, uint32_t& lo, uint32_t& hi, uint32_t& tot) {
+    const uint32_t lowkey = key & ~0xFFu;
+    uint32_t sk0, sk1, dd;
+    uint64_t m1, m2, sav;
+    asm volatile(
+        "s_mov_b64 %[sav], exec\n\t"
+        "v_readlane_b32 %[sk0], %[key], 0\n\t"
+        "s_mov_b64 exec, -2\n\t"
+        "s_nop 1\n\t"
+        ".set rc_i, 0\n\t"
+        ".rept 32\n\t"
+        "v_sub_u32 %[dd], %[sk0], %[lowkey]\n\t"
+        "v_readlane_b32 %[sk1], %[key], rc_i + 1\n\t"
+        "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
+        "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
+        "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
+        "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
+        "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
+        "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
+        "s_lshl_b64 exec, exec, 1\n\t"
+        "v_sub_u32 %[dd], %[sk1], %[lowkey]\n\t"
+        "v_readlane_b32 %[sk0], %[key], (rc_i + 2) & 63\n\t"
+        "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
+        "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
+        "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
+        "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
+        "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
+        "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
+        "s_lshl_b64 exec, exec, 1\n\t"
+        ".set rc_i, rc_i + 2\n\t"
+        ".endr\n\t"
+        "s_mov_b64 exec, %[sav]\n\t"
+        : [lo] "+v"(lo), [hi] "+v"(hi), [tot] "+v"(tot), [sk0] "=&s"(sk0), [sk1] "=&s"(sk1), [dd] "=&v"(dd),
+          [m1] "=&s"(m1), [m2] "=&s"(m2), [sav] "=&s"(sav)
+        : [key] "v"(key), [lowkey] "v"(lowkey), [c] "v"(c), [k256] "s"(256u)
+        : "vcc");
+}
+
 // The modeler of ONE block, run by one wave (lane = symbol of the current tile of 64): the adaptive order-0 models of the block in
 // LDS (two-level cumulative counts, rc_model.h; numeric models beyond the LDS slots in a global overflow area), and per tile every
 // symbol's (cumLow, cumLow + freq, total) = the counts at the tile start + the earlier symbols of the tile, then
@@ -102,42 +143,8 @@ struct RcModeler {
         // tot += #(same model) over the lanes before this one -- 64 steps of a broadcast and three
         // compare/add-with-carry pairs; the lane mask "after lane i" is exec itself, shifted once per step
         // (one asm block, exec restored inside it)
+        rc_rank_loop(key, c, lo, hi, tot);
         {
-            const uint32_t lowkey = m << 8;
-            uint32_t sk0, sk1, dd;
-            uint64_t m1, m2, sav;
-            asm volatile(
-                "s_mov_b64 %[sav], exec\n\t"
-                "v_readlane_b32 %[sk0], %[key], 0\n\t"
-                "s_mov_b64 exec, -2\n\t"
-                "s_nop 1\n\t"
-                ".set rc_i, 0\n\t"
-                ".rept 32\n\t"
-                "v_sub_u32 %[dd], %[sk0], %[lowkey]\n\t"
-                "v_readlane_b32 %[sk1], %[key], rc_i + 1\n\t"
-                "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
-                "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
-                "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
-                "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
-                "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
-                "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
-                "s_lshl_b64 exec, exec, 1\n\t"
-                "v_sub_u32 %[dd], %[sk1], %[lowkey]\n\t"
-                "v_readlane_b32 %[sk0], %[key], (rc_i + 2) & 63\n\t"
-                "v_cmp_lt_u32 vcc, %[dd], %[c]\n\t"
-                "v_cmp_le_u32 %[m1], %[dd], %[c]\n\t"
-                "v_cmp_gt_u32 %[m2], %[k256], %[dd]\n\t"
-                "v_addc_co_u32 %[lo], vcc, 0, %[lo], vcc\n\t"
-                "v_addc_co_u32 %[hi], %[m1], 0, %[hi], %[m1]\n\t"
-                "v_addc_co_u32 %[tot], %[m2], 0, %[tot], %[m2]\n\t"
-                "s_lshl_b64 exec, exec, 1\n\t"
-                ".set rc_i, rc_i + 2\n\t"
-                ".endr\n\t"
-                "s_mov_b64 exec, %[sav]\n\t"
-                : [lo] "+v"(lo), [hi] "+v"(hi), [tot] "+v"(tot), [sk0] "=&s"(sk0), [sk1] "=&s"(sk1), [dd] "=&v"(dd),
-                  [m1] "=&s"(m1), [m2] "=&s"(m2), [sav] "=&s"(sav)
-                : [key] "v"(key), [lowkey] "v"(lowkey), [c] "v"(c), [k256] "s"(256u)
-                : "vcc");
             if (!act) { lo = 0; hi = 1; tot = 1; }         // past the block's end: a record that leaves the chain as it is
         }
         // Order0Model::update for the whole tile, lane = symbol: F(x) += 1 for x > c, i.e. H[k] for k > c >> 4
@@ -391,11 +398,139 @@ __global__ void __launch_bounds__(64) k_rc_records(const uint8_t* syms, const ui
         __syncthreads();
     }
 }
+// The same with FOUR waves per block (round 5).  A tile's 64-step rank loop -- nine tenths of the modeler's instructions -- depends on
+// the tile's own symbols only, so wave w takes the loops of tiles w, w + 4, ... with counts that start from zero; what must go in tile
+// order -- a new numeric model's slot, the counts at the tile start (added to the loop's), the record, Order0Model::update -- is a
+// short serial section that the waves enter in turn (`turn` in LDS, raised behind the section's own LDS operations, which execute in
+// order).  One block's pass: ~0.6 us per tile instead of a lone wave's 2.8.
+__global__ void __launch_bounds__(256) k_rc_records4(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint32_t tile0, uint32_t tile1,
+                                                    uint64_t* recs, const uint64_t* rec_off, uint32_t* state, uint32_t* scratch, int* err, uint32_t small_sizes) {
+    __shared__ uint32_t models[RCR_MW];
+    __shared__ uint32_t slotmap_w[RC_NNUM / 4];
+    __shared__ uint32_t turn, nused_s;
+    uint8_t* slotmap = (uint8_t*)slotmap_w;
+    const uint16_t* sym16 = (const uint16_t*)syms;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr uint32_t NSLOT = RC_NSLOT_BIG;
+    // per-lane constants of the overflow area's update (RcModeler::init)
+    const bool is_lw = lane < 16;
+    const uint32_t upd_lane = is_lw ? lane : (lane < 33 ? lane - 16 : 0), upd_base = is_lw ? RC_LW + lane : upd_lane, upd_blkmask = is_lw ? ~0u : 0u;
+    for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const uint64_t s0 = blk_begin[b], s1 = blk_begin[b + 1];
+        if (s1 - s0 >= (1ull << 22) - 512) { if (threadIdx.x == 0) atomicExch(err, 2); continue; }     // (the host checks before it launches: 22-bit counts)
+        const uint32_t ntiles = (uint32_t)((s1 - s0 + 63) / 64);
+        const uint32_t ta = tile0 < ntiles ? tile0 : ntiles, tb = tile1 < ntiles ? tile1 : ntiles;
+        if (ta >= tb) continue;
+        uint32_t* st = state + b * (uint64_t)RCR_STATE_WORDS;
+        uint32_t* gm = scratch + b * (uint64_t)(RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE;
+        __syncthreads();
+        if (ta == 0) {                                           // AbstractDnaCoder::startBlock
+            if (wv == 0) for (uint32_t m = 0; m < N_SMALL_MODELS; m++) model_init(&models[m * RC_SSTRIDE], lane, true);
+            for (uint32_t i = threadIdx.x; i < RC_NNUM; i += 256) slotmap[i] = 255;
+            if (threadIdx.x == 0) nused_s = 0;
+        } else {                                                 // the block goes on where the launch before left it
+            for (uint32_t i = threadIdx.x; i < RCR_MW; i += 256) models[i] = st[i];
+            for (uint32_t i = threadIdx.x; i < RC_NNUM / 4; i += 256) slotmap_w[i] = st[RCR_MW + i];
+            if (threadIdx.x == 0) nused_s = st[RCR_MW + RC_NNUM / 4];
+        }
+        if (threadIdx.x == 0) turn = ta;
+        __syncthreads();
+        uint64_t* out = recs + rec_off[b];
+        auto load_raw = [&](uint32_t t) -> uint32_t {
+            const uint64_t base = s0 + (uint64_t)t * 64;
+            return (t < tb && lane < (uint32_t)((s1 - base) < 64 ? (s1 - base) : 64)) ? sym16[base + lane] : 0xFFFFu;
+        };
+        uint32_t raw_next = load_raw(ta + wv);
+        for (uint32_t t = ta + wv; t < tb; t += 4) {
+            const uint64_t base = s0 + (uint64_t)t * 64;
+            const bool act = base + lane < s1;
+            const uint32_t raw = raw_next;
+            raw_next = load_raw(t + 4);                          // (a global load costs ~2000 cycles: the next tile's symbols one tile ahead)
+            const uint32_t m = raw & 0xff, c = raw >> 8, key = (m << 8) | c;
+            // ---- on its own: the tile's 64-step loop
+            uint32_t lo = 0, hi = 0, tot = 0;
+            rc_rank_loop(key, c, lo, hi, tot);
+            // ---- in tile order
+            while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != t) __builtin_amdgcn_s_sleep(0);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            const bool numeric = act && m >= N_SMALL_MODELS;
+            uint32_t slot = numeric ? slotmap[m - N_SMALL_MODELS] : 0;
+            unsigned long long need = __ballot(numeric && slot == 255);
+            if (need) {
+                uint32_t nused = nused_s;
+                while (need) {                                   // slots for numeric models first seen in this tile
+                    const uint32_t l = (uint32_t)__builtin_ctzll(need);
+                    const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)l);
+                    const uint32_t ns = nused++;
+                    if (lane == 0) slotmap[mm - N_SMALL_MODELS] = (uint8_t)ns;
+                    if (ns < NSLOT) model_init(&models[RC_SMALL_WORDS + ns * RC_STRIDE], lane, false);
+                    else { model_init(gm + (uint64_t)(ns - NSLOT) * RC_STRIDE, lane, false); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                    if (numeric && m == mm) slot = ns;
+                    need &= ~__ballot(numeric && m == mm);
+                }
+                if (lane == 0) nused_s = nused;
+            }
+            uint32_t mb = 0;                                     // word offset of this lane's model (RC_GLOBAL | offset for the overflow area)
+            if (act) mb = !numeric ? m * RC_SSTRIDE : (slot < NSLOT ? RC_SMALL_WORDS + slot * RC_STRIDE : (RC_GLOBAL | ((slot - NSLOT) * RC_STRIDE)));
+            __builtin_amdgcn_wave_barrier();
+            uint32_t blo = 0, bhi = 1;                           // the counts at the tile start (the records carry no totals: the host counts them)
+            if (act) {
+                if (!(mb & RC_GLOBAL)) {
+                    const uint32_t* sm = &models[mb];
+                    blo = sm[c >> 4] + sm[RC_LW + c]; bhi = sm[(c + 1) >> 4] + sm[RC_LW + c + 1];
+                } else {                                         // (through L2: another wave's updates)
+                    const uint32_t* sg = gm + (mb & ~RC_GLOBAL);
+                    auto ld = [&](uint32_t i) { return __hip_atomic_load(sg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                    blo = ld(c >> 4) + ld(RC_LW + c); bhi = ld((c + 1) >> 4) + ld(RC_LW + c + 1);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (act) out[(uint64_t)(t - ta) * 64 + lane] = (uint64_t)(blo + lo) | ((uint64_t)((bhi + hi) - (blo + lo)) << 22) | ((uint64_t)(raw & 0xFFu) << 44);
+            {   // Order0Model::update for the whole tile (RcModeler::tile's)
+                const bool in_lds = act && !(mb & RC_GLOBAL);
+                uint32_t* mp = &models[in_lds ? mb : 0];
+                const uint32_t h4 = (in_lds && numeric) ? c >> 4 : 64u;
+                const uint32_t l4 = in_lds ? c & 15u : 64u, ymax = numeric ? 15u : small_size_of(small_sizes, m);
+                uint32_t* lp = mp + RC_LW + (in_lds ? (c & ~15u) : 0u);
+#pragma unroll
+                for (uint32_t k = 1; k <= 16; k++)
+                    if (k > h4) (void)__hip_atomic_fetch_add(&mp[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (uint32_t y = 1; y <= 15; y++)
+                    if (y > l4 && y <= ymax) (void)__hip_atomic_fetch_add(&lp[y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unsigned long long gl = __ballot(act && (mb & RC_GLOBAL));
+                while (gl) {
+                    const uint32_t i = (uint32_t)__builtin_ctzll(gl);
+                    gl &= gl - 1;
+                    const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)i);
+                    const uint32_t mbi = (uint32_t)__builtin_amdgcn_readlane((int)mb, (int)i);
+                    const uint32_t thr = is_lw ? (ci & 15u) : (ci >> 4);
+                    const uint32_t idx = upd_base + ((ci & ~15u) & upd_blkmask);
+                    if (upd_lane > thr) (void)__hip_atomic_fetch_add(gm + (mbi & ~RC_GLOBAL) + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __hip_atomic_store(&turn, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        if (tb < ntiles) {                                       // to be continued
+            for (uint32_t i = threadIdx.x; i < RCR_MW; i += 256) st[i] = models[i];
+            for (uint32_t i = threadIdx.x; i < RC_NNUM / 4; i += 256) st[RCR_MW + i] = slotmap_w[i];
+            if (threadIdx.x == 0) st[RCR_MW + RC_NNUM / 4] = nused_s;
+        }
+    }
+}
 void launch_rc_records(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint32_t tile0, uint32_t tile1, uint64_t* recs,
                        const uint64_t* rec_off, uint32_t* state, uint32_t* model_scratch, int* err, uint32_t small_sizes) {
     if (!n_blocks || tile0 >= tile1) return;
-    hipLaunchKernelGGL(k_rc_records, dim3((uint32_t)std::min<uint64_t>(n_blocks, 256 * 4)), dim3(64), 0, s, syms, blk_begin, n_blocks, tile0, tile1, recs, rec_off,
-                       state, model_scratch, err, small_sizes);
+    static const bool one_wave = [] { const char* e = getenv("LEON_RC_RECORDS_WAVES"); return e && atoi(e) == 1; }();     // (measurement: the round-4 kernel)
+    if (one_wave) hipLaunchKernelGGL(k_rc_records, dim3((uint32_t)std::min<uint64_t>(n_blocks, 256 * 4)), dim3(64), 0, s, syms, blk_begin, n_blocks, tile0, tile1, recs, rec_off,
+                                     state, model_scratch, err, small_sizes);
+    else hipLaunchKernelGGL(k_rc_records4, dim3((uint32_t)std::min<uint64_t>(n_blocks, 256 * 4)), dim3(256), 0, s, syms, blk_begin, n_blocks, tile0, tile1, recs, rec_off,
+                            state, model_scratch, err, small_sizes);
 }
 
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint8_t* out,
