@@ -355,7 +355,7 @@ template <typename K> __device__ inline K canon_from_words16(uint32_t words, uin
 // anchor at all) the reads, their filter probes, the dictionary probes behind a filter "maybe" and their bloom probes (k-mers
 // tested), summed per wave and added to trace[12] once per wave.
 template <typename K, bool TRACE>
-__global__ void __launch_bounds__(256) k_lookup_cand(ReadsDev R, BloomDev B, const uint16_t* rv16g, DictDev D, ResolveDev V,
+__global__ void __launch_bounds__(256, (KT<K>::W == 2 ? 5 : 8)) k_lookup_cand(ReadsDev R, BloomDev B, const uint16_t* rv16g, DictDev D, ResolveDev V,
                                                     uint64_t w0, uint64_t w1, uint64_t first_global,
                                                     uint32_t* ulist, uint32_t* ucount, unsigned long long* trace,
                                                     uint64_t* xres, uint64_t xbase, uint32_t dry) {
