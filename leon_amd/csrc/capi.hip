@@ -1398,6 +1398,13 @@ int leon_dna_reserve(leon_dna_ctx* c, uint64_t max_reads, uint64_t max_bases) {
         HIPCHK(c, hipHostMalloc(&c->h_payload, want, hipHostMallocDefault));
         c->h_payload_cap = want;
     }
+    // the walk's path cache (sized as encode_batch sizes it: a bucket per ~8 solid k-mers, at most 2^27; best effort)
+    if (c->B.n_hash == 7 && c->shard_world <= 2) {
+        uint64_t want = c->cfg.bloom_tai / 12 / 8, buckets = 1024;
+        while (buckets < want && buckets < (1ull << 27)) buckets <<= 1;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && buckets * 64 <= free_b / 8 && c->wcache.ensure(buckets * 64) != hipSuccess) (void)hipGetLastError();
+    }
     // the dictionary: one anchor per ~6 reads of a 30x read set; it grows (rehash) if the data want more
     if (int rc = dict_reserve(c, c->n_keys + n / 6 + 1024)) return rc;
     if ((n / 6) * 8 * kmer_words(c->cfg.kmer_size) > c->anchor_kmers.cap && c->n_anchors == 0) HIPCHK(c, c->anchor_kmers.ensure((n / 6) * 8 * kmer_words(c->cfg.kmer_size)));
