@@ -1245,7 +1245,8 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, c->rc_scratch.ensure(rc_model_scratch_bytes(nbl)));
     HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
     launch_rc_encode(s, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, c->rc_out.as<uint8_t>(),
-                     c->out_off.as<uint64_t>(), c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>(), max_block_syms);
+                     c->out_off.as<uint64_t>(), c->out_size.as<uint64_t>(), c->rc_scratch.as<uint32_t>(), c->errflag.as<int>(), max_block_syms,
+                     SMALL_SIZES_DNA, true);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[7], s));
 
@@ -1254,6 +1255,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipMemcpyAsync(sizes.data(), c->out_size.p, nbl * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(&errflag, c->errflag.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (errflag == 3) return fail(c, LEON_E_STATE, "a numeric value's byte count above 8 in the symbol stream (internal error)");
     if (errflag) return fail(c, LEON_E_OVERFLOW, errflag == 2 ? "a read block has 2^32 symbols or more"
                                                               : "range coder output exceeded its 3 bytes/symbol bound");
     for (uint64_t b = 0; b < nbl; b++) dst[b + 1] = dst[b] + sizes[b];

@@ -147,7 +147,9 @@ void launch_max_block_syms(hipStream_t s, const uint64_t* sym_off /*offsets, n_r
 // max_block_syms: the longest block's symbol count (an upper bound will do): picks the instantiation that can divide exactly
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                       uint8_t* out, const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err,
-                      uint64_t max_block_syms, uint32_t small_sizes = SMALL_SIZES_DNA);
+                      uint64_t max_block_syms, uint32_t small_sizes = SMALL_SIZES_DNA, bool counts_apart = false);
+// counts_apart: the caller vouches that every numeric group's first model (CompressionUtils::encodeNumeric's byte count) only sees symbols
+// 0..8 -- true of k_symbols' stream -- so those models can live apart from the 256-symbol slots; a symbol above 8 there sets *err = 3
 // the modelers alone, tiles [tile0, tile1) of every block: a 64-bit record per symbol (cumLow | freq << 22 | model << 44) at
 // recs + rec_off[block] (the launch's tiles of the block, in stream order); `state` carries a block's models from one launch to the next
 size_t rc_records_state_bytes(uint64_t n_blocks);

@@ -21,7 +21,11 @@ size_t rc_model_scratch_bytes(uint64_t n_blocks) {
 // Waves of a workgroup land on the CU's four SIMDs round-robin.  Wave 0 is the coder; the waves whose index is a multiple
 // of 4 would share its SIMD and stay idle (they only keep the barriers), so the chain never waits for a modeler's
 // vector instruction; the other waves are the modelers.
+// One more wave behind them, never on the coder's SIMD (11, 6, 3, 2 for groups of 8, 4, 2, 1): the emitter.
 __host__ __device__ constexpr uint32_t rc_waves(uint32_t g) { return g + 1 + (g - 1) / 3; }
+static_assert((rc_waves(8) & 3u) != 0 && (rc_waves(4) & 3u) != 0 && (rc_waves(2) & 3u) != 0 && (rc_waves(1) & 3u) != 0, "the emitter would share the coder's SIMD");
+// a step's word for the emitter: the three top bytes of `low` | how many of them leave (0..3); or RC_EMIT_SKIP | bytes the coder wrote itself << 8
+constexpr uint32_t RC_EMIT_BYTES = 0xFFFFFF00u, RC_EMIT_SKIP = 0x80u;
 
 // The earlier symbols of a tile, lane = symbol: lo += #(same model, smaller symbol), hi += #(same model, symbol <= mine),
 // tot += #(same model) over the lanes before this one -- 64 steps of a broadcast and three compare/add-with-carry pairs; the lane
@@ -69,17 +73,22 @@ __device__ inline void rc_rank_loop(uint32_t key, uint32_t c, uint32_t& lo, uint
 // symbol's (cumLow, cumLow + freq, total) = the counts at the tile start + the earlier symbols of the tile, then
 // Order0Model::update for the whole tile.  Used by the block coder below (records into an LDS ring for the coder wave) and by
 // k_rc_records (records into global memory for host chains).
-template <uint32_t RC_NSLOT>
+// CMP: a numeric group's byte-COUNT model (encodeNumeric's first symbol: 0..8 of its 256) keeps to the small layout in a place of its own
+// -- Lw[x] = F(x) for x <= 16, total = F(16) + 240 -- so the slots, 280 words each, serve the byte models only: the nine or ten of them a
+// read set uses all the time then fit the 12 a workgroup of 8 blocks has room for, and nothing hot is left to the global overflow area.
+template <uint32_t RC_NSLOT, bool CMP>
 struct RcModeler {
-    uint32_t* models; uint8_t* slotmap; uint32_t* gmodels; const uint16_t* sym16;
+    static constexpr uint32_t SLOT_BASE = RC_SMALL_WORDS + (CMP ? RC_CMP_WORDS : 0);
+    static constexpr uint32_t WORDS = SLOT_BASE + RC_NSLOT * RC_STRIDE;
+    uint32_t* models; uint8_t* slotmap; uint32_t* gmodels; const uint16_t* sym16; int* err;
     uint64_t s0, s1;
     uint32_t nused, raw_next, small_sizes;
     // per-lane constants of the branch-free Order0Model::update of the overflow area: lanes 0..15 own Lw of the symbol's 16-block,
     // lanes 16..32 own H[0..16]
     bool is_lw; uint32_t upd_lane, upd_base, upd_blkmask;
 
-    __device__ inline void init(uint32_t* models_, uint8_t* slotmap_, const uint16_t* sym16_, uint32_t small_sizes_, uint32_t lane) {
-        models = models_; slotmap = slotmap_; sym16 = sym16_; small_sizes = small_sizes_;
+    __device__ inline void init(uint32_t* models_, uint8_t* slotmap_, const uint16_t* sym16_, uint32_t small_sizes_, uint32_t lane, int* err_) {
+        models = models_; slotmap = slotmap_; sym16 = sym16_; small_sizes = small_sizes_; err = err_;
         is_lw = lane < 16;
         upd_lane = is_lw ? lane : (lane < 33 ? lane - 16 : 0);
         upd_base = is_lw ? RC_LW + lane : upd_lane;
@@ -91,7 +100,7 @@ struct RcModeler {
     __device__ inline void start_block(uint64_t s0_, uint64_t s1_, uint32_t* gmodels_, uint32_t lane) {
         s0 = s0_; s1 = s1_; gmodels = gmodels_; nused = 0;
         raw_next = lane < (uint32_t)((s1 - s0) < 64 ? (s1 - s0) : 64) ? sym16[s0 + lane] : 0xFFFFu;
-        for (uint32_t m = 0; m < N_SMALL_MODELS; m++) model_init(&models[m * RC_SSTRIDE], lane, true);
+        for (uint32_t m = 0; m < N_SMALL_MODELS + (CMP ? N_NUM_GROUPS : 0); m++) model_init(&models[m * RC_SSTRIDE], lane, true);
         for (uint32_t i = lane; i < RC_NNUM; i += 64) slotmap[i] = 255;
     }
     // tile t of the block: this lane's record (lanes past the block's end: cumLow 0, freq = total = 1, which leaves a chain as it is)
@@ -104,9 +113,16 @@ struct RcModeler {
             const uint64_t nb = base + 64;
             raw_next = (nb < s1 && lane < (uint32_t)((s1 - nb) < 64 ? (s1 - nb) : 64)) ? sym16[nb + lane] : 0xFFFFu;
         }
-        const uint32_t m = raw & 0xff, c = raw >> 8;
+        const uint32_t m = raw & 0xff;
+        const uint32_t grp = ((m - N_SMALL_MODELS) * 57u) >> 9;       // (m - 8) / 9 for the 72 numeric ids
+        const bool cmodel = CMP && act && m >= N_SMALL_MODELS && (m - N_SMALL_MODELS) == grp * MODELS_PER_NUMERIC;
+        uint32_t c = raw >> 8;
+        if (CMP && __builtin_expect(__ballot(cmodel && c > 8u) != 0, 0)) {     // not from k_symbols (a value has at most 8 bytes): the launch fails, nothing is written out of place
+            if (lane == 0) atomicExch(err, 3);
+            if (cmodel && c > 8u) c = 8u;
+        }
         const uint32_t key = (m << 8) | c;
-        const bool numeric = act && m >= N_SMALL_MODELS;
+        const bool numeric = act && m >= N_SMALL_MODELS && !cmodel;
         // slots for numeric models first seen in this tile
         uint32_t slot = numeric ? slotmap[m - N_SMALL_MODELS] : 0;
         unsigned long long need = __ballot(numeric && slot == 255);
@@ -115,23 +131,24 @@ struct RcModeler {
             const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)l);
             const uint32_t ns = nused++;
             if (lane == 0) slotmap[mm - N_SMALL_MODELS] = (uint8_t)ns;
-            if (ns < RC_NSLOT) model_init(&models[RC_SMALL_WORDS + ns * RC_STRIDE], lane, false);
+            if (ns < RC_NSLOT) model_init(&models[SLOT_BASE + ns * RC_STRIDE], lane, false);
             else { model_init(gmodels + (uint64_t)(ns - RC_NSLOT) * RC_STRIDE, lane, false); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             if (numeric && m == mm) slot = ns;
             need &= ~__ballot(numeric && m == mm);
         }
         // word offset of this lane's model (RC_GLOBAL | offset for the overflow area)
         uint32_t mb = 0;
-        if (act) mb = !numeric ? m * RC_SSTRIDE
-                               : (slot < RC_NSLOT ? RC_SMALL_WORDS + slot * RC_STRIDE : (RC_GLOBAL | ((slot - RC_NSLOT) * RC_STRIDE)));
-        const uint32_t tot_idx = numeric ? 16u : RC_LW + small_size_of(small_sizes, m);
+        if (act) mb = cmodel ? RC_SMALL_WORDS + grp * RC_SSTRIDE
+                    : !numeric ? m * RC_SSTRIDE
+                               : (slot < RC_NSLOT ? SLOT_BASE + slot * RC_STRIDE : (RC_GLOBAL | ((slot - RC_NSLOT) * RC_STRIDE)));
+        const uint32_t tot_idx = numeric ? 16u : RC_LW + (cmodel ? 16u : small_size_of(small_sizes, m));
         __builtin_amdgcn_wave_barrier();
         // counts at the tile start
         lo = 0; hi = 1; tot = 1;
         if (act) {
             if (!(mb & RC_GLOBAL)) {
                 const uint32_t* s = &models[mb];
-                lo = s[c >> 4] + s[RC_LW + c]; hi = s[(c + 1) >> 4] + s[RC_LW + c + 1]; tot = s[tot_idx];
+                lo = s[c >> 4] + s[RC_LW + c]; hi = s[(c + 1) >> 4] + s[RC_LW + c + 1]; tot = s[tot_idx] + (cmodel ? 240u : 0u);
             } else {
                 const uint32_t* s = gmodels + (mb & ~RC_GLOBAL);
                 lo = s[c >> 4] + s[RC_LW + c]; hi = s[(c + 1) >> 4] + s[RC_LW + c + 1]; tot = s[tot_idx];
@@ -156,13 +173,13 @@ struct RcModeler {
             const bool in_lds = act && !(mb & RC_GLOBAL);
             uint32_t* mp = &models[in_lds ? mb : 0];
             const uint32_t h4 = (in_lds && numeric) ? c >> 4 : 64u;
-            const uint32_t l4 = in_lds ? c & 15u : 64u, ymax = numeric ? 15u : small_size_of(small_sizes, m);
+            const uint32_t l4 = in_lds ? c & 15u : 64u, ymax = numeric ? 15u : (cmodel ? 16u : small_size_of(small_sizes, m));
             uint32_t* lp = mp + RC_LW + (in_lds ? (c & ~15u) : 0u);
 #pragma unroll
             for (uint32_t k = 1; k <= 16; k++)
                 if (k > h4) (void)__hip_atomic_fetch_add(&mp[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #pragma unroll
-            for (uint32_t y = 1; y <= 15; y++)
+            for (uint32_t y = 1; y <= (CMP ? 16u : 15u); y++)
                 if (y > l4 && y <= ymax) (void)__hip_atomic_fetch_add(&lp[y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             // symbols of models that live in the global overflow area: one at a time, lanes 0..32 own the entries
             unsigned long long gl = __ballot(act && (mb & RC_GLOBAL));
@@ -184,8 +201,11 @@ struct RcModeler {
 
 // The coder's 64 steps of one tile, lane = block: RangeEncoder::encode for every record of the tile.  EXACT: the quotient by a
 // 64-bit division (totals of 2^30 and more); else a truncated multiply-high by the total's reciprocal with a 32-bit fix-up.
-template <bool EXACT>
-__device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint64_t& low, uint64_t& range, uint32_t& nout, uint8_t* dst, uint32_t cap4) {
+// The bytes a step sends out do not go to memory from here: the step leaves ONE word in LDS -- the three top bytes of `low` and how many of
+// them leave (RC_EMIT_*) -- and the group's emitter wave (rc_emit_tile, on another SIMD, a tile behind) turns a tile's 64 words into byte
+// stores, lane = step.  That takes the cursor's clamp, the address, the byte swap and the store off the chain's instruction stream.
+template <bool EXACT, bool EMIT>
+__device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint32_t* re, uint64_t& low, uint64_t& range, uint32_t& nout, uint8_t* dst, uint32_t cap) {
     uint4 pa = ra[0];
     uint2 pb = rb[0];
 #pragma clang loop unroll_count(EXACT ? 1 : 4)
@@ -193,51 +213,91 @@ __device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint64_t&
         const uint32_t s_lo = pa.x, s_fr = pa.y, s_tot = pa.z, s_hc = pa.w, b0 = pb.x, b1 = pb.y;
         const uint32_t jn = j + 1;                                 // next step's record, fetched under this step
         pa = ra[jn]; pb = rb[jn];
-        uint64_t q;
-        if (EXACT) q = range / (uint64_t)s_tot;
-        else {
-            // q = floor(range / tot): truncated multiply-high by the reciprocal (at most 3 short, since total < 2^30), fixed up on the low word
+        // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq), q = floor(range / total)
+        // (a third product and not `low + range`: the add waits for both products; profiles/r4_minimizer_filter.txt)
+        uint64_t top;
+        if (EXACT) {
+            const uint64_t q = range / (uint64_t)s_tot;
+            const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
+            top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
+            low = (uint64_t)q0 * s_lo + low;   low += (uint64_t)(q1 * s_lo) << 32;
+            range = (uint64_t)q0 * s_fr;       range += (uint64_t)(q1 * s_fr) << 32;
+        } else {
+            // The step is as long as its DEPENDENT path (a lone wave issues in order; round 5: leaving instructions out of the step changed
+            // nothing, the emitter wave's four and the modelers' updates alike).  The quotient is a truncated multiply-high by the total's
+            // reciprocal, at most 3 short (total < 2^30); the three products start from that estimate while the remainder is compared, and
+            // the 0..3 it was short by goes into each with one multiply-add -- two levels fewer than fixing the quotient first.
             const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
-            q = (uint64_t)r1 * b1 + __umulhi(r1, b0);
-            q += __umulhi(r0, b1);
-            const uint32_t rem = r0 - (uint32_t)q * s_tot;          // true remainder < 4 * tot < 2^32
+            uint64_t qe = (uint64_t)r1 * b1 + __umulhi(r1, b0);
+            qe += __umulhi(r0, b1);
+            const uint32_t q0 = (uint32_t)qe, q1 = (uint32_t)(qe >> 32);
+            uint64_t T0 = (uint64_t)q0 * s_hc + low;   T0 += (uint64_t)(q1 * s_hc) << 32;
+            uint64_t L0 = (uint64_t)q0 * s_lo + low;   L0 += (uint64_t)(q1 * s_lo) << 32;
+            uint64_t R0 = (uint64_t)q0 * s_fr;         R0 += (uint64_t)(q1 * s_fr) << 32;
+            asm volatile("" : "+v"(T0), "+v"(L0), "+v"(R0));        // (as written: the compiler would fold the fix-up back into the quotient)
+            const uint32_t rem = r0 - q0 * s_tot;                   // true remainder < 4 * tot < 2^32
             const uint32_t t2 = s_tot << 1, t3 = t2 + s_tot;
             uint32_t e = (rem >= s_tot ? 1u : 0u) + (rem >= t2 ? 1u : 0u) + (rem >= t3 ? 1u : 0u);
-            asm volatile("" : "+v"(e));                             // (one 64-bit add, not three)
-            q += e;
+            asm volatile("" : "+v"(e));
+            top = (uint64_t)e * s_hc + T0;
+            low = (uint64_t)e * s_lo + L0;
+            range = (uint64_t)e * s_fr + R0;
         }
-        const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
-        // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq)
-        // (a third product and not `low + range`: the add waits for both products, and the step is bound by its dependent path as
-        // much as by its issue slots -- 128 ms per launch at 100 M reads this way, 133 with the add; profiles/r4_minimizer_filter.txt)
-        uint64_t top = (uint64_t)q0 * s_hc + low;   top += (uint64_t)(q1 * s_hc) << 32;
-        low = (uint64_t)q0 * s_lo + low;            low += (uint64_t)(q1 * s_lo) << 32;
-        range = (uint64_t)q0 * s_fr;                range += (uint64_t)(q1 * s_fr) << 32;
-        // RangeEncoder::encode's while loop.  Usual case: low and low + range agree on their top 0..2
+        // RangeEncoder::encode's while loop.  Usual case: low and low + range agree on their top 0..3
         // bytes and the shifted range stays >= BOTTOM: those bytes leave at once -- one unaligned 4-byte
         // store at the cursor (what lies past the cursor is overwritten by the stores that follow)
         const uint32_t lh = (uint32_t)(low >> 32);
-        const uint32_t xh = lh ^ (uint32_t)(top >> 32);
-        const uint32_t sh = (uint32_t)__builtin_clz(xh | 1u) & 24u;
+        uint32_t xh = lh ^ (uint32_t)(top >> 32);
+        uint32_t lead;                                              // v_ffbh_u32 answers -1 for 0: & 24 = 24 either way, without the `| 1` a level before it
+        asm("v_ffbh_u32 %0, %1" : "=v"(lead), "+v"(xh));            // (xh in and out: the compiler would widen `xh == 0` below to a 64-bit compare of low ^ top)
+        const uint32_t sh = lead & 24u;
         const uint64_t range_s = range << sh;
-        const bool rare = xh < 256u || (uint32_t)(range_s >> 32) < (1u << 16);
-        *(uint32_t*)(dst + (nout < cap4 ? nout : cap4)) = __builtin_bswap32(lh);
+        // rare: four bytes or more leave, or the shifted range is below BOTTOM (one compare: the branch waits for it)
+        uint32_t rare_below = xh == 0u ? 0xFFFFFFFFu : 0xFFFFu;
+        asm volatile("" : "+v"(rare_below));
+        const bool rare = (uint32_t)(range_s >> 32) <= rare_below;
+        const uint32_t nb = sh >> 3;
+        if (EMIT) re[j] = (lh & RC_EMIT_BYTES) | nb;
+        else {                                                      // (measurement: the round-4 form -- one unaligned 4-byte store at the cursor)
+            const uint32_t cap4 = cap - 4;
+            *(uint32_t*)(dst + (nout < cap4 ? nout : cap4)) = __builtin_bswap32(lh);
+        }
         uint64_t low_n = low << sh, range_n = range_s;
-        uint32_t nout_n = nout + (sh >> 3);
+        uint32_t nout_n = nout + nb;
         // (the step is paid in instructions, ~5 cycles each for a wave alone on its SIMD -- profiles/r4_issue_costs.txt --: the rare case
         // is ONE scalar branch on "any lane", not an exec mask saved and restored around the lanes' own test)
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0) && rare) {
+            // RangeEncoder::encode's loop as it is written; its bytes go out from here, and the emitter only moves its cursor past them
             low_n = low; range_n = range; nout_n = nout;
             while ((low_n ^ (low_n + range_n)) < (1ull << 56) ||
                    (range_n < RC_BOTTOM && ((range_n = (0 - low_n) & (RC_BOTTOM - 1)), true))) {
-                dst[nout_n < cap4 ? nout_n : cap4] = (uint8_t)(low_n >> 56);
+                if (nout_n < cap) dst[nout_n] = (uint8_t)(low_n >> 56);
                 nout_n++;
                 range_n <<= 8;
                 low_n <<= 8;
             }
+            if (EMIT) re[j] = RC_EMIT_SKIP | ((nout_n - nout) << 8);
         }
         low = low_n; range = range_n; nout = nout_n;
     }
+}
+
+// The emitter's share of one tile of one block, lane = step: where each step's bytes go is a prefix sum of the tile's byte counts.
+__device__ inline void rc_emit_tile(const uint32_t* re, uint32_t lane, uint8_t* dst, uint32_t cap, uint32_t& cursor) {
+    const uint32_t w = re[lane];
+    const bool skip = (w & RC_EMIT_SKIP) != 0;
+    const uint32_t nb = skip ? 0u : (w & 3u), adv = skip ? (w >> 8) : nb;
+    uint32_t incl = adv;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    const uint32_t at = cursor + incl - adv;
+    if (nb > 0 && at < cap) dst[at] = (uint8_t)(w >> 24);
+    if (nb > 1 && at + 1 < cap) dst[at + 1] = (uint8_t)(w >> 16);
+    if (nb > 2 && at + 2 < cap) dst[at + 2] = (uint8_t)(w >> 8);
+    cursor += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 
 // One workgroup codes G blocks: G modeler waves, and one coder wave that runs the G serial chains
@@ -246,35 +306,37 @@ __device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint64_t&
 // usual cases (0..2 bytes leave, no range < BOTTOM reset) and falls back to RangeEncoder::encode's loop per lane otherwise.
 // BIGOK: some block of the launch is long enough for a model's total to reach 2^30 (the host knows the blocks' symbol counts):
 // that instantiation also carries the exact-division steps, tile by tile; the other one is the plain fast chain.
-template <uint32_t G, uint32_t RC_NSLOT, bool BIGOK>
-__global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
+template <uint32_t G, uint32_t RC_NSLOT, bool BIGOK, bool EMIT, bool CMP>
+__global__ void __launch_bounds__(64 * (rc_waves(G) + (EMIT ? 1 : 0))) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                                                             uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
                                                             uint32_t* scratch, int* err, uint32_t small_sizes, uint32_t fast_total) {
-    constexpr uint32_t MW = RC_SMALL_WORDS + RC_NSLOT * RC_STRIDE;
+    constexpr uint32_t MW = RcModeler<RC_NSLOT, CMP>::WORDS;
     __shared__ uint32_t models_all[G * MW];
     // a step's record: {cumLow, freq, total, cumLow + freq} and the total's 64-bit reciprocal -- two LDS reads for the coder (its
     // step is paid in issue slots); one spare entry per row: the coder prefetches record j + 1
     __shared__ uint4 ring_a[G][2][RC_RING];
     __shared__ uint2 ring_b[G][2][RC_RING];
+    __shared__ uint32_t ring_e[EMIT ? G : 1][2][64];                      // the coder's words for the emitter (rc_coder_tile)
     __shared__ uint8_t slotmap_all[G][RC_NNUM];
     __shared__ uint32_t ntiles_s[G];
     __shared__ uint32_t tile_big[BIGOK ? G : 1][2];              // a total of fast_total or more in the tile: the coder divides exactly
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const bool is_coder = wave == 0, is_idle = wave != 0 && (wave & 3u) == 0;
+    const bool is_coder = wave == 0, is_emitter = EMIT && wave == rc_waves(G), is_idle = (wave != 0 && (wave & 3u) == 0) || is_emitter;
     const uint32_t mi = is_coder || is_idle ? 0 : wave - 1 - (wave >> 2);     // the modeler's block inside the group
-    RcModeler<RC_NSLOT> M;
-    M.init(models_all + mi * MW, slotmap_all[mi], (const uint16_t*)syms, small_sizes, lane);
+    RcModeler<RC_NSLOT, CMP> M;
+    M.init(models_all + mi * MW, slotmap_all[mi], (const uint16_t*)syms, small_sizes, lane, err);
 
     const uint64_t n_groups = (n_blocks + G - 1) / G;
     for (uint64_t bg = blockIdx.x; bg < n_groups; bg += gridDim.x) {
-        // this thread's block: the wave's for a modeler, the lane's for the coder
-        const uint64_t b = bg * G + (is_coder ? lane : mi);
-        bool valid = (is_coder ? lane < G : !is_idle) && b < n_blocks;
+        // this thread's block: the wave's for a modeler, the lane's for the coder and the emitter
+        const bool by_lane = is_coder || is_emitter;
+        const uint64_t b = bg * G + (by_lane ? lane : mi);
+        bool valid = (by_lane ? lane < G : !is_idle) && b < n_blocks;
         uint64_t s0 = 0, s1 = 0;
         if (valid) { s0 = blk_begin[b]; s1 = blk_begin[b + 1]; }
         if (valid && s1 - s0 >= 0xFFFFFF00ull) {                 // the models' counts are 32-bit words (upstream's are 64-bit [RECALLED]: it would go on)
-            if (is_coder || lane == 0) atomicExch(err, 2);
+            if (is_coder || (lane == 0 && !is_emitter)) atomicExch(err, 2);
             if (is_coder) out_size[b] = 0;
             valid = false;
         }
@@ -284,20 +346,34 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
         uint64_t low = 0, range = ~0ull;
         uint32_t nout = 0;
         uint8_t* dst = nullptr;
-        uint64_t cap = 0;
-        uint32_t cap4 = 0;                                       // last cursor a 4-byte store may start at; stores clamp to it
-        if (is_coder && valid) {                                 // and the block reports overflow at its end (the cursor only grows)
-            dst = out + out_off[b]; cap = out_off[b + 1] - out_off[b];
-            cap4 = (uint32_t)(cap < 0xFFFFFFFFull ? cap : 0xFFFFFFFFull) - 4;
+        uint32_t cap = 0;                                        // stores stop at the block's room; the block reports overflow at its end (the cursor only grows)
+        if (by_lane && valid) {
+            dst = out + out_off[b];
+            const uint64_t room = out_off[b + 1] - out_off[b];
+            cap = (uint32_t)(room < 0xFFFFFFFFull ? room : 0xFFFFFFFFull);
         }
+        uint32_t cursor[G];                                      // emitter: bytes out so far, per block of the group (wave-uniform)
+#pragma unroll
+        for (uint32_t w = 0; w < G; w++) cursor[w] = 0;
         if (!is_coder && !is_idle && valid)                        // AbstractDnaCoder::startBlock
             M.start_block(s0, s1, scratch + b * (uint64_t)(RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE, lane);
         __syncthreads();
         uint32_t T = 0;
         for (uint32_t w = 0; w < G; w++) T = ntiles_s[w] > T ? ntiles_s[w] : T;
 
-        for (uint32_t t = 0; t <= T; t++) {
-            if (is_idle) {
+        for (uint32_t t = 0; t <= T + (EMIT ? 1 : 0); t++) {
+            if (is_emitter) {
+                // =================== emitter: tile t-2 of every block of the group, lane = step ===================
+                if (t >= 2) {
+#pragma unroll
+                    for (uint32_t w = 0; w < G; w++) {
+                        uint8_t* const d = (uint8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)dst >> 32), (int)w) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)dst, (int)w));
+                        const uint32_t cp = (uint32_t)__builtin_amdgcn_readlane((int)cap, (int)w);
+                        if (d) rc_emit_tile(&ring_e[w][t & 1][0], lane, d, cp, cursor[w]);
+                    }
+                }
+            } else if (is_idle) {
             } else if (!is_coder) {
                 if (t < ntiles) {
                     // =================== modeler: tile t -> ring[mi][t & 1] ===================
@@ -316,24 +392,25 @@ __global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* s
                     ring_b[mi][t & 1][lane] = make_uint2(~0u, ~0u);
                     if (BIGOK && lane == 0) tile_big[mi][t & 1] = 0u;
                 }
-            } else if (t > 0) {
+            } else if (t > 0 && t <= T) {
                 // =================== coder: tile t-1 of every block of the group, lane = block ===================
                 // (symbols past a block's end are "leave as it is" records, so the 64 steps are uniform)
                 if (valid) {
                     const uint4* ra = &ring_a[lane][(t - 1) & 1][0];
                     const uint2* rb = &ring_b[lane][(t - 1) & 1][0];
+                    uint32_t* re = &ring_e[EMIT ? lane : 0][(t - 1) & 1][0];
                     // (a tile in which some block's total has reached fast_total takes the same steps with the exact division)
                     bool any_big = false;
                     if (BIGOK) any_big = __ballot(tile_big[lane < G ? lane : 0][(t - 1) & 1] != 0 && lane < G) != 0;
-                    if (!BIGOK || __builtin_expect(!any_big, 1)) rc_coder_tile<false>(ra, rb, low, range, nout, dst, cap4);
-                    else rc_coder_tile<true>(ra, rb, low, range, nout, dst, cap4);
+                    if (!BIGOK || __builtin_expect(!any_big, 1)) rc_coder_tile<false, EMIT>(ra, rb, re, low, range, nout, dst, cap);
+                    else rc_coder_tile<true, EMIT>(ra, rb, re, low, range, nout, dst, cap);
                 }
             }
             __syncthreads();
         }
         if (is_coder && valid) {
             for (int i = 0; i < 8; i++) {                               // RangeEncoder::flush
-                dst[nout < cap4 ? nout : cap4] = (uint8_t)(low >> 56);
+                if (nout < cap) dst[nout] = (uint8_t)(low >> 56);
                 nout++;
                 low <<= 8;
             }
@@ -361,8 +438,8 @@ __global__ void __launch_bounds__(64) k_rc_records(const uint8_t* syms, const ui
     __shared__ uint32_t slotmap_w[RC_NNUM / 4];
     uint8_t* slotmap = (uint8_t*)slotmap_w;
     const uint32_t lane = threadIdx.x;
-    RcModeler<RC_NSLOT_BIG> M;
-    M.init(models, slotmap, (const uint16_t*)syms, small_sizes, lane);
+    RcModeler<RC_NSLOT_BIG, false> M;
+    M.init(models, slotmap, (const uint16_t*)syms, small_sizes, lane, err);
     for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         const uint64_t s0 = blk_begin[b], s1 = blk_begin[b + 1];
         if (s1 - s0 >= (1ull << 22) - 512) { if (lane == 0) atomicExch(err, 2); continue; }     // (the host checks before it launches: 22-bit counts)
@@ -534,11 +611,11 @@ void launch_rc_records(hipStream_t s, const uint8_t* syms, const uint64_t* blk_b
 }
 
 void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks, uint8_t* out,
-                      const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err, uint64_t max_block_syms, uint32_t small_sizes) {
+                      const uint64_t* out_off, uint64_t* out_size, uint32_t* model_scratch, int* err, uint64_t max_block_syms, uint32_t small_sizes, bool counts_apart) {
     if (!n_blocks) return;
     // blocks per workgroup: as few as keeps every block resident on the 256 CUs (LDS: 8 blocks of 19.6 KB per CU)
     const uint64_t per_cu = (n_blocks + 255) / 256;
-    static const char* force = getenv("LEON_RC_GROUP");       // measurement override: blocks per workgroup
+    const char* force = getenv("LEON_RC_GROUP");              // measurement / test override: blocks per workgroup
     uint32_t G = per_cu <= 1 ? 1u : per_cu <= 2 ? 2u : per_cu <= 4 ? 4u : 8u;
     if (force) { int v = atoi(force); if (v == 1 || v == 2 || v == 4 || v == 8) G = (uint32_t)v; }
     const uint64_t n_groups = (n_blocks + G - 1) / G;
@@ -547,12 +624,28 @@ void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_be
     uint32_t fast_total = RC_MAX_TOTAL;
     if (const char* e = getenv("LEON_RC_FAST_TOTAL_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 30) fast_total = 1u << v; }
     const bool big = max_block_syms + 512 >= fast_total;      // (a model's total is at most its block's symbol count + 256)
-#define RC_LAUNCH(GG, N, B) hipLaunchKernelGGL((k_rc_encode<GG, N, B>), dim3(g), dim3(64 * rc_waves(GG)), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err, small_sizes, fast_total)
-#define RC_PICK(GG, N) do { if (big) RC_LAUNCH(GG, N, true); else RC_LAUNCH(GG, N, false); } while (0)
-    if (G == 1) RC_PICK(1, RC_NSLOT_BIG);
-    else if (G == 2) RC_PICK(2, RC_NSLOT_BIG);
-    else if (G == 4) RC_PICK(4, RC_NSLOT_BIG);
-    else RC_PICK(8, RC_NSLOT_SMALL);
+    // counts_apart (the read blocks' symbols, made by k_symbols: a numeric group's first model only ever sees 0..8): emitter wave + byte-count models
+    // apart (round 5); every other caller's streams -- the header stream's 14 byte models, leon_rc_encode_streams' arbitrary symbols -- as before.
+    // LEON_RC_EMIT=0 / LEON_RC_CMP=0: measurement, one at a time at 8 blocks per workgroup
+    const bool env_emit = [] { const char* e = getenv("LEON_RC_EMIT"); return !e || atoi(e) != 0; }();
+    const bool env_cmp = [] { const char* e = getenv("LEON_RC_CMP"); return !e || atoi(e) != 0; }();
+    const bool emit = counts_apart && env_emit, cmp = counts_apart && env_cmp;
+#define RC_LAUNCH(GG, N, B, E, C) hipLaunchKernelGGL((k_rc_encode<GG, N, B, E, C>), dim3(g), dim3(64 * (rc_waves(GG) + (E ? 1 : 0))), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err, small_sizes, fast_total)
+#define RC_PICK(GG, N, E, C) do { if (big) RC_LAUNCH(GG, N, true, E, C); else RC_LAUNCH(GG, N, false, E, C); } while (0)
+    if (G == 8) {                                             // (slots: what 160 KB of LDS leave room for)
+        if (emit && cmp) RC_PICK(8, 12, true, true);
+        else if (cmp) RC_PICK(8, 13, false, true);
+        else if (emit) RC_PICK(8, 13, true, false);
+        else RC_PICK(8, 14, false, false);
+    } else if (emit || cmp) {
+        if (G == 1) RC_PICK(1, RC_NSLOT_BIG, true, true);
+        else if (G == 2) RC_PICK(2, RC_NSLOT_BIG, true, true);
+        else RC_PICK(4, RC_NSLOT_BIG, true, true);
+    } else {
+        if (G == 1) RC_PICK(1, RC_NSLOT_BIG, false, false);
+        else if (G == 2) RC_PICK(2, RC_NSLOT_BIG, false, false);
+        else RC_PICK(4, RC_NSLOT_BIG, false, false);
+    }
 #undef RC_PICK
 #undef RC_LAUNCH
 }
