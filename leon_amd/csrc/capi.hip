@@ -775,9 +775,9 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     // input bounds (reads in genome-position order make one chain of a whole window).  After kRoundsAhead rounds -- more while the
     // list keeps halving, kRoundsMax at most -- what is left goes, in read order, through the exact sequential pass (chain_tail below).
     // LEON_RESOLVE_ROUNDS=a[:m]: rounds launched ahead / at most (measurement aid; any values give the same bytes).
-    static const uint32_t kRoundsAhead = [] { const char* e = getenv("LEON_RESOLVE_ROUNDS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (uint32_t)v : 3u; }();
-    static const uint32_t kRoundsMax = [] { const char* e = getenv("LEON_RESOLVE_ROUNDS"); const char* q = e ? strchr(e, ':') : nullptr; const int v = q ? atoi(q + 1) : 0;
-                                            return std::max<uint32_t>(kRoundsAhead, v >= 1 && v <= 62 ? (uint32_t)v : 9u); }();
+    const uint32_t kRoundsAhead = [] { const char* e = getenv("LEON_RESOLVE_ROUNDS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (uint32_t)v : 3u; }();
+    const uint32_t kRoundsMax = [&] { const char* e = getenv("LEON_RESOLVE_ROUNDS"); const char* q = e ? strchr(e, ':') : nullptr; const int v = q ? atoi(q + 1) : 0;
+                                      return std::max<uint32_t>(kRoundsAhead, v >= 1 && v <= 62 ? (uint32_t)v : 9u); }();
     constexpr uint32_t kRoundsMore = 2, kHist = 64;
     HIPCHK(c, c->round_hist.ensure(kHist * 4));
     uint32_t* d_hist = c->round_hist.as<uint32_t>();
@@ -821,8 +821,9 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
         HIPCHK(c, prim::ExclusiveSum(c->cub_tmp.p, scan_tmp, V.ins_flag, rank, w1 - w0, s));
         launch_chain_compact(s, V, w0, w1, rank, clist);
         // (LEON_CHAIN_CHUNK: reads per k_chain_seq, at most the 2^CHAIN_LOG2 its LDS holds a bit for -- a test hook: the path a window of more than
-        // half a million unsettled reads takes, chunk after chunk with tent re-proposed in between, on inputs the oracle codes in seconds)
-        static const uint32_t CH = [] { const char* e = getenv("LEON_CHAIN_CHUNK"); const long v = e ? atol(e) : 0; return v >= 1 && v <= (1l << CHAIN_LOG2) ? (uint32_t)v : 1u << CHAIN_LOG2; }();
+        // half a million unsettled reads takes, chunk after chunk with tent re-proposed in between, on inputs the oracle codes in seconds;
+        // read at every call: the tests change it inside one process)
+        const uint32_t CH = [] { const char* e = getenv("LEON_CHAIN_CHUNK"); const long v = e ? atol(e) : 0; return v >= 1 && v <= (1l << CHAIN_LOG2) ? (uint32_t)v : 1u << CHAIN_LOG2; }();
         unsigned long long* d_ctrace = nullptr;
         if (trace_chain) { HIPCHK(c, c->chain_trace.ensure(8 * 8)); d_ctrace = c->chain_trace.as<unsigned long long>(); HIPCHK(c, hipMemsetAsync(d_ctrace, 0, 8 * 8, s)); }
         for (uint32_t c0 = 0; c0 < left; c0 += CH) {

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import common  # noqa: E402
+import synth  # noqa: E402
 import oracle_lib as O  # noqa: E402
 import leon_amd  # noqa: E402
 from leon_amd import capi  # noqa: E402
@@ -26,7 +27,22 @@ for it in range(draws):
     window = rnd.choice([0, 16, 64, 300, 4096])
     G = rnd.choice([300, 3000, 20000, 200000])
     what = dict(it=it, k=k, rpb=rpb, n_hash=n_hash, nbits=nbits, L=L, n=n, window=window, G=G, **kw)
-    bases, off = common.synthetic(n, L, G, seed=5000 + it, **kw)
+    # (round 5) every draw picks a structure, as tests/test_gpu_fuzz.py does, a chunk size for the sequential resolution pass and a form of the block coder
+    shape = rnd.choice(["iid", "iid", "sorted", "pairs", "random", "sorted-strands"])
+    if shape == "iid":
+        bases, off = common.synthetic(n, L, G, seed=5000 + it, **kw)
+    else:
+        g = synth.make_structured_genome(G, seed=5000 + it, dispersed=rnd.choice([0, 3, 10]), tandem=rnd.choice([0, 4, 30]))
+        b_, off = synth.make_structured_reads(g, n, L, seed=5001 + it, order=shape, dup_rate=rnd.choice([0, 0.1, 0.5]),
+                                              skew=rnd.choice([0, 0.5]), stride=rnd.choice([None, None, 1, 7]), **kw)
+        bases = b_.tobytes()
+    env = {"LEON_CHAIN_CHUNK": rnd.choice([None, None, "1", "64", "1000"]), "LEON_RC_GROUP": rnd.choice([None, "1", "2", "4", "8"]),
+           "LEON_RC_HOST_BLOCKS": rnd.choice([None, "0", "400"]), "LEON_RC_EMIT": rnd.choice([None, "0"]), "LEON_RC_CMP": rnd.choice([None, "0"]),
+           "LEON_RESOLVE_ROUNDS": rnd.choice([None, None, "1", "9"])}
+    for kk, vv in env.items():
+        if vv is None: os.environ.pop(kk, None)
+        else: os.environ[kk] = vv
+    what.update(shape=shape, **{kk: vv for kk, vv in env.items() if vv is not None})
     bl, solid, tai = common.make_bloom(bases, off, k, rnd.choice([1, 2, 3]), n_hash, nbits)
     ref = O.encode(bases, off, k, rpb, bl, trace=False)
     ctx = leon_amd.DnaEncodeContext(kmer_size=k, reads_per_block=rpb, bloom_tai=tai, bloom_n_hash=n_hash, bloom_block_nbits=nbits, resolve_window=window)
