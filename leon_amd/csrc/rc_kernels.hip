@@ -21,11 +21,7 @@ size_t rc_model_scratch_bytes(uint64_t n_blocks) {
 // Waves of a workgroup land on the CU's four SIMDs round-robin.  Wave 0 is the coder; the waves whose index is a multiple
 // of 4 would share its SIMD and stay idle (they only keep the barriers), so the chain never waits for a modeler's
 // vector instruction; the other waves are the modelers.
-// One more wave behind them, never on the coder's SIMD (11, 6, 3, 2 for groups of 8, 4, 2, 1): the emitter.
 __host__ __device__ constexpr uint32_t rc_waves(uint32_t g) { return g + 1 + (g - 1) / 3; }
-static_assert((rc_waves(8) & 3u) != 0 && (rc_waves(4) & 3u) != 0 && (rc_waves(2) & 3u) != 0 && (rc_waves(1) & 3u) != 0, "the emitter would share the coder's SIMD");
-// a step's word for the emitter: the three top bytes of `low` | how many of them leave (0..3); or RC_EMIT_SKIP | bytes the coder wrote itself << 8
-constexpr uint32_t RC_EMIT_BYTES = 0xFFFFFF00u, RC_EMIT_SKIP = 0x80u;
 
 // The earlier symbols of a tile, lane = symbol: lo += #(same model, smaller symbol), hi += #(same model, symbol <= mine),
 // tot += #(same model) over the lanes before this one -- 64 steps of a broadcast and three compare/add-with-carry pairs; the lane
@@ -201,18 +197,17 @@ struct RcModeler {
 
 // The coder's 64 steps of one tile, lane = block: RangeEncoder::encode for every record of the tile.  EXACT: the quotient by a
 // 64-bit division (totals of 2^30 and more); else a truncated multiply-high by the total's reciprocal with a 32-bit fix-up.
-// The bytes a step sends out do not go to memory from here: the step leaves ONE word in LDS -- the three top bytes of `low` and how many of
-// them leave (RC_EMIT_*) -- and the group's emitter wave (rc_emit_tile, on another SIMD, a tile behind) turns a tile's 64 words into byte
-// stores, lane = step.  That takes the cursor's clamp, the address, the byte swap and the store off the chain's instruction stream.
-template <bool EXACT, bool EMIT>
-__device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint32_t* re, uint64_t& low, uint64_t& range, uint32_t& nout, uint8_t* dst, uint32_t cap) {
-    uint4 pa = ra[0];
-    uint2 pb = rb[0];
+template <bool EXACT>
+__device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint64_t& low, uint64_t& range, uint32_t& nout, uint8_t* dst, uint32_t cap) {
+    // the record TWO steps on is fetched under this step (one step ahead the coder still waited for the LDS now and then: 122.6 -> 118.9 ms
+    // at 100 M reads, 175 -> 167 at the k = 63 shape; three ahead is slower again; the row's 65th entry is a spare)
+    uint4 pa = ra[0], pa1 = ra[1];
+    uint2 pb = rb[0], pb1 = rb[1];
 #pragma clang loop unroll_count(EXACT ? 1 : 4)
     for (uint32_t j = 0; j < 64; j++) {
         const uint32_t s_lo = pa.x, s_fr = pa.y, s_tot = pa.z, s_hc = pa.w, b0 = pb.x, b1 = pb.y;
-        const uint32_t jn = j + 1;                                 // next step's record, fetched under this step
-        pa = ra[jn]; pb = rb[jn];
+        const uint32_t jn = j + 2 < 64 ? j + 2 : 64;
+        pa = pa1; pb = pb1; pa1 = ra[jn]; pb1 = rb[jn];
         // low += cumLow * q; range = q * freq; top = low + range = low + q * (cumLow + freq), q = floor(range / total)
         // (a third product and not `low + range`: the add waits for both products; profiles/r4_minimizer_filter.txt)
         uint64_t top;
@@ -224,7 +219,7 @@ __device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint32_t*
             range = (uint64_t)q0 * s_fr;       range += (uint64_t)(q1 * s_fr) << 32;
         } else {
             // The step is as long as its DEPENDENT path (a lone wave issues in order; round 5: leaving instructions out of the step changed
-            // nothing, the emitter wave's four and the modelers' updates alike).  The quotient is a truncated multiply-high by the total's
+            // nothing, an emitter wave's four and the modelers' updates alike -- DESIGN.md 4.3).  The quotient is a truncated multiply-high by the total's
             // reciprocal, at most 3 short (total < 2^30); the three products start from that estimate while the remainder is compared, and
             // the 0..3 it was short by goes into each with one multiply-add -- two levels fewer than fixing the quotient first.
             const uint32_t r0 = (uint32_t)range, r1 = (uint32_t)(range >> 32);
@@ -256,18 +251,15 @@ __device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint32_t*
         uint32_t rare_below = xh == 0u ? 0xFFFFFFFFu : 0xFFFFu;
         asm volatile("" : "+v"(rare_below));
         const bool rare = (uint32_t)(range_s >> 32) <= rare_below;
-        const uint32_t nb = sh >> 3;
-        if (EMIT) re[j] = (lh & RC_EMIT_BYTES) | nb;
-        else {                                                      // (measurement: the round-4 form -- one unaligned 4-byte store at the cursor)
-            const uint32_t cap4 = cap - 4;
+        {
+            const uint32_t cap4 = cap - 4;                          // (stores clamp to the block's room; the block reports overflow at its end)
             *(uint32_t*)(dst + (nout < cap4 ? nout : cap4)) = __builtin_bswap32(lh);
         }
         uint64_t low_n = low << sh, range_n = range_s;
-        uint32_t nout_n = nout + nb;
-        // (the step is paid in instructions, ~5 cycles each for a wave alone on its SIMD -- profiles/r4_issue_costs.txt --: the rare case
-        // is ONE scalar branch on "any lane", not an exec mask saved and restored around the lanes' own test)
+        uint32_t nout_n = nout + (sh >> 3);
+        // (the rare case is ONE scalar branch on "any lane", not an exec mask saved and restored around the lanes' own test)
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0) && rare) {
-            // RangeEncoder::encode's loop as it is written; its bytes go out from here, and the emitter only moves its cursor past them
+            // RangeEncoder::encode's loop as it is written
             low_n = low; range_n = range; nout_n = nout;
             while ((low_n ^ (low_n + range_n)) < (1ull << 56) ||
                    (range_n < RC_BOTTOM && ((range_n = (0 - low_n) & (RC_BOTTOM - 1)), true))) {
@@ -276,28 +268,9 @@ __device__ inline void rc_coder_tile(const uint4* ra, const uint2* rb, uint32_t*
                 range_n <<= 8;
                 low_n <<= 8;
             }
-            if (EMIT) re[j] = RC_EMIT_SKIP | ((nout_n - nout) << 8);
         }
         low = low_n; range = range_n; nout = nout_n;
     }
-}
-
-// The emitter's share of one tile of one block, lane = step: where each step's bytes go is a prefix sum of the tile's byte counts.
-__device__ inline void rc_emit_tile(const uint32_t* re, uint32_t lane, uint8_t* dst, uint32_t cap, uint32_t& cursor) {
-    const uint32_t w = re[lane];
-    const bool skip = (w & RC_EMIT_SKIP) != 0;
-    const uint32_t nb = skip ? 0u : (w & 3u), adv = skip ? (w >> 8) : nb;
-    uint32_t incl = adv;
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
-        if (lane >= d) incl += v;
-    }
-    const uint32_t at = cursor + incl - adv;
-    if (nb > 0 && at < cap) dst[at] = (uint8_t)(w >> 24);
-    if (nb > 1 && at + 1 < cap) dst[at + 1] = (uint8_t)(w >> 16);
-    if (nb > 2 && at + 2 < cap) dst[at + 2] = (uint8_t)(w >> 8);
-    cursor += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 
 // One workgroup codes G blocks: G modeler waves, and one coder wave that runs the G serial chains
@@ -306,8 +279,8 @@ __device__ inline void rc_emit_tile(const uint32_t* re, uint32_t lane, uint8_t* 
 // usual cases (0..2 bytes leave, no range < BOTTOM reset) and falls back to RangeEncoder::encode's loop per lane otherwise.
 // BIGOK: some block of the launch is long enough for a model's total to reach 2^30 (the host knows the blocks' symbol counts):
 // that instantiation also carries the exact-division steps, tile by tile; the other one is the plain fast chain.
-template <uint32_t G, uint32_t RC_NSLOT, bool BIGOK, bool EMIT, bool CMP>
-__global__ void __launch_bounds__(64 * (rc_waves(G) + (EMIT ? 1 : 0))) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
+template <uint32_t G, uint32_t RC_NSLOT, bool BIGOK, bool CMP>
+__global__ void __launch_bounds__(64 * rc_waves(G)) k_rc_encode(const uint8_t* syms, const uint64_t* blk_begin, uint64_t n_blocks,
                                                             uint8_t* out, const uint64_t* out_off, uint64_t* out_size,
                                                             uint32_t* scratch, int* err, uint32_t small_sizes, uint32_t fast_total) {
     constexpr uint32_t MW = RcModeler<RC_NSLOT, CMP>::WORDS;
@@ -316,27 +289,25 @@ __global__ void __launch_bounds__(64 * (rc_waves(G) + (EMIT ? 1 : 0))) k_rc_enco
     // step is paid in issue slots); one spare entry per row: the coder prefetches record j + 1
     __shared__ uint4 ring_a[G][2][RC_RING];
     __shared__ uint2 ring_b[G][2][RC_RING];
-    __shared__ uint32_t ring_e[EMIT ? G : 1][2][64];                      // the coder's words for the emitter (rc_coder_tile)
     __shared__ uint8_t slotmap_all[G][RC_NNUM];
     __shared__ uint32_t ntiles_s[G];
     __shared__ uint32_t tile_big[BIGOK ? G : 1][2];              // a total of fast_total or more in the tile: the coder divides exactly
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const bool is_coder = wave == 0, is_emitter = EMIT && wave == rc_waves(G), is_idle = (wave != 0 && (wave & 3u) == 0) || is_emitter;
+    const bool is_coder = wave == 0, is_idle = wave != 0 && (wave & 3u) == 0;
     const uint32_t mi = is_coder || is_idle ? 0 : wave - 1 - (wave >> 2);     // the modeler's block inside the group
     RcModeler<RC_NSLOT, CMP> M;
     M.init(models_all + mi * MW, slotmap_all[mi], (const uint16_t*)syms, small_sizes, lane, err);
 
     const uint64_t n_groups = (n_blocks + G - 1) / G;
     for (uint64_t bg = blockIdx.x; bg < n_groups; bg += gridDim.x) {
-        // this thread's block: the wave's for a modeler, the lane's for the coder and the emitter
-        const bool by_lane = is_coder || is_emitter;
-        const uint64_t b = bg * G + (by_lane ? lane : mi);
-        bool valid = (by_lane ? lane < G : !is_idle) && b < n_blocks;
+        // this thread's block: the wave's for a modeler, the lane's for the coder
+        const uint64_t b = bg * G + (is_coder ? lane : mi);
+        bool valid = (is_coder ? lane < G : !is_idle) && b < n_blocks;
         uint64_t s0 = 0, s1 = 0;
         if (valid) { s0 = blk_begin[b]; s1 = blk_begin[b + 1]; }
         if (valid && s1 - s0 >= 0xFFFFFF00ull) {                 // the models' counts are 32-bit words (upstream's are 64-bit [RECALLED]: it would go on)
-            if (is_coder || (lane == 0 && !is_emitter)) atomicExch(err, 2);
+            if (is_coder || lane == 0) atomicExch(err, 2);
             if (is_coder) out_size[b] = 0;
             valid = false;
         }
@@ -347,33 +318,19 @@ __global__ void __launch_bounds__(64 * (rc_waves(G) + (EMIT ? 1 : 0))) k_rc_enco
         uint32_t nout = 0;
         uint8_t* dst = nullptr;
         uint32_t cap = 0;                                        // stores stop at the block's room; the block reports overflow at its end (the cursor only grows)
-        if (by_lane && valid) {
+        if (is_coder && valid) {
             dst = out + out_off[b];
             const uint64_t room = out_off[b + 1] - out_off[b];
             cap = (uint32_t)(room < 0xFFFFFFFFull ? room : 0xFFFFFFFFull);
         }
-        uint32_t cursor[G];                                      // emitter: bytes out so far, per block of the group (wave-uniform)
-#pragma unroll
-        for (uint32_t w = 0; w < G; w++) cursor[w] = 0;
         if (!is_coder && !is_idle && valid)                        // AbstractDnaCoder::startBlock
             M.start_block(s0, s1, scratch + b * (uint64_t)(RC_NNUM - RC_NSLOT_SMALL) * RC_STRIDE, lane);
         __syncthreads();
         uint32_t T = 0;
         for (uint32_t w = 0; w < G; w++) T = ntiles_s[w] > T ? ntiles_s[w] : T;
 
-        for (uint32_t t = 0; t <= T + (EMIT ? 1 : 0); t++) {
-            if (is_emitter) {
-                // =================== emitter: tile t-2 of every block of the group, lane = step ===================
-                if (t >= 2) {
-#pragma unroll
-                    for (uint32_t w = 0; w < G; w++) {
-                        uint8_t* const d = (uint8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)dst >> 32), (int)w) << 32) |
-                                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)dst, (int)w));
-                        const uint32_t cp = (uint32_t)__builtin_amdgcn_readlane((int)cap, (int)w);
-                        if (d) rc_emit_tile(&ring_e[w][t & 1][0], lane, d, cp, cursor[w]);
-                    }
-                }
-            } else if (is_idle) {
+        for (uint32_t t = 0; t <= T; t++) {
+            if (is_idle) {
             } else if (!is_coder) {
                 if (t < ntiles) {
                     // =================== modeler: tile t -> ring[mi][t & 1] ===================
@@ -392,18 +349,17 @@ __global__ void __launch_bounds__(64 * (rc_waves(G) + (EMIT ? 1 : 0))) k_rc_enco
                     ring_b[mi][t & 1][lane] = make_uint2(~0u, ~0u);
                     if (BIGOK && lane == 0) tile_big[mi][t & 1] = 0u;
                 }
-            } else if (t > 0 && t <= T) {
+            } else if (t > 0) {
                 // =================== coder: tile t-1 of every block of the group, lane = block ===================
                 // (symbols past a block's end are "leave as it is" records, so the 64 steps are uniform)
                 if (valid) {
                     const uint4* ra = &ring_a[lane][(t - 1) & 1][0];
                     const uint2* rb = &ring_b[lane][(t - 1) & 1][0];
-                    uint32_t* re = &ring_e[EMIT ? lane : 0][(t - 1) & 1][0];
                     // (a tile in which some block's total has reached fast_total takes the same steps with the exact division)
                     bool any_big = false;
                     if (BIGOK) any_big = __ballot(tile_big[lane < G ? lane : 0][(t - 1) & 1] != 0 && lane < G) != 0;
-                    if (!BIGOK || __builtin_expect(!any_big, 1)) rc_coder_tile<false, EMIT>(ra, rb, re, low, range, nout, dst, cap);
-                    else rc_coder_tile<true, EMIT>(ra, rb, re, low, range, nout, dst, cap);
+                    if (!BIGOK || __builtin_expect(!any_big, 1)) rc_coder_tile<false>(ra, rb, low, range, nout, dst, cap);
+                    else rc_coder_tile<true>(ra, rb, low, range, nout, dst, cap);
                 }
             }
             __syncthreads();
@@ -624,27 +580,22 @@ void launch_rc_encode(hipStream_t s, const uint8_t* syms, const uint64_t* blk_be
     uint32_t fast_total = RC_MAX_TOTAL;
     if (const char* e = getenv("LEON_RC_FAST_TOTAL_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 30) fast_total = 1u << v; }
     const bool big = max_block_syms + 512 >= fast_total;      // (a model's total is at most its block's symbol count + 256)
-    // counts_apart (the read blocks' symbols, made by k_symbols: a numeric group's first model only ever sees 0..8): emitter wave + byte-count models
-    // apart (round 5); every other caller's streams -- the header stream's 14 byte models, leon_rc_encode_streams' arbitrary symbols -- as before.
-    // LEON_RC_EMIT=0 / LEON_RC_CMP=0: measurement, one at a time at 8 blocks per workgroup
-    const bool env_emit = [] { const char* e = getenv("LEON_RC_EMIT"); return !e || atoi(e) != 0; }();
-    const bool env_cmp = [] { const char* e = getenv("LEON_RC_CMP"); return !e || atoi(e) != 0; }();
-    const bool emit = counts_apart && env_emit, cmp = counts_apart && env_cmp;
-#define RC_LAUNCH(GG, N, B, E, C) hipLaunchKernelGGL((k_rc_encode<GG, N, B, E, C>), dim3(g), dim3(64 * (rc_waves(GG) + (E ? 1 : 0))), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err, small_sizes, fast_total)
-#define RC_PICK(GG, N, E, C) do { if (big) RC_LAUNCH(GG, N, true, E, C); else RC_LAUNCH(GG, N, false, E, C); } while (0)
-    if (G == 8) {                                             // (slots: what 160 KB of LDS leave room for)
-        if (emit && cmp) RC_PICK(8, 12, true, true);
-        else if (cmp) RC_PICK(8, 13, false, true);
-        else if (emit) RC_PICK(8, 13, true, false);
-        else RC_PICK(8, 14, false, false);
-    } else if (emit || cmp) {
-        if (G == 1) RC_PICK(1, RC_NSLOT_BIG, true, true);
-        else if (G == 2) RC_PICK(2, RC_NSLOT_BIG, true, true);
-        else RC_PICK(4, RC_NSLOT_BIG, true, true);
+    // counts_apart (the read blocks' symbols, made by k_symbols: a numeric group's first model only ever sees 0..8): the byte-count models apart from
+    // the 256-symbol slots (round 5); every other caller's streams -- the header stream's 14 byte models, leon_rc_encode_streams' arbitrary symbols --
+    // as before.  LEON_RC_CMP=0: measurement / test, the round-4 layout for the read blocks too
+    const bool cmp = counts_apart && [] { const char* e = getenv("LEON_RC_CMP"); return !e || atoi(e) != 0; }();
+#define RC_LAUNCH(GG, N, B, C) hipLaunchKernelGGL((k_rc_encode<GG, N, B, C>), dim3(g), dim3(64 * rc_waves(GG)), 0, s, syms, blk_begin, n_blocks, out, out_off, out_size, model_scratch, err, small_sizes, fast_total)
+#define RC_PICK(GG, N, C) do { if (big) RC_LAUNCH(GG, N, true, C); else RC_LAUNCH(GG, N, false, C); } while (0)
+    if (cmp) {                                                // (slots at 8 blocks per workgroup: what 160 KB of LDS leave room for)
+        if (G == 1) RC_PICK(1, RC_NSLOT_BIG, true);
+        else if (G == 2) RC_PICK(2, RC_NSLOT_BIG, true);
+        else if (G == 4) RC_PICK(4, RC_NSLOT_BIG, true);
+        else RC_PICK(8, RC_NSLOT_SMALL, true);
     } else {
-        if (G == 1) RC_PICK(1, RC_NSLOT_BIG, false, false);
-        else if (G == 2) RC_PICK(2, RC_NSLOT_BIG, false, false);
-        else RC_PICK(4, RC_NSLOT_BIG, false, false);
+        if (G == 1) RC_PICK(1, RC_NSLOT_BIG, false);
+        else if (G == 2) RC_PICK(2, RC_NSLOT_BIG, false);
+        else if (G == 4) RC_PICK(4, RC_NSLOT_BIG, false);
+        else RC_PICK(8, RC_NSLOT_SMALL + 1, false);
     }
 #undef RC_PICK
 #undef RC_LAUNCH

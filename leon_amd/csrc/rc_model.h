@@ -6,7 +6,7 @@
 namespace leon {
 
 constexpr uint32_t RC_NSLOT_BIG = 24;        // numeric models cached in LDS per block (5 blocks per CU) ...
-constexpr uint32_t RC_NSLOT_SMALL = 12;      // ... or, when there are more blocks than that keeps resident, 8 per CU
+constexpr uint32_t RC_NSLOT_SMALL = 13;      // ... or, when there are more blocks than that keeps resident, 8 per CU
 constexpr uint32_t RC_LW = 20;               // word offset of Lw[] inside a model
 constexpr uint32_t RC_STRIDE = 280;          // 256-ary model: H[17] pad Lw[256] + one zero word (F(256) = H[16] + 0)
 constexpr uint32_t RC_SSTRIDE = 40;          // small model (alphabet <= 5): same layout, only the first 16-block

@@ -37,7 +37,7 @@ for it in range(draws):
                                               skew=rnd.choice([0, 0.5]), stride=rnd.choice([None, None, 1, 7]), **kw)
         bases = b_.tobytes()
     env = {"LEON_CHAIN_CHUNK": rnd.choice([None, None, "1", "64", "1000"]), "LEON_RC_GROUP": rnd.choice([None, "1", "2", "4", "8"]),
-           "LEON_RC_HOST_BLOCKS": rnd.choice([None, "0", "400"]), "LEON_RC_EMIT": rnd.choice([None, "0"]), "LEON_RC_CMP": rnd.choice([None, "0"]),
+           "LEON_RC_HOST_BLOCKS": rnd.choice([None, "0", "400"]), "LEON_RC_CMP": rnd.choice([None, "0"]),
            "LEON_RESOLVE_ROUNDS": rnd.choice([None, None, "1", "9"])}
     for kk, vv in env.items():
         if vv is None: os.environ.pop(kk, None)

@@ -191,16 +191,15 @@ def test_toy_fasta_bit_exact():
 
 
 @pytest.mark.parametrize("group", ["1", "2", "4", "8"])
-@pytest.mark.parametrize("form", ["emitter+counts-apart", "emitter", "counts-apart", "round-4"])
-def test_block_coder_every_group_size_and_form(monkeypatch, group, form):
+@pytest.mark.parametrize("counts_apart", ["1", "0"])
+def test_block_coder_every_group_size_and_layout(monkeypatch, group, counts_apart):
     """k_rc_encode codes 1, 2, 4 or 8 read blocks per workgroup (the launcher picks by the number of blocks; 8 only beyond 1 024 blocks, which no small
-    test reaches) and has, for the read blocks' symbols, an emitter wave and the byte-count models kept apart from the 256-symbol slots (12 slots per
-    block at 8 per workgroup, so reads with N, errors and ragged lengths here push some numeric models to the global overflow area): every
-    combination against the oracle's bytes."""
+    test reaches) and keeps, for the read blocks' symbols, the byte-count models apart from the 256-symbol slots (13 slots per block at 8 per workgroup,
+    so reads with N, errors, ragged lengths and no anchor here push some numeric models to the global overflow area): every combination against the
+    oracle's bytes."""
     monkeypatch.setenv("LEON_RC_HOST_BLOCKS", "0")
     monkeypatch.setenv("LEON_RC_GROUP", group)
-    monkeypatch.setenv("LEON_RC_EMIT", "1" if "emitter" in form else "0")
-    monkeypatch.setenv("LEON_RC_CMP", "1" if "counts-apart" in form else "0")
+    monkeypatch.setenv("LEON_RC_CMP", counts_apart)
     bases, off = common.synthetic(2500, 150, 12000, seed=23, junk_reads=40, ragged=True, n_rate=0.002, err=0.02)
     _full_compare(bases, off, 31, 100)
 
