@@ -1,4 +1,5 @@
 # round 5: k_rc_encode, 8 blocks per workgroup, on reads of ragged length (more numeric models in use than the 150 bp default: READSIZE every read):
+# (ran while the emitter wave, LEON_RC_EMIT, was still in the kernel)
 # byte-count models apart or not, emitter or not.  200 blocks in groups of 8 take as long as 2 000 (every block's chain runs at once either way).
 R=$GRAFT_REPO_ROOT
 cd $R

@@ -1,4 +1,5 @@
 # round 5: k_rc_encode with the ring kept by counters (depth 3) -- parity tests that reach it under a short limit first, then timing
+# (ran against the counter-kept ring, which was dropped: HISTORY.md, Round 5)
 R=$GRAFT_REPO_ROOT
 cd $R
 O=gpurun_out/r5rc
