@@ -1,6 +1,6 @@
 # round 5: what k_rc_encode's phases wait for -- the kernel with one part left out at a time (builds with -DRC_EXP_*: wrong bytes, timing only)
-# (ran against builds of commit ae31f6b's rc_kernels.hip with -DRC_EXP_NO_UPDATE / _NO_RANK / _NO_CODER compiled into leon_amd/lib_<variant>/: the macros
-# were removed again after the measurement -- `git log -S RC_EXP_` finds them)
+# (ran against builds of rc_kernels.hip with the models' updates / the rank loop / the coder compiled out by -DRC_EXP_NO_UPDATE / _NO_RANK / _NO_CODER,
+# linked into leon_amd/lib_<variant>/; the three #ifdefs were taken out again after the measurement and never committed: kept as the record of what ran)
 R=$GRAFT_REPO_ROOT
 cd $R
 O=gpurun_out/r5rc

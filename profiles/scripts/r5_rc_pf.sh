@@ -1,6 +1,6 @@
 # k_rc_encode: the coder's records fetched one / two / three steps ahead (lib_pf1, lib, lib_pf3), same box: default workload and the k = 63 shape,
-# (ran against builds with -DRC_PF=1 / 3 in leon_amd/lib_pf1, lib_pf3 and with the emitter wave still in the kernel: both removed after the
-# measurement -- `git log -S RC_PF` finds them)
+# (ran against builds with the fetch distance as a macro, -DRC_PF=1 / 3, in leon_amd/lib_pf1 / lib_pf3, and with the emitter wave still in the kernel:
+# both taken out after the measurement; kept as the record of what ran)
 # emitter x counts-apart
 R=$GRAFT_REPO_ROOT
 cd $R
