@@ -79,23 +79,31 @@ void launch_read_slots(hipStream_t s, const uint64_t* off, uint64_t n, uint64_t*
 // One lane per OUTPUT dword (16 bases): a workgroup takes 64 consecutive reads, stages their slot and base offsets in LDS and
 // walks the dwords of those reads in order, so neighbouring lanes load neighbouring 16-byte pieces of the caller's bases --
 // coalesced loads in, coalesced dword stores out.  (It was one lane per read: 64 lanes striding 150 bytes apart, 0.83 TB/s.)
-constexpr uint32_t PACK_READS = 64;
+constexpr uint32_t PACK_READS = 256;
+constexpr uint32_t PACK_MAP = 4096;          // slots whose read a byte of LDS names (256 reads of up to 512 bases; longer ones are found by bisection)
 __global__ void __launch_bounds__(256) k_pack(const uint8_t* bases, const uint64_t* off, const uint64_t* slot_off, uint64_t n,
                                              uint32_t* packed, uint32_t* nmask, uint32_t* len_out, uint32_t* ncount) {
     __shared__ uint64_t so[PACK_READS + 1], bo[PACK_READS + 1];
     __shared__ uint32_t nn[PACK_READS];
+    __shared__ uint8_t rmap[PACK_MAP];
     const uint64_t r0 = blockIdx.x * (uint64_t)PACK_READS;
     const uint32_t nr = (uint32_t)(n - r0 < PACK_READS ? n - r0 : PACK_READS);
-    if (threadIdx.x <= nr) { so[threadIdx.x] = slot_off[r0 + threadIdx.x]; bo[threadIdx.x] = off[r0 + threadIdx.x]; }
-    if (threadIdx.x < PACK_READS) nn[threadIdx.x] = 0;
+    for (uint32_t t = threadIdx.x; t <= nr; t += blockDim.x) { so[t] = slot_off[r0 + t]; bo[t] = off[r0 + t]; }     // (nr + 1 entries: one more than the workgroup has threads)
+    for (uint32_t t = threadIdx.x; t < PACK_READS; t += blockDim.x) nn[t] = 0;
     __syncthreads();
     const uint64_t s0 = so[0];
     const uint64_t total_dw = 2 * (so[nr] - s0);
+    const bool mapped = so[nr] - s0 <= PACK_MAP;              // (round 5: six dependent LDS reads per dword were most of this kernel's time)
+    if (mapped) {
+        for (uint32_t t = threadIdx.x; t < nr; t += blockDim.x) for (uint64_t q = so[t]; q < so[t + 1]; q++) rmap[q - s0] = (uint8_t)t;
+        __syncthreads();
+    }
     uint16_t* nmask16 = (uint16_t*)nmask;
     for (uint64_t d = threadIdx.x; d < total_dw; d += blockDim.x) {
         const uint64_t slot = s0 + (d >> 1);
         uint32_t lo = 0, hi = nr;                              // the read r with so[r] <= slot < so[r + 1]
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (so[mid] <= slot) lo = mid; else hi = mid; }
+        if (mapped) lo = rmap[d >> 1];
+        else while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (so[mid] <= slot) lo = mid; else hi = mid; }
         const uint32_t r = lo;
         const uint32_t len = (uint32_t)(bo[r + 1] - bo[r]);
         const uint32_t j0 = (uint32_t)(2 * s0 + d - 2 * so[r]) * 16;   // first base of this dword inside the read
@@ -112,25 +120,24 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t* bases, const uint64
                 fours[q4] = four;
             }
         }
+        // four bases at a time: a byte is valid when it equals 'A', 'C', 'G' or 'T' (exact per-byte zero test of the XOR: the 7-bit add cannot carry
+        // into the next byte), its code is bits 2..1; the four codes / flags are gathered into a byte / nibble by one multiply each
         uint32_t word = 0, nb = 0;
 #pragma unroll
         for (uint32_t q4 = 0; q4 < 4; q4++) {
             const uint32_t four = fours[q4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t c = (four >> (8 * j)) & 0xFFu;
-                const bool valid = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
-                const uint32_t code = valid ? ((c >> 1) & 3u) : 0u;
-                word |= code << (30 - 2 * (4 * q4 + j));
-                nb |= (valid ? 0u : 1u) << (4 * q4 + j);
-            }
+            auto eq = [&](uint32_t letter) { const uint32_t x = four ^ (letter * 0x01010101u); return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; };
+            const uint32_t ok = (eq('A') | eq('C') | eq('G') | eq('T')) >> 7;              // 1 per valid byte
+            const uint32_t codes = (four >> 1) & 0x03030303u & (ok * 3u);
+            word |= ((codes * 0x40100401u) >> 24) << (24 - 8 * q4);
+            nb |= (((ok ^ 0x01010101u) * 0x01020408u) >> 24) << (4 * q4);
         }
         packed[2 * s0 + d] = word;
         nmask16[2 * s0 + d] = (uint16_t)nb;                    // the even dword's 16 flags are the low half of the slot's mask word
         if (nb) atomicAdd(&nn[r], (uint32_t)__popc(nb));
     }
     __syncthreads();
-    if (threadIdx.x < nr) { len_out[r0 + threadIdx.x] = (uint32_t)(bo[threadIdx.x + 1] - bo[threadIdx.x]); ncount[r0 + threadIdx.x] = nn[threadIdx.x]; }
+    for (uint32_t t = threadIdx.x; t < nr; t += blockDim.x) { len_out[r0 + t] = (uint32_t)(bo[t + 1] - bo[t]); ncount[r0 + t] = nn[t]; }
 }
 void launch_pack(hipStream_t s, const uint8_t* bases, const uint64_t* off, const uint64_t* slot_off, uint64_t n,
                  uint32_t* packed, uint32_t* nmask, uint32_t* len, uint32_t* ncount) {
