@@ -1724,6 +1724,7 @@ void launch_prev_anchored(hipStream_t s, const int32_t* anchor_pos, uint64_t n, 
     hipLaunchKernelGGL(k_prev_anchored, dim3((uint32_t)n_blocks), dim3(256), 0, s, anchor_pos, n, rpb, first_block, prev);
 }
 
+constexpr uint32_t SYM_STAGE = 2048;         // symbols of a wave's 64 reads staged in LDS by k_symbols (23 per 150 bp read)
 struct SymSink {
     uint8_t* p;           // nullptr: count only
     uint64_t n;
@@ -1755,15 +1756,29 @@ template <bool EMIT>
 __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr,
                                                 const uint8_t* flags, const int64_t* prev, const uint8_t* events,
                                                 uint64_t r0, uint64_t n_local, uint64_t* sym_off, uint32_t* n_err, uint8_t* syms) {
-    uint64_t li = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (li >= n_local) return;
+    const uint64_t li = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    // EMIT: the symbols of a wave's 64 reads are ONE contiguous span of the stream (sym_off is a prefix sum in read order).  Lanes storing two bytes
+    // at a time, each into its own read's part, made every store instruction 64 partial lines; the span is put together in LDS instead (4 KB per
+    // wave) and leaves in whole lines.  A span beyond the buffer (reads without an anchor: a symbol per base) is stored directly, as before.
+    __shared__ uint16_t stage[EMIT ? 4 : 1][EMIT ? SYM_STAGE : 1];
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint64_t li0 = li - (threadIdx.x & 63);                // (wave-uniform)
+    if (li0 >= n_local) return;
+    uint64_t w_begin = 0, w_end = 0;
+    bool staged = false;
+    if (EMIT) {
+        w_begin = sym_off[li0];
+        w_end = sym_off[li0 + 64 < n_local ? li0 + 64 : n_local];
+        staged = w_end - w_begin <= SYM_STAGE;
+    }
+    if (li < n_local) {
     const uint64_t i = r0 + li;
     uint32_t len = R.len[i], k = R.k;
     const uint32_t* pk = R.packed + 2 * R.slot_off[i];
     const uint32_t* nm = R.nmask + R.slot_off[i];
     uint32_t nN = R.n_count[i];
     SymSink S;
-    S.p = EMIT ? syms + 2 * sym_off[li] : nullptr;
+    S.p = !EMIT ? nullptr : staged ? (uint8_t*)&stage[wv][sym_off[li] - w_begin] : syms + 2 * sym_off[li];
     S.n = 0;
     int32_t a = anchor_pos[i];
     if (a < 0) {                                              // DnaEncoder::encodeNoAnchorRead
@@ -1872,6 +1887,14 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
         }
     }
     if (!EMIT) sym_off[li] = S.n;
+    }
+    if (EMIT && staged) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the lanes' stores went through flat addresses: both counters)
+        __builtin_amdgcn_wave_barrier();
+        uint16_t* const out = (uint16_t*)syms + w_begin;
+        const uint32_t ns = (uint32_t)(w_end - w_begin), lane = threadIdx.x & 63;
+        for (uint32_t x = lane; x < ns; x += 64) out[x] = stage[wv][x];
+    }
 }
 void launch_symbols(hipStream_t s, ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr, const uint8_t* flags,
                     const int64_t* prev, const uint8_t* events, uint64_t r0, uint64_t n_local, uint64_t* sym_off, uint32_t* n_err,
