@@ -1201,7 +1201,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     // ---- symbols ----
     HIPCHK(c, c->prev.ensure(n * 8));
     HIPCHK(c, c->sym_off.ensure((nl + 1) * 8));
-    HIPCHK(c, c->nerr.ensure(nl * 4));
+    HIPCHK(c, c->nerr.ensure(nl * 8));                         // (two words per read: error positions, chunks that hold events)
     launch_prev_anchored(s, V.anchor_pos, n, rpb, lb0, nbl, c->prev.as<int64_t>());
     HIPCHK(c, hipMemsetAsync(c->sym_off.as<uint64_t>() + nl, 0, 8, s));
     launch_symbols(s, R, V.anchor_pos, V.anchor_addr, V.flags, c->prev.as<int64_t>(), c->events.as<uint8_t>(), r0, nl,
@@ -1381,7 +1381,7 @@ int leon_dna_reserve(leon_dna_ctx* c, uint64_t max_reads, uint64_t max_bases) {
     HIPCHK(c, c->ulist0.ensure(W * 4)); HIPCHK(c, c->ulist1.ensure(W * 4));
     HIPCHK(c, c->sort_key2.ensure(n * 8)); HIPCHK(c, c->perm.ensure(n * 4)); HIPCHK(c, c->perm2.ensure(n * 4));
     HIPCHK(c, c->events.ensure(max_bases + 16));
-    HIPCHK(c, c->prev.ensure(n * 8)); HIPCHK(c, c->sym_off.ensure((n + 1) * 8)); HIPCHK(c, c->nerr.ensure(n * 4));
+    HIPCHK(c, c->prev.ensure(n * 8)); HIPCHK(c, c->sym_off.ensure((n + 1) * 8)); HIPCHK(c, c->nerr.ensure(n * 8));
     HIPCHK(c, c->syms.ensure(est_syms * 2 + 256));
     HIPCHK(c, c->blk_begin.ensure((nbl + 1) * 8)); HIPCHK(c, c->out_off.ensure((nbl + 1) * 8));
     HIPCHK(c, c->out_size.ensure(nbl * 8)); HIPCHK(c, c->dst_off.ensure((nbl + 1) * 8));

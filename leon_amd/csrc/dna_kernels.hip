@@ -1749,8 +1749,8 @@ struct SymSink {
     }
 };
 
-// EMIT = false: sym_off[li] = number of symbols of the read and n_err[li] = its number of error positions, from ONE
-// scan of the read's event bytes; EMIT = true: the symbols, written at syms + 2 * sym_off[li].  One lane per read; the
+// EMIT = false: sym_off[li] = number of symbols of the read and n_err[2 li], n_err[2 li + 1] = its number of error positions and which of its
+// 16-byte chunks of event bytes hold an event, from ONE scan of the read's event bytes; EMIT = true: the symbols, written at syms + 2 * sym_off[li].  One lane per read; the
 // events are read as dwords (the memory pipeline charges per wave-wide instruction, not per byte).
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anchor_pos, const uint32_t* anchor_addr,
@@ -1820,11 +1820,12 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
         };
         if (!EMIT) {
             // one ascending scan: error positions (count + their numerics' sizes) and the number of bifurcation symbols
-            uint32_t nErr = 0, prevE = 0, nBif = 0;
+            uint32_t nErr = 0, prevE = 0, nBif = 0, cm = 0;
             for (uint32_t p0 = 0; p0 < len; p0 += 16) {
                 uint32_t w[4];
                 chunk(p0, w);
                 if (!(w[0] | w[1] | w[2] | w[3])) continue;
+                cm |= 1u << ((p0 >> 4) < 31u ? (p0 >> 4) : 31u);     // which 16-byte chunks hold an event at all (bit 31: some chunk from the 32nd on)
 #pragma unroll
                 for (uint32_t d = 0; d < 4; d++) {
                     const uint32_t w4 = w[d], p = p0 + 4 * d;
@@ -1840,13 +1841,15 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
             }
             S.numeric(G_LEFT_ERROR, nErr);
             S.n += nBif;
-            n_err[li] = nErr;
+            n_err[2 * li] = nErr; n_err[2 * li + 1] = cm;        // (the emitting pass loads only the chunks named here: ~2.5 of a 150 bp read's 10)
         } else {
-            const uint32_t nErr = n_err[li];                  // error positions, ascending
+            const uint32_t nErr = n_err[2 * li], cm = n_err[2 * li + 1];     // error positions, ascending
+            auto holds = [&](uint32_t p0) { const uint32_t c = p0 >> 4; return ((cm >> (c < 31u ? c : 31u)) & 1u) != 0; };
             S.numeric(G_LEFT_ERROR, nErr);
             if (nErr) {
                 uint32_t prevE = 0, left = nErr;
                 for (uint32_t p0 = 0; p0 < len && left; p0 += 16) {
+                    if (!holds(p0)) continue;
                     uint32_t w[4];
                     chunk(p0, w);
 #pragma unroll
@@ -1862,6 +1865,7 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
             }
             // bifurcations: left walk (a-1 .. 0), then right walk (a+k .. len-1)
             for (int32_t p0 = a > 0 ? ((a - 1) & ~15) : -16; p0 >= 0; p0 -= 16) {     // chunks descending, bytes descending
+                if (!holds((uint32_t)p0)) continue;
                 uint32_t w[4];
                 chunk((uint32_t)p0, w);
                 if (((w[0] | w[1] | w[2] | w[3]) & 0x07070707u) == 0) continue;
@@ -1874,6 +1878,7 @@ __global__ void __launch_bounds__(256) k_symbols(ReadsDev R, const int32_t* anch
             }
             const uint32_t rs = (uint32_t)a + k;
             for (uint32_t p0 = rs & ~15u; p0 < len; p0 += 16) {
+                if (!holds(p0)) continue;
                 uint32_t w[4];
                 chunk(p0, w);
                 if (((w[0] | w[1] | w[2] | w[3]) & 0x07070707u) == 0) continue;
