@@ -429,10 +429,30 @@ def self_launch(a):
     raise SystemExit(p.returncode if p.returncode else (0 if lines else 1))
 
 
+_LINE_FD = None
+
+
+def claim_stdout():
+    """The driver takes ONE JSON line from rank 0's stdout.  Libraries write there too -- RCCL prints a five-line version banner on stdout when its
+    first communicator starts (seen on one box of the pool, not on others) -- so from here on descriptor 1 IS stderr for everything in this
+    process, and the line goes out through a copy of the real stdout kept aside."""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(text):
+    sys.stdout.flush()
+    os.write(_LINE_FD if _LINE_FD is not None else 1, (text + "\n").encode())
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         self_launch(a)
+    claim_stdout()
     pg_world = int(os.environ.get("WORLD_SIZE", "1"))        # the process group: one process per GPU
     pg_rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -870,8 +890,7 @@ def main():
                       "symbols": int(stage["n_symbols"]), "resolve_rounds": int(stage["resolve_rounds"]), "resolve_chain_reads": int(stage["resolve_chain_reads"]),
                       "bits_per_base": round(8.0 * (payload[0] + dict_bytes) / (max(n_local, 1) * L), 4)},
         }
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit_line(json.dumps(out))
     if use_dist:
         with WATCH("barrier (end of the run)"):
             dist.barrier()

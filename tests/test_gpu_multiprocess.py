@@ -123,7 +123,9 @@ def test_rccl_path_with_one_rank():
     N > 1 CODE can: one rank under torch.distributed.run with LEON_BENCH_FORCE_DIST=1 goes through init_process_group("nccl",
     device_id=...), the device-to-device broadcast of the bloom, the reductions, the gather of the block tables and the barriers
     -- every RCCL call the 8-GPU run makes, with a world of one.  Same bytes as the plain run."""
-    env = dict(os.environ, LEON_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (NCCL_DEBUG=VERSION: RCCL then prints its version banner on STDOUT when the communicator starts, as one box of the pool did unasked;
+    # the driver takes one JSON line from there, so bench.py keeps everything else off it)
+    env = dict(os.environ, LEON_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="VERSION")
     for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LEON_BENCH_BACKEND"):
         env.pop(v, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
@@ -131,6 +133,8 @@ def test_rccl_path_with_one_rank():
            "--cpu-sample", "0", "--quick", "--verify"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "RCCL version" not in p.stdout and "NCCL version" not in p.stdout, p.stdout[:600]
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["bloom_bcast_ms"] > 0            # the broadcast ran (through RCCL)
     plain = _bench(1, extra_args=("--quick", "--verify"))
