@@ -470,6 +470,10 @@ def main():
             raise SystemExit("LEON_BENCH_AS_RANK=%r: expected r:N" % as_rank)
         if not 0 <= rank < world:
             raise SystemExit("LEON_BENCH_AS_RANK=%r: rank out of range" % as_rank)
+        # A rank of a real job shares its node's CPUs with the other ranks, and the library gives it 1 / world of them for its host threads
+        # (capi.hip rc_host_threads); the seat is alone on this box and stands for a rank on a node that grants EVERY rank this box's CPUs
+        # (8 x 16 on the pool's 8-GPU nodes, if they are sized like its one-GPU boxes): the threads one process gets, named.
+        os.environ.setdefault("LEON_RC_HOST_THREADS", str(max(2, min(32, host_info(0, 0)["cpus_usable"] - 1))))
     import torch.distributed as dist
     n_dev = torch.cuda.device_count()
     if local >= n_dev:                       # rehearsal of the N>1 path on a one-GPU box (LEON_BENCH_BACKEND=gloo)
@@ -842,7 +846,7 @@ def main():
             "n_gpus": pg_world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
             **({"as_rank": as_rank, "as_rank_note": "ONE process in the seat of rank %d of a %d-rank job (leon_dna_set_shard): `value` and `ms_per_step` are the wall time "
                                                      "MINUS what this process did in the other ranks' stead (ms_emulated: their slices of the walk, their window look-ups), and at least the seat's dictionary chain (rank 0's) -- what that job would "
-                                                     "report if this rank were its slowest, not a measured %d-GPU figure" % (rank, world, world)} if as_rank else {}),
+                                                     "report if this rank were its slowest, not a measured %d-GPU figure; host threads for the blocks' chains as on a node that grants every rank this box's CPUs (LEON_RC_HOST_THREADS=%s)" % (rank, world, world, os.environ.get("LEON_RC_HOST_THREADS"))} if as_rank else {}),
             "value_hbm_resident": round(value, 1),
             "value_h2d_inclusive": pcie.get("value") if pcie else None,
             "cold_first_step_ms": round(cold_first_step_ms, 2),

@@ -270,10 +270,15 @@ uint64_t rc_host_blocks() {
     if (const char* e = getenv("LEON_RC_HOST_BLOCKS")) return (uint64_t)std::max<long long>(0, atoll(e));
     return 400;
 }
-uint32_t rc_host_threads(uint64_t n_blocks) {
+uint32_t rc_host_threads(uint64_t n_blocks, uint32_t world) {
     // (all but one of the process's CPUs: the dictionary chain and its helpers are busy for the first part of a small file's step only --
-    // configuration #2, 200 blocks: 88.9 ms with 12 threads and 4 chunks, 73.4 with 15 and 8, 63.9 with 15 and 16; profiles/r4_hostchains_sweep_config2.txt)
-    uint32_t n_thr = std::max<uint32_t>(2, std::min<uint32_t>(32, usable_cpus() > 2 ? usable_cpus() - 1 : 2));
+    // configuration #2, 200 blocks: 88.9 ms with 12 threads and 4 chunks, 73.4 with 15 and 8, 63.9 with 15 and 16; profiles/r4_hostchains_sweep_config2.txt.
+    // A rank of a job of `world` (leon_dna_set_shard: the GPUs of ONE node) shares the host, and its CPU quota, with the others: an equal share of
+    // what rank 0's dictionary chain and its helpers leave.  Eight ranks taking 32 threads each would run the cgroup out of its quota, and the
+    // throttling that follows stops the chain -- the one thing the job's step waits for -- along with everything else.)
+    const uint32_t cpus = usable_cpus();
+    uint32_t n_thr = world > 1 ? std::max<uint32_t>(2, (cpus > 6 ? cpus - 6 : 0) / world) : (cpus > 2 ? cpus - 1 : 2);
+    n_thr = std::max<uint32_t>(2, std::min<uint32_t>(32, n_thr));
     if (const char* e = getenv("LEON_RC_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_thr = (uint32_t)v; }
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_thr, n_blocks));
 }
@@ -282,13 +287,13 @@ uint32_t rc_host_threads(uint64_t n_blocks) {
 // the modelers' pass over the longest block (four waves per block since round 5), the records' 8 bytes per symbol over PCIe, the host
 // threads' chains (two side by side per thread) -- a chunk behind one another.  10 M reads of 150 bp in 200 blocks: 116 against ~42 ms,
 // the host (measured 134 and 45); 20 M reads of 250 bp in 400 blocks of 1.9 M symbols: 190 against ~140 (measured 174 and 142): left to the device, see below.
-bool rc_on_host(uint64_t n_blocks, uint64_t n_syms, uint64_t max_block_syms) {
+bool rc_on_host(uint64_t n_blocks, uint64_t n_syms, uint64_t max_block_syms, uint32_t world) {
     if (!n_blocks || n_blocks > rc_host_blocks() || max_block_syms + 1024 >= (1ull << HB_COUNT_BITS) || n_syms * 8 > (12ull << 30)) return false;
     if (getenv("LEON_RC_HOST_BLOCKS")) return true;              // (asked for by name: the tests, measurements)
     const double device_ns = 100.0 * (double)max_block_syms * (double)((n_blocks + 2047) / 2048);
     // (round 5: four modeler waves per block -- ~12 ns per symbol of the longest block --, the records' 8 bytes per symbol over PCIe at ~52 GB/s,
     // the chains two side by side per thread at ~2.6 ns per symbol; whichever is slowest, a sixteenth later for the first chunk's way in)
-    const double thr = (double)rc_host_threads(n_blocks);
+    const double thr = (double)rc_host_threads(n_blocks, world);
     const double host_ns = 1.0625 * std::max(12.0 * (double)max_block_syms, std::max(0.16 * (double)n_syms, 2.6 * (double)n_syms / thr));
     // (a near tie goes to the device: the host's cores have other work -- the dictionary chain, which is what a step waits for: at the k = 63 / 250 bp
     // shape, 400 blocks of 1.9 M symbols, the host's way takes 142 ms against the device's 174 and the step 554 ms against 542)
@@ -350,7 +355,7 @@ int rc_blocks_on_host(leon_dna_ctx* c, const uint8_t* d_syms, const uint64_t* d_
     HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 4, s));
     if (c->hb_coders.size() < nbl) c->hb_coders.resize(nbl);
     // the host threads
-    const uint32_t n_thr = rc_host_threads(nbl);
+    const uint32_t n_thr = rc_host_threads(nbl, c->shard_world);
     static const bool trace = getenv("LEON_TRACE_RC_HOST") != nullptr;     // measurement aid: when each chunk was modelled / had crossed / was coded, on stderr
     const auto t_begin = std::chrono::steady_clock::now();
     auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
@@ -1225,7 +1230,7 @@ static int encode_batch_impl(leon_dna_ctx* c, const uint8_t* d_bases, const uint
     HIPCHK(c, hipEventRecord(c->ev[6], s));
 
     // ---- range coder ----
-    bool host_chains = rc_on_host(nbl, n_syms, max_block_syms);
+    bool host_chains = rc_on_host(nbl, n_syms, max_block_syms, c->shard_world);
     std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
     uint64_t payload_bytes = 0;
     if (host_chains) {
@@ -1472,7 +1477,7 @@ static int header_batch_impl(leon_dna_ctx* c, const uint8_t* d_hdr, const uint64
         HIPCHK(c, c->blk_begin.ensure((nbl + 1) * 8)); HIPCHK(c, c->out_off.ensure((nbl + 1) * 8));
         HIPCHK(c, c->out_size.ensure(nbl * 8)); HIPCHK(c, c->dst_off.ensure((nbl + 1) * 8));
         launch_block_ranges(s, c->sym_off.as<uint64_t>(), nl, rpb, nbl, c->blk_begin.as<uint64_t>(), c->out_off.as<uint64_t>());
-        bool host_chains = rc_on_host(nbl, n_syms, max_block_syms);
+        bool host_chains = rc_on_host(nbl, n_syms, max_block_syms, c->shard_world);
         std::vector<uint64_t> sizes(nbl), dst(nbl + 1, 0);
         if (host_chains) {                                       // a small launch: the blocks' chains on host cores (host_blocks.h)
             const int rc = rc_blocks_on_host(c, c->syms.as<uint8_t>(), c->blk_begin.as<uint64_t>(), nbl, n_syms, SMALL_SIZES_HEADER, N_SMALL_MODELS);
